@@ -1,0 +1,222 @@
+/*
+ * smallvcm_amd.h -- C-ABI of the MI355X-native VCM integrator.
+ *
+ * This is the drop-in boundary for SmallVCM's `VertexCM::RunIteration`
+ * (reference: src/vertexcm.hxx:284-548) behind `AbstractRenderer`
+ * (src/renderer.hxx:33-70).  Everything crossing it is plain C: POD structs,
+ * pointers and sizes.  The C++ shim `smallvcm_amd/dropin/vertexcm.hxx` binds
+ * these entry points under the reference's own class name/ctor so that
+ * `smallvcm.cxx` and `config.hxx` compile unchanged.
+ *
+ * Conventions
+ *   - all entry points returning int return 0 on success, non-zero on error;
+ *     `vcm_last_error()` then holds a message (thread-local).
+ *   - "paths" are indexed 0..N-1, N = resX*resY, light path p and camera
+ *     path (pixel) p share the index (vertexcm.hxx:321, :415, :504-506).
+ *   - random numbers: counter-based Philox4x32-10 keyed by
+ *     (seed, renderer-local iteration count), counter (path, kind, block);
+ *     replaces src/rng.hxx (see DESIGN.md "RNG").
+ */
+#ifndef SMALLVCM_AMD_H
+#define SMALLVCM_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCM_MAX_PRIMS      32
+#define VCM_MAX_MATERIALS  16
+#define VCM_MAX_LIGHTS      8
+
+/* ---- scene description: POD flattening of the public members of `Scene`
+ *      (src/scene.hxx:476-485) ------------------------------------------- */
+
+enum { VCM_PRIM_TRIANGLE = 0, VCM_PRIM_SPHERE = 1 };
+
+/* Triangle {p[3], matID, mNormal} (src/geometry.hxx:174-176) or
+ * Sphere {center, radius, matID} (src/geometry.hxx:263-265: p0 = center,
+ * p1[0] = radius).  Primitives keep the order of GeometryList::mGeometry
+ * (src/geometry.hxx:104); closest-hit ties resolve to the first one. */
+typedef struct vcm_prim {
+    int   type;
+    int   matID;
+    float p0[3];
+    float p1[3];
+    float p2[3];
+    float n[3];
+} vcm_prim;
+
+/* Material (src/materials.hxx:54-65) */
+typedef struct vcm_material {
+    float diffuse[3];
+    float phong[3];
+    float phongExp;
+    float mirror[3];
+    float ior;
+} vcm_material;
+
+enum {
+    VCM_LIGHT_AREA = 0,        /* src/lights.hxx:112 */
+    VCM_LIGHT_DIRECTIONAL = 1, /* src/lights.hxx:236 */
+    VCM_LIGHT_POINT = 2,       /* src/lights.hxx:320 */
+    VCM_LIGHT_BACKGROUND = 3   /* src/lights.hxx:401 */
+};
+
+/* Tagged union of the public light fields (src/lights.hxx:229-232, 314-315,
+ * 395-396, 512-513).
+ *   area:        p0,e1,e2, frame (mX,mY,mZ), intensity, invArea
+ *   directional: frame, intensity
+ *   point:       p0 = mPosition, intensity
+ *   background:  intensity = mBackgroundColor, scale = mScale            */
+typedef struct vcm_light {
+    int   type;
+    float p0[3];
+    float e1[3];
+    float e2[3];
+    float frameX[3];
+    float frameY[3];
+    float frameZ[3];
+    float intensity[3];
+    float invArea;
+    float scale;
+} vcm_light;
+
+/* Camera (src/camera.hxx:121-126).  Matrices are the 16 floats of Mat4f in
+ * its memory order (column-major, src/math.hxx:255-259). */
+typedef struct vcm_camera {
+    float position[3];
+    float forward[3];
+    float resolution[2];
+    float rasterToWorld[16];
+    float worldToRaster[16];
+    float imagePlaneDist;
+} vcm_camera;
+
+typedef struct vcm_scene_desc {
+    int          nPrims;
+    vcm_prim     prims[VCM_MAX_PRIMS];
+    int          nMaterials;
+    vcm_material materials[VCM_MAX_MATERIALS];
+    int          mat2light[VCM_MAX_MATERIALS]; /* Scene::mMaterial2Light, -1 = none */
+    int          nLights;
+    vcm_light    lights[VCM_MAX_LIGHTS];
+    int          backgroundLight;              /* index into lights or -1 (Scene::mBackground) */
+    float        sceneCenter[3];               /* SceneSphere (src/lights.hxx:32-40) */
+    float        sceneRadius;
+    float        invSceneRadiusSqr;
+    vcm_camera   camera;
+} vcm_scene_desc;
+
+/* VertexCM::AlgorithmType (src/vertexcm.hxx:182-204) -- same values */
+enum {
+    VCM_ALGO_LIGHT_TRACE = 0,
+    VCM_ALGO_PPM = 1,
+    VCM_ALGO_BPM = 2,
+    VCM_ALGO_BPT = 3,
+    VCM_ALGO_VCM = 4
+};
+
+/* Per-iteration workload counters (what SURVEY.md section 8(d) calls N_LV, C, A, K, S)
+ * of the most recent iteration on this rank, plus kernel times in ms measured
+ * with HIP events on the context's stream. */
+typedef struct vcm_stats {
+    long long lightVertices;   /* N_LV stored on this rank                    */
+    long long gridVertices;    /* vertices in the hash grid (all ranks)       */
+    long long lightRays;       /* Scene::Intersect calls, light pass          */
+    long long cameraRays;      /* Scene::Intersect calls, camera pass         */
+    long long shadowRays;      /* Scene::Occluded calls                       */
+    long long mergeQueries;    /* HashGrid::Process calls                     */
+    long long mergeCandidates; /* C: distance tests (hashgrid.hxx:162-165)    */
+    long long mergeAccepted;   /* A: RangeQuery::Process calls                */
+    long long connections;     /* K: ConnectVertices calls                    */
+    long long lightSplats;     /* S: Framebuffer::AddColor from light paths   */
+    float msLight, msGrid, msCamera, msTotal;
+    float radius;              /* merge radius of the iteration               */
+} vcm_stats;
+
+typedef struct vcm_ctx vcm_ctx;
+
+/* Record layout used to exchange light vertices between ranks (13 floats =
+ * 52 bytes: the part of LightVertex that RangeQuery::Process reads,
+ * src/vertexcm.hxx:130-169). */
+#define VCM_MERGE_RECORD_FLOATS 13
+
+int         vcm_device_count(void);
+const char *vcm_last_error(void);
+
+/* Replaces `new VertexCM(scene, algo, radiusFactor, radiusAlpha, seed)`
+ * (src/vertexcm.hxx:208-282, called from src/config.hxx:124-138).
+ * Includes the PPM->BPM downgrade of :246-278.  Device resources are
+ * allocated lazily at the first iteration (unused renderers exist:
+ * src/renderer.hxx:58, src/smallvcm.cxx:66). */
+vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm,
+                    float radiusFactor, float radiusAlpha, int seed);
+
+/* Same, for one rank of a sharded renderer: rank r of worldSize traces light
+ * paths and pixels [r*N/W, (r+1)*N/W) on HIP device `device`. */
+vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm,
+                            float radiusFactor, float radiusAlpha, int seed,
+                            int device, int rank, int worldSize);
+
+void vcm_destroy(vcm_ctx *ctx);
+
+/* Use an externally owned HIP stream (e.g. torch's current stream) for all
+ * work of this context; NULL = the context's own stream. */
+int vcm_set_stream(vcm_ctx *ctx, void *hipStream);
+
+/* Replaces VertexCM::RunIteration(aIteration) (src/vertexcm.hxx:284-548) for a
+ * single-GPU renderer.  minLen/maxLen are AbstractRenderer::mMinPathLength /
+ * mMaxPathLength, which the driver assigns after construction
+ * (src/smallvcm.cxx:70-71).  Asynchronous on the context's stream. */
+int vcm_run_iteration(vcm_ctx *ctx, int iteration, unsigned minLen, unsigned maxLen);
+
+/* Phase-level entry points: vcm_run_iteration == begin, trace_light,
+ * build_grid, trace_camera, end.  A multi-GPU host puts the all-gather of the
+ * light-vertex records between trace_light and build_grid. */
+int vcm_begin_iteration(vcm_ctx *ctx, int iteration, unsigned minLen, unsigned maxLen); /* :288-316 */
+int vcm_trace_light(vcm_ctx *ctx);   /* :321-396, then compaction into merge records */
+int vcm_build_grid(vcm_ctx *ctx);    /* :403-408 -> hashgrid.hxx:41-107 */
+int vcm_trace_camera(vcm_ctx *ctx);  /* :415-545 */
+int vcm_end_iteration(vcm_ctx *ctx); /* :547 */
+
+/* Local merge records of this rank after vcm_trace_light: device pointer to
+ * count x VCM_MERGE_RECORD_FLOATS floats, in the reference's vertex order.
+ * `count` is read back from the device (synchronises the stream). */
+int vcm_light_records(vcm_ctx *ctx, void **devPtr, long long *count);
+
+/* Install the all-gathered records: nSeg segments (one per rank, rank order),
+ * segment s holds counts[s] records starting at devPtr + s*strideRecords
+ * records.  Repacks them contiguously; build_grid then uses them. */
+int vcm_import_light_records(vcm_ctx *ctx, const void *devPtr,
+                             const long long *counts, int nSeg,
+                             long long strideRecords);
+
+/* Framebuffer = running SUM over iterations of this context (the reference's
+ * mFramebuffer, src/renderer.hxx:68); W*H*3 floats, row-major, RGB. */
+int vcm_read_framebuffer(vcm_ctx *ctx, float *rgbHost);
+int vcm_framebuffer_device(vcm_ctx *ctx, void **devPtr);
+int vcm_clear_framebuffer(vcm_ctx *ctx);
+
+int vcm_iterations(vcm_ctx *ctx); /* AbstractRenderer::mIterations */
+int vcm_synchronize(vcm_ctx *ctx);
+int vcm_get_stats(vcm_ctx *ctx, vcm_stats *out);
+
+/* Number of random floats each path consumed in the last iteration (local
+ * paths of this rank): the "tape" that lets the unmodified reference replay
+ * the same random numbers (oracle/ref_driver.cpp).  Host buffers of
+ * localPathCount bytes each. */
+int vcm_get_rng_counts(vcm_ctx *ctx, unsigned char *lightCounts, unsigned char *cameraCounts);
+int vcm_local_path_range(vcm_ctx *ctx, int *first, int *count);
+
+/* Host-side restatement of Scene::LoadCornellBox + BuildSceneSphere
+ * (src/scene.hxx:132-398) and Camera::Setup (src/camera.hxx:37-76) for hosts
+ * that do not link the reference's scene code (Python, bench). boxMask uses
+ * Scene::BoxMask bits (src/scene.hxx:112-126). */
+int vcm_scene_cornell(int resX, int resY, unsigned boxMask, vcm_scene_desc *out);
+/* g_SceneConfigs[sceneID] (src/config.hxx:146-151) */
+unsigned vcm_scene_config_mask(int sceneID);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMALLVCM_AMD_H */

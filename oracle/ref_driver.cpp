@@ -1,0 +1,279 @@
+/*
+ * TEST INFRASTRUCTURE (oracle) -- not part of the shipped product path.
+ *
+ * ref_driver.cpp -- harness around the UNMODIFIED reference sources.  It is
+ * compiled against /root/reference/src by include path (nothing is copied;
+ * see oracle/Makefile) into oracle/_ref/:
+ *
+ *   libsmallvcm_ref_tape.so   (-DREF_TAPE)
+ *       the reference's VertexCM::RunIteration with
+ *       (a) `class Rng` replaced WITHOUT editing any reference file: the
+ *           include guard __RNG_HXX__ (src/rng.hxx:25-26) is pre-defined and
+ *           a tape-replay Rng is supplied.  The tape is the per-path count of
+ *           floats the implementation under test consumed; the floats
+ *           themselves are the counter-based stream of philox_ref.h.  The
+ *           reference therefore sees exactly the random numbers the
+ *           implementation under test used, in its own serial order
+ *           (light paths 0..N-1, then camera paths 0..N-1:
+ *           src/vertexcm.hxx:321, :415);
+ *       (b) sinf/cosf/sincosf/powf interposed with detmath_ref.h (linked
+ *           -Bsymbolic), see that header for why.
+ *       Output: the raw fp32 framebuffer SUM (renderer.hxx:68).
+ *
+ *   libsmallvcm_ref_stock.so  (-DREF_STOCK)
+ *       the reference exactly as its Makefile builds it (mt19937_64 Rng,
+ *       glibc libm), driven by a restatement of render()
+ *       (src/smallvcm.cxx:52-151) that takes resolution / threads / seed as
+ *       arguments (they are not on the reference CLI: src/config.hxx:233-237)
+ *       and measures wall-clock time.  Used for statistical parity and as the
+ *       "reference" CPU baseline.
+ *
+ * Both also export ref_flatten_scene(), which builds the reference's Cornell
+ * scenes (src/scene.hxx:132) and flattens them with the product's
+ * smallvcm_amd/dropin/flatten_scene.hxx -- the source of tests/golden/scene_*.
+ */
+#include <vector>
+#include <cmath>
+#include <map>
+#include <set>
+#include <string>
+#include <sstream>
+#include <fstream>
+#include <random>
+#include <cassert>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <string.h>
+#include <time.h>
+#include <algorithm>
+#include <chrono>
+#include <omp.h>
+#include <stdint.h>
+
+#include "philox_ref.h"
+#include "detmath_ref.h"
+
+#ifdef REF_TAPE
+/* ---- (b) libm interposition ------------------------------------------- */
+static long long g_detmath_calls = 0;
+extern "C" {
+float sinf(float x) noexcept { g_detmath_calls++; return dmr_sinf(x); }
+float cosf(float x) noexcept { g_detmath_calls++; return dmr_cosf(x); }
+void  sincosf(float x, float *s, float *c) noexcept { g_detmath_calls++; *s = dmr_sinf(x); *c = dmr_cosf(x); }
+float powf(float x, float y) noexcept { g_detmath_calls++; return dmr_powf(x, y); }
+}
+#endif
+
+/* the harness reads AbstractRenderer::mFramebuffer / Framebuffer::mColor
+   (renderer.hxx:68, framebuffer.hxx:255), which have no raw accessor */
+#define private public
+#define protected public
+
+#include "math.hxx"
+
+#ifdef REF_TAPE
+/* ---- (a) tape-replay Rng ---------------------------------------------- */
+#define __RNG_HXX__
+struct RefTape {
+    const unsigned char *counts[2];   /* [0] light, [1] camera; N entries each */
+    int N;
+    uint32_t key[2];
+    int phase, path;
+    uint32_t k;
+    uint32_t blk[4];
+    long long consumed;
+    int overrun;
+};
+static RefTape g_tape;
+
+static inline float tape_next()
+{
+    RefTape &t = g_tape;
+    while (t.phase < 2 && t.k == (uint32_t)t.counts[t.phase][t.path]) {
+        t.k = 0;
+        t.path++;
+        if (t.path == t.N) { t.path = 0; t.phase++; }
+    }
+    if (t.phase >= 2) { t.overrun++; return 0.5f; }
+    if ((t.k & 3u) == 0u) {
+        const uint32_t ctr[4] = { (uint32_t)t.path, (uint32_t)t.phase, t.k >> 2, 0u };
+        philox4x32_10_ref(ctr, t.key, t.blk);
+    }
+    const float f = philox_u32_to_float_ref(t.blk[t.k & 3u]);
+    t.k++;
+    t.consumed++;
+    return f;
+}
+
+class Rng
+{
+public:
+    Rng(int /*aSeed*/ = 1234) {}
+    int   GetInt()   { return int(tape_next() * 2147483647.f); }
+    uint  GetUint()  { return uint(tape_next() * 4294967295.f); }
+    float GetFloat() { return tape_next(); }
+    Vec2f GetVec2f() { float a = GetFloat(); float b = GetFloat(); return Vec2f(a, b); }
+    Vec3f GetVec3f() { float a = GetFloat(); float b = GetFloat(); float c = GetFloat(); return Vec3f(a, b, c); }
+};
+#endif
+
+#include "ray.hxx"
+#include "geometry.hxx"
+#include "camera.hxx"
+#include "framebuffer.hxx"
+#include "scene.hxx"
+#include "eyelight.hxx"
+#include "pathtracer.hxx"
+#include "bsdf.hxx"
+#include "vertexcm.hxx"
+#include "html_writer.hxx"
+#include "config.hxx"
+
+#undef private
+#undef protected
+
+#include "../smallvcm_amd/dropin/flatten_scene.hxx"
+
+static Scene *make_scene(unsigned boxMask, int resX, int resY)
+{   /* as ParseCommandline does: src/config.hxx:366-370 */
+    Scene *scene = new Scene;
+    scene->LoadCornellBox(Vec2i(resX, resY), boxMask);
+    scene->BuildSceneSphere();
+    return scene;
+}
+
+static Config::Algorithm algo_from_vcm(int vcmAlgo)
+{
+    switch (vcmAlgo) {
+    case VCM_ALGO_LIGHT_TRACE: return Config::kLightTracing;
+    case VCM_ALGO_PPM: return Config::kProgressivePhotonMapping;
+    case VCM_ALGO_BPM: return Config::kBidirectionalPhotonMapping;
+    case VCM_ALGO_BPT: return Config::kBidirectionalPathTracing;
+    default: return Config::kVertexConnectionMerging;
+    }
+}
+
+extern "C" {
+
+unsigned ref_scene_config_mask(int sceneID) { return g_SceneConfigs[sceneID]; }
+
+int ref_flatten_scene(unsigned boxMask, int resX, int resY, vcm_scene_desc *out)
+{
+    Scene *scene = make_scene(boxMask, resX, resY);
+    const int rc = smallvcm_amd::FlattenScene(*scene, *out);
+    delete scene;
+    return rc;
+}
+
+/* function-level known-answer hooks (T0): the reference's own camera maths */
+void ref_world_to_raster(unsigned boxMask, int resX, int resY, int n, const float *pts, float *out)
+{
+    Scene *scene = make_scene(boxMask, resX, resY);
+    for (int i = 0; i < n; i++) {
+        const Vec2f r = scene->mCamera.WorldToRaster(Vec3f(pts[3*i], pts[3*i+1], pts[3*i+2]));
+        out[2*i] = r.x; out[2*i+1] = r.y;
+    }
+    delete scene;
+}
+
+#ifdef REF_TAPE
+long long ref_detmath_calls(void) { return g_detmath_calls; }
+
+/* Runs nIter iterations (global iteration index = firstIteration + i, RNG
+ * local iteration = i) of the reference's VertexCM on one renderer.
+ * lightCounts / camCounts: nIter*N bytes each.  Returns 0 if the reference
+ * consumed exactly the taped number of floats, 1 otherwise. */
+int ref_run_tape(unsigned boxMask, int resX, int resY, int vcmAlgo,
+                 float radiusFactor, float radiusAlpha, int seed,
+                 int firstIteration, int nIter, unsigned minLen, unsigned maxLen,
+                 const unsigned char *lightCounts, const unsigned char *camCounts,
+                 float *fbSumOut, long long *consumedOut)
+{
+    Scene *scene = make_scene(boxMask, resX, resY);
+    const int N = resX * resY;
+    VertexCM *r = new VertexCM(*scene, (VertexCM::AlgorithmType)vcmAlgo, radiusFactor, radiusAlpha, seed);
+    r->mMaxPathLength = maxLen;   /* src/smallvcm.cxx:70-71 */
+    r->mMinPathLength = minLen;
+    int bad = 0;
+    long long total = 0;
+    for (int i = 0; i < nIter; i++) {
+        memset(&g_tape, 0, sizeof(g_tape));
+        g_tape.counts[0] = lightCounts + (size_t)i * N;
+        g_tape.counts[1] = camCounts + (size_t)i * N;
+        g_tape.N = N;
+        g_tape.key[0] = (uint32_t)seed;
+        g_tape.key[1] = (uint32_t)i;
+        long long expect = 0;
+        for (int p = 0; p < N; p++) expect += g_tape.counts[0][p];
+        if (!r->mLightTraceOnly) for (int p = 0; p < N; p++) expect += g_tape.counts[1][p];
+        r->RunIteration(firstIteration + i);
+        if (g_tape.overrun || g_tape.consumed != expect) bad = 1;
+        total += g_tape.consumed;
+    }
+    memcpy(fbSumOut, &r->mFramebuffer.mColor[0], (size_t)N * 3 * sizeof(float));
+    if (consumedOut) *consumedOut = total;
+    delete r;
+    delete scene;
+    return bad;
+}
+#endif
+
+#ifdef REF_STOCK
+/* render() of src/smallvcm.cxx:52-151, iteration-based branch (:96-109),
+ * with resolution / threads / seed as parameters and wall-clock timing.
+ * fbOut = averaged framebuffer exactly as render() leaves it (:116-142). */
+int ref_render_stock(unsigned boxMask, int resX, int resY, int configAlgo /* Config::Algorithm or -1 */,
+                     int vcmAlgo, int iterations, int numThreads, int baseSeed,
+                     unsigned minLen, unsigned maxLen, float radiusFactor, float radiusAlpha,
+                     float *fbOut, double *wallSeconds)
+{
+    Scene *scene = make_scene(boxMask, resX, resY);
+    Config config;
+    config.mScene = scene;
+    config.mAlgorithm = (configAlgo >= 0) ? (Config::Algorithm)configAlgo : algo_from_vcm(vcmAlgo);
+    config.mIterations = iterations;
+    config.mMaxTime = -1.f;
+    config.mRadiusFactor = radiusFactor;
+    config.mRadiusAlpha = radiusAlpha;
+    config.mNumThreads = numThreads > 0 ? numThreads : omp_get_num_procs();
+    config.mBaseSeed = baseSeed;
+    config.mMaxPathLength = maxLen;
+    config.mMinPathLength = minLen;
+    config.mResolution = Vec2i(resX, resY);
+    config.mFullReport = false;
+    Framebuffer fb;
+    config.mFramebuffer = &fb;
+
+    omp_set_num_threads(config.mNumThreads);
+    std::vector<AbstractRenderer*> renderers((size_t)config.mNumThreads);
+    for (int i = 0; i < config.mNumThreads; i++) {
+        renderers[i] = CreateRenderer(config, config.mBaseSeed + i);
+        renderers[i]->mMaxPathLength = config.mMaxPathLength;
+        renderers[i]->mMinPathLength = config.mMinPathLength;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int iter;
+#pragma omp parallel for
+    for (iter = 0; iter < config.mIterations; iter++) {
+        const int threadId = omp_get_thread_num();
+        renderers[threadId]->RunIteration(iter);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    int usedRenderers = 0;
+    for (int i = 0; i < config.mNumThreads; i++) {
+        if (!renderers[i]->WasUsed()) continue;
+        if (usedRenderers == 0) renderers[i]->GetFramebuffer(fb);
+        else { Framebuffer tmp; renderers[i]->GetFramebuffer(tmp); fb.Add(tmp); }
+        usedRenderers++;
+    }
+    fb.Scale(1.f / usedRenderers);
+    for (int i = 0; i < config.mNumThreads; i++) delete renderers[i];
+    if (fbOut) memcpy(fbOut, &fb.mColor[0], (size_t)resX * resY * 3 * sizeof(float));
+    if (wallSeconds) *wallSeconds = std::chrono::duration<double>(t1 - t0).count();
+    delete scene;
+    return usedRenderers;
+}
+#endif
+
+} // extern "C"
