@@ -130,7 +130,8 @@ typedef struct vcm_stats {
     long long mergeAccepted;   /* A: RangeQuery::Process calls                */
     long long connections;     /* K: ConnectVertices calls                    */
     long long lightSplats;     /* S: Framebuffer::AddColor from light paths   */
-    float msLight, msGrid, msCamera, msTotal;
+    float msLight, msGrid, msCamera, msTotal; /* phases: light(+compaction), grid build, camera(+resolve) */
+    float msLightKernel, msCameraKernel;      /* k_light_trace / k_camera_trace alone        */
     float radius;              /* merge radius of the iteration               */
 } vcm_stats;
 
@@ -183,6 +184,12 @@ int vcm_end_iteration(vcm_ctx *ctx); /* :547 */
  * count x VCM_MERGE_RECORD_FLOATS floats, in the reference's vertex order.
  * `count` is read back from the device (synchronises the stream). */
 int vcm_light_records(vcm_ctx *ctx, void **devPtr, long long *count);
+
+/* Copy the local merge records (count from vcm_light_records) / the
+ * framebuffer into caller-owned DEVICE memory (e.g. a torch tensor that is
+ * then handed to an RCCL collective).  Asynchronous on the context's stream. */
+int vcm_export_light_records(vcm_ctx *ctx, void *dstDev, long long count);
+int vcm_export_framebuffer(vcm_ctx *ctx, void *dstDev);
 
 /* Install the all-gathered records: nSeg segments (one per rank, rank order),
  * segment s holds counts[s] records starting at devPtr + s*strideRecords

@@ -71,6 +71,7 @@ class Stats(C.Structure):
                 ("connections", C.c_longlong), ("lightSplats", C.c_longlong),
                 ("msLight", C.c_float), ("msGrid", C.c_float),
                 ("msCamera", C.c_float), ("msTotal", C.c_float),
+                ("msLightKernel", C.c_float), ("msCameraKernel", C.c_float),
                 ("radius", C.c_float)]
 
     def asdict(self):

@@ -1,0 +1,67 @@
+// philox.h -- the counter-based RNG that replaces the reference's sequential
+// `Rng` (src/rng.hxx:41-86), host+device.
+//
+// Philox4x32-10 (Salmon et al., SC'11).  Stream definition:
+//   key     = (seed, localIteration)       localIteration = RunIteration calls
+//                                          made so far on this renderer
+//   counter = (pathIndex, kind, block, 0)  kind 0 = light sub-path, 1 = camera
+//   float k of a path = word (k&3) of block (k>>2), (word >> 8) * 2^-24 in [0,1)
+// Draw order inside a path is the reference's (vertexcm.hxx:822-824, :576,
+// :672-673, :944, :964).  One lane owns one path: 4 words are generated per
+// 10-round call and kept in registers, so a path costs <= 18 Philox calls.
+#ifndef SMALLVCM_AMD_PHILOX_H
+#define SMALLVCM_AMD_PHILOX_H
+#include "vcm_math.h"
+
+namespace vcm {
+
+VCM_HD uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+struct PathRng {
+    uint32_t key0, key1, path, kind;
+    uint32_t k;               /* floats drawn so far */
+    uint32_t b0, b1, b2, b3;  /* current block */
+};
+
+VCM_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+VCM_HD void rng_init(PathRng &r, uint32_t seed, uint32_t localIter, uint32_t path, uint32_t kind)
+{
+    r.key0 = seed; r.key1 = localIter; r.path = path; r.kind = kind; r.k = 0;
+    r.b0 = r.b1 = r.b2 = r.b3 = 0;
+}
+
+VCM_HD float rng_float(PathRng &r)
+{
+    const uint32_t i = r.k & 3u;
+    if (i == 0u) philox4x32_10(r.path, r.kind, r.k >> 2, 0u, r.key0, r.key1, r.b0, r.b1, r.b2, r.b3);
+    const uint32_t w = (i == 0u) ? r.b0 : (i == 1u) ? r.b1 : (i == 2u) ? r.b2 : r.b3;
+    r.k++;
+    return (float)(w >> 8) * (1.0f / 16777216.0f);
+}
+
+} // namespace vcm
+#endif

@@ -1,0 +1,642 @@
+// vcm_api.hip -- implementation of the C-ABI (include/smallvcm_amd.h): context
+// management, device memory, kernel launches for one VCM iteration.
+//
+// No host<->device synchronisation happens inside an iteration: vertex counts
+// stay on the device (GridHeader) and the grid-build kernels are grid-stride
+// over a device-resident count.  The only sync points are the read-back entry
+// points (framebuffer, stats, light-record count for the multi-GPU exchange).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <new>
+
+#include "vcm_kernels.h"
+
+using namespace vcm;
+
+static thread_local std::string g_err;
+static int fail(const char *what, const char *detail)
+{
+    g_err = std::string(what) + ": " + (detail ? detail : "");
+    return -1;
+}
+#define HIPCHK(expr)                                                            \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));        \
+    } while (0)
+
+enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_CAMERA, EV_COUNT };
+
+struct vcm_ctx {
+    vcm_scene_desc scene;
+    bool useVM, useVC, lightTraceOnly, ppm;
+    float baseRadius, radiusAlpha;
+    int seed, device, rank, world;
+    int resX, resY, N, p0, nLocal;
+    int iterations;
+
+    hipStream_t stream;
+    bool ownStream;
+    bool deviceReady;
+    int allocS;
+
+    vcm_scene_desc *dScene;
+    float *dFb;                       /* N*3, running sum */
+    LightStore store;                 /* S*nLocal slots */
+    unsigned char *dRngLight, *dRngCam;
+    int *dPathStart;                  /* nLocal */
+    int *dLocalTotal;                 /* 1 */
+    int *dTileSums;                   /* scan scratch */
+    float *dRecordsLocal;             /* S*nLocal records */
+    float *dRecordsAll;               /* S*N records (multi-rank only) */
+    bool importedRecords;
+    GridHeader *dHdr;
+    int *dCellCount, *dCellStart, *dCellFill;   /* nCells+1 each */
+    int *dCellId, *dUnsorted;         /* per record */
+    F4 *dG0, *dG1, *dG2; float *dG3;
+    int *dSortedIndex;                /* debug/parity: grid position -> record index */
+    F4 *dCamOut;                      /* nLocal */
+    unsigned long long *dStats;
+
+    IterParams P;
+    bool inIteration;
+    hipEvent_t ev[EV_COUNT];
+    bool evValid;
+    vcm_stats lastStats;
+};
+
+static int use_device(vcm_ctx *c) { HIPCHK(hipSetDevice(c->device)); return 0; }
+
+template <typename T> static int dalloc(T **p, size_t n)
+{
+    void *v = NULL;
+    HIPCHK(hipMalloc(&v, (n ? n : 1) * sizeof(T)));
+    *p = (T *)v;
+    return 0;
+}
+#define DFREE(p) do { if (p) { (void)hipFree(p); p = NULL; } } while (0)
+
+static void free_iteration_buffers(vcm_ctx *c)
+{
+    DFREE(c->store.v0); DFREE(c->store.v1); DFREE(c->store.v2); DFREE(c->store.v3); DFREE(c->store.v4);
+    DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll);
+    DFREE(c->dCellId); DFREE(c->dUnsorted);
+    DFREE(c->dG0); DFREE(c->dG1); DFREE(c->dG2); DFREE(c->dG3); DFREE(c->dSortedIndex);
+    c->allocS = 0;
+}
+
+static int ensure_device(vcm_ctx *c, int S)
+{
+    if (use_device(c)) return -1;
+    if (!c->deviceReady) {
+        if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
+        for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+        if (dalloc(&c->dScene, 1)) return -1;
+        HIPCHK(hipMemcpy(c->dScene, &c->scene, sizeof(vcm_scene_desc), hipMemcpyHostToDevice));
+        if (dalloc(&c->dFb, (size_t)c->N * 3)) return -1;
+        HIPCHK(hipMemset(c->dFb, 0, (size_t)c->N * 3 * sizeof(float)));
+        if (dalloc(&c->store.count, (size_t)c->nLocal)) return -1;
+        if (dalloc(&c->dRngLight, (size_t)c->nLocal)) return -1;
+        if (dalloc(&c->dRngCam, (size_t)c->nLocal)) return -1;
+        HIPCHK(hipMemset(c->dRngLight, 0, (size_t)c->nLocal));
+        HIPCHK(hipMemset(c->dRngCam, 0, (size_t)c->nLocal));
+        if (dalloc(&c->dPathStart, (size_t)c->nLocal + 1)) return -1;
+        if (dalloc(&c->dLocalTotal, 1)) return -1;
+        const size_t maxScan = (size_t)(c->N > c->nLocal ? c->N : c->nLocal) + 1;
+        if (dalloc(&c->dTileSums, maxScan / VCM_SCAN_TILE + 2)) return -1;
+        if (dalloc(&c->dHdr, 1)) return -1;
+        HIPCHK(hipMemset(c->dHdr, 0, sizeof(GridHeader)));
+        if (dalloc(&c->dCellCount, (size_t)c->N + 1)) return -1;
+        if (dalloc(&c->dCellStart, (size_t)c->N + 1)) return -1;
+        if (dalloc(&c->dCellFill, (size_t)c->N + 1)) return -1;
+        if (dalloc(&c->dCamOut, (size_t)c->nLocal)) return -1;
+        if (dalloc(&c->dStats, STAT_COUNT)) return -1;
+        c->deviceReady = true;
+    }
+    if (S > 0 && c->allocS != S) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_iteration_buffers(c);
+        const size_t slots = (size_t)S * (size_t)c->nLocal;
+        const size_t allRecs = (size_t)S * (size_t)c->N;
+        if (dalloc(&c->store.v0, slots) || dalloc(&c->store.v1, slots) || dalloc(&c->store.v2, slots) ||
+            dalloc(&c->store.v3, slots) || dalloc(&c->store.v4, slots)) return -1;
+        if (dalloc(&c->dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
+        if (c->world > 1 && dalloc(&c->dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
+        if (dalloc(&c->dCellId, allRecs) || dalloc(&c->dUnsorted, allRecs)) return -1;
+        if (dalloc(&c->dG0, allRecs) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
+            dalloc(&c->dG3, allRecs) || dalloc(&c->dSortedIndex, allRecs)) return -1;
+        c->allocS = S;
+    }
+    return 0;
+}
+
+/* exclusive scan of n ints/bytes on the context's stream */
+template <typename T>
+static int launch_scan(vcm_ctx *c, const T *in, int n, int *out, int *totalOut, int writeTotalAtN)
+{
+    const int nTiles = (n + VCM_SCAN_TILE - 1) / VCM_SCAN_TILE;
+    hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, c->stream, in, n, c->dTileSums);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(VCM_SCAN_BLOCK), 0, c->stream, c->dTileSums, nTiles, totalOut);
+    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, c->stream, in, n, c->dTileSums, out,
+                       writeTotalAtN);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void trace_launch_shape(int nLocal, int *blocks, int *chunk)
+{
+    /* persistent waves: enough to fill 256 CUs several times over, each wave
+       owning a contiguous chunk of paths (>= 64) */
+    int waves = (nLocal + VCM_WAVE - 1) / VCM_WAVE;
+    const int maxWaves = 256 * 32;
+    if (waves > maxWaves) waves = maxWaves;
+    if (waves < 1) waves = 1;
+    const int wavesPerBlock = VCM_TRACE_BLOCK / VCM_WAVE;
+    *blocks = (waves + wavesPerBlock - 1) / wavesPerBlock;
+    const int totalWaves = *blocks * wavesPerBlock;
+    *chunk = (nLocal + totalWaves - 1) / totalWaves;
+    if (*chunk < 1) *chunk = 1;
+}
+
+extern "C" {
+
+const char *vcm_last_error(void) { return g_err.c_str(); }
+
+int vcm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha,
+                            int seed, int device, int rank, int worldSize)
+{
+    if (!scene) { fail("vcm_create", "scene is NULL"); return NULL; }
+    if (worldSize < 1 || rank < 0 || rank >= worldSize) { fail("vcm_create", "bad rank/worldSize"); return NULL; }
+    if (scene->nPrims < 0 || scene->nPrims > VCM_MAX_PRIMS || scene->nMaterials > VCM_MAX_MATERIALS ||
+        scene->nLights < 1 || scene->nLights > VCM_MAX_LIGHTS) { fail("vcm_create", "scene exceeds fixed capacities"); return NULL; }
+    int ndev = vcm_device_count();
+    if (ndev <= 0) { fail("vcm_create", "no HIP device available (this library has no CPU path)"); return NULL; }
+    if (device < 0 || device >= ndev) { fail("vcm_create", "device index out of range"); return NULL; }
+    vcm_ctx *c = new (std::nothrow) vcm_ctx();
+    if (!c) { fail("vcm_create", "out of host memory"); return NULL; }
+    memset((void *)c, 0, sizeof(*c));
+    c->scene = *scene;
+    /* VertexCM::VertexCM vertexcm.hxx:222-244 */
+    switch (algorithm) {
+    case VCM_ALGO_LIGHT_TRACE: c->lightTraceOnly = true; break;
+    case VCM_ALGO_PPM: c->ppm = true; c->useVM = true; break;
+    case VCM_ALGO_BPM: c->useVM = true; break;
+    case VCM_ALGO_BPT: c->useVC = true; break;
+    case VCM_ALGO_VCM: c->useVC = true; c->useVM = true; break;
+    default: delete c; fail("vcm_create", "unknown algorithm"); return NULL;
+    }
+    if (c->ppm) {   /* PPM -> BPM downgrade :246-278 */
+        for (int i = 0; i < scene->nMaterials; i++) {
+            const vcm_material &m = scene->materials[i];
+            const bool hasNonSpecular = (vmax3(ld3(m.diffuse)) > 0) || (vmax3(ld3(m.phong)) > 0);
+            const bool hasSpecular = (vmax3(ld3(m.mirror)) > 0) || (m.ior > 0);
+            if (hasNonSpecular && hasSpecular) {
+                fprintf(stderr, "smallvcm_amd: scene mixes specular and non-specular BSDFs in one material, "
+                                "switching from PPM to BPM (vertexcm.hxx:262-275)\n");
+                c->ppm = false;
+                break;
+            }
+        }
+    }
+    c->baseRadius = radiusFactor * scene->sceneRadius;   /* :280 */
+    c->radiusAlpha = radiusAlpha;
+    c->seed = seed;
+    c->device = device; c->rank = rank; c->world = worldSize;
+    c->resX = (int)scene->camera.resolution[0];
+    c->resY = (int)scene->camera.resolution[1];
+    c->N = c->resX * c->resY;
+    if (c->N <= 0) { delete c; fail("vcm_create", "empty resolution"); return NULL; }
+    c->p0 = (int)((long long)c->N * rank / worldSize);
+    c->nLocal = (int)((long long)c->N * (rank + 1) / worldSize) - c->p0;
+    c->ownStream = true;
+    return c;
+}
+
+vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha, int seed)
+{
+    int dev = 0;
+    if (vcm_device_count() > 0) (void)hipGetDevice(&dev);
+    return vcm_create_sharded(scene, algorithm, radiusFactor, radiusAlpha, seed, dev, 0, 1);
+}
+
+void vcm_destroy(vcm_ctx *c)
+{
+    if (!c) return;
+    if (c->deviceReady) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        free_iteration_buffers(c);
+        DFREE(c->dScene); DFREE(c->dFb); DFREE(c->store.count); DFREE(c->dRngLight); DFREE(c->dRngCam);
+        DFREE(c->dPathStart); DFREE(c->dLocalTotal); DFREE(c->dTileSums); DFREE(c->dHdr);
+        DFREE(c->dCellCount); DFREE(c->dCellStart); DFREE(c->dCellFill); DFREE(c->dCamOut); DFREE(c->dStats);
+        for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
+        if (c->ownStream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+int vcm_set_stream(vcm_ctx *c, void *hipStream)
+{
+    if (!c) return fail("vcm_set_stream", "ctx is NULL");
+    if (c->deviceReady) {
+        if (use_device(c)) return -1;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->ownStream) { (void)hipStreamDestroy(c->stream); }
+    }
+    if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
+    else if (c->deviceReady) { HIPCHK(hipStreamCreate(&c->stream)); c->ownStream = true; }
+    else { c->stream = NULL; c->ownStream = true; }
+    return 0;
+}
+
+int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)
+{   /* vertexcm.hxx:288-316 */
+    if (!c) return fail("vcm_begin_iteration", "ctx is NULL");
+    if (c->inIteration) return fail("vcm_begin_iteration", "previous iteration not ended");
+    if (maxLen > 255) return fail("vcm_begin_iteration", "maxPathLength > 255 unsupported (8-bit vertex counts)");
+    const int S = (maxLen >= 2) ? (int)maxLen - 1 : 1;
+    if (ensure_device(c, S)) return -1;
+
+    IterParams &P = c->P;
+    memset(&P, 0, sizeof(P));
+    P.seed = (uint32_t)c->seed;
+    P.localIter = (uint32_t)c->iterations;
+    P.minLen = minLen; P.maxLen = maxLen;
+    P.resX = c->resX; P.resY = c->resY; P.N = c->N;
+    P.p0 = c->p0; P.nLocal = c->nLocal; P.S = S;
+    P.useVM = c->useVM; P.useVC = c->useVC; P.lightTraceOnly = c->lightTraceOnly; P.ppm = c->ppm;
+    P.lightSubPathCount = float(c->resX * c->resY);                       /* :292 */
+    float radius = c->baseRadius;                                         /* :295 */
+    radius /= dm_powf(float(iteration + 1), 0.5f * (1 - c->radiusAlpha)); /* :296 */
+    radius = smax(radius, 1e-7f);                                         /* :298 */
+    const float radiusSqr = sqr(radius);
+    P.radius = radius; P.radiusSqr = radiusSqr;
+    P.vmNormalization = 1.f / (radiusSqr * VCM_PI_F * P.lightSubPathCount);   /* :303 */
+    const float etaVCM = (VCM_PI_F * radiusSqr) * P.lightSubPathCount;        /* :306 */
+    P.misVmWeightFactor = c->useVM ? mis(etaVCM) : 0.f;                       /* :307 */
+    P.misVcWeightFactor = c->useVC ? mis(1.f / etaVCM) : 0.f;                 /* :308 */
+    P.cellSize = radius * 2.f;                                                /* hashgrid.hxx:47 */
+    P.invCellSize = 1.f / P.cellSize;                                         /* :48 */
+    P.nCells = c->N;                                                          /* vertexcm.hxx:406 */
+
+    HIPCHK(hipEventRecord(c->ev[EV_START], c->stream));
+    HIPCHK(hipMemsetAsync(c->dStats, 0, STAT_COUNT * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
+    c->importedRecords = false;
+    c->inIteration = true;
+    c->evValid = false;
+    return 0;
+}
+
+int vcm_trace_light(vcm_ctx *c)
+{   /* vertexcm.hxx:321-396 */
+    if (!c || !c->inIteration) return fail("vcm_trace_light", "no iteration in progress");
+    if (use_device(c)) return -1;
+    int blocks, chunk;
+    trace_launch_shape(c->nLocal, &blocks, &chunk);
+    HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K0], c->stream));
+    hipLaunchKernelGGL(k_light_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
+                       c->dFb, c->dRngLight, c->dStats, chunk);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K1], c->stream));
+    /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
+       record array in the reference's vertex order */
+    if (launch_scan<unsigned char>(c, c->store.count, c->nLocal, c->dPathStart, c->dLocalTotal, 0)) return -1;
+    if (c->useVM) {
+        hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
+                           c->dRecordsLocal);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[EV_LIGHT], c->stream));
+    return 0;
+}
+
+int vcm_light_records(vcm_ctx *c, void **devPtr, long long *count)
+{
+    if (!c || !c->deviceReady) return fail("vcm_light_records", "no iteration has run");
+    if (use_device(c)) return -1;
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, c->dLocalTotal, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (devPtr) *devPtr = c->dRecordsLocal;
+    if (count) *count = n;
+    return 0;
+}
+
+int vcm_export_light_records(vcm_ctx *c, void *dstDev, long long count)
+{
+    if (!c || !c->deviceReady || !dstDev) return fail("vcm_export_light_records", "bad argument");
+    if (use_device(c)) return -1;
+    if (count > 0)
+        HIPCHK(hipMemcpyAsync(dstDev, c->dRecordsLocal, (size_t)count * VCM_MERGE_RECORD_FLOATS * sizeof(float),
+                              hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int vcm_export_framebuffer(vcm_ctx *c, void *dstDev)
+{
+    if (!c || !dstDev) return fail("vcm_export_framebuffer", "bad argument");
+    if (ensure_device(c, 0)) return -1;
+    HIPCHK(hipMemcpyAsync(dstDev, c->dFb, (size_t)c->N * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int vcm_import_light_records(vcm_ctx *c, const void *devPtr, const long long *counts, int nSeg, long long strideRecords)
+{
+    if (!c || !c->inIteration) return fail("vcm_import_light_records", "no iteration in progress");
+    if (c->world <= 1 || !c->dRecordsAll) return fail("vcm_import_light_records", "context is not sharded");
+    if (use_device(c)) return -1;
+    long long total = 0;
+    const size_t recBytes = VCM_MERGE_RECORD_FLOATS * sizeof(float);
+    for (int s = 0; s < nSeg; s++) {
+        if (counts[s] < 0) return fail("vcm_import_light_records", "negative count");
+        if (total + counts[s] > (long long)c->allocS * c->N) return fail("vcm_import_light_records", "too many records");
+        if (counts[s] > 0)
+            HIPCHK(hipMemcpyAsync((char *)c->dRecordsAll + (size_t)total * recBytes,
+                                  (const char *)devPtr + (size_t)s * (size_t)strideRecords * recBytes,
+                                  (size_t)counts[s] * recBytes, hipMemcpyDeviceToDevice, c->stream));
+        total += counts[s];
+    }
+    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 0, (int)total);
+    HIPCHK(hipGetLastError());
+    c->importedRecords = true;
+    return 0;
+}
+
+int vcm_build_grid(vcm_ctx *c)
+{   /* vertexcm.hxx:403-408 -> HashGrid::Build hashgrid.hxx:41-107 */
+    if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
+    if (use_device(c)) return -1;
+    if (c->useVM) {
+        const float *recs = c->importedRecords ? c->dRecordsAll : c->dRecordsLocal;
+        const int nCells = c->P.nCells;
+        const dim3 g(2048), b(256);
+        HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
+        HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr);
+        hipLaunchKernelGGL(k_bbox, g, b, 0, c->stream, recs, c->dHdr);
+        hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr);
+        hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
+                           c->dCellCount);
+        HIPCHK(hipGetLastError());
+        if (launch_scan<int>(c, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
+        hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
+                           (const int *)c->dCellStart, c->dCellFill, c->dUnsorted);
+        hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, c->stream, (const GridHeader *)c->dHdr, recs,
+                           (const int *)c->dCellId, (const int *)c->dCellStart, (const int *)c->dUnsorted, c->dG0,
+                           c->dG1, c->dG2, c->dG3, c->dSortedIndex);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[EV_GRID], c->stream));
+    return 0;
+}
+
+int vcm_trace_camera(vcm_ctx *c)
+{   /* vertexcm.hxx:415-545 */
+    if (!c || !c->inIteration) return fail("vcm_trace_camera", "no iteration in progress");
+    if (use_device(c)) return -1;
+    if (!c->lightTraceOnly) {
+        int blocks, chunk;
+        trace_launch_shape(c->nLocal, &blocks, &chunk);
+        GridStore grid;
+        grid.cellStart = c->dCellStart; grid.g0 = c->dG0; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
+        grid.hdr = c->dHdr;
+        hipLaunchKernelGGL(k_camera_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
+                           grid, c->dCamOut, c->dRngCam, c->dStats, chunk);
+        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+        hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut, c->dFb);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[EV_CAMERA], c->stream));
+    return 0;
+}
+
+int vcm_end_iteration(vcm_ctx *c)
+{
+    if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
+    c->iterations++;   /* :547 */
+    c->inIteration = false;
+    c->evValid = true;
+    return 0;
+}
+
+int vcm_run_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)
+{
+    if (c && c->world > 1)
+        return fail("vcm_run_iteration", "sharded context: the host must exchange light records between "
+                                         "vcm_trace_light and vcm_build_grid (see smallvcm_amd/renderer.py)");
+    if (vcm_begin_iteration(c, iteration, minLen, maxLen)) return -1;
+    if (vcm_trace_light(c)) return -1;
+    if (vcm_build_grid(c)) return -1;
+    if (vcm_trace_camera(c)) return -1;
+    return vcm_end_iteration(c);
+}
+
+int vcm_synchronize(vcm_ctx *c)
+{
+    if (!c) return fail("vcm_synchronize", "ctx is NULL");
+    if (!c->deviceReady) return 0;
+    if (use_device(c)) return -1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vcm_read_framebuffer(vcm_ctx *c, float *rgbHost)
+{
+    if (!c || !rgbHost) return fail("vcm_read_framebuffer", "NULL argument");
+    if (!c->deviceReady) { memset(rgbHost, 0, (size_t)c->N * 3 * sizeof(float)); return 0; }
+    if (use_device(c)) return -1;
+    HIPCHK(hipMemcpyAsync(rgbHost, c->dFb, (size_t)c->N * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vcm_framebuffer_device(vcm_ctx *c, void **devPtr)
+{
+    if (!c || !devPtr) return fail("vcm_framebuffer_device", "NULL argument");
+    if (ensure_device(c, 0)) return -1;
+    *devPtr = c->dFb;
+    return 0;
+}
+
+int vcm_clear_framebuffer(vcm_ctx *c)
+{
+    if (!c) return fail("vcm_clear_framebuffer", "ctx is NULL");
+    if (!c->deviceReady) return 0;
+    if (use_device(c)) return -1;
+    HIPCHK(hipMemsetAsync(c->dFb, 0, (size_t)c->N * 3 * sizeof(float), c->stream));
+    return 0;
+}
+
+int vcm_iterations(vcm_ctx *c) { return c ? c->iterations : 0; }
+
+int vcm_get_stats(vcm_ctx *c, vcm_stats *out)
+{
+    if (!c || !out) return fail("vcm_get_stats", "NULL argument");
+    memset(out, 0, sizeof(*out));
+    if (!c->deviceReady) return 0;
+    if (use_device(c)) return -1;
+    unsigned long long h[STAT_COUNT];
+    GridHeader hdr;
+    HIPCHK(hipMemcpyAsync(h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&hdr, c->dHdr, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    out->lightVertices = (long long)h[STAT_STORED];
+    out->gridVertices = c->useVM ? hdr.nRecords : 0;
+    out->lightRays = (long long)h[STAT_LIGHT_RAYS];
+    out->cameraRays = (long long)h[STAT_CAMERA_RAYS];
+    out->shadowRays = (long long)h[STAT_SHADOW_RAYS];
+    out->mergeQueries = (long long)h[STAT_MERGE_QUERIES];
+    out->mergeCandidates = (long long)h[STAT_MERGE_CANDIDATES];
+    out->mergeAccepted = (long long)h[STAT_MERGE_ACCEPTED];
+    out->connections = (long long)h[STAT_CONNECTIONS];
+    out->lightSplats = (long long)h[STAT_LIGHT_SPLATS];
+    out->radius = c->P.radius;
+    if (c->evValid) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_LIGHT]) == hipSuccess) out->msLight = ms;
+        if (hipEventElapsedTime(&ms, c->ev[EV_LIGHT], c->ev[EV_GRID]) == hipSuccess) out->msGrid = ms;
+        if (hipEventElapsedTime(&ms, c->ev[EV_GRID], c->ev[EV_CAMERA]) == hipSuccess) out->msCamera = ms;
+        if (hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_CAMERA]) == hipSuccess) out->msTotal = ms;
+        if (hipEventElapsedTime(&ms, c->ev[EV_LIGHT_K0], c->ev[EV_LIGHT_K1]) == hipSuccess) out->msLightKernel = ms;
+        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_GRID], c->ev[EV_CAMERA_K1]) == hipSuccess)
+            out->msCameraKernel = ms;
+    }
+    c->lastStats = *out;
+    return 0;
+}
+
+int vcm_get_rng_counts(vcm_ctx *c, unsigned char *lightCounts, unsigned char *cameraCounts)
+{
+    if (!c) return fail("vcm_get_rng_counts", "ctx is NULL");
+    if (!c->deviceReady) return fail("vcm_get_rng_counts", "no iteration has run");
+    if (use_device(c)) return -1;
+    if (lightCounts) HIPCHK(hipMemcpyAsync(lightCounts, c->dRngLight, (size_t)c->nLocal, hipMemcpyDeviceToHost, c->stream));
+    if (cameraCounts) HIPCHK(hipMemcpyAsync(cameraCounts, c->dRngCam, (size_t)c->nLocal, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vcm_local_path_range(vcm_ctx *c, int *first, int *count)
+{
+    if (!c) return fail("vcm_local_path_range", "ctx is NULL");
+    if (first) *first = c->p0;
+    if (count) *count = c->nLocal;
+    return 0;
+}
+
+/* ---- parity/debug read-backs (used by tests/, not by the render path) ---- */
+
+/* hash grid of the last iteration: cellStart (nCells+1 ints), sortedIndex
+ * (grid position -> record index, nRecords ints), bbox (6 floats) */
+int vcm_debug_read_grid(vcm_ctx *c, int *cellStart, int *sortedIndex, float *bbox6, long long *nRecords)
+{
+    if (!c || !c->deviceReady) return fail("vcm_debug_read_grid", "no iteration has run");
+    if (use_device(c)) return -1;
+    GridHeader hdr;
+    HIPCHK(hipMemcpy(&hdr, c->dHdr, sizeof(hdr), hipMemcpyDeviceToHost));
+    if (nRecords) *nRecords = hdr.nRecords;
+    if (cellStart) HIPCHK(hipMemcpy(cellStart, c->dCellStart, ((size_t)c->P.nCells + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (sortedIndex && hdr.nRecords > 0)
+        HIPCHK(hipMemcpy(sortedIndex, c->dSortedIndex, (size_t)hdr.nRecords * sizeof(int), hipMemcpyDeviceToHost));
+    if (bbox6) { memcpy(bbox6, hdr.bboxMin, 12); memcpy(bbox6 + 3, hdr.bboxMax, 12); }
+    return 0;
+}
+
+/* local merge records of the last iteration, host copy (count from vcm_light_records) */
+int vcm_debug_read_records(vcm_ctx *c, float *out, long long count)
+{
+    if (!c || !c->deviceReady) return fail("vcm_debug_read_records", "no iteration has run");
+    if (use_device(c)) return -1;
+    if (count > 0)
+        HIPCHK(hipMemcpy(out, c->dRecordsLocal, (size_t)count * VCM_MERGE_RECORD_FLOATS * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* element-wise device evaluation of the numeric spec (detmath / philox):
+ * op 0 sinf(a), 1 cosf(a), 2 powf(a,b), 3 a/b, 4 sqrtf(a), 5 dot-style a*b+c via mul,add */
+} // extern "C"
+
+namespace vcm {
+__global__ void k_numeric_spec(int op, int n, const float *a, const float *b, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+    case 0: r = dm_sinf(a[i]); break;
+    case 1: r = dm_cosf(a[i]); break;
+    case 2: r = dm_powf(a[i], b[i]); break;
+    case 3: r = a[i] / b[i]; break;
+    case 4: r = sqrtf(a[i]); break;
+    default: { float t = a[i] * b[i]; t += a[i]; r = t; } break;
+    }
+    out[i] = r;
+}
+__global__ void k_philox_spec(uint32_t seed, uint32_t iter, uint32_t kind, int nPaths, int nFloats, float *out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPaths) return;
+    PathRng r;
+    rng_init(r, seed, iter, (uint32_t)p, kind);
+    for (int k = 0; k < nFloats; k++) out[(size_t)p * nFloats + k] = rng_float(r);
+}
+} // namespace vcm
+
+extern "C" {
+
+int vcm_debug_numeric_spec(int op, int n, const float *a, const float *b, float *out)
+{
+    float *da = NULL, *db = NULL, *dout = NULL;
+    HIPCHK(hipMalloc((void **)&da, (size_t)n * 4)); HIPCHK(hipMalloc((void **)&db, (size_t)n * 4));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)n * 4));
+    HIPCHK(hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_numeric_spec, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return 0;
+}
+
+int vcm_debug_philox_spec(unsigned seed, unsigned iter, unsigned kind, int nPaths, int nFloats, float *out)
+{
+    float *dout = NULL;
+    const size_t n = (size_t)nPaths * nFloats;
+    HIPCHK(hipMalloc((void **)&dout, n * 4));
+    hipLaunchKernelGGL(k_philox_spec, dim3((nPaths + 255) / 256), dim3(256), 0, 0, seed, iter, kind, nPaths, nFloats, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dout);
+    return 0;
+}
+
+/* host-side evaluation of the same spec functions (the radius schedule uses
+ * dm_powf on the host: vcm_begin_iteration) */
+float vcm_host_sinf(float x) { return dm_sinf(x); }
+float vcm_host_cosf(float x) { return dm_cosf(x); }
+float vcm_host_powf(float x, float y) { return dm_powf(x, y); }
+float vcm_host_path_float(unsigned seed, unsigned iter, unsigned path, unsigned kind, unsigned k)
+{
+    PathRng r;
+    rng_init(r, seed, iter, path, kind);
+    float f = 0;
+    for (unsigned i = 0; i <= k; i++) f = rng_float(r);
+    return f;
+}
+unsigned vcm_sizeof_scene_desc(void) { return (unsigned)sizeof(vcm_scene_desc); }
+unsigned vcm_sizeof_stats(void) { return (unsigned)sizeof(vcm_stats); }
+
+} // extern "C"

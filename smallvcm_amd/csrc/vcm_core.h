@@ -1,0 +1,1039 @@
+// vcm_core.h -- device functions of the VCM hot path (host+device so that the
+// unit tests can also drive them on the CPU; the shipped library only ever
+// runs them inside the HIP kernels of vcm_kernels.hip).
+//
+// One lane owns one sub-path.  Every function states which reference code it
+// replaces; expression order is the reference's (see vcm_math.h).
+//
+//   geometry     src/geometry.hxx:65-237, src/scene.hxx:53-102
+//   BSDF         src/bsdf.hxx:95-566
+//   lights       src/lights.hxx:112-514
+//   samplers     src/utils.hxx:36-259
+//   integrator   src/vertexcm.hxx:284-1006
+//   hash grid    src/hashgrid.hxx:110-201 (query side; build is in the kernels)
+#ifndef SMALLVCM_AMD_VCM_CORE_H
+#define SMALLVCM_AMD_VCM_CORE_H
+
+#include "../../include/smallvcm_amd.h"
+#include "vcm_math.h"
+#include "detmath.h"
+#include "philox.h"
+
+namespace vcm {
+
+/* ------------------------------------------------------------------ */
+/* per-iteration constants (vertexcm.hxx:288-308) + launch geometry     */
+struct IterParams {
+    uint32_t seed, localIter;
+    uint32_t minLen, maxLen;
+    int   resX, resY, N;
+    int   p0, nLocal;          /* local path range [p0, p0+nLocal) */
+    int   S;                   /* light-vertex slots per path = max(1, maxLen-1) */
+    int   useVM, useVC, lightTraceOnly, ppm;
+    float radius, radiusSqr, vmNormalization, misVmWeightFactor, misVcWeightFactor;
+    float lightSubPathCount;
+    float cellSize, invCellSize;   /* hashgrid.hxx:47-48 */
+    int   nCells;                  /* = N (vertexcm.hxx:406) */
+};
+
+/* device-resident hash-grid header: bbox is reduced on the device */
+struct GridHeader {
+    uint32_t bboxMinU[3], bboxMaxU[3];   /* order-preserving uint encoding during the reduce */
+    float bboxMin[3], bboxMax[3];
+    int   nRecords;                      /* vertices in the grid */
+    int   nLocalRecords;                 /* vertices stored by this rank */
+    int   pad[2];
+};
+
+/* Light-vertex store, slot-major SoA: vertex j of local path lp lives at
+ * [j * nLocal + lp] so that a wave (64 consecutive paths at the same bounce)
+ * writes 64 consecutive 16-byte elements.  Replaces the AoS
+ * std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
+struct LightStore {
+    F4 *v0;   /* hitpoint.xyz | pathLength (bits 0-7) , matID (bits 8-15)   */
+    F4 *v1;   /* throughput.xyz | dVCM                                       */
+    F4 *v2;   /* isect.normal.xyz | dVC                                      */
+    F4 *v3;   /* localDirFix.xyz | dVM                                       */
+    F4 *v4;   /* WorldDirFix().xyz | ContinuationProb()                      */
+    unsigned char *count;   /* stored vertices per local path (mPathEnds, :395) */
+};
+
+/* Hash grid, vertices sorted by cell (replaces mIndices indirection,
+ * hashgrid.hxx:83-88): cell c = [cellStart[c], cellStart[c+1]) */
+struct GridStore {
+    const int *cellStart;   /* nCells+1 */
+    const F4 *g0;           /* position.xyz | pathLength bits */
+    const F4 *g1;           /* WorldDirFix.xyz | light ContinuationProb */
+    const F4 *g2;           /* throughput.xyz | dVCM */
+    const float *g3;        /* dVM */
+    const GridHeader *hdr;
+};
+
+struct LaneStats {
+    uint32_t lightRays, cameraRays, shadowRays, mergeQueries, mergeCandidates, mergeAccepted,
+             connections, lightSplats, stored;
+};
+VCM_HD void lane_stats_zero(LaneStats &s)
+{
+    s.lightRays = s.cameraRays = s.shadowRays = s.mergeQueries = s.mergeCandidates = 0;
+    s.mergeAccepted = s.connections = s.lightSplats = s.stored = 0;
+}
+
+/* float atomic add to the framebuffer (light splats land on arbitrary
+ * pixels: vertexcm.hxx:931).  Order of concurrent adds is not defined, which
+ * is the one place results are not bit-reproducible (DESIGN.md "Parity"). */
+VCM_HD void fb_atomic_add(float *addr, float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsafeAtomicAdd(addr, v);
+#else
+    *addr = *addr + v;
+#endif
+}
+
+/* ------------------------------------------------------------------ */
+/* Ray / Isect: ray.hxx:34-65                                           */
+struct Ray { V3 org, dir; float tmin; };
+struct Isect { float dist; int matID; int lightID; V3 normal; };
+
+/* ---- utils.hxx ---------------------------------------------------- */
+VCM_HD float luminance(V3 c)
+{   /* :36-41 */
+    return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z;
+}
+VCM_HD float fresnel_dielectric(float cosInc, float ior)
+{   /* :43-74 */
+    if (ior < 0.f) return 1.f;
+    float eta;
+    if (cosInc < 0.f) { cosInc = -cosInc; eta = ior; }
+    else              { eta = 1.f / ior; }
+    const float sinTrans2 = sqr(eta) * (1.f - sqr(cosInc));
+    const float cosTrans = sqrtf(smax(0.f, 1.f - sinTrans2));
+    const float term1 = eta * cosTrans;
+    const float rParallel = (cosInc - term1) / (cosInc + term1);
+    const float term2 = eta * cosInc;
+    const float rPerp = (term2 - cosTrans) / (term2 + cosTrans);
+    return 0.5f * (sqr(rParallel) + sqr(rPerp));
+}
+VCM_HD V3 reflect_local(V3 v) { return mk3(-v.x, -v.y, v.z); }   /* :77-80 */
+
+VCM_HD V3 sample_power_cos_hemisphere(float sx, float sy, float power)
+{   /* :85-103, oPdfW == NULL at its only call site (bsdf.hxx:296) */
+    const float term1 = 2.f * VCM_PI_F * sx;
+    const float term2 = dm_powf(sy, 1.f / (power + 1.f));
+    const float term3 = sqrtf(1.f - term2 * term2);
+    float s, c;
+    dm_sincosf(term1, s, c);
+    return mk3(c * term3, s * term3, term2);
+}
+VCM_HD float power_cos_hemisphere_pdf(V3 n, V3 d, float power)
+{   /* :105-113 */
+    const float cosTheta = smax(0.f, dot(n, d));
+    return (power + 1.f) * dm_powf(cosTheta, power) * (VCM_INV_PI_F * 0.5f);
+}
+VCM_HD void sample_concentric_disc(float sx, float sy, float &ox, float &oy)
+{   /* :119-160 */
+    float phi, r;
+    const float a = 2 * sx - 1;
+    const float b = 2 * sy - 1;
+    if (a > -b) {
+        if (a > b) { r = a;  phi = (VCM_PI_F / 4.f) * (b / a); }
+        else       { r = b;  phi = (VCM_PI_F / 4.f) * (2.f - (a / b)); }
+    } else {
+        if (a < b) { r = -a; phi = (VCM_PI_F / 4.f) * (4.f + (b / a)); }
+        else {
+            r = -b;
+            if (b != 0) phi = (VCM_PI_F / 4.f) * (6.f - (a / b));
+            else        phi = 0;
+        }
+    }
+    float s, c;
+    dm_sincosf(phi, s, c);
+    ox = r * c;
+    oy = r * s;
+}
+VCM_HD float concentric_disc_pdf_a() { return VCM_INV_PI_F; }   /* :162-165 */
+VCM_HD V3 sample_cos_hemisphere(float sx, float sy, float &pdfW)
+{   /* :173-190 */
+    const float term1 = 2.f * VCM_PI_F * sx;
+    const float term2 = sqrtf(1.f - sy);
+    float s, c;
+    dm_sincosf(term1, s, c);
+    const V3 ret = mk3(c * term2, s * term2, sqrtf(sy));
+    pdfW = ret.z * VCM_INV_PI_F;
+    return ret;
+}
+VCM_HD float cos_hemisphere_pdf(V3 n, V3 d) { return smax(0.f, dot(n, d)) * VCM_INV_PI_F; }   /* :192-197 */
+VCM_HD void sample_uniform_triangle(float sx, float sy, float &u, float &v)
+{   /* :202-207 */
+    const float term = sqrtf(sx);
+    u = 1.f - term;
+    v = sy * term;
+}
+VCM_HD V3 sample_uniform_sphere(float sx, float sy, float &pdf)
+{   /* :212-230 */
+    const float term1 = 2.f * VCM_PI_F * sx;
+    const float term2 = 2.f * sqrtf(sy - sy * sy);
+    float s, c;
+    dm_sincosf(term1, s, c);
+    const V3 ret = mk3(c * term2, s * term2, 1.f - 2.f * sy);
+    pdf = VCM_INV_PI_F * 0.25f;
+    return ret;
+}
+VCM_HD float uniform_sphere_pdf() { return VCM_INV_PI_F * 0.25f; }   /* :232-236 */
+VCM_HD float pdf_w_to_a(float pdfW, float dist, float cosThere)
+{   /* :245-251 */
+    return pdfW * fabsf(cosThere) / sqr(dist);
+}
+
+/* ---- geometry.hxx ------------------------------------------------- */
+VCM_HD bool tri_intersect(const vcm_prim &t, const Ray &ray, Isect &res)
+{   /* Triangle::Intersect :125-156 */
+    const V3 ao = ld3(t.p0) - ray.org;
+    const V3 bo = ld3(t.p1) - ray.org;
+    const V3 co = ld3(t.p2) - ray.org;
+    const V3 v0 = cross(co, bo);
+    const V3 v1 = cross(bo, ao);
+    const V3 v2 = cross(ao, co);
+    const float v0d = dot(v0, ray.dir);
+    const float v1d = dot(v1, ray.dir);
+    const float v2d = dot(v2, ray.dir);
+    if (((v0d < 0.f) && (v1d < 0.f) && (v2d < 0.f)) ||
+        ((v0d >= 0.f) && (v1d >= 0.f) && (v2d >= 0.f))) {
+        const V3 n = ld3(t.n);
+        const float distance = dot(n, ao) / dot(n, ray.dir);
+        if ((distance > ray.tmin) && (distance < res.dist)) {
+            res.normal = n;
+            res.matID = t.matID;
+            res.dist = distance;
+            return true;
+        }
+    }
+    return false;
+}
+VCM_HD bool sph_intersect(const vcm_prim &s, const Ray &ray, Isect &res)
+{   /* Sphere::Intersect :198-237.  The discriminant is evaluated in float and
+       only then widened (:211); sqrt, q, t0, t1 are double (:216-220). */
+    const V3 center = ld3(s.p0);
+    const float radius = s.p1[0];
+    const V3 to = ray.org - center;
+    const float A = dot(ray.dir, ray.dir);
+    const float B = 2 * dot(ray.dir, to);
+    const float C = dot(to, to) - (radius * radius);
+    const float discF = B * B - 4 * A * C;
+    const double disc = discF;
+    if (disc < 0) return false;
+    const double discSqrt = sqrt(disc);
+    const double q = (B < 0) ? ((-B - discSqrt) / 2.f) : ((-B + discSqrt) / 2.f);
+    double t0 = q / A;
+    double t1 = C / q;
+    if (t0 > t1) { const double t = t0; t0 = t1; t1 = t; }
+    float resT;
+    if (t0 > ray.tmin && t0 < res.dist)      resT = float(t0);
+    else if (t1 > ray.tmin && t1 < res.dist) resT = float(t1);
+    else return false;
+    res.dist = resT;
+    res.matID = s.matID;
+    res.normal = normalize(to + sp3(resT) * ray.dir);
+    return true;
+}
+VCM_HD bool prim_intersect(const vcm_prim &p, const Ray &ray, Isect &res)
+{
+    return (p.type == VCM_PRIM_TRIANGLE) ? tri_intersect(p, ray, res) : sph_intersect(p, ray, res);
+}
+/* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78):
+ * brute force over <= 22 primitives; the index is wave-uniform, so the
+ * primitive data comes in through scalar loads. */
+VCM_HD bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res)
+{
+    bool any = false;
+    for (int i = 0; i < sc.nPrims; i++) {
+        const bool hit = prim_intersect(sc.prims[i], ray, res);
+        if (hit) any = hit;
+    }
+    if (any) res.lightID = sc.mat2light[res.matID];
+    return any;
+}
+/* Scene::Occluded scene.hxx:72-85 (+ GeometryList::IntersectP geometry.hxx:80-91) */
+VCM_HD bool scene_occluded(const vcm_scene_desc &sc, V3 point, V3 dir, float tmax)
+{
+    Ray ray;
+    ray.org = point + dir * VCM_EPS_RAY;
+    ray.dir = dir;
+    ray.tmin = 0;
+    Isect isect;
+    isect.dist = tmax - 2 * VCM_EPS_RAY;
+    bool occluded = false;
+    for (int i = 0; i < sc.nPrims; i++)
+        if (!occluded && prim_intersect(sc.prims[i], ray, isect)) occluded = true;
+    return occluded;
+}
+
+/* ---- BSDF: bsdf.hxx:61-576 ---------------------------------------- */
+enum { kDiffuse = 1, kPhong = 2, kReflect = 4, kRefract = 8, kSpecular = 12 };
+struct Bsdf {
+    int   matID;          /* < 0: invalid (bsdf.hxx:260) */
+    Frame frame;
+    V3    localDirFix;
+    bool  isDelta;
+    float diffProb, phongProb, reflProb, refrProb;
+    float contProb;
+    float reflectCoeff;
+};
+
+VCM_HD void bsdf_component_probabilities(Bsdf &b, const vcm_material &m)
+{   /* GetComponentProbabilities :528-566 */
+    b.reflectCoeff = fresnel_dielectric(b.localDirFix.z, m.ior);
+    const float albedoDiffuse = luminance(ld3(m.diffuse));
+    const float albedoPhong   = luminance(ld3(m.phong));
+    const float albedoReflect = b.reflectCoeff * luminance(ld3(m.mirror));
+    const float albedoRefract = (1.f - b.reflectCoeff) * (m.ior > 0.f ? 1.f : 0.f);
+    const float totalAlbedo = albedoDiffuse + albedoPhong + albedoReflect + albedoRefract;
+    if (totalAlbedo < 1e-9f) {
+        b.diffProb = b.phongProb = b.reflProb = b.refrProb = 0.f;
+        b.contProb = 0.f;
+    } else {
+        b.diffProb  = albedoDiffuse / totalAlbedo;
+        b.phongProb = albedoPhong / totalAlbedo;
+        b.reflProb  = albedoReflect / totalAlbedo;
+        b.refrProb  = albedoRefract / totalAlbedo;
+        b.contProb = vmax3(ld3(m.diffuse) + ld3(m.phong) + b.reflectCoeff * ld3(m.mirror)) +
+                     (1.f - b.reflectCoeff);
+        b.contProb = smin(1.f, smax(0.f, b.contProb));
+    }
+}
+/* Setup :95-117.  rayDir = the incoming ray direction, normal = isect.normal */
+VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, const vcm_scene_desc &sc)
+{
+    b.matID = -1;
+    frame_from_z(b.frame, normal);
+    b.localDirFix = to_local(b.frame, -rayDir);
+    if (fabsf(b.localDirFix.z) < VCM_EPS_COSINE) return;
+    bsdf_component_probabilities(b, sc.materials[matID]);
+    b.isDelta = (b.diffProb == 0.f) && (b.phongProb == 0.f);
+    b.matID = matID;
+}
+/* Rebuild the BSDF of a STORED light vertex from (isect.normal, mLocalDirFix,
+ * matID): the same operations Setup ran, hence the same bits. */
+VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, int matID, const vcm_scene_desc &sc)
+{
+    frame_from_z(b.frame, normal);
+    b.localDirFix = localDirFix;
+    bsdf_component_probabilities(b, sc.materials[matID]);
+    b.isDelta = false;
+    b.matID = matID;
+}
+VCM_HD V3 bsdf_eval_diffuse(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf)
+{   /* EvaluateDiffuse :393-412 */
+    if (b.diffProb == 0.f) return sp3(0.f);
+    if (b.localDirFix.z < VCM_EPS_COSINE || gen.z < VCM_EPS_COSINE) return sp3(0.f);
+    if (dirPdf) *dirPdf += b.diffProb * smax(0.f, gen.z * VCM_INV_PI_F);
+    if (revPdf) *revPdf += b.diffProb * smax(0.f, b.localDirFix.z * VCM_INV_PI_F);
+    return ld3(m.diffuse) * VCM_INV_PI_F;
+}
+VCM_HD V3 bsdf_eval_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf)
+{   /* EvaluatePhong :414-446 */
+    if (b.phongProb == 0.f) return sp3(0.f);
+    if (b.localDirFix.z < VCM_EPS_COSINE || gen.z < VCM_EPS_COSINE) return sp3(0.f);
+    const V3 refl = reflect_local(b.localDirFix);
+    const float dot_R_Wi = dot(refl, gen);
+    if (dot_R_Wi <= VCM_EPS_PHONG) return sp3(0.f);
+    /* pow(dot_R_Wi, n) is needed by the pdf (PowerCosHemispherePdfW, whose
+       cosTheta = max(0, dot) == dot here) and by the value: evaluate once */
+    const float pw = dm_powf(dot_R_Wi, m.phongExp);
+    if (dirPdf || revPdf) {
+        const float pdfW = b.phongProb * ((m.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
+        if (dirPdf) *dirPdf += pdfW;
+        if (revPdf) *revPdf += pdfW;
+    }
+    const V3 rho = ld3(m.phong) * (m.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;
+    return rho * pw;
+}
+VCM_HD void bsdf_pdf_diffuse(const Bsdf &b, V3 gen, float *dirPdf, float *revPdf)
+{   /* PdfDiffuse :456-472 (no EPS_COSINE guard, unlike EvaluateDiffuse) */
+    if (b.diffProb == 0.f) return;
+    if (dirPdf) *dirPdf += b.diffProb * smax(0.f, gen.z * VCM_INV_PI_F);
+    if (revPdf) *revPdf += b.diffProb * smax(0.f, b.localDirFix.z * VCM_INV_PI_F);
+}
+VCM_HD void bsdf_pdf_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf)
+{   /* PdfPhong :474-503 */
+    if (b.phongProb == 0.f) return;
+    const V3 refl = reflect_local(b.localDirFix);
+    const float dot_R_Wi = dot(refl, gen);
+    if (dot_R_Wi <= VCM_EPS_PHONG) return;
+    const float pdfW = power_cos_hemisphere_pdf(refl, gen, m.phongExp) * b.phongProb;
+    if (dirPdf) *dirPdf += pdfW;
+    if (revPdf) *revPdf += pdfW;
+}
+VCM_HD V3 bsdf_evaluate(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, float &cosThetaGen,
+                        float *dirPdf, float *revPdf)
+{   /* Evaluate :128-153 */
+    V3 result = sp3(0.f);
+    if (dirPdf) *dirPdf = 0.f;
+    if (revPdf) *revPdf = 0.f;
+    const V3 gen = to_local(b.frame, worldDirGen);
+    if (gen.z * b.localDirFix.z < 0.f) return result;
+    cosThetaGen = fabsf(gen.z);
+    const vcm_material &m = sc.materials[b.matID];
+    result = result + bsdf_eval_diffuse(b, m, gen, dirPdf, revPdf);
+    result = result + bsdf_eval_phong(b, m, gen, dirPdf, revPdf);
+    return result;
+}
+VCM_HD float bsdf_pdf(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, bool evalRev)
+{   /* Pdf :161-180 */
+    const V3 gen = to_local(b.frame, worldDirGen);
+    if (gen.z * b.localDirFix.z < 0.f) return 0.f;
+    const vcm_material &m = sc.materials[b.matID];
+    float directPdfW = 0.f, reversePdfW = 0.f;
+    bsdf_pdf_diffuse(b, gen, &directPdfW, &reversePdfW);
+    bsdf_pdf_phong(b, m, gen, &directPdfW, &reversePdfW);
+    return evalRev ? reversePdfW : directPdfW;
+}
+/* Sample :191-257 with SampleDiffuse :274, SamplePhong :290, SampleReflect :320,
+ * SampleRefract :335.  fixIsLight is the reference's template argument. */
+VCM_HD V3 bsdf_sample(const Bsdf &b, const vcm_scene_desc &sc, bool fixIsLight, float r0, float r1, float r2,
+                      V3 &worldDirGen, float &pdfW, float &cosThetaGen, uint32_t &sampledEvent)
+{
+    if (r2 < b.diffProb) sampledEvent = kDiffuse;
+    else if (r2 < b.diffProb + b.phongProb) sampledEvent = kPhong;
+    else if (r2 < b.diffProb + b.phongProb + b.reflProb) sampledEvent = kReflect;
+    else sampledEvent = kRefract;
+
+    const vcm_material &m = sc.materials[b.matID];
+    pdfW = 0.f;
+    V3 result = sp3(0.f);
+    V3 gen = sp3(0.f);
+
+    if (sampledEvent == kDiffuse) {
+        if (b.localDirFix.z < VCM_EPS_COSINE) return sp3(0.f);
+        float unweightedPdfW;
+        gen = sample_cos_hemisphere(r0, r1, unweightedPdfW);
+        pdfW += unweightedPdfW * b.diffProb;
+        result = result + ld3(m.diffuse) * VCM_INV_PI_F;
+        if (iszero(result)) return sp3(0.f);
+        result = result + bsdf_eval_phong(b, m, gen, &pdfW, (float *)0);
+    } else if (sampledEvent == kPhong) {
+        gen = sample_power_cos_hemisphere(r0, r1, m.phongExp);
+        const V3 refl = reflect_local(b.localDirFix);
+        {
+            Frame fr;
+            frame_from_z(fr, refl);
+            gen = to_world(fr, gen);
+        }
+        const float dot_R_Wi = dot(refl, gen);
+        if (dot_R_Wi <= VCM_EPS_PHONG) return sp3(0.f);
+        /* PdfPhong(:309) and the value (:317) use the same pow */
+        const float pw = dm_powf(dot_R_Wi, m.phongExp);
+        if (b.phongProb != 0.f)
+            pdfW += ((m.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f)) * b.phongProb;
+        const V3 rho = ld3(m.phong) * (m.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;
+        result = result + rho * pw;
+        if (iszero(result)) return sp3(0.f);
+        result = result + bsdf_eval_diffuse(b, m, gen, &pdfW, (float *)0);
+    } else if (sampledEvent == kReflect) {
+        gen = reflect_local(b.localDirFix);
+        pdfW += b.reflProb;
+        result = result + b.reflectCoeff * ld3(m.mirror) / fabsf(gen.z);
+        if (iszero(result)) return sp3(0.f);
+    } else {
+        if (m.ior < 0.f) return sp3(0.f);
+        float cosI = b.localDirFix.z;
+        float cosT, eta;
+        if (cosI < 0.f) { eta = m.ior; cosI = -cosI; cosT = 1.f; }
+        else            { eta = 1.f / m.ior; cosT = -1.f; }
+        const float sinI2 = 1.f - cosI * cosI;
+        const float sinT2 = sqr(eta) * sinI2;
+        if (sinT2 < 1.f) {
+            cosT *= sqrtf(smax(0.f, 1.f - sinT2));
+            gen = mk3(-eta * b.localDirFix.x, -eta * b.localDirFix.y, cosT);
+            pdfW += b.refrProb;
+            const float refractCoeff = 1.f - b.reflectCoeff;
+            if (!fixIsLight) result = result + sp3(refractCoeff * sqr(eta) / fabsf(cosT));
+            else             result = result + sp3(refractCoeff / fabsf(cosT));
+        } else {
+            return sp3(0.f);
+        }
+        if (iszero(result)) return sp3(0.f);
+    }
+
+    cosThetaGen = fabsf(gen.z);
+    if (cosThetaGen < VCM_EPS_COSINE) return sp3(0.f);
+    worldDirGen = to_world(b.frame, gen);
+    return result;
+}
+
+/* ---- lights.hxx ---------------------------------------------------- */
+VCM_HD bool light_is_finite(const vcm_light &l) { return l.type == VCM_LIGHT_AREA || l.type == VCM_LIGHT_POINT; }
+VCM_HD bool light_is_delta(const vcm_light &l) { return l.type == VCM_LIGHT_DIRECTIONAL || l.type == VCM_LIGHT_POINT; }
+VCM_HD const vcm_light &get_light(const vcm_scene_desc &sc, int idx)
+{   /* Scene::GetLightPtr scene.hxx:98-102 */
+    idx = (sc.nLights - 1 < idx) ? sc.nLights - 1 : idx;
+    return sc.lights[idx];
+}
+
+VCM_HD V3 light_illuminate(const vcm_light &l, const vcm_scene_desc &sc, V3 recvPos, float rx, float ry,
+                           V3 &dirToLight, float &distance, float &directPdfW, float &emissionPdfW,
+                           float &cosAtLight)
+{
+    if (l.type == VCM_LIGHT_AREA) {   /* AreaLight::Illuminate :129-166 */
+        float u, v;
+        sample_uniform_triangle(rx, ry, u, v);
+        const V3 lightPoint = ld3(l.p0) + ld3(l.e1) * u + ld3(l.e2) * v;
+        dirToLight = lightPoint - recvPos;
+        const float distSqr = lensqr(dirToLight);
+        distance = sqrtf(distSqr);
+        dirToLight = dirToLight / distance;
+        const float cosNormalDir = dot(ld3(l.frameZ), -dirToLight);
+        if (cosNormalDir < VCM_EPS_COSINE) return sp3(0.f);
+        directPdfW = l.invArea * distSqr / cosNormalDir;
+        cosAtLight = cosNormalDir;
+        emissionPdfW = l.invArea * cosNormalDir * VCM_INV_PI_F;
+        return ld3(l.intensity);
+    } else if (l.type == VCM_LIGHT_DIRECTIONAL) {   /* :245-265 */
+        dirToLight = -ld3(l.frameZ);
+        distance = 1e36f;
+        directPdfW = 1.f;
+        cosAtLight = 1.f;
+        emissionPdfW = concentric_disc_pdf_a() * sc.invSceneRadiusSqr;
+        return ld3(l.intensity);
+    } else if (l.type == VCM_LIGHT_POINT) {   /* :330-353 */
+        dirToLight = ld3(l.p0) - recvPos;
+        const float distSqr = lensqr(dirToLight);
+        directPdfW = distSqr;
+        distance = sqrtf(distSqr);
+        dirToLight = dirToLight / distance;
+        cosAtLight = 1.f;
+        emissionPdfW = uniform_sphere_pdf();
+        return ld3(l.intensity);
+    } else {   /* BackgroundLight::Illuminate :410-437 */
+        dirToLight = sample_uniform_sphere(rx, ry, directPdfW);
+        const V3 radiance = ld3(l.intensity) * l.scale;
+        distance = 1e36f;
+        emissionPdfW = directPdfW * concentric_disc_pdf_a() * sc.invSceneRadiusSqr;
+        cosAtLight = 1.f;
+        return radiance;
+    }
+}
+
+VCM_HD V3 light_emit(const vcm_light &l, const vcm_scene_desc &sc, float dx, float dy, float px, float py,
+                     V3 &position, V3 &direction, float &emissionPdfW, float &directPdfA, float &cosThetaLight)
+{
+    if (l.type == VCM_LIGHT_AREA) {   /* AreaLight::Emit :168-198 */
+        float u, v;
+        sample_uniform_triangle(px, py, u, v);
+        position = ld3(l.p0) + ld3(l.e1) * u + ld3(l.e2) * v;
+        V3 localDirOut = sample_cos_hemisphere(dx, dy, emissionPdfW);
+        emissionPdfW *= l.invArea;
+        localDirOut.z = smax(localDirOut.z, VCM_EPS_COSINE);
+        Frame f; f.mX = ld3(l.frameX); f.mY = ld3(l.frameY); f.mZ = ld3(l.frameZ);
+        direction = to_world(f, localDirOut);
+        directPdfA = l.invArea;
+        cosThetaLight = localDirOut.z;
+        return ld3(l.intensity) * localDirOut.z;
+    } else if (l.type == VCM_LIGHT_DIRECTIONAL) {   /* :267-294 */
+        float x, y;
+        sample_concentric_disc(px, py, x, y);
+        position = ld3(sc.sceneCenter) + sc.sceneRadius * (-ld3(l.frameZ) + ld3(l.frameX) * x + ld3(l.frameY) * y);
+        direction = ld3(l.frameZ);
+        emissionPdfW = concentric_disc_pdf_a() * sc.invSceneRadiusSqr;
+        directPdfA = 1.f;
+        cosThetaLight = 1.f;
+        return ld3(l.intensity);
+    } else if (l.type == VCM_LIGHT_POINT) {   /* :355-376 */
+        position = ld3(l.p0);
+        direction = sample_uniform_sphere(dx, dy, emissionPdfW);
+        directPdfA = 1.f;
+        cosThetaLight = 1.f;
+        return ld3(l.intensity);
+    } else {   /* BackgroundLight::Emit :439-481 */
+        float directPdf;
+        direction = sample_uniform_sphere(dx, dy, directPdf);
+        const V3 radiance = ld3(l.intensity) * l.scale;
+        float x, y;
+        sample_concentric_disc(px, py, x, y);
+        Frame frame;
+        frame_from_z(frame, direction);
+        position = ld3(sc.sceneCenter) + sc.sceneRadius * (-direction + frame.mX * x + frame.mY * y);
+        emissionPdfW = directPdf * concentric_disc_pdf_a() * sc.invSceneRadiusSqr;
+        directPdfA = directPdf;
+        cosThetaLight = 1.f;
+        return radiance;
+    }
+}
+
+VCM_HD V3 light_get_radiance(const vcm_light &l, const vcm_scene_desc &sc, V3 rayDir,
+                             float &directPdfA, float &emissionPdfW)
+{
+    if (l.type == VCM_LIGHT_AREA) {   /* :200-221 */
+        const float cosOutL = smax(0.f, dot(ld3(l.frameZ), -rayDir));
+        if (cosOutL == 0.f) return sp3(0.f);
+        directPdfA = l.invArea;
+        emissionPdfW = cos_hemisphere_pdf(ld3(l.frameZ), -rayDir);
+        emissionPdfW *= l.invArea;
+        return ld3(l.intensity);
+    } else if (l.type == VCM_LIGHT_BACKGROUND) {   /* :483-504 */
+        const float directPdf = uniform_sphere_pdf();
+        const V3 radiance = ld3(l.intensity) * l.scale;
+        const float positionPdf = concentric_disc_pdf_a() * sc.invSceneRadiusSqr;
+        directPdfA = directPdf;
+        emissionPdfW = directPdf * positionPdf;
+        return radiance;
+    }
+    return sp3(0.f);   /* directional :296-304, point :378-386 */
+}
+
+/* ------------------------------------------------------------------ */
+/* sub-path state: vertexcm.hxx:64-76                                   */
+struct SubPathState {
+    V3 origin, direction, throughput;
+    uint32_t pathLength;
+    uint32_t isFiniteLight;
+    uint32_t specularPath;
+    float dVCM, dVC, dVM;
+};
+VCM_HD float mis(float pdf) { return pdf; }   /* :553-557 (balance heuristic) */
+
+/* SampleScattering<tLightSample> :938-1006 */
+VCM_HD bool sample_scattering(const vcm_scene_desc &sc, const IterParams &P, bool lightSample, PathRng &rng,
+                              const Bsdf &bsdf, V3 hitPoint, SubPathState &st)
+{
+    const float r0 = rng_float(rng);
+    const float r1 = rng_float(rng);
+    const float r2 = rng_float(rng);
+    float bsdfDirPdfW, cosThetaOut;
+    uint32_t sampledEvent;
+    const V3 bsdfFactor = bsdf_sample(bsdf, sc, lightSample, r0, r1, r2, st.direction, bsdfDirPdfW, cosThetaOut,
+                                      sampledEvent);
+    if (iszero(bsdfFactor)) return false;
+    float bsdfRevPdfW = bsdfDirPdfW;
+    if ((sampledEvent & kSpecular) == 0) bsdfRevPdfW = bsdf_pdf(bsdf, sc, st.direction, true);
+    const float contProb = bsdf.contProb;
+    if (rng_float(rng) > contProb) return false;
+    bsdfDirPdfW *= contProb;
+    bsdfRevPdfW *= contProb;
+    if (sampledEvent & kSpecular) {
+        st.dVCM = 0.f;
+        st.dVC *= mis(cosThetaOut);
+        st.dVM *= mis(cosThetaOut);
+        st.specularPath &= 1;
+    } else {
+        st.dVC = mis(cosThetaOut / bsdfDirPdfW) * (st.dVC * mis(bsdfRevPdfW) + st.dVCM + P.misVmWeightFactor);
+        st.dVM = mis(cosThetaOut / bsdfDirPdfW) * (st.dVM * mis(bsdfRevPdfW) + st.dVCM * P.misVcWeightFactor + 1.f);
+        st.dVCM = mis(1.f / bsdfDirPdfW);
+        st.specularPath &= 0;
+    }
+    st.origin = hitPoint;
+    st.throughput = st.throughput * (bsdfFactor * (cosThetaOut / bsdfDirPdfW));
+    return true;
+}
+
+/* ================= light sub-path (vertexcm.hxx:321-396) ============== */
+
+/* GenerateLightSample :816-858 */
+VCM_HD void generate_light_sample(const vcm_scene_desc &sc, const IterParams &P, PathRng &rng, SubPathState &st)
+{
+    const int lightCount = sc.nLights;
+    const float lightPickProb = 1.f / lightCount;
+    const int lightID = int(rng_float(rng) * lightCount);
+    const float dx = rng_float(rng);
+    const float dy = rng_float(rng);
+    const float px = rng_float(rng);
+    const float py = rng_float(rng);
+    const vcm_light &light = get_light(sc, lightID);
+    float emissionPdfW, directPdfA, cosLight;
+    st.throughput = light_emit(light, sc, dx, dy, px, py, st.origin, st.direction, emissionPdfW, directPdfA, cosLight);
+    emissionPdfW *= lightPickProb;
+    directPdfA *= lightPickProb;
+    st.throughput = st.throughput / emissionPdfW;
+    st.pathLength = 1;
+    st.isFiniteLight = light_is_finite(light) ? 1u : 0u;
+    st.specularPath = 0;
+    st.dVCM = mis(directPdfA / emissionPdfW);
+    if (!light_is_delta(light)) {
+        const float usedCosLight = light_is_finite(light) ? cosLight : 1.f;
+        st.dVC = mis(usedCosLight / emissionPdfW);
+    } else {
+        st.dVC = 0.f;
+    }
+    st.dVM = st.dVC * P.misVcWeightFactor;
+}
+
+/* ConnectToCamera :862-933; the splat is an atomic add (Framebuffer::AddColor
+ * framebuffer.hxx:43-57 on an arbitrary pixel) */
+VCM_HD void connect_to_camera(const vcm_scene_desc &sc, const IterParams &P, const SubPathState &st, V3 hitpoint,
+                              const Bsdf &bsdf, float *fb, LaneStats &ls)
+{
+    const vcm_camera &cam = sc.camera;
+    V3 directionToCamera = ld3(cam.position) - hitpoint;
+    if (dot(ld3(cam.forward), -directionToCamera) <= 0.f) return;
+    const V3 ip = transform_point(cam.worldToRaster, hitpoint);
+    if (!(ip.x >= 0 && ip.y >= 0 && ip.x < cam.resolution[0] && ip.y < cam.resolution[1])) return;
+    const float distEye2 = lensqr(directionToCamera);
+    const float distance = sqrtf(distEye2);
+    directionToCamera = directionToCamera / distance;
+    float cosToCamera, bsdfDirPdfW, bsdfRevPdfW;
+    const V3 bsdfFactor = bsdf_evaluate(bsdf, sc, directionToCamera, cosToCamera, &bsdfDirPdfW, &bsdfRevPdfW);
+    if (iszero(bsdfFactor)) return;
+    bsdfRevPdfW *= bsdf.contProb;
+    const float cosAtCamera = dot(ld3(cam.forward), -directionToCamera);
+    const float imagePointToCameraDist = cam.imagePlaneDist / cosAtCamera;
+    const float imageToSolidAngleFactor = sqr(imagePointToCameraDist) / cosAtCamera;
+    const float imageToSurfaceFactor = imageToSolidAngleFactor * fabsf(cosToCamera) / sqr(distance);
+    const float cameraPdfA = imageToSurfaceFactor;
+    const float wLight = mis(cameraPdfA / P.lightSubPathCount) *
+                         (P.misVmWeightFactor + st.dVCM + st.dVC * mis(bsdfRevPdfW));
+    const float misWeight = P.lightTraceOnly ? 1.f : (1.f / (wLight + 1.f));
+    const float surfaceToImageFactor = 1.f / imageToSurfaceFactor;
+    const V3 contrib = misWeight * st.throughput * bsdfFactor / (P.lightSubPathCount * surfaceToImageFactor);
+    if (!iszero(contrib)) {
+        ls.shadowRays++;
+        if (scene_occluded(sc, hitpoint, directionToCamera, distance)) return;
+        const int x = int(ip.x), y = int(ip.y);
+        float *px = fb + (size_t)(x + y * P.resX) * 3;
+        fb_atomic_add(px + 0, contrib.x);
+        fb_atomic_add(px + 1, contrib.y);
+        fb_atomic_add(px + 2, contrib.z);
+        ls.lightSplats++;
+    }
+}
+
+struct LightPath {
+    SubPathState st;
+    PathRng rng;
+    int lp;          /* local path index */
+    int nStored;
+};
+
+VCM_HD void light_path_begin(const vcm_scene_desc &sc, const IterParams &P, LightPath &lp, int localPath)
+{
+    lp.lp = localPath;
+    lp.nStored = 0;
+    rng_init(lp.rng, P.seed, P.localIter, (uint32_t)(P.p0 + localPath), 0u);
+    generate_light_sample(sc, P, lp.rng, lp.st);
+}
+
+/* one iteration of the for(;;) at :328-393; returns false when the path ends */
+VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, LightPath &lp, const LightStore &store,
+                            float *fb, LaneStats &ls)
+{
+    SubPathState &st = lp.st;
+    Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    ls.lightRays++;
+    if (!scene_intersect(sc, ray, isect)) return false;
+    const V3 hitPoint = ray.org + ray.dir * isect.dist;
+    isect.dist += VCM_EPS_RAY;
+    Bsdf bsdf;
+    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, sc);
+    if (bsdf.matID < 0) return false;
+    {   /* :351-360 */
+        if (st.pathLength > 1 || st.isFiniteLight == 1) st.dVCM *= mis(sqr(isect.dist));
+        st.dVCM /= mis(fabsf(bsdf.localDirFix.z));
+        st.dVC  /= mis(fabsf(bsdf.localDirFix.z));
+        st.dVM  /= mis(fabsf(bsdf.localDirFix.z));
+    }
+    if (!bsdf.isDelta && (P.useVC || P.useVM)) {   /* :364-377 */
+        const size_t slot = (size_t)lp.nStored * (size_t)P.nLocal + (size_t)lp.lp;
+        const V3 wdir = to_world(bsdf.frame, bsdf.localDirFix);   /* WorldDirFix bsdf.hxx:264 */
+        store.v0[slot] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
+        store.v1[slot] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVCM);
+        store.v2[slot] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, st.dVC);
+        store.v3[slot] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
+        store.v4[slot] = mk4(wdir.x, wdir.y, wdir.z, bsdf.contProb);
+        lp.nStored++;
+        ls.stored++;
+    }
+    if (!bsdf.isDelta && (P.useVC || P.lightTraceOnly)) {   /* :380-384 */
+        if (st.pathLength + 1 >= P.minLen) connect_to_camera(sc, P, st, hitPoint, bsdf, fb, ls);
+    }
+    if (st.pathLength + 2 > P.maxLen) return false;   /* :387 */
+    if (!sample_scattering(sc, P, true, lp.rng, bsdf, hitPoint, st)) return false;
+    ++st.pathLength;
+    return true;
+}
+
+/* ================= camera sub-path (vertexcm.hxx:415-545) ============= */
+
+/* GetLightRadiance :617-658 */
+VCM_HD V3 get_light_radiance(const vcm_scene_desc &sc, const IterParams &P, const vcm_light &light,
+                             const SubPathState &st, V3 rayDir)
+{
+    const int lightCount = sc.nLights;
+    const float lightPickProb = 1.f / lightCount;
+    float directPdfA = 0.f, emissionPdfW = 0.f;
+    const V3 radiance = light_get_radiance(light, sc, rayDir, directPdfA, emissionPdfW);
+    if (iszero(radiance)) return sp3(0.f);
+    if (st.pathLength == 1) return radiance;
+    if (P.useVM && !P.useVC) return st.specularPath ? radiance : sp3(0.f);
+    directPdfA *= lightPickProb;
+    emissionPdfW *= lightPickProb;
+    const float wCamera = mis(directPdfA) * st.dVCM + mis(emissionPdfW) * st.dVC;
+    const float misWeight = 1.f / (1.f + wCamera);
+    return misWeight * radiance;
+}
+
+/* DirectIllumination :663-738 */
+VCM_HD V3 direct_illumination(const vcm_scene_desc &sc, const IterParams &P, PathRng &rng, const SubPathState &st,
+                              V3 hitpoint, const Bsdf &bsdf, LaneStats &ls)
+{
+    const int lightCount = sc.nLights;
+    const float lightPickProb = 1.f / lightCount;
+    const int lightID = int(rng_float(rng) * lightCount);
+    const float rx = rng_float(rng);
+    const float ry = rng_float(rng);
+    const vcm_light &light = get_light(sc, lightID);
+    V3 directionToLight;
+    float distance, directPdfW, emissionPdfW, cosAtLight;
+    const V3 radiance = light_illuminate(light, sc, hitpoint, rx, ry, directionToLight, distance, directPdfW,
+                                         emissionPdfW, cosAtLight);
+    if (iszero(radiance)) return sp3(0.f);
+    float bsdfDirPdfW, bsdfRevPdfW, cosToLight;
+    const V3 bsdfFactor = bsdf_evaluate(bsdf, sc, directionToLight, cosToLight, &bsdfDirPdfW, &bsdfRevPdfW);
+    if (iszero(bsdfFactor)) return sp3(0.f);
+    const float continuationProbability = bsdf.contProb;
+    bsdfDirPdfW *= light_is_delta(light) ? 0.f : continuationProbability;
+    bsdfRevPdfW *= continuationProbability;
+    const float wLight = mis(bsdfDirPdfW / (lightPickProb * directPdfW));
+    const float wCamera = mis(emissionPdfW * cosToLight / (directPdfW * cosAtLight)) *
+                          (P.misVmWeightFactor + st.dVCM + st.dVC * mis(bsdfRevPdfW));
+    const float misWeight = 1.f / (wLight + 1.f + wCamera);
+    const V3 contrib = (misWeight * cosToLight / (lightPickProb * directPdfW)) * (radiance * bsdfFactor);
+    if (iszero(contrib)) return sp3(0.f);
+    ls.shadowRays++;
+    if (scene_occluded(sc, hitpoint, directionToLight, distance)) return sp3(0.f);
+    return contrib;
+}
+
+/* ConnectVertices :743-809; the light vertex comes from the LightStore */
+VCM_HD V3 connect_vertices(const vcm_scene_desc &sc, const IterParams &P, V3 lvHitpoint, const Bsdf &lvBsdf,
+                           float lvdVCM, float lvdVC, const Bsdf &cameraBsdf, V3 cameraHitpoint,
+                           const SubPathState &st, LaneStats &ls)
+{
+    ls.connections++;
+    V3 direction = lvHitpoint - cameraHitpoint;
+    const float dist2 = lensqr(direction);
+    const float distance = sqrtf(dist2);
+    direction = direction / distance;
+    float cosCamera, cameraBsdfDirPdfW, cameraBsdfRevPdfW;
+    const V3 cameraBsdfFactor = bsdf_evaluate(cameraBsdf, sc, direction, cosCamera, &cameraBsdfDirPdfW, &cameraBsdfRevPdfW);
+    if (iszero(cameraBsdfFactor)) return sp3(0.f);
+    const float cameraCont = cameraBsdf.contProb;
+    cameraBsdfDirPdfW *= cameraCont;
+    cameraBsdfRevPdfW *= cameraCont;
+    float cosLight, lightBsdfDirPdfW, lightBsdfRevPdfW;
+    const V3 lightBsdfFactor = bsdf_evaluate(lvBsdf, sc, -direction, cosLight, &lightBsdfDirPdfW, &lightBsdfRevPdfW);
+    if (iszero(lightBsdfFactor)) return sp3(0.f);
+    const float lightCont = lvBsdf.contProb;
+    lightBsdfDirPdfW *= lightCont;
+    lightBsdfRevPdfW *= lightCont;
+    const float geometryTerm = cosLight * cosCamera / dist2;
+    if (geometryTerm < 0.f) return sp3(0.f);
+    const float cameraBsdfDirPdfA = pdf_w_to_a(cameraBsdfDirPdfW, distance, cosLight);
+    const float lightBsdfDirPdfA = pdf_w_to_a(lightBsdfDirPdfW, distance, cosCamera);
+    const float wLight = mis(cameraBsdfDirPdfA) * (P.misVmWeightFactor + lvdVCM + lvdVC * mis(lightBsdfRevPdfW));
+    const float wCamera = mis(lightBsdfDirPdfA) * (P.misVmWeightFactor + st.dVCM + st.dVC * mis(cameraBsdfRevPdfW));
+    const float misWeight = 1.f / (wLight + 1.f + wCamera);
+    const V3 contrib = (misWeight * geometryTerm) * cameraBsdfFactor * lightBsdfFactor;
+    if (iszero(contrib)) return sp3(0.f);
+    ls.shadowRays++;
+    if (scene_occluded(sc, cameraHitpoint, direction, distance)) return sp3(0.f);
+    return contrib;
+}
+
+/* HashGrid::GetCellIndex(Vec3i) hashgrid.hxx:179-187 */
+VCM_HD int grid_cell_hash(int cx, int cy, int cz, int nCells)
+{
+    const uint32_t x = (uint32_t)cx, y = (uint32_t)cy, z = (uint32_t)cz;
+    return (int)(((x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u)) % (uint32_t)nCells);
+}
+/* HashGrid::GetCellIndex(Vec3f) :189-201 */
+VCM_HD int grid_cell_of_point(V3 p, V3 bboxMin, float invCellSize, int nCells)
+{
+    const V3 distMin = p - bboxMin;
+    const float fx = floorf(invCellSize * distMin.x);
+    const float fy = floorf(invCellSize * distMin.y);
+    const float fz = floorf(invCellSize * distMin.z);
+    return grid_cell_hash(int(fx), int(fy), int(fz), nCells);
+}
+
+/* RangeQuery::Process vertexcm.hxx:130-169 for one accepted photon */
+VCM_HD void merge_photon(const vcm_scene_desc &sc, const IterParams &P, const Bsdf &cameraBsdf,
+                         const SubPathState &st, uint32_t lvLen, V3 lightDirection, float lvContProb,
+                         V3 lvThroughput, float lvdVCM, float lvdVM, V3 &contrib)
+{
+    if ((lvLen + st.pathLength > P.maxLen) || (lvLen + st.pathLength < P.minLen)) return;
+    float cosCamera, cameraBsdfDirPdfW, cameraBsdfRevPdfW;
+    const V3 cameraBsdfFactor = bsdf_evaluate(cameraBsdf, sc, lightDirection, cosCamera, &cameraBsdfDirPdfW,
+                                              &cameraBsdfRevPdfW);
+    if (iszero(cameraBsdfFactor)) return;
+    cameraBsdfDirPdfW *= cameraBsdf.contProb;
+    cameraBsdfRevPdfW *= lvContProb;
+    const float wLight = lvdVCM * P.misVcWeightFactor + lvdVM * mis(cameraBsdfDirPdfW);
+    const float wCamera = st.dVCM * P.misVcWeightFactor + st.dVM * mis(cameraBsdfRevPdfW);
+    const float misWeight = P.ppm ? 1.f : 1.f / (wLight + 1.f + wCamera);
+    contrib = contrib + misWeight * cameraBsdfFactor * lvThroughput;
+}
+
+/* HashGrid::Process hashgrid.hxx:110-169: the 8 hashed cells toward the
+ * nearer faces, in the reference's order (duplicates included, :142-155) */
+VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
+                      const SubPathState &st, V3 queryPos, LaneStats &ls)
+{
+    V3 contrib = sp3(0.f);
+    const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
+    const V3 distMin = queryPos - bmin;
+    const V3 distMax = bmax - queryPos;
+    if (distMin.x < 0.f || distMax.x < 0.f) return contrib;
+    if (distMin.y < 0.f || distMax.y < 0.f) return contrib;
+    if (distMin.z < 0.f || distMax.z < 0.f) return contrib;
+    const V3 cellPt = P.invCellSize * distMin;
+    const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+    const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
+    const V3 fractCoord = cellPt - coordF;
+    const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+    const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+    const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+    for (int j = 0; j < 8; j++) {
+        const int cx = (j & 4) ? pxo : px;
+        const int cy = (j & 2) ? pyo : py;
+        const int cz = (j & 1) ? pzo : pz;
+        const int cell = grid_cell_hash(cx, cy, cz, P.nCells);
+        int lo = g.cellStart[cell];
+        const int hi = g.cellStart[cell + 1];
+        for (; lo < hi; lo++) {
+            const F4 a = g.g0[lo];
+            const float distSqr = lensqr(queryPos - mk3(a.x, a.y, a.z));
+            ls.mergeCandidates++;
+            if (distSqr <= P.radiusSqr) {
+                ls.mergeAccepted++;
+                const F4 b = g.g1[lo];
+                const F4 c = g.g2[lo];
+                const float dVM = g.g3[lo];
+                merge_photon(sc, P, cameraBsdf, st, f2u(a.w), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM,
+                             contrib);
+            }
+        }
+    }
+    return contrib;
+}
+
+struct CameraPath {
+    SubPathState st;
+    PathRng rng;
+    V3 color;
+    int lp;
+    float sx, sy;    /* the jittered screen sample (:576) */
+};
+
+/* GenerateCameraSample :564-606 (+ Camera::GenerateRay camera.hxx:108-117) */
+VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, int localPath)
+{
+    const vcm_camera &cam = sc.camera;
+    const int pathIdx = P.p0 + localPath;
+    cp.lp = localPath;
+    cp.color = sp3(0.f);
+    rng_init(cp.rng, P.seed, P.localIter, (uint32_t)pathIdx, 1u);
+    const int x = pathIdx % P.resX;
+    const int y = pathIdx / P.resX;
+    const float jx = rng_float(cp.rng);
+    const float jy = rng_float(cp.rng);
+    cp.sx = float(x) + jx;
+    cp.sy = float(y) + jy;
+    const V3 worldRaster = transform_point(cam.rasterToWorld, mk3(cp.sx, cp.sy, 0.f));
+    const V3 org = ld3(cam.position);
+    const V3 dir = normalize(worldRaster - org);
+    const float cosAtCamera = dot(ld3(cam.forward), dir);
+    const float imagePointToCameraDist = cam.imagePlaneDist / cosAtCamera;
+    const float imageToSolidAngleFactor = sqr(imagePointToCameraDist) / cosAtCamera;
+    const float cameraPdfW = imageToSolidAngleFactor;
+    SubPathState &st = cp.st;
+    st.origin = org;
+    st.direction = dir;
+    st.throughput = sp3(1.f);
+    st.pathLength = 1;
+    st.specularPath = 1;
+    st.isFiniteLight = 0;
+    st.dVCM = mis(P.lightSubPathCount / cameraPdfW);
+    st.dVC = 0.f;
+    st.dVM = 0.f;
+}
+
+/* one iteration of the for(;;) at :423-542; returns false when the path ends */
+VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
+                             const GridStore &grid, LaneStats &ls)
+{
+    SubPathState &st = cp.st;
+    Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    ls.cameraRays++;
+    if (!scene_intersect(sc, ray, isect)) {   /* :434-447 */
+        if (sc.backgroundLight >= 0) {
+            if (st.pathLength >= P.minLen)
+                cp.color = cp.color + st.throughput * get_light_radiance(sc, P, sc.lights[sc.backgroundLight], st, ray.dir);
+        }
+        return false;
+    }
+    const V3 hitPoint = ray.org + ray.dir * isect.dist;
+    isect.dist += VCM_EPS_RAY;
+    Bsdf bsdf;
+    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, sc);
+    if (bsdf.matID < 0) return false;
+    {   /* :459-464 */
+        st.dVCM *= mis(sqr(isect.dist));
+        st.dVCM /= mis(fabsf(bsdf.localDirFix.z));
+        st.dVC  /= mis(fabsf(bsdf.localDirFix.z));
+        st.dVM  /= mis(fabsf(bsdf.localDirFix.z));
+    }
+    if (isect.lightID >= 0) {   /* :468-479 */
+        const vcm_light &light = get_light(sc, isect.lightID);
+        if (st.pathLength >= P.minLen)
+            cp.color = cp.color + st.throughput * get_light_radiance(sc, P, light, st, ray.dir);
+        return false;
+    }
+    if (st.pathLength >= P.maxLen) return false;   /* :482 */
+
+    if (!bsdf.isDelta && P.useVC) {   /* :487-494 */
+        if (st.pathLength + 1 >= P.minLen)
+            cp.color = cp.color + st.throughput * direct_illumination(sc, P, cp.rng, st, hitPoint, bsdf, ls);
+    }
+    if (!bsdf.isDelta && P.useVC) {   /* :498-526: the light path of the same index */
+        const int n = store.count[cp.lp];
+        for (int j = 0; j < n; j++) {
+            const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)cp.lp;
+            const F4 a = store.v0[slot];
+            const uint32_t lvLen = f2u(a.w) & 0xffu;
+            if (lvLen + 1 + st.pathLength < P.minLen) continue;
+            if (lvLen + 1 + st.pathLength > P.maxLen) break;
+            const F4 b = store.v1[slot];
+            const F4 c = store.v2[slot];
+            const F4 d = store.v3[slot];
+            Bsdf lvBsdf;
+            bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
+            cp.color = cp.color + st.throughput * mk3(b.x, b.y, b.z) *
+                       connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, bsdf, hitPoint, st, ls);
+        }
+    }
+    if (!bsdf.isDelta && P.useVM) {   /* :530-538 */
+        ls.mergeQueries++;
+        const V3 contrib = merge_query(sc, P, grid, bsdf, st, hitPoint, ls);
+        cp.color = cp.color + st.throughput * P.vmNormalization * contrib;
+        if (P.ppm) return false;
+    }
+    if (!sample_scattering(sc, P, false, cp.rng, bsdf, hitPoint, st)) return false;
+    ++st.pathLength;
+    return true;
+}
+
+/* Framebuffer::AddColor(screenSample, color) vertexcm.hxx:544, framebuffer.hxx:43-57:
+ * the pixel comes from the JITTERED sample; float(x)+jitter can round up to
+ * x+1, so the colour may belong to the next pixel or be dropped at the edge. */
+VCM_HD int camera_path_target(const IterParams &P, const CameraPath &cp)
+{
+    const float rx = (float)P.resX, ry = (float)P.resY;
+    if (cp.sx < 0 || cp.sx >= rx) return -1;
+    if (cp.sy < 0 || cp.sy >= ry) return -1;
+    return int(cp.sx) + int(cp.sy) * P.resX;
+}
+
+} // namespace vcm
+#endif

@@ -1,0 +1,349 @@
+// vcm_kernels.h -- HIP kernels of one VCM iteration on gfx950 (MI355X).
+//
+//   K1  k_light_trace     light sub-paths, vertex store, camera splats
+//   K1b k_compact_records slot-major store -> contiguous merge records
+//   K2  k_bbox / k_cell_count / scan / k_cell_scatter / k_cell_rank_gather
+//                         hash-grid build with vertices SORTED BY CELL
+//   K3  k_camera_trace    camera sub-paths: emission, direct illumination,
+//                         vertex connection, range-merge, scattering
+//   K5  k_resolve         Framebuffer::AddColor of the camera colours
+//
+// Execution model: one lane per sub-path.  K1/K3 are persistent: each wave
+// owns a contiguous chunk of path indices and REFILLS lanes whose path ended
+// with the next unstarted index, found with a wave ballot + prefix popcount
+// (no atomics, no LDS) -- paths are independent because every path has its
+// own counter-based random stream (philox.h).  The scene (<= 32 primitives)
+// is read with wave-uniform indices, i.e. through scalar loads.
+#ifndef SMALLVCM_AMD_VCM_KERNELS_H
+#define SMALLVCM_AMD_VCM_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "vcm_core.h"
+
+namespace vcm {
+
+enum { STAT_LIGHT_RAYS = 0, STAT_CAMERA_RAYS, STAT_SHADOW_RAYS, STAT_MERGE_QUERIES, STAT_MERGE_CANDIDATES,
+       STAT_MERGE_ACCEPTED, STAT_CONNECTIONS, STAT_LIGHT_SPLATS, STAT_STORED, STAT_COUNT };
+
+#define VCM_TRACE_BLOCK 256
+#define VCM_WAVE 64
+
+__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long long *g)
+{
+    const uint32_t v[STAT_COUNT] = { ls.lightRays, ls.cameraRays, ls.shadowRays, ls.mergeQueries, ls.mergeCandidates,
+                                     ls.mergeAccepted, ls.connections, ls.lightSplats, ls.stored };
+    /* per-lane counters are 32 bit; a lane sees < 2^32 events per launch, the
+       wave sum is widened before it leaves the wave */
+#pragma unroll
+    for (int i = 0; i < STAT_COUNT; i++) {
+        unsigned long long lo = wave_sum_u32(v[i] & 0xffffu);
+        unsigned long long hi = wave_sum_u32(v[i] >> 16);
+        const unsigned long long s = lo + (hi << 16);
+        if (lane_id() == 0 && s) atomicAdd(&g[i], s);
+    }
+}
+
+/* ---------------- K1: light sub-paths (vertexcm.hxx:321-396) ------------ */
+__global__ void __launch_bounds__(VCM_TRACE_BLOCK)
+k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, float *fb,
+              unsigned char *rngCount, unsigned long long *gstats, int chunk)
+{
+    const vcm_scene_desc &sc = *scp;
+    const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
+    const unsigned lane = lane_id();
+    int next = wave * chunk;                              /* wave-uniform */
+    const int end = min(P.nLocal, next + chunk);
+    LaneStats ls; lane_stats_zero(ls);
+    LightPath path;
+    bool alive = false;
+    for (;;) {
+        /* refill dead lanes: ballot + prefix popcount over the wave */
+        const unsigned long long need = __ballot(!alive);
+        if (!alive) {
+            const int idx = next + __popcll(need & ((1ull << lane) - 1ull));
+            if (idx < end) { light_path_begin(sc, P, path, idx); alive = true; }
+        }
+        next += __popcll(need);
+        if (!__any(alive)) break;
+        if (alive) {
+            alive = light_path_step(sc, P, path, store, fb, ls);
+            if (!alive) {
+                store.count[path.lp] = (unsigned char)path.nStored;   /* mPathEnds :395 */
+                rngCount[path.lp] = (unsigned char)path.rng.k;
+            }
+        }
+    }
+    flush_stats(ls, gstats);
+}
+
+/* ---------------- K3: camera sub-paths (vertexcm.hxx:415-545) ----------- */
+__global__ void __launch_bounds__(VCM_TRACE_BLOCK)
+k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, GridStore grid,
+               F4 *camOut, unsigned char *rngCount, unsigned long long *gstats, int chunk)
+{
+    const vcm_scene_desc &sc = *scp;
+    const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
+    const unsigned lane = lane_id();
+    int next = wave * chunk;
+    const int end = min(P.nLocal, next + chunk);
+    LaneStats ls; lane_stats_zero(ls);
+    CameraPath path;
+    bool alive = false;
+    for (;;) {
+        const unsigned long long need = __ballot(!alive);
+        if (!alive) {
+            const int idx = next + __popcll(need & ((1ull << lane) - 1ull));
+            if (idx < end) { camera_path_begin(sc, P, path, idx); alive = true; }
+        }
+        next += __popcll(need);
+        if (!__any(alive)) break;
+        if (alive) {
+            alive = camera_path_step(sc, P, path, store, grid, ls);
+            if (!alive) {
+                const int target = camera_path_target(P, path);
+                camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
+                rngCount[path.lp] = (unsigned char)path.rng.k;
+            }
+        }
+    }
+    flush_stats(ls, gstats);
+}
+
+/* ---------------- K5: Framebuffer::AddColor of camera colours ----------- */
+/* vertexcm.hxx:544 adds colour p to the pixel of its jittered sample, in path
+ * order.  Pixel q can receive from paths q-resX-1, q-resX, q-1, q (ascending
+ * = the reference's order); light splats of the iteration are already in. */
+__global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, float *fb)
+{
+    const int lastQ = min(P.N, P.p0 + P.nLocal + P.resX + 1);
+    for (int q = P.p0 + blockIdx.x * blockDim.x + threadIdx.x; q < lastQ; q += gridDim.x * blockDim.x) {
+        const int src[4] = { q - P.resX - 1, q - P.resX, q - 1, q };
+        float r = fb[(size_t)q * 3 + 0], g = fb[(size_t)q * 3 + 1], b = fb[(size_t)q * 3 + 2];
+        bool touched = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int lp = src[i] - P.p0;
+            if (lp < 0 || lp >= P.nLocal) continue;
+            const F4 c = camOut[lp];
+            if ((int)f2u(c.w) != q) continue;
+            r = r + c.x; g = g + c.y; b = b + c.z;
+            touched = true;
+        }
+        if (touched) { fb[(size_t)q * 3 + 0] = r; fb[(size_t)q * 3 + 1] = g; fb[(size_t)q * 3 + 2] = b; }
+    }
+}
+
+/* ---------------- exclusive scan (ints), 3 launches ---------------------- */
+#define VCM_SCAN_BLOCK 256
+#define VCM_SCAN_ITEMS 8
+#define VCM_SCAN_TILE (VCM_SCAN_BLOCK * VCM_SCAN_ITEMS)
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total)
+{   /* blockDim.x == VCM_SCAN_BLOCK */
+    __shared__ int s[VCM_SCAN_BLOCK];
+    const int t = threadIdx.x;
+    s[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int o = 1; o < VCM_SCAN_BLOCK; o <<= 1) {
+        const int add = (t >= o) ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    const int incl = s[t];
+    if (total) *total = s[VCM_SCAN_BLOCK - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(VCM_SCAN_BLOCK) k_scan_tile_sums(const T *__restrict__ in, int n, int *tileSums)
+{
+    const int base = blockIdx.x * VCM_SCAN_TILE + threadIdx.x * VCM_SCAN_ITEMS;
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < VCM_SCAN_ITEMS; i++) if (base + i < n) sum += (int)in[base + i];
+    int total;
+    block_exclusive_scan(sum, &total);
+    if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(VCM_SCAN_BLOCK) k_scan_tile_offsets(int *tileSums, int nTiles, int *totalOut)
+{
+    int carry = 0;
+    for (int base = 0; base < nTiles; base += VCM_SCAN_BLOCK) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nTiles) ? tileSums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        if (i < nTiles) tileSums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && totalOut) *totalOut = carry;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(VCM_SCAN_BLOCK)
+k_scan_apply(const T *__restrict__ in, int n, const int *__restrict__ tileOffsets, int *out, int writeTotalAtN)
+{
+    const int base = blockIdx.x * VCM_SCAN_TILE + threadIdx.x * VCM_SCAN_ITEMS;
+    int v[VCM_SCAN_ITEMS];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < VCM_SCAN_ITEMS; i++) { v[i] = (base + i < n) ? (int)in[base + i] : 0; sum += v[i]; }
+    int total;
+    int run = block_exclusive_scan(sum, &total) + tileOffsets[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < VCM_SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (writeTotalAtN && blockIdx.x == gridDim.x - 1 && threadIdx.x == VCM_SCAN_BLOCK - 1) out[n] = run;
+}
+
+/* ---------------- K1b: compaction into merge records --------------------- */
+/* Record = the 13 floats of LightVertex that RangeQuery::Process reads
+ * (vertexcm.hxx:130-169): pos, WorldDirFix, throughput, dVCM, dVM,
+ * ContinuationProb, pathLength.  Record order = the reference's
+ * mLightVertices order (path-major, then bounce). */
+__global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records)
+{
+    const long long total = (long long)P.S * P.nLocal;
+    for (long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x; slot < total;
+         slot += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(slot / P.nLocal);
+        const int lp = (int)(slot - (long long)j * P.nLocal);
+        if (j >= (int)store.count[lp]) continue;
+        const F4 a = store.v0[slot], b = store.v1[slot], d = store.v3[slot], e = store.v4[slot];
+        float *r = records + (size_t)(pathStart[lp] + j) * VCM_MERGE_RECORD_FLOATS;
+        r[0] = a.x; r[1] = a.y; r[2] = a.z;
+        r[3] = e.x; r[4] = e.y; r[5] = e.z;
+        r[6] = b.x; r[7] = b.y; r[8] = b.z;
+        r[9] = b.w; r[10] = d.w; r[11] = e.w;
+        r[12] = u2f(f2u(a.w) & 0xffu);
+    }
+}
+
+__global__ void k_set_counts(GridHeader *hdr, const int *localTotal, int useLocalAsGlobal, int globalTotal)
+{
+    hdr->nLocalRecords = *localTotal;
+    hdr->nRecords = useLocalAsGlobal ? *localTotal : globalTotal;
+}
+
+/* ---------------- K2: hash-grid build (hashgrid.hxx:41-107) ------------- */
+__device__ __forceinline__ uint32_t float_order_key(float f)
+{   /* order-preserving float -> uint */
+    const uint32_t u = f2u(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_key(uint32_t k)
+{
+    return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ void k_grid_init(GridHeader *hdr)
+{
+    if (threadIdx.x < 3) { hdr->bboxMinU[threadIdx.x] = 0xffffffffu; hdr->bboxMaxU[threadIdx.x] = 0u; }
+}
+
+__global__ void k_bbox(const float *__restrict__ records, GridHeader *hdr)
+{   /* :50-61 */
+    const int n = hdr->nRecords;
+    uint32_t mn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, mx[3] = { 0u, 0u, 0u };
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const uint32_t k = float_order_key(r[c]);
+            mn[c] = min(mn[c], k);
+            mx[c] = max(mx[c], k);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = min(mn[c], (uint32_t)__shfl_xor((int)mn[c], o, 64));
+            mx[c] = max(mx[c], (uint32_t)__shfl_xor((int)mx[c], o, 64));
+        }
+        if (lane_id() == 0) { atomicMin(&hdr->bboxMinU[c], mn[c]); atomicMax(&hdr->bboxMaxU[c], mx[c]); }
+    }
+}
+
+__global__ void k_bbox_finalize(GridHeader *hdr)
+{
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        if (hdr->nRecords > 0) {
+            hdr->bboxMin[c] = float_from_order_key(hdr->bboxMinU[c]);
+            hdr->bboxMax[c] = float_from_order_key(hdr->bboxMaxU[c]);
+        } else {   /* :47-48 initial values */
+            hdr->bboxMin[c] = 1e36f;
+            hdr->bboxMax[c] = -1e36f;
+        }
+    }
+}
+
+__global__ void k_cell_count(IterParams P, const float *__restrict__ records, const GridHeader *__restrict__ hdr,
+                             int *cellId, int *cellCount)
+{   /* :67-71 */
+    const int n = hdr->nRecords;
+    const V3 bmin = ld3(hdr->bboxMin);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
+        const int cell = grid_cell_of_point(mk3(r[0], r[1], r[2]), bmin, P.invCellSize, P.nCells);
+        cellId[i] = cell;
+        atomicAdd(&cellCount[cell], 1);
+    }
+}
+
+__global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__restrict__ cellId,
+                               const int *__restrict__ cellStart, int *cellFill, int *unsorted)
+{   /* :83-88, but in arbitrary order inside a cell; k_cell_rank_gather restores the order */
+    const int n = hdr->nRecords;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cell = cellId[i];
+        const int pos = cellStart[cell] + atomicAdd(&cellFill[cell], 1);
+        unsorted[pos] = i;
+    }
+}
+
+/* The reference's counting sort is stable: inside a cell, vertices keep their
+ * index order (:83-88), and the merge sums contributions in that order
+ * (:157-167).  Rank of vertex i inside its cell = number of vertices of the
+ * cell with a smaller index; the vertex data is then written to its final
+ * position, so the query reads contiguous, cell-sorted memory and needs no
+ * mIndices indirection. */
+__global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, const float *__restrict__ records,
+                                   const int *__restrict__ cellId, const int *__restrict__ cellStart,
+                                   const int *__restrict__ unsorted, F4 *g0, F4 *g1, F4 *g2, float *g3, int *sortedIndex)
+{
+    const int n = hdr->nRecords;
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
+        const int i = unsorted[pos];
+        const int cell = cellId[i];
+        const int lo = cellStart[cell], hi = cellStart[cell + 1];
+        int rank = 0;
+        for (int q = lo; q < hi; q++) rank += (unsorted[q] < i) ? 1 : 0;
+        const int dst = lo + rank;
+        const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
+        g0[dst] = mk4(r[0], r[1], r[2], r[12]);
+        g1[dst] = mk4(r[3], r[4], r[5], r[11]);
+        g2[dst] = mk4(r[6], r[7], r[8], r[9]);
+        g3[dst] = r[10];
+        if (sortedIndex) sortedIndex[dst] = i;
+    }
+}
+
+} // namespace vcm
+#endif

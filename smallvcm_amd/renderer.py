@@ -1,0 +1,347 @@
+"""Python host of the MI355X VCM integrator.
+
+Mirrors the reference's renderer plug-in surface (src/renderer.hxx:33-70,
+src/vertexcm.hxx:61, :182-214) on top of the C-ABI (include/smallvcm_amd.h):
+
+    r = VertexCM(scene, VertexCM.kVcm, radius_factor, radius_alpha, seed)
+    r.mMaxPathLength = 10; r.mMinPathLength = 0      # smallvcm.cxx:70-71
+    r.RunIteration(i)                                 # vertexcm.hxx:284
+    fb = r.GetFramebuffer()                           # renderer.hxx:49-55
+
+All compute happens in libsmallvcm_amd.so (HIP, gfx950).  There is no CPU
+fallback: a missing library or GPU raises.
+
+`ShardedVertexCM` is the one-process-per-GPU host: light sub-paths and pixels
+are sharded by path index; between the light pass and the grid build every
+rank all-gathers the light-vertex merge records (RCCL via torch.distributed),
+and the framebuffers are summed once at read-out.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (SceneDesc, Stats, SCENE_CONFIGS, VCM_MERGE_RECORD_FLOATS, ALGO_LIGHT_TRACE, ALGO_PPM, ALGO_BPM,
+                   ALGO_BPT, ALGO_VCM)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmallvcm_amd.so")
+
+_lib = None
+
+
+def load_library(require_gpu=True):
+    """Load the HIP library and declare the C-ABI.  Raises if it is missing
+    (build it with `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("smallvcm_amd: %s not built; the HIP library is the only compute path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, ip, llp, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_float)
+        L.vcm_last_error.restype = C.c_char_p
+        L.vcm_device_count.restype = C.c_int
+        L.vcm_create.restype = vp
+        L.vcm_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int]
+        L.vcm_create_sharded.restype = vp
+        L.vcm_create_sharded.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                         C.c_int, C.c_int]
+        L.vcm_destroy.argtypes = [vp]
+        L.vcm_destroy.restype = None
+        L.vcm_set_stream.argtypes = [vp, vp]
+        L.vcm_run_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
+        L.vcm_begin_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
+        for n in ("vcm_trace_light", "vcm_build_grid", "vcm_trace_camera", "vcm_end_iteration", "vcm_synchronize",
+                  "vcm_clear_framebuffer", "vcm_iterations"):
+            getattr(L, n).argtypes = [vp]
+        L.vcm_light_records.argtypes = [vp, C.POINTER(vp), llp]
+        L.vcm_export_light_records.argtypes = [vp, vp, C.c_longlong]
+        L.vcm_export_framebuffer.argtypes = [vp, vp]
+        L.vcm_import_light_records.argtypes = [vp, vp, llp, C.c_int, C.c_longlong]
+        L.vcm_read_framebuffer.argtypes = [vp, fp]
+        L.vcm_framebuffer_device.argtypes = [vp, C.POINTER(vp)]
+        L.vcm_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.vcm_get_rng_counts.argtypes = [vp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
+        L.vcm_local_path_range.argtypes = [vp, ip, ip]
+        L.vcm_scene_cornell.argtypes = [C.c_int, C.c_int, C.c_uint, C.POINTER(SceneDesc)]
+        L.vcm_scene_config_mask.argtypes = [C.c_int]
+        L.vcm_scene_config_mask.restype = C.c_uint
+        L.vcm_debug_read_grid.argtypes = [vp, ip, ip, fp, llp]
+        L.vcm_debug_read_records.argtypes = [vp, fp, C.c_longlong]
+        L.vcm_debug_numeric_spec.argtypes = [C.c_int, C.c_int, fp, fp, fp]
+        L.vcm_debug_philox_spec.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_int, fp]
+        for n in ("vcm_host_sinf", "vcm_host_cosf"):
+            getattr(L, n).argtypes = [C.c_float]
+            getattr(L, n).restype = C.c_float
+        L.vcm_host_powf.argtypes = [C.c_float, C.c_float]
+        L.vcm_host_powf.restype = C.c_float
+        L.vcm_host_path_float.argtypes = [C.c_uint] * 5
+        L.vcm_host_path_float.restype = C.c_float
+        L.vcm_sizeof_scene_desc.restype = C.c_uint
+        L.vcm_sizeof_stats.restype = C.c_uint
+        _lib = L
+    if require_gpu and _lib.vcm_device_count() <= 0:
+        raise RuntimeError("smallvcm_amd: no HIP device visible; this package has no CPU compute path")
+    return _lib
+
+
+def _check(L, rc, what):
+    if rc != 0:
+        raise RuntimeError("smallvcm_amd: %s failed: %s" % (what, (L.vcm_last_error() or b"").decode()))
+
+
+def cornell_scene(scene_id_or_mask, resx=512, resy=512, is_mask=False):
+    """Built-in Cornell box (reference src/scene.hxx:132, scene ids of
+    src/config.hxx:146-151) as a SceneDesc.  Host-only, needs no GPU."""
+    L = load_library(require_gpu=False)
+    mask = scene_id_or_mask if is_mask else SCENE_CONFIGS[scene_id_or_mask]
+    d = SceneDesc()
+    _check(L, L.vcm_scene_cornell(resx, resy, mask, C.byref(d)), "vcm_scene_cornell")
+    return d
+
+
+class HipBackend:
+    """One vcm_ctx: the phases of an iteration on one GPU (include/smallvcm_amd.h)."""
+
+    def __init__(self, scene, algorithm, radius_factor, radius_alpha, seed, device=0, rank=0, world=1):
+        self.L = load_library()
+        self.scene = scene
+        self.resx = int(scene.camera.resolution[0])
+        self.resy = int(scene.camera.resolution[1])
+        self.N = self.resx * self.resy
+        self.ctx = self.L.vcm_create_sharded(C.byref(scene), algorithm, radius_factor, radius_alpha, seed, device,
+                                             rank, world)
+        if not self.ctx:
+            raise RuntimeError("smallvcm_amd: vcm_create failed: %s" % self.L.vcm_last_error().decode())
+        first, count = C.c_int(), C.c_int()
+        self.L.vcm_local_path_range(self.ctx, C.byref(first), C.byref(count))
+        self.first, self.count = first.value, count.value
+        self.world = world
+        self.device = device
+        self._tstream = None
+
+    def stream_context(self):
+        """Run this context's kernels and the caller's torch ops (collectives,
+        copies) on ONE non-default torch stream, so they are ordered without
+        host synchronisation."""
+        import torch
+        if self._tstream is None:
+            self._tstream = torch.cuda.Stream(device=self.device)
+            self.set_stream(self._tstream.cuda_stream)
+        return torch.cuda.stream(self._tstream)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.vcm_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        _check(self.L, self.L.vcm_set_stream(self.ctx, stream_handle), "vcm_set_stream")
+
+    def begin(self, it, min_len, max_len):
+        _check(self.L, self.L.vcm_begin_iteration(self.ctx, it, min_len, max_len), "vcm_begin_iteration")
+
+    def trace_light(self):
+        _check(self.L, self.L.vcm_trace_light(self.ctx), "vcm_trace_light")
+
+    def build_grid(self):
+        _check(self.L, self.L.vcm_build_grid(self.ctx), "vcm_build_grid")
+
+    def trace_camera(self):
+        _check(self.L, self.L.vcm_trace_camera(self.ctx), "vcm_trace_camera")
+
+    def end(self):
+        _check(self.L, self.L.vcm_end_iteration(self.ctx), "vcm_end_iteration")
+
+    def run_iteration(self, it, min_len, max_len):
+        _check(self.L, self.L.vcm_run_iteration(self.ctx, it, min_len, max_len), "vcm_run_iteration")
+
+    def synchronize(self):
+        _check(self.L, self.L.vcm_synchronize(self.ctx), "vcm_synchronize")
+
+    # ---- exchange (multi-GPU) -------------------------------------------
+    def local_record_count(self):
+        ptr, n = C.c_void_p(), C.c_longlong()
+        _check(self.L, self.L.vcm_light_records(self.ctx, C.byref(ptr), C.byref(n)), "vcm_light_records")
+        return n.value
+
+    def export_records(self, dst_tensor, count):
+        """copy `count` local records into a torch device tensor"""
+        _check(self.L, self.L.vcm_export_light_records(self.ctx, dst_tensor.data_ptr(), count),
+               "vcm_export_light_records")
+
+    def import_records(self, gathered_tensor, counts, stride_records):
+        arr = (C.c_longlong * len(counts))(*[int(c) for c in counts])
+        _check(self.L, self.L.vcm_import_light_records(self.ctx, gathered_tensor.data_ptr(), arr, len(counts),
+                                                       stride_records), "vcm_import_light_records")
+
+    def export_framebuffer(self, dst_tensor):
+        _check(self.L, self.L.vcm_export_framebuffer(self.ctx, dst_tensor.data_ptr()), "vcm_export_framebuffer")
+
+    def new_tensor(self, n_floats):
+        import torch
+        return torch.empty(int(n_floats), dtype=torch.float32, device="cuda")
+
+    # ---- read-back --------------------------------------------------------
+    def framebuffer_sum(self):
+        out = np.zeros((self.resy, self.resx, 3), np.float32)
+        _check(self.L, self.L.vcm_read_framebuffer(self.ctx, out.ctypes.data_as(C.POINTER(C.c_float))),
+               "vcm_read_framebuffer")
+        return out
+
+    def clear_framebuffer(self):
+        _check(self.L, self.L.vcm_clear_framebuffer(self.ctx), "vcm_clear_framebuffer")
+
+    def stats(self):
+        s = Stats()
+        _check(self.L, self.L.vcm_get_stats(self.ctx, C.byref(s)), "vcm_get_stats")
+        return s.asdict()
+
+    def rng_counts(self):
+        a = np.zeros(self.count, np.uint8)
+        b = np.zeros(self.count, np.uint8)
+        _check(self.L, self.L.vcm_get_rng_counts(self.ctx, a.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                                 b.ctypes.data_as(C.POINTER(C.c_ubyte))), "vcm_get_rng_counts")
+        return a, b
+
+    def records(self):
+        n = self.local_record_count()
+        out = np.zeros((n, VCM_MERGE_RECORD_FLOATS), np.float32)
+        _check(self.L, self.L.vcm_debug_read_records(self.ctx, out.ctypes.data_as(C.POINTER(C.c_float)), n),
+               "vcm_debug_read_records")
+        return out
+
+    def grid(self):
+        cs = np.zeros(self.N + 1, np.int32)
+        nrec = C.c_longlong()
+        bbox = np.zeros(6, np.float32)
+        _check(self.L, self.L.vcm_debug_read_grid(self.ctx, None, None, None, C.byref(nrec)), "vcm_debug_read_grid")
+        idx = np.zeros(max(nrec.value, 1), np.int32)
+        _check(self.L, self.L.vcm_debug_read_grid(self.ctx, cs.ctypes.data_as(C.POINTER(C.c_int)),
+                                                  idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                                  bbox.ctypes.data_as(C.POINTER(C.c_float)), C.byref(nrec)),
+               "vcm_debug_read_grid")
+        return cs, idx[:nrec.value], bbox
+
+
+class VertexCM:
+    """Single-GPU renderer with the reference's interface (src/vertexcm.hxx:61,
+    src/renderer.hxx:33-70)."""
+
+    # AlgorithmType, src/vertexcm.hxx:182-204
+    kLightTrace, kPpm, kBpm, kBpt, kVcm = ALGO_LIGHT_TRACE, ALGO_PPM, ALGO_BPM, ALGO_BPT, ALGO_VCM
+
+    def __init__(self, aScene, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed=1234, device=0):
+        self.mScene = aScene
+        self.mMaxPathLength = 2      # renderer.hxx:40
+        self.mMinPathLength = 0      # renderer.hxx:39
+        self.backend = HipBackend(aScene, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed, device=device)
+        self.mIterations = 0
+
+    def RunIteration(self, aIteration):
+        self.backend.run_iteration(aIteration, self.mMinPathLength, self.mMaxPathLength)
+        self.mIterations += 1
+
+    def WasUsed(self):
+        return self.mIterations > 0
+
+    def GetFramebuffer(self):
+        """renderer.hxx:49-55: the running sum scaled by 1/mIterations."""
+        fb = self.backend.framebuffer_sum()
+        if self.mIterations > 0:
+            fb = fb * np.float32(1.0 / self.mIterations)
+        return fb
+
+    def framebuffer_sum(self):
+        return self.backend.framebuffer_sum()
+
+    def stats(self):
+        return self.backend.stats()
+
+    def close(self):
+        self.backend.close()
+
+
+class ShardedVertexCM:
+    """One rank of a renderer sharded over `world` processes (one GPU each).
+
+    Rank r owns light paths and pixels [r*N/W, (r+1)*N/W).  Per iteration:
+      trace_light (local) -> all-gather of the 52-byte merge records (ragged:
+      counts first, then one all_gather_into_tensor on max-padded slabs) ->
+      identical hash grid on every rank -> trace_camera (local pixels).
+    Light splats land on arbitrary pixels, so every rank keeps a full
+    framebuffer; they are summed once at read-out (all_reduce).
+
+    `backend` is anything with HipBackend's phase interface -- the CPU tests
+    drive this same class with an oracle-backed backend over gloo.
+    """
+
+    def __init__(self, backend, rank, world, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.backend = backend
+        self.rank, self.world, self.group = rank, world, group
+        self.mMaxPathLength = 2
+        self.mMinPathLength = 0
+        self.mIterations = 0
+        self._gather = None
+        self._local = None
+
+    def RunIteration(self, aIteration):
+        with self.backend.stream_context():
+            self._run_iteration(aIteration)
+        self.mIterations += 1
+
+    def _run_iteration(self, aIteration):
+        import torch
+        b, dist = self.backend, self.dist
+        b.begin(aIteration, self.mMinPathLength, self.mMaxPathLength)
+        b.trace_light()
+        if self.world > 1:
+            n_local = b.local_record_count()
+            # 1) counts (tiny all-gather)
+            dev = b.new_tensor(1).device
+            cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+            cnts = torch.empty(self.world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(cnts, cnt, group=self.group)
+            counts = [int(x) for x in cnts.tolist()]
+            stride = max(max(counts), 1)
+            # 2) records, padded to the largest shard
+            need = stride * VCM_MERGE_RECORD_FLOATS
+            if self._local is None or self._local.numel() < need:
+                self._local = b.new_tensor(need)
+                self._gather = b.new_tensor(need * self.world)
+            local = self._local[:need]
+            gathered = self._gather[:need * self.world]
+            b.export_records(local, n_local)
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+            b.import_records(gathered, counts, stride)
+        b.build_grid()
+        b.trace_camera()
+        b.end()
+
+    def WasUsed(self):
+        return self.mIterations > 0
+
+    def framebuffer_sum(self):
+        """Sum over ranks of the running-sum framebuffers (valid on every rank)."""
+        b, dist = self.backend, self.dist
+        with b.stream_context():
+            t = b.new_tensor(b.N * 3)
+            b.export_framebuffer(t)
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            out = t.cpu()
+        return out.numpy().reshape(b.resy, b.resx, 3)
+
+    def GetFramebuffer(self):
+        fb = self.framebuffer_sum()
+        if self.mIterations > 0:
+            fb = fb * np.float32(1.0 / self.mIterations)
+        return fb

@@ -1,0 +1,82 @@
+"""ctypes binding of tests/host_emul/libemul.so (product device functions on the CPU; test infrastructure)."""
+import ctypes as C
+import os
+import numpy as np
+from smallvcm_amd._abi import SceneDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_E = None
+
+
+def emul():
+    global _E
+    if _E is None:
+        E = C.CDLL(os.path.join(_HERE, "host_emul", "libemul.so"))
+        E.emul_create.restype = C.c_void_p
+        E.emul_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+        E.emul_destroy.argtypes = [C.c_void_p]
+        E.emul_run_iteration.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
+        E.emul_get_framebuffer.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        E.emul_get_counts.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
+        E.emul_get_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        E.emul_record_count.argtypes = [C.c_void_p]
+        E.emul_record_count.restype = C.c_longlong
+        E.emul_get_records.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        E.vcm_scene_cornell.argtypes = [C.c_int, C.c_int, C.c_uint, C.POINTER(SceneDesc)]
+        for n in ("emul_sinf", "emul_cosf"):
+            getattr(E, n).argtypes = [C.c_float]
+            getattr(E, n).restype = C.c_float
+        E.emul_powf.argtypes = [C.c_float, C.c_float]
+        E.emul_powf.restype = C.c_float
+        E.emul_path_float.argtypes = [C.c_uint32] * 5
+        E.emul_path_float.restype = C.c_float
+        _E = E
+    return _E
+
+
+class Emul:
+    def __init__(self, scene, algo, radius_factor=0.003, radius_alpha=0.75, seed=1234, rank=0, world=1):
+        self.E = emul()
+        self.h = self.E.emul_create(C.byref(scene), algo, radius_factor, radius_alpha, seed, rank, world)
+        self.resx = int(scene.camera.resolution[0])
+        self.resy = int(scene.camera.resolution[1])
+        self.N = self.resx * self.resy
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.E.emul_destroy(self.h)
+            self.h = None
+
+    def run_iteration(self, it, min_len=0, max_len=10):
+        self.E.emul_run_iteration(self.h, it, min_len, max_len)
+
+    def framebuffer(self):
+        out = np.zeros((self.resy, self.resx, 3), np.float32)
+        self.E.emul_get_framebuffer(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def counts(self):
+        a = np.zeros(self.N, np.uint8)
+        b = np.zeros(self.N, np.uint8)
+        self.E.emul_get_counts(self.h, a.ctypes.data_as(C.POINTER(C.c_ubyte)), b.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        return a, b
+
+    def records(self):
+        n = self.E.emul_record_count(self.h)
+        out = np.zeros((n, 13), np.float32)
+        if n:
+            self.E.emul_get_records(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def stats(self):
+        st = (C.c_longlong * 9)()
+        self.E.emul_get_stats(self.h, st)
+        keys = ("lightRays", "cameraRays", "shadowRays", "mergeQueries", "mergeCandidates", "mergeAccepted",
+                "connections", "lightSplats", "lightVertices")
+        return dict(zip(keys, list(st)))
+
+
+def emul_scene(mask, resx, resy):
+    d = SceneDesc()
+    assert emul().vcm_scene_cornell(resx, resy, mask, C.byref(d)) == 0
+    return d

@@ -1,0 +1,191 @@
+// TEST INFRASTRUCTURE.  Compiles the product's device functions
+// (smallvcm_amd/csrc/vcm_core.h) for the HOST with g++ and drives them
+// serially, so that `-m "not gpu"` tests can compare the product's path logic
+// and arithmetic against the oracle without a GPU.  This is not a fallback:
+// it is never built into libsmallvcm_amd.so and nothing in the package loads it.
+#include <vector>
+#include <algorithm>
+#include <string.h>
+#include "../../smallvcm_amd/csrc/vcm_core.h"
+
+using namespace vcm;
+
+struct Emul {
+    vcm_scene_desc sc;
+    bool useVM, useVC, lightTraceOnly, ppm;
+    float baseRadius, radiusAlpha;
+    int seed, iterations;
+    int resX, resY, N, p0, nLocal;
+    IterParams P;
+    std::vector<F4> v0, v1, v2, v3, v4, g0, g1, g2, camOut;
+    std::vector<float> g3, fb, records;
+    std::vector<unsigned char> count, rngL, rngC;
+    std::vector<int> cellStart;
+    GridHeader hdr;
+    LaneStats ls;
+};
+
+extern "C" {
+
+void *emul_create(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha, int seed,
+                  int rank, int world)
+{
+    Emul *e = new Emul();
+    e->sc = *scene;
+    e->useVM = e->useVC = e->lightTraceOnly = e->ppm = false;
+    switch (algorithm) {
+    case VCM_ALGO_LIGHT_TRACE: e->lightTraceOnly = true; break;
+    case VCM_ALGO_PPM: e->ppm = true; e->useVM = true; break;
+    case VCM_ALGO_BPM: e->useVM = true; break;
+    case VCM_ALGO_BPT: e->useVC = true; break;
+    default: e->useVC = true; e->useVM = true; break;
+    }
+    if (e->ppm) {
+        for (int i = 0; i < scene->nMaterials; i++) {
+            const vcm_material &m = scene->materials[i];
+            if (((vmax3(ld3(m.diffuse)) > 0) || (vmax3(ld3(m.phong)) > 0)) && ((vmax3(ld3(m.mirror)) > 0) || (m.ior > 0))) {
+                e->ppm = false; break;
+            }
+        }
+    }
+    e->baseRadius = radiusFactor * scene->sceneRadius;
+    e->radiusAlpha = radiusAlpha;
+    e->seed = seed; e->iterations = 0;
+    e->resX = (int)scene->camera.resolution[0]; e->resY = (int)scene->camera.resolution[1];
+    e->N = e->resX * e->resY;
+    e->p0 = (int)((long long)e->N * rank / world);
+    e->nLocal = (int)((long long)e->N * (rank + 1) / world) - e->p0;
+    e->fb.assign((size_t)e->N * 3, 0.f);
+    return e;
+}
+void emul_destroy(void *h) { delete (Emul *)h; }
+
+void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen)
+{
+    Emul &e = *(Emul *)h;
+    IterParams &P = e.P;
+    memset(&P, 0, sizeof(P));
+    const int S = (maxLen >= 2) ? (int)maxLen - 1 : 1;
+    P.seed = (uint32_t)e.seed; P.localIter = (uint32_t)e.iterations;
+    P.minLen = minLen; P.maxLen = maxLen;
+    P.resX = e.resX; P.resY = e.resY; P.N = e.N; P.p0 = e.p0; P.nLocal = e.nLocal; P.S = S;
+    P.useVM = e.useVM; P.useVC = e.useVC; P.lightTraceOnly = e.lightTraceOnly; P.ppm = e.ppm;
+    P.lightSubPathCount = float(e.resX * e.resY);
+    float radius = e.baseRadius;
+    radius /= dm_powf(float(iteration + 1), 0.5f * (1 - e.radiusAlpha));
+    radius = smax(radius, 1e-7f);
+    const float radiusSqr = sqr(radius);
+    P.radius = radius; P.radiusSqr = radiusSqr;
+    P.vmNormalization = 1.f / (radiusSqr * VCM_PI_F * P.lightSubPathCount);
+    const float etaVCM = (VCM_PI_F * radiusSqr) * P.lightSubPathCount;
+    P.misVmWeightFactor = e.useVM ? mis(etaVCM) : 0.f;
+    P.misVcWeightFactor = e.useVC ? mis(1.f / etaVCM) : 0.f;
+    P.cellSize = radius * 2.f;
+    P.invCellSize = 1.f / P.cellSize;
+    P.nCells = e.N;
+
+    const size_t slots = (size_t)S * e.nLocal;
+    e.v0.assign(slots, mk4(0, 0, 0, 0)); e.v1 = e.v0; e.v2 = e.v0; e.v3 = e.v0; e.v4 = e.v0;
+    e.count.assign((size_t)e.nLocal, 0); e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
+    lane_stats_zero(e.ls);
+    LightStore store; store.v0 = e.v0.data(); store.v1 = e.v1.data(); store.v2 = e.v2.data(); store.v3 = e.v3.data();
+    store.v4 = e.v4.data(); store.count = e.count.data();
+
+    /* K1 */
+    for (int lp = 0; lp < e.nLocal; lp++) {
+        LightPath path;
+        light_path_begin(e.sc, P, path, lp);
+        while (light_path_step(e.sc, P, path, store, e.fb.data(), e.ls)) {}
+        e.count[lp] = (unsigned char)path.nStored;
+        e.rngL[lp] = (unsigned char)path.rng.k;
+    }
+    /* K1b: records in reference order */
+    e.records.clear();
+    for (int lp = 0; lp < e.nLocal; lp++)
+        for (int j = 0; j < e.count[lp]; j++) {
+            const size_t slot = (size_t)j * e.nLocal + lp;
+            const F4 a = e.v0[slot], b = e.v1[slot], d = e.v3[slot], w = e.v4[slot];
+            const float r[13] = { a.x, a.y, a.z, w.x, w.y, w.z, b.x, b.y, b.z, b.w, d.w, w.w, u2f(f2u(a.w) & 0xffu) };
+            e.records.insert(e.records.end(), r, r + 13);
+        }
+    const int n = (int)(e.records.size() / 13);
+    /* K2: stable counting sort by cell */
+    memset(&e.hdr, 0, sizeof(e.hdr));
+    e.hdr.nRecords = n;
+    for (int c = 0; c < 3; c++) { e.hdr.bboxMin[c] = 1e36f; e.hdr.bboxMax[c] = -1e36f; }
+    e.cellStart.assign((size_t)P.nCells + 1, 0);
+    e.g0.assign((size_t)n, mk4(0, 0, 0, 0)); e.g1 = e.g0; e.g2 = e.g0; e.g3.assign((size_t)n, 0.f);
+    if (e.useVM) {
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++) {
+                e.hdr.bboxMax[c] = smax(e.hdr.bboxMax[c], e.records[(size_t)i * 13 + c]);
+                e.hdr.bboxMin[c] = smin(e.hdr.bboxMin[c], e.records[(size_t)i * 13 + c]);
+            }
+        std::vector<int> cell((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const float *r = &e.records[(size_t)i * 13];
+            cell[i] = grid_cell_of_point(mk3(r[0], r[1], r[2]), ld3(e.hdr.bboxMin), P.invCellSize, P.nCells);
+            e.cellStart[cell[i] + 1]++;
+        }
+        for (int c = 0; c < P.nCells; c++) e.cellStart[c + 1] += e.cellStart[c];
+        std::vector<int> fill(e.cellStart.begin(), e.cellStart.end() - 1);
+        for (int i = 0; i < n; i++) {
+            const float *r = &e.records[(size_t)i * 13];
+            const int dst = fill[cell[i]]++;
+            e.g0[dst] = mk4(r[0], r[1], r[2], r[12]);
+            e.g1[dst] = mk4(r[3], r[4], r[5], r[11]);
+            e.g2[dst] = mk4(r[6], r[7], r[8], r[9]);
+            e.g3[dst] = r[10];
+        }
+    }
+    /* K3 */
+    GridStore grid; grid.cellStart = e.cellStart.data(); grid.g0 = e.g0.data(); grid.g1 = e.g1.data();
+    grid.g2 = e.g2.data(); grid.g3 = e.g3.data(); grid.hdr = &e.hdr;
+    if (!e.lightTraceOnly) {
+        e.camOut.assign((size_t)e.nLocal, mk4(0, 0, 0, 0));
+        for (int lp = 0; lp < e.nLocal; lp++) {
+            CameraPath path;
+            camera_path_begin(e.sc, P, path, lp);
+            while (camera_path_step(e.sc, P, path, store, grid, e.ls)) {}
+            e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
+            e.rngC[lp] = (unsigned char)path.rng.k;
+        }
+        /* K5 in path order */
+        for (int lp = 0; lp < e.nLocal; lp++) {
+            const int t = (int)f2u(e.camOut[lp].w);
+            if (t < 0) continue;
+            float *px = &e.fb[(size_t)t * 3];
+            px[0] = px[0] + e.camOut[lp].x; px[1] = px[1] + e.camOut[lp].y; px[2] = px[2] + e.camOut[lp].z;
+        }
+    }
+    e.iterations++;
+}
+
+void emul_get_framebuffer(void *h, float *out) { Emul &e = *(Emul *)h; memcpy(out, e.fb.data(), e.fb.size() * 4); }
+void emul_get_counts(void *h, unsigned char *l, unsigned char *c)
+{
+    Emul &e = *(Emul *)h;
+    memcpy(l, e.rngL.data(), e.rngL.size()); memcpy(c, e.rngC.data(), e.rngC.size());
+}
+long long emul_record_count(void *h) { return (long long)(((Emul *)h)->records.size() / 13); }
+void emul_get_records(void *h, float *out) { Emul &e = *(Emul *)h; memcpy(out, e.records.data(), e.records.size() * 4); }
+void emul_get_stats(void *h, long long *out9)
+{
+    const LaneStats &s = ((Emul *)h)->ls;
+    const uint32_t v[9] = { s.lightRays, s.cameraRays, s.shadowRays, s.mergeQueries, s.mergeCandidates, s.mergeAccepted,
+                            s.connections, s.lightSplats, s.stored };
+    for (int i = 0; i < 9; i++) out9[i] = v[i];
+}
+float emul_sinf(float x) { return dm_sinf(x); }
+float emul_cosf(float x) { return dm_cosf(x); }
+float emul_powf(float x, float y) { return dm_powf(x, y); }
+float emul_path_float(uint32_t seed, uint32_t iter, uint32_t path, uint32_t kind, uint32_t k)
+{
+    PathRng r; rng_init(r, seed, iter, path, kind);
+    float f = 0;
+    for (uint32_t i = 0; i <= k; i++) f = rng_float(r);
+    return f;
+}
+int emul_scene_cornell(int resX, int resY, unsigned mask, vcm_scene_desc *out);
+
+} // extern "C"

@@ -1,0 +1,60 @@
+"""The C-ABI library loads (without a GPU) and exports every symbol that
+include/smallvcm_amd.h declares; PODs have the sizes the ctypes mirror assumes."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from smallvcm_amd import _abi
+from smallvcm_amd.renderer import LIB_PATH, load_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "smallvcm_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vcm_[a-z_]+)\s*\(", src)))
+
+
+def test_library_is_built():
+    assert os.path.exists(LIB_PATH), "run __graft_entry__.build() first"
+
+
+def test_exports_every_declared_symbol():
+    L = load_library(require_gpu=False)
+    names = _declared_symbols()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_pod_sizes_match_ctypes_mirror():
+    L = load_library(require_gpu=False)
+    assert L.vcm_sizeof_scene_desc() == C.sizeof(_abi.SceneDesc)
+    assert L.vcm_sizeof_stats() == C.sizeof(_abi.Stats)
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must refuse to create a renderer."""
+    L = load_library(require_gpu=False)
+    if L.vcm_device_count() > 0:
+        pytest.skip("GPU present")
+    from smallvcm_amd.renderer import VertexCM, cornell_scene
+    sc = cornell_scene(1, 16, 16)
+    with pytest.raises(RuntimeError):
+        VertexCM(sc, VertexCM.kVcm, 0.003, 0.75)
+
+
+def test_product_does_not_reference_oracle():
+    """Nothing under smallvcm_amd/ (the shipped path) may include, import or link oracle/."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "smallvcm_amd")):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hxx", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                for line in txt.splitlines():
+                    if re.search(r"#\s*include.*oracle|import\s+oracle|from\s+oracle|liboracle|oracle_lib", line):
+                        bad.append((f, line.strip()))
+    assert not bad, bad
