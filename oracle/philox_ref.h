@@ -14,8 +14,8 @@
  *                                             RunIteration calls made so far
  *                                             on this renderer
  *   counter = (pathIndex, kind, block, 0)     kind 0 = light path, 1 = camera
- *   float k of a path = word (k & 3) of block (k >> 2), mapped to [0,1) as
- *                       (word >> 8) * 2^-24
+ *   float k of a path = word (k & 3) of block (k >> 2), mapped to the OPEN
+ *                       interval (0,1) as (2*(word >> 9) + 1) * 2^-24
  * The reference draws floats in a fixed order inside a path
  * (vertexcm.hxx:822-824, :576, :672-673, :944, :964); this keeps that order
  * and makes paths independent of each other.
@@ -44,7 +44,12 @@ static inline void philox4x32_10_ref(const uint32_t ctr[4], const uint32_t key[2
 
 static inline float philox_u32_to_float_ref(uint32_t w)
 {
-    return (float)(w >> 8) * (1.0f / 16777216.0f);
+    /* open interval: (2k+1) * 2^-24, k = top 23 bits -> [2^-24, 1-2^-24], every value
+       exact in binary32.  Exact 0 or 1 must not occur: the reference's own generators
+       never produce them (rng.hxx:141 is (0,1]; generate_canonical hits 0 with
+       probability 2^-64), and u = 0 makes AreaLight::Emit return emissionPdfW = 0
+       (lights.hxx:178-186), i.e. an infinite path throughput and NaN pixels. */
+    return (float)(((w >> 9) << 1) | 1u) * (1.0f / 16777216.0f);
 }
 
 /* Sequential view of one path's stream. */

@@ -5,7 +5,7 @@
 //   key     = (seed, localIteration)       localIteration = RunIteration calls
 //                                          made so far on this renderer
 //   counter = (pathIndex, kind, block, 0)  kind 0 = light sub-path, 1 = camera
-//   float k of a path = word (k&3) of block (k>>2), (word >> 8) * 2^-24 in [0,1)
+//   float k of a path = word (k&3) of block (k>>2), (2*(word >> 9) + 1) * 2^-24 in (0,1)
 // Draw order inside a path is the reference's (vertexcm.hxx:822-824, :576,
 // :672-673, :944, :964).  One lane owns one path: 4 words are generated per
 // 10-round call and kept in registers, so a path costs <= 18 Philox calls.
@@ -60,7 +60,9 @@ VCM_HD float rng_float(PathRng &r)
     if (i == 0u) philox4x32_10(r.path, r.kind, r.k >> 2, 0u, r.key0, r.key1, r.b0, r.b1, r.b2, r.b3);
     const uint32_t w = (i == 0u) ? r.b0 : (i == 1u) ? r.b1 : (i == 2u) ? r.b2 : r.b3;
     r.k++;
-    return (float)(w >> 8) * (1.0f / 16777216.0f);
+    /* open interval (0,1): (2k+1) * 2^-24 with k = top 23 bits; exact 0 would make
+       AreaLight::Emit return a zero pdf (lights.hxx:178-186) -> inf throughput -> NaN */
+    return (float)(((w >> 9) << 1) | 1u) * (1.0f / 16777216.0f);
 }
 
 } // namespace vcm

@@ -31,7 +31,7 @@ def test_path_stream_product_equals_oracle():
         for k in range(0, 40):
             a = L.oracle_path_float(seed, it, path, kind, k)
             b = E.emul_path_float(seed, it, path, kind, k)
-            assert a == b and 0.0 <= a < 1.0
+            assert a == b and 0.0 < a < 1.0
 
 
 def test_stream_is_uniform():
