@@ -85,6 +85,19 @@ VCM_HD float dm_powf(float xf, float yf)
     if (xf == 1.0f) return 1.0f;
 
     const double x = (double)xf;
+    /* small positive integer exponent (the Phong exponent, 90 in the built-in
+       scenes): binary exponentiation in binary64, least-significant bit first */
+    if (yf >= 1.0f && yf <= 256.0f && yf == floorf(yf)) {
+        unsigned n = (unsigned)yf;
+        double b = x, r = 1.0;
+        for (;;) {
+            if (n & 1u) r = r * b;
+            n >>= 1;
+            if (n == 0u) break;
+            b = b * b;
+        }
+        return (float)r;
+    }
     const uint64_t bits = d2bits(x);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     double m = bits2d((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);

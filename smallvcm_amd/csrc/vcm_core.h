@@ -874,18 +874,61 @@ VCM_HD void merge_photon(const vcm_scene_desc &sc, const IterParams &P, const Bs
     contrib = contrib + misWeight * cameraBsdfFactor * lvThroughput;
 }
 
+/* wave-level "any lane" (one lane on the host build) */
+VCM_HD bool wave_any(bool x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(x);
+#else
+    return x;
+#endif
+}
+
+/* Per-lane queue of accepted photon indices, in LDS on the device:
+ * entry k of this lane is q[k * stride]. */
+#define VCM_MERGE_Q 16
+#define VCM_MERGE_UNROLL 4
+struct MergeScratch { uint32_t *q; int stride; };
+
+VCM_HD void merge_drain(const vcm_scene_desc &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
+                        const SubPathState &st, const MergeScratch &ms, int qn, V3 &contrib)
+{
+    for (int k = 0; k < VCM_MERGE_Q; k++) {
+        if (!wave_any(k < qn)) break;
+        if (k < qn) {
+            const uint32_t idx = ms.q[k * ms.stride];
+            const float lenBits = g.g0[idx].w;
+            const F4 b = g.g1[idx];
+            const F4 c = g.g2[idx];
+            const float dVM = g.g3[idx];
+            merge_photon(sc, P, cameraBsdf, st, f2u(lenBits), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM,
+                         contrib);
+        }
+    }
+}
+
 /* HashGrid::Process hashgrid.hxx:110-169: the 8 hashed cells toward the
- * nearer faces, in the reference's order (duplicates included, :142-155) */
+ * nearer faces, in the reference's order (duplicates included, :142-155).
+ *
+ * GPU shape: the cheap part (distance test, :162-165) and the expensive part
+ * (RangeQuery::Process, a BSDF evaluation) are separated.  All lanes of the
+ * wave walk the 8 cells in lockstep, each testing up to 4 candidates of ITS
+ * cell range per step with the 4 loads in flight together (the vertices of a
+ * cell are contiguous: cell-sorted SoA); accepted indices go to a per-lane
+ * LDS queue.  When some lane's queue is nearly full the whole wave drains:
+ * every lane evaluates its queued photons, so the evaluation runs with most
+ * lanes active instead of the ~18 % that accept at any one candidate.  Each
+ * lane still processes ITS photons in the reference's order, so the sum
+ * (:168) is bit-identical. */
 VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
-                      const SubPathState &st, V3 queryPos, LaneStats &ls)
+                      const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms)
 {
     V3 contrib = sp3(0.f);
     const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
     const V3 distMin = queryPos - bmin;
     const V3 distMax = bmax - queryPos;
-    if (distMin.x < 0.f || distMax.x < 0.f) return contrib;
-    if (distMin.y < 0.f || distMax.y < 0.f) return contrib;
-    if (distMin.z < 0.f || distMax.z < 0.f) return contrib;
+    const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
+                          distMin.z < 0.f || distMax.z < 0.f);   /* :116-122 */
     const V3 cellPt = P.invCellSize * distMin;
     const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
     const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
@@ -893,27 +936,51 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
     const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
     const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
     const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+    int qn = 0;
     for (int j = 0; j < 8; j++) {
-        const int cx = (j & 4) ? pxo : px;
-        const int cy = (j & 2) ? pyo : py;
-        const int cz = (j & 1) ? pzo : pz;
-        const int cell = grid_cell_hash(cx, cy, cz, P.nCells);
-        int lo = g.cellStart[cell];
-        const int hi = g.cellStart[cell + 1];
-        for (; lo < hi; lo++) {
-            const F4 a = g.g0[lo];
-            const float distSqr = lensqr(queryPos - mk3(a.x, a.y, a.z));
-            ls.mergeCandidates++;
-            if (distSqr <= P.radiusSqr) {
-                ls.mergeAccepted++;
-                const F4 b = g.g1[lo];
-                const F4 c = g.g2[lo];
-                const float dVM = g.g3[lo];
-                merge_photon(sc, P, cameraBsdf, st, f2u(a.w), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM,
-                             contrib);
+        int lo = 0, hi = 0;
+        if (inside) {
+            const int cx = (j & 4) ? pxo : px;
+            const int cy = (j & 2) ? pyo : py;
+            const int cz = (j & 1) ? pzo : pz;
+            const int cell = grid_cell_hash(cx, cy, cz, P.nCells);
+            lo = g.cellStart[cell];
+            hi = g.cellStart[cell + 1];
+        }
+        while (wave_any(lo < hi)) {
+            F4 a[VCM_MERGE_UNROLL];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int u = 0; u < VCM_MERGE_UNROLL; u++) {   /* 4 independent loads in flight */
+                int ci = lo + u;
+                ci = (ci < hi) ? ci : hi - 1;
+                ci = (ci < 0) ? 0 : ci;
+                a[u] = g.g0[ci];
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
+                const int idx = lo + u;
+                if (idx < hi) {
+                    const float distSqr = lensqr(queryPos - mk3(a[u].x, a[u].y, a[u].z));
+                    ls.mergeCandidates++;
+                    if (distSqr <= P.radiusSqr) {   /* :165 */
+                        ms.q[qn * ms.stride] = (uint32_t)idx;
+                        qn++;
+                        ls.mergeAccepted++;
+                    }
+                }
+            }
+            lo = (lo + VCM_MERGE_UNROLL < hi) ? lo + VCM_MERGE_UNROLL : hi;
+            if (wave_any(qn > VCM_MERGE_Q - VCM_MERGE_UNROLL)) {
+                merge_drain(sc, P, g, cameraBsdf, st, ms, qn, contrib);
+                qn = 0;
             }
         }
     }
+    merge_drain(sc, P, g, cameraBsdf, st, ms, qn, contrib);
     return contrib;
 }
 
@@ -960,7 +1027,7 @@ VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, Cam
 
 /* one iteration of the for(;;) at :423-542; returns false when the path ends */
 VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
-                             const GridStore &grid, LaneStats &ls)
+                             const GridStore &grid, LaneStats &ls, const MergeScratch &ms)
 {
     SubPathState &st = cp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
@@ -1015,7 +1082,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
     }
     if (!bsdf.isDelta && P.useVM) {   /* :530-538 */
         ls.mergeQueries++;
-        const V3 contrib = merge_query(sc, P, grid, bsdf, st, hitPoint, ls);
+        const V3 contrib = merge_query(sc, P, grid, bsdf, st, hitPoint, ls, ms);
         cp.color = cp.color + st.throughput * P.vmNormalization * contrib;
         if (P.ppm) return false;
     }

@@ -96,6 +96,8 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     int next = wave * chunk;
     const int end = min(P.nLocal, next + chunk);
     LaneStats ls; lane_stats_zero(ls);
+    __shared__ uint32_t accQ[VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
+    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_TRACE_BLOCK;
     CameraPath path;
     bool alive = false;
     for (;;) {
@@ -107,7 +109,7 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
         next += __popcll(need);
         if (!__any(alive)) break;
         if (alive) {
-            alive = camera_path_step(sc, P, path, store, grid, ls);
+            alive = camera_path_step(sc, P, path, store, grid, ls, ms);
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));

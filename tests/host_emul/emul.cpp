@@ -145,8 +145,10 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
         e.camOut.assign((size_t)e.nLocal, mk4(0, 0, 0, 0));
         for (int lp = 0; lp < e.nLocal; lp++) {
             CameraPath path;
+            uint32_t q[VCM_MERGE_Q];
+            MergeScratch ms; ms.q = q; ms.stride = 1;
             camera_path_begin(e.sc, P, path, lp);
-            while (camera_path_step(e.sc, P, path, store, grid, e.ls)) {}
+            while (camera_path_step(e.sc, P, path, store, grid, e.ls, ms)) {}
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;
         }
