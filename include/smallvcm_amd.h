@@ -132,6 +132,7 @@ typedef struct vcm_stats {
     long long lightSplats;     /* S: Framebuffer::AddColor from light paths   */
     float msLight, msGrid, msCamera, msTotal; /* phases: light(+compaction), grid build, camera(+resolve) */
     float msLightKernel, msCameraKernel;      /* k_light_trace / k_camera_trace alone        */
+    float msMergeKernel;                      /* k_merge_wave (0 in strict-order mode)       */
     float radius;              /* merge radius of the iteration               */
 } vcm_stats;
 
@@ -160,6 +161,16 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm,
                             int device, int rank, int worldSize);
 
 void vcm_destroy(vcm_ctx *ctx);
+
+/* Summation-order mode.  0 (default): merge queries are deferred to a
+ * wave-per-query kernel; every control-flow decision, the random-number tape,
+ * the light-vertex records and the hash grid are bit-identical to the
+ * reference, the per-pixel colour differs from it only by the fp32 rounding of
+ * a different (fixed, deterministic) summation order.  1: the merge runs
+ * inside the camera path in the reference's order of additions (slower);
+ * algorithms without light splats are then bit-exact end to end.
+ * The environment variable SMALLVCM_AMD_STRICT_ORDER=1 sets the default. */
+int vcm_set_strict_order(vcm_ctx *ctx, int on);
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all
  * work of this context; NULL = the context's own stream. */

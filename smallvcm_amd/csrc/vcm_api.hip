@@ -28,7 +28,7 @@ static int fail(const char *what, const char *detail)
         if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));        \
     } while (0)
 
-enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_CAMERA, EV_COUNT };
+enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
 
 struct vcm_ctx {
     vcm_scene_desc scene;
@@ -59,6 +59,11 @@ struct vcm_ctx {
     F4 *dG0, *dG1, *dG2; float *dG3;
     int *dSortedIndex;                /* debug/parity: grid position -> record index */
     F4 *dCamOut;                      /* nLocal */
+    uint32_t *dCamMask;               /* nLocal: path lengths at which a merge query was queued */
+    QueryStore qs;                    /* maxLen*nLocal queries */
+    F4 *dMergeOut;                    /* maxLen*nLocal slots (pathLength, path) */
+    int allocL;
+    bool strictOrder;
     unsigned long long *dStats;
 
     IterParams P;
@@ -85,10 +90,11 @@ static void free_iteration_buffers(vcm_ctx *c)
     DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll);
     DFREE(c->dCellId); DFREE(c->dUnsorted);
     DFREE(c->dG0); DFREE(c->dG1); DFREE(c->dG2); DFREE(c->dG3); DFREE(c->dSortedIndex);
-    c->allocS = 0;
+    DFREE(c->qs.q0); DFREE(c->qs.q1); DFREE(c->qs.q2); DFREE(c->qs.q3); DFREE(c->dMergeOut);
+    c->allocS = 0; c->allocL = 0;
 }
 
-static int ensure_device(vcm_ctx *c, int S)
+static int ensure_device(vcm_ctx *c, int S, int L = 0)
 {
     if (use_device(c)) return -1;
     if (!c->deviceReady) {
@@ -113,10 +119,12 @@ static int ensure_device(vcm_ctx *c, int S)
         if (dalloc(&c->dCellStart, (size_t)c->N + 1)) return -1;
         if (dalloc(&c->dCellFill, (size_t)c->N + 1)) return -1;
         if (dalloc(&c->dCamOut, (size_t)c->nLocal)) return -1;
+        if (dalloc(&c->dCamMask, (size_t)c->nLocal)) return -1;
+        if (dalloc(&c->qs.count, 1)) return -1;
         if (dalloc(&c->dStats, STAT_COUNT)) return -1;
         c->deviceReady = true;
     }
-    if (S > 0 && c->allocS != S) {
+    if (S > 0 && (c->allocS != S || c->allocL != L)) {
         HIPCHK(hipStreamSynchronize(c->stream));
         free_iteration_buffers(c);
         const size_t slots = (size_t)S * (size_t)c->nLocal;
@@ -128,7 +136,10 @@ static int ensure_device(vcm_ctx *c, int S)
         if (dalloc(&c->dCellId, allRecs) || dalloc(&c->dUnsorted, allRecs)) return -1;
         if (dalloc(&c->dG0, allRecs) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
             dalloc(&c->dG3, allRecs) || dalloc(&c->dSortedIndex, allRecs)) return -1;
-        c->allocS = S;
+        const size_t qslots = (size_t)(L > 0 ? L : 1) * (size_t)c->nLocal;
+        if (c->useVM && (dalloc(&c->qs.q0, qslots) || dalloc(&c->qs.q1, qslots) || dalloc(&c->qs.q2, qslots) ||
+                         dalloc(&c->qs.q3, qslots) || dalloc(&c->dMergeOut, qslots))) return -1;
+        c->allocS = S; c->allocL = L;
     }
     return 0;
 }
@@ -219,6 +230,8 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     c->p0 = (int)((long long)c->N * rank / worldSize);
     c->nLocal = (int)((long long)c->N * (rank + 1) / worldSize) - c->p0;
     c->ownStream = true;
+    const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
+    c->strictOrder = (so && so[0] == '1');
     return c;
 }
 
@@ -239,10 +252,19 @@ void vcm_destroy(vcm_ctx *c)
         DFREE(c->dScene); DFREE(c->dFb); DFREE(c->store.count); DFREE(c->dRngLight); DFREE(c->dRngCam);
         DFREE(c->dPathStart); DFREE(c->dLocalTotal); DFREE(c->dTileSums); DFREE(c->dHdr);
         DFREE(c->dCellCount); DFREE(c->dCellStart); DFREE(c->dCellFill); DFREE(c->dCamOut); DFREE(c->dStats);
+        DFREE(c->dCamMask); DFREE(c->qs.count);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
+}
+
+int vcm_set_strict_order(vcm_ctx *c, int on)
+{
+    if (!c) return fail("vcm_set_strict_order", "ctx is NULL");
+    if (c->inIteration) return fail("vcm_set_strict_order", "iteration in progress");
+    c->strictOrder = on != 0;
+    return 0;
 }
 
 int vcm_set_stream(vcm_ctx *c, void *hipStream)
@@ -265,7 +287,8 @@ int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned max
     if (c->inIteration) return fail("vcm_begin_iteration", "previous iteration not ended");
     if (maxLen > 255) return fail("vcm_begin_iteration", "maxPathLength > 255 unsupported (8-bit vertex counts)");
     const int S = (maxLen >= 2) ? (int)maxLen - 1 : 1;
-    if (ensure_device(c, S)) return -1;
+    const int L = (maxLen >= 1) ? (int)maxLen : 1;
+    if (ensure_device(c, S, L)) return -1;
 
     IterParams &P = c->P;
     memset(&P, 0, sizeof(P));
@@ -288,10 +311,12 @@ int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned max
     P.cellSize = radius * 2.f;                                                /* hashgrid.hxx:47 */
     P.invCellSize = 1.f / P.cellSize;                                         /* :48 */
     P.nCells = c->N;                                                          /* vertexcm.hxx:406 */
+    P.deferMerge = (c->useVM && !c->strictOrder && maxLen <= 31) ? 1 : 0;
 
     HIPCHK(hipEventRecord(c->ev[EV_START], c->stream));
     HIPCHK(hipMemsetAsync(c->dStats, 0, STAT_COUNT * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
+    HIPCHK(hipMemsetAsync(c->qs.count, 0, sizeof(int), c->stream));
     c->importedRecords = false;
     c->inIteration = true;
     c->evValid = false;
@@ -413,10 +438,21 @@ int vcm_trace_camera(vcm_ctx *c)
         GridStore grid;
         grid.cellStart = c->dCellStart; grid.g0 = c->dG0; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
         grid.hdr = c->dHdr;
-        hipLaunchKernelGGL(k_camera_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                           grid, c->dCamOut, c->dRngCam, c->dStats, chunk);
-        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
-        hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut, c->dFb);
+        if (c->P.deferMerge) {
+            hipLaunchKernelGGL(k_camera_trace<true>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+                               c->store, grid, c->qs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+            HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+            hipLaunchKernelGGL(k_merge_wave, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid,
+                               c->qs, c->dMergeOut, c->dStats);
+            HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
+        } else {
+            hipLaunchKernelGGL(k_camera_trace<false>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+                               c->store, grid, c->qs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+            HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+            HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
+        }
+        hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
+                           (const uint32_t *)c->dCamMask, (const F4 *)c->dMergeOut, c->dFb);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[EV_CAMERA], c->stream));
@@ -513,6 +549,8 @@ int vcm_get_stats(vcm_ctx *c, vcm_stats *out)
         if (hipEventElapsedTime(&ms, c->ev[EV_LIGHT_K0], c->ev[EV_LIGHT_K1]) == hipSuccess) out->msLightKernel = ms;
         if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_GRID], c->ev[EV_CAMERA_K1]) == hipSuccess)
             out->msCameraKernel = ms;
+        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_MERGE_K1]) == hipSuccess)
+            out->msMergeKernel = ms;
     }
     c->lastStats = *out;
     return 0;

@@ -34,6 +34,7 @@ struct IterParams {
     float lightSubPathCount;
     float cellSize, invCellSize;   /* hashgrid.hxx:47-48 */
     int   nCells;                  /* = N (vertexcm.hxx:406) */
+    int   deferMerge;              /* 1: camera pass emits merge queries for k_merge_wave */
 };
 
 /* device-resident hash-grid header: bbox is reduced on the device */
@@ -67,6 +68,16 @@ struct GridStore {
     const F4 *g2;           /* throughput.xyz | dVCM */
     const float *g3;        /* dVM */
     const GridHeader *hdr;
+};
+
+/* Merge queries emitted by the camera pass (deferred mode): everything
+ * RangeQuery (vertexcm.hxx:109-178) needs from the camera vertex, 64 B. */
+struct QueryStore {
+    F4 *q0;      /* hitpoint.xyz | local path index                    */
+    F4 *q1;      /* isect.normal.xyz | pathLength (bits 0-7), matID (8-15) */
+    F4 *q2;      /* localDirFix.xyz | dVCM                              */
+    F4 *q3;      /* throughput.xyz | dVM                                */
+    int *count;  /* number of queries appended                          */
 };
 
 struct LaneStats {
@@ -990,7 +1001,19 @@ struct CameraPath {
     V3 color;
     int lp;
     float sx, sy;    /* the jittered screen sample (:576) */
+    uint32_t queryMask;   /* deferred mode: bit L set = a merge query was emitted at path length L */
 };
+
+/* append slot in the query queue; hipcc aggregates the per-lane atomic into
+ * one atomic per wave (ballot + prefix popcount, i.e. v_mbcnt) */
+VCM_HD int queue_slot(int *counter)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(counter, 1);
+#else
+    return (*counter)++;
+#endif
+}
 
 /* GenerateCameraSample :564-606 (+ Camera::GenerateRay camera.hxx:108-117) */
 VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, int localPath)
@@ -999,6 +1022,7 @@ VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, Cam
     const int pathIdx = P.p0 + localPath;
     cp.lp = localPath;
     cp.color = sp3(0.f);
+    cp.queryMask = 0u;
     rng_init(cp.rng, P.seed, P.localIter, (uint32_t)pathIdx, 1u);
     const int x = pathIdx % P.resX;
     const int y = pathIdx / P.resX;
@@ -1026,8 +1050,9 @@ VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, Cam
 }
 
 /* one iteration of the for(;;) at :423-542; returns false when the path ends */
+template <bool DEFER>
 VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
-                             const GridStore &grid, LaneStats &ls, const MergeScratch &ms)
+                             const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const QueryStore &qs)
 {
     SubPathState &st = cp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
@@ -1082,8 +1107,21 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
     }
     if (!bsdf.isDelta && P.useVM) {   /* :530-538 */
         ls.mergeQueries++;
-        const V3 contrib = merge_query(sc, P, grid, bsdf, st, hitPoint, ls, ms);
-        cp.color = cp.color + st.throughput * P.vmNormalization * contrib;
+        if (DEFER) {
+            /* the merge only adds to the colour (never steers the path), so it
+               can run later in k_merge_wave; its result comes back through the
+               slot (pathLength, path) and is added by k_resolve */
+            const int qi = queue_slot(qs.count);
+            qs.q0[qi] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
+            qs.q1[qi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z,
+                            u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
+            qs.q2[qi] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
+            qs.q3[qi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
+            cp.queryMask |= 1u << st.pathLength;
+        } else {
+            const V3 contrib = merge_query(sc, P, grid, bsdf, st, hitPoint, ls, ms);
+            cp.color = cp.color + st.throughput * P.vmNormalization * contrib;
+        }
         if (P.ppm) return false;
     }
     if (!sample_scattering(sc, P, false, cp.rng, bsdf, hitPoint, st)) return false;

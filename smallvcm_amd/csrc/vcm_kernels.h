@@ -5,7 +5,8 @@
 //   K2  k_bbox / k_cell_count / scan / k_cell_scatter / k_cell_rank_gather
 //                         hash-grid build with vertices SORTED BY CELL
 //   K3  k_camera_trace    camera sub-paths: emission, direct illumination,
-//                         vertex connection, range-merge, scattering
+//                         vertex connection, scattering; merge queries queued
+//   K4  k_merge_wave      range-merge of the queued queries, one wave per query
 //   K5  k_resolve         Framebuffer::AddColor of the camera colours
 //
 // Execution model: one lane per sub-path.  K1/K3 are persistent: each wave
@@ -86,9 +87,14 @@ k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore s
 }
 
 /* ---------------- K3: camera sub-paths (vertexcm.hxx:415-545) ----------- */
+/* DEFER = false: the merge runs inside the path (reference order of every
+ *                floating-point addition; "strict" mode);
+ * DEFER = true : the path appends a 64-byte query and k_merge_wave does the
+ *                range search afterwards (default). */
+template <bool DEFER>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
-k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, GridStore grid,
-               F4 *camOut, unsigned char *rngCount, unsigned long long *gstats, int chunk)
+k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, GridStore grid, QueryStore qs,
+               F4 *camOut, uint32_t *camMask, unsigned char *rngCount, unsigned long long *gstats, int chunk)
 {
     const vcm_scene_desc &sc = *scp;
     const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
@@ -96,8 +102,8 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     int next = wave * chunk;
     const int end = min(P.nLocal, next + chunk);
     LaneStats ls; lane_stats_zero(ls);
-    __shared__ uint32_t accQ[VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
-    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_TRACE_BLOCK;
+    __shared__ uint32_t accQ[DEFER ? 1 : VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
+    MergeScratch ms; ms.q = accQ + (DEFER ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK;
     CameraPath path;
     bool alive = false;
     for (;;) {
@@ -109,10 +115,11 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
         next += __popcll(need);
         if (!__any(alive)) break;
         if (alive) {
-            alive = camera_path_step(sc, P, path, store, grid, ls, ms);
+            alive = camera_path_step<DEFER>(sc, P, path, store, grid, ls, ms, qs);
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
+                if (DEFER) camMask[path.lp] = path.queryMask;
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
         }
@@ -120,11 +127,111 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     flush_stats(ls, gstats);
 }
 
+/* ---------------- K4: range-merge, one WAVE per query -------------------- */
+/* HashGrid::Process + RangeQuery::Process (hashgrid.hxx:110-169,
+ * vertexcm.hxx:130-169) for the queries the camera pass queued.
+ *
+ * The query is wave-uniform: its 8 hashed cell ranges are found once, their
+ * concatenation (the reference's visiting order, duplicates included) is
+ * strided over by the 64 lanes, so candidate positions are read as
+ * contiguous 16-byte elements of the cell-sorted array and every lane runs
+ * the same number of steps.  Each lane sums the photons it accepted (in index
+ * order), the 64 partial sums are combined by an xor-butterfly (a fixed
+ * order: results are deterministic, but not the reference's left-to-right
+ * order), and lane 0 stores  throughput * vmNormalization * contrib
+ * (vertexcm.hxx:534) into the slot (pathLength, path). */
+#define VCM_MERGE_BLOCK 256
+__global__ void __launch_bounds__(VCM_MERGE_BLOCK)
+k_merge_wave(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, QueryStore qs, F4 *mergeOut,
+             unsigned long long *gstats)
+{
+    const vcm_scene_desc &sc = *scp;
+    const int nQ = *qs.count;
+    const int nWaves = gridDim.x * (VCM_MERGE_BLOCK / VCM_WAVE);
+    const int wave = (blockIdx.x * VCM_MERGE_BLOCK + threadIdx.x) / VCM_WAVE;
+    const int lane = (int)lane_id();
+    const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
+    uint32_t nCand = 0, nAcc = 0;
+    for (int q0 = wave; q0 < nQ; q0 += nWaves) {
+        const int q = __builtin_amdgcn_readfirstlane(q0);
+        const F4 r0 = qs.q0[q], r1 = qs.q1[q], r2 = qs.q2[q], r3 = qs.q3[q];
+        const V3 queryPos = mk3(r0.x, r0.y, r0.z);
+        const uint32_t lp = f2u(r0.w);
+        const uint32_t pathLength = f2u(r1.w) & 0xffu;
+        Bsdf bsdf;
+        bsdf_restore(bsdf, mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z), (int)((f2u(r1.w) >> 8) & 0xffu), sc);
+        SubPathState st;   /* only the fields RangeQuery::Process reads */
+        st.pathLength = pathLength; st.dVCM = r2.w; st.dVM = r3.w;
+        const V3 throughput = mk3(r3.x, r3.y, r3.z);
+
+        /* hashgrid.hxx:116-155 */
+        const V3 distMin = queryPos - bmin;
+        const V3 distMax = bmax - queryPos;
+        const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
+                              distMin.z < 0.f || distMax.z < 0.f);
+        const V3 cellPt = P.invCellSize * distMin;
+        const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+        const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
+        const V3 fractCoord = cellPt - coordF;
+        const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+        const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+        const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+        int lo[8], cum[9];
+        cum[0] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
+            int a = 0, b = 0;
+            if (inside) { a = g.cellStart[cell]; b = g.cellStart[cell + 1]; }
+            lo[j] = __builtin_amdgcn_readfirstlane(a);
+            cum[j + 1] = cum[j] + __builtin_amdgcn_readfirstlane(b - a);
+        }
+        const int total = cum[8];
+        V3 part = sp3(0.f);
+        for (int base = 0; base < total; base += VCM_WAVE) {
+            const int i = base + lane;
+            if (i < total) {
+                int idx = lo[7] + (i - cum[7]);
+#pragma unroll
+                for (int j = 6; j >= 0; j--) idx = (i < cum[j + 1]) ? lo[j] + (i - cum[j]) : idx;
+                const F4 a = g.g0[idx];
+                const float distSqr = lensqr(queryPos - mk3(a.x, a.y, a.z));
+                nCand++;
+                if (distSqr <= P.radiusSqr) {   /* :165 */
+                    nAcc++;
+                    const F4 b = g.g1[idx];
+                    const F4 c = g.g2[idx];
+                    const float dVM = g.g3[idx];
+                    merge_photon(sc, P, bsdf, st, f2u(a.w), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM, part);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            part.x = part.x + __shfl_xor(part.x, o, 64);
+            part.y = part.y + __shfl_xor(part.y, o, 64);
+            part.z = part.z + __shfl_xor(part.z, o, 64);
+        }
+        if (lane == 0) {
+            const V3 v = throughput * P.vmNormalization * part;   /* :534 */
+            mergeOut[(size_t)(pathLength - 1u) * (size_t)P.nLocal + lp] = mk4(v.x, v.y, v.z, 0.f);
+        }
+    }
+    {
+        unsigned long long c = wave_sum_u32(nCand & 0xffffu) + ((unsigned long long)wave_sum_u32(nCand >> 16) << 16);
+        unsigned long long a = wave_sum_u32(nAcc & 0xffffu) + ((unsigned long long)wave_sum_u32(nAcc >> 16) << 16);
+        if (lane == 0) { if (c) atomicAdd(&gstats[STAT_MERGE_CANDIDATES], c); if (a) atomicAdd(&gstats[STAT_MERGE_ACCEPTED], a); }
+    }
+}
+
 /* ---------------- K5: Framebuffer::AddColor of camera colours ----------- */
 /* vertexcm.hxx:544 adds colour p to the pixel of its jittered sample, in path
  * order.  Pixel q can receive from paths q-resX-1, q-resX, q-1, q (ascending
- * = the reference's order); light splats of the iteration are already in. */
-__global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, float *fb)
+ * = the reference's order); light splats of the iteration are already in.
+ * Deferred mode: a path's colour = its non-merge terms (camOut) + its merge
+ * terms in increasing path length. */
+__global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, const uint32_t *__restrict__ camMask,
+                          const F4 *__restrict__ mergeOut, float *fb)
 {
     const int lastQ = min(P.N, P.p0 + P.nLocal + P.resX + 1);
     for (int q = P.p0 + blockIdx.x * blockDim.x + threadIdx.x; q < lastQ; q += gridDim.x * blockDim.x) {
@@ -137,7 +244,17 @@ __global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, float *fb
             if (lp < 0 || lp >= P.nLocal) continue;
             const F4 c = camOut[lp];
             if ((int)f2u(c.w) != q) continue;
-            r = r + c.x; g = g + c.y; b = b + c.z;
+            V3 col = mk3(c.x, c.y, c.z);
+            if (P.deferMerge) {
+                uint32_t m = camMask[lp];
+                while (m) {
+                    const int L = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const F4 t = mergeOut[(size_t)(L - 1) * (size_t)P.nLocal + lp];
+                    col = col + mk3(t.x, t.y, t.z);
+                }
+            }
+            r = r + col.x; g = g + col.y; b = b + col.z;
             touched = true;
         }
         if (touched) { fb[(size_t)q * 3 + 0] = r; fb[(size_t)q * 3 + 1] = g; fb[(size_t)q * 3 + 2] = b; }

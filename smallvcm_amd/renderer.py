@@ -49,6 +49,7 @@ def load_library(require_gpu=True):
         L.vcm_destroy.argtypes = [vp]
         L.vcm_destroy.restype = None
         L.vcm_set_stream.argtypes = [vp, vp]
+        L.vcm_set_strict_order.argtypes = [vp, C.c_int]
         L.vcm_run_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
         L.vcm_begin_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
         for n in ("vcm_trace_light", "vcm_build_grid", "vcm_trace_camera", "vcm_end_iteration", "vcm_synchronize",
@@ -140,6 +141,10 @@ class HipBackend:
             self.close()
         except Exception:
             pass
+
+    def set_strict_order(self, on):
+        """True: merges inside the camera path, reference order of additions (bit-exact, slower)."""
+        _check(self.L, self.L.vcm_set_strict_order(self.ctx, 1 if on else 0), "vcm_set_strict_order")
 
     def set_stream(self, stream_handle):
         _check(self.L, self.L.vcm_set_stream(self.ctx, stream_handle), "vcm_set_stream")
@@ -237,11 +242,13 @@ class VertexCM:
     # AlgorithmType, src/vertexcm.hxx:182-204
     kLightTrace, kPpm, kBpm, kBpt, kVcm = ALGO_LIGHT_TRACE, ALGO_PPM, ALGO_BPM, ALGO_BPT, ALGO_VCM
 
-    def __init__(self, aScene, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed=1234, device=0):
+    def __init__(self, aScene, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed=1234, device=0, strict_order=None):
         self.mScene = aScene
         self.mMaxPathLength = 2      # renderer.hxx:40
         self.mMinPathLength = 0      # renderer.hxx:39
         self.backend = HipBackend(aScene, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed, device=device)
+        if strict_order is not None:
+            self.backend.set_strict_order(strict_order)
         self.mIterations = 0
 
     def RunIteration(self, aIteration):

@@ -28,12 +28,14 @@ def _rmse(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-def _check_fb(gpu, ref, algo):
-    if algo in SPLAT_ALGOS:
-        assert np.all(np.abs(gpu - ref) <= 1e-5 * np.abs(ref) + 1e-7), float(np.abs(gpu - ref).max())
-        assert _rmse(gpu, ref) < 1e-6
-    else:
+def _check_fb(gpu, ref, algo, strict=True):
+    """strict order + no light splats: bit-exact.  Otherwise only fp32 summation
+    order differs (atomic splats; deferred merges summed by a fixed tree)."""
+    if strict and algo not in SPLAT_ALGOS:
         assert np.array_equal(gpu, ref)
+    else:
+        assert np.all(np.abs(gpu - ref) <= 2e-5 * np.abs(ref) + 2e-7), float(np.abs(gpu - ref).max())
+        assert _rmse(gpu, ref) < 1e-6
 
 
 def test_numeric_spec_on_device():
@@ -71,11 +73,12 @@ CASES = [(sid, algo, 64, 1, 0, 10) for sid in range(4) for algo in range(5)] + [
     (1, 4, 64, 1, 0, 2), (2, 3, 100, 1, 0, 10), (1, 4, 8, 1, 0, 10), (1, 2, 130, 3, 0, 5)]
 
 
+@pytest.mark.parametrize("strict", [False, True], ids=["deferred", "strict"])
 @pytest.mark.parametrize("sid,algo,res,nit,mn,mx", CASES)
-def test_hip_equals_oracle(sid, algo, res, nit, mn, mx):
+def test_hip_equals_oracle(sid, algo, res, nit, mn, mx, strict):
     sc = cornell_scene(sid, res, res)
     o = Oracle(sc, algo, threads=8)
-    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234, strict_order=strict)
     r.mMinPathLength, r.mMaxPathLength = mn, mx
     for it in range(nit):
         o.run_iteration(it, mn, mx)
@@ -96,17 +99,18 @@ def test_hip_equals_oracle(sid, algo, res, nit, mn, mx):
             assert np.array_equal(gb, bbox)
             assert cs[0] == 0 and np.array_equal(cs[1:], ce), "cell ranges"
             assert np.array_equal(sidx, idx), "in-cell order (stable counting sort)"
-    _check_fb(r.framebuffer_sum(), o.framebuffer(), algo)
+    _check_fb(r.framebuffer_sum(), o.framebuffer(), algo, strict)
     r.close()
 
 
 @pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not shipped")
 @pytest.mark.parametrize("sid,algo,res,nit", [(1, 4, 128, 2), (3, 4, 128, 1), (0, 2, 96, 1), (2, 1, 96, 2), (1, 3, 96, 1)])
-def test_hip_equals_unmodified_reference(sid, algo, res, nit):
+@pytest.mark.parametrize("strict", [False, True], ids=["deferred", "strict"])
+def test_hip_equals_unmodified_reference(sid, algo, res, nit, strict):
     """The GPU's tape replayed into the unmodified reference build."""
     mask = SCENE_CONFIGS[sid]
     sc = cornell_scene(sid, res, res)
-    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234, strict_order=strict)
     r.mMaxPathLength = 10
     lcs, ccs = [], []
     for it in range(nit):
@@ -116,7 +120,7 @@ def test_hip_equals_unmodified_reference(sid, algo, res, nit):
         ccs.append(b)
     fb, consumed, bad = oracle_lib.ref_run_tape(mask, res, res, algo, np.concatenate(lcs), np.concatenate(ccs), n_iter=nit)
     assert bad == 0, "reference consumed a different number of random floats than the GPU"
-    _check_fb(r.framebuffer_sum(), fb, algo)
+    _check_fb(r.framebuffer_sum(), fb, algo, strict)
     r.close()
 
 
@@ -124,7 +128,7 @@ def test_determinism_and_linearity():
     """bpm: two runs bit-identical; framebuffer after 2 iterations == sum of the
     two single-iteration images accumulated in order."""
     sc = cornell_scene(1, 128, 128)
-    a = VertexCM(sc, 2, 0.003, 0.75, 7)
+    a = VertexCM(sc, 2, 0.003, 0.75, 7)      # default (deferred) mode is deterministic too
     b = VertexCM(sc, 2, 0.003, 0.75, 7)
     a.mMaxPathLength = b.mMaxPathLength = 10
     a.RunIteration(0)
