@@ -15,10 +15,10 @@ iteration and the framebuffers are summed once at the end.  Total work is
 fixed as N grows ("strong" scaling).
 
 The JSON line also carries
-  roofline      for the dominant kernel k_camera_trace: algorithmic bytes of
-                its merge / connect / framebuffer traffic (SURVEY.md section 8(d)
-                formula with the run's own counters) / its mean HIP-event time
-                / 8 TB/s;
+  roofline      for the kernel with the largest mean HIP-event time: its share of
+                the algorithmic bytes (SURVEY.md section 8(d) formula, split per
+                kernel in DESIGN.md, evaluated with the run's own counters)
+                / its time / 8 TB/s; per-kernel and whole-iteration figures too;
   cpu_baseline  the oracle port (oracle/vcm_oracle.cpp, OpenMP over paths, all
                 host cores) on a bounded sample of the same workload; rank 0,
                 N=1 only.
@@ -39,10 +39,11 @@ def algorithmic_bytes(st, n_paths, n_cells):
     """SURVEY.md section 8(d).  Returns (whole iteration, camera kernel share)."""
     nlv, A, Cc, K, S = st["lightVertices"], st["mergeAccepted"], st["mergeCandidates"], st["connections"], st["lightSplats"]
     gridv = st["gridVertices"]
-    light = 68 * nlv + 24 * S
-    grid = 20 * gridv + 8 * n_cells
-    camera = 52 * A + 16 * (Cc - A) + 68 * K + 24 * n_paths
-    return light + grid + camera, camera
+    parts = {"light": 68 * nlv + 24 * S,                 # vertex store + splat RMW
+             "grid": 20 * gridv + 8 * n_cells,           # position read, index write, histogram + scan
+             "camera": 68 * K + 24 * n_paths,            # one LightVertex per connection + framebuffer RMW
+             "merge": 52 * A + 16 * (Cc - A)}            # accepted photons 52 B, rejected candidates 16 B
+    return sum(parts.values()), parts
 
 
 def cpu_baseline(res, budget_rows=8):
@@ -123,7 +124,7 @@ def main():
         it += 1
     sync()
     t0 = time.perf_counter()
-    cam_ms, light_ms, total_ms = [], [], []
+    cam_ms, light_ms, total_ms, merge_ms, sort_ms = [], [], [], [], []
     st = None
     for _ in range(args.steps):
         r.RunIteration(it)
@@ -141,6 +142,8 @@ def main():
         it += 1
         st = backend.stats()
         cam_ms.append(st["msCameraKernel"])
+        merge_ms.append(st["msMergeKernel"])
+        sort_ms.append(st["msQuerySort"])
         light_ms.append(st["msLightKernel"])
         total_ms.append(st["msTotal"])
 
@@ -148,9 +151,15 @@ def main():
 
     if rank == 0:
         value = 2.0 * n_paths * args.steps / elapsed / 1e6
-        b_iter, b_cam = algorithmic_bytes(st, backend.count, n_paths)
-        cam_s = sum(cam_ms) / len(cam_ms) / 1e3
-        achieved = b_cam / cam_s / 1e9 if cam_s > 0 else 0.0
+        b_iter, b_parts = algorithmic_bytes(st, backend.count, n_paths)
+        mean = lambda v: sum(v) / len(v)
+        kernels = {"k_light_trace": (mean(light_ms), b_parts["light"]),
+                   "k_camera_trace": (mean(cam_ms), b_parts["camera"]),
+                   "k_merge_lane": (mean(merge_ms), b_parts["merge"])}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dom_s, dom_b = kernels[dom][0] / 1e3, kernels[dom][1]
+        achieved = dom_b / dom_s / 1e9 if dom_s > 0 else 0.0
+        iter_s = mean(total_ms) / 1e3
         out = {
             "metric": "Mpaths/sec (light+camera), VCM scene 1 at 2048^2",
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,12 +169,19 @@ def main():
                                    "seed 1234, iterations %d..%d timed" % (args.scene, args.algo, res, res, args.warmup,
                                                                            args.warmup + args.steps - 1),
                        "paths_per_step": 2 * n_paths, "parallelism": "path-index shards x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_camera_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(b_cam), "kernel_ms": round(cam_s * 1e3, 3),
+                         "algorithmic_bytes_per_launch": int(dom_b), "kernel_ms": round(dom_s * 1e3, 3),
                          "iteration_algorithmic_bytes": int(b_iter),
-                         "iteration_ms": round(sum(total_ms) / len(total_ms), 3),
+                         "iteration_ms": round(iter_s * 1e3, 3),
+                         "iteration_achieved_GBs": round(b_iter / iter_s / 1e9, 2),
+                         "iteration_frac": round(b_iter / iter_s / 1e9 / HBM_PEAK_GBS, 5),
+                         "per_kernel": {k: {"ms": round(v[0], 3), "algorithmic_bytes": int(v[1]),
+                                            "GBs": round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else 0.0}
+                                        for k, v in kernels.items()},
+                         "query_sort_ms": round(mean(sort_ms), 3),
                          "light_kernel_ms": round(sum(light_ms) / len(light_ms), 3),
+                         "merge_kernel_ms": round(sum(merge_ms) / len(merge_ms), 3),
                          "scope": "rank 0 shard"},
             "counters": {k: int(st[k]) for k in ("lightVertices", "gridVertices", "mergeQueries", "mergeCandidates",
                                                  "mergeAccepted", "connections", "lightSplats", "lightRays", "cameraRays",

@@ -132,7 +132,8 @@ typedef struct vcm_stats {
     long long lightSplats;     /* S: Framebuffer::AddColor from light paths   */
     float msLight, msGrid, msCamera, msTotal; /* phases: light(+compaction), grid build, camera(+resolve) */
     float msLightKernel, msCameraKernel;      /* k_light_trace / k_camera_trace alone        */
-    float msMergeKernel;                      /* k_merge_wave (0 in strict-order mode)       */
+    float msMergeKernel;                      /* k_merge_lane (0 in strict-order mode)       */
+    float msQuerySort;                        /* query counting sort (0 in strict-order mode)*/
     float radius;              /* merge radius of the iteration               */
 } vcm_stats;
 
@@ -162,8 +163,8 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm,
 
 void vcm_destroy(vcm_ctx *ctx);
 
-/* Summation-order mode.  0 (default): merge queries are deferred to a
- * wave-per-query kernel; every control-flow decision, the random-number tape,
+/* Summation-order mode.  0 (default): merge queries are deferred to their own
+ * kernel (queries sorted by cell, one lane each); every control-flow decision, the random-number tape,
  * the light-vertex records and the hash grid are bit-identical to the
  * reference, the per-pixel colour differs from it only by the fp32 rounding of
  * a different (fixed, deterministic) summation order.  1: the merge runs

@@ -28,7 +28,7 @@ static int fail(const char *what, const char *detail)
         if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));        \
     } while (0)
 
-enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
+enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
 
 struct vcm_ctx {
     vcm_scene_desc scene;
@@ -62,6 +62,9 @@ struct vcm_ctx {
     uint32_t *dCamMask;               /* nLocal: path lengths at which a merge query was queued */
     QueryStore qs;                    /* maxLen*nLocal queries */
     F4 *dMergeOut;                    /* maxLen*nLocal slots (pathLength, path) */
+    QueryStore qsSorted;              /* queries sorted by base-cell bucket */
+    int *dQueryKey;                   /* maxLen*nLocal */
+    int *dQueryStart;                 /* nCells+2 */
     int allocL;
     bool strictOrder;
     unsigned long long *dStats;
@@ -91,6 +94,7 @@ static void free_iteration_buffers(vcm_ctx *c)
     DFREE(c->dCellId); DFREE(c->dUnsorted);
     DFREE(c->dG0); DFREE(c->dG1); DFREE(c->dG2); DFREE(c->dG3); DFREE(c->dSortedIndex);
     DFREE(c->qs.q0); DFREE(c->qs.q1); DFREE(c->qs.q2); DFREE(c->qs.q3); DFREE(c->dMergeOut);
+    DFREE(c->qsSorted.q0); DFREE(c->qsSorted.q1); DFREE(c->qsSorted.q2); DFREE(c->qsSorted.q3); DFREE(c->dQueryKey);
     c->allocS = 0; c->allocL = 0;
 }
 
@@ -115,12 +119,13 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->dTileSums, maxScan / VCM_SCAN_TILE + 2)) return -1;
         if (dalloc(&c->dHdr, 1)) return -1;
         HIPCHK(hipMemset(c->dHdr, 0, sizeof(GridHeader)));
-        if (dalloc(&c->dCellCount, (size_t)c->N + 1)) return -1;
+        if (dalloc(&c->dCellCount, (size_t)c->N + 2)) return -1;
         if (dalloc(&c->dCellStart, (size_t)c->N + 1)) return -1;
-        if (dalloc(&c->dCellFill, (size_t)c->N + 1)) return -1;
+        if (dalloc(&c->dCellFill, (size_t)c->N + 2)) return -1;
         if (dalloc(&c->dCamOut, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->dCamMask, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->qs.count, 1)) return -1;
+        if (dalloc(&c->dQueryStart, (size_t)c->N + 2)) return -1;
         if (dalloc(&c->dStats, STAT_COUNT)) return -1;
         c->deviceReady = true;
     }
@@ -138,7 +143,11 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
             dalloc(&c->dG3, allRecs) || dalloc(&c->dSortedIndex, allRecs)) return -1;
         const size_t qslots = (size_t)(L > 0 ? L : 1) * (size_t)c->nLocal;
         if (c->useVM && (dalloc(&c->qs.q0, qslots) || dalloc(&c->qs.q1, qslots) || dalloc(&c->qs.q2, qslots) ||
-                         dalloc(&c->qs.q3, qslots) || dalloc(&c->dMergeOut, qslots))) return -1;
+                         dalloc(&c->qs.q3, qslots) || dalloc(&c->dMergeOut, qslots) ||
+                         dalloc(&c->qsSorted.q0, qslots) || dalloc(&c->qsSorted.q1, qslots) ||
+                         dalloc(&c->qsSorted.q2, qslots) || dalloc(&c->qsSorted.q3, qslots) ||
+                         dalloc(&c->dQueryKey, qslots))) return -1;
+        c->qsSorted.count = c->qs.count;
         c->allocS = S; c->allocL = L;
     }
     return 0;
@@ -252,7 +261,7 @@ void vcm_destroy(vcm_ctx *c)
         DFREE(c->dScene); DFREE(c->dFb); DFREE(c->store.count); DFREE(c->dRngLight); DFREE(c->dRngCam);
         DFREE(c->dPathStart); DFREE(c->dLocalTotal); DFREE(c->dTileSums); DFREE(c->dHdr);
         DFREE(c->dCellCount); DFREE(c->dCellStart); DFREE(c->dCellFill); DFREE(c->dCamOut); DFREE(c->dStats);
-        DFREE(c->dCamMask); DFREE(c->qs.count);
+        DFREE(c->dCamMask); DFREE(c->qs.count); DFREE(c->dQueryStart);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
@@ -442,13 +451,25 @@ int vcm_trace_camera(vcm_ctx *c)
             hipLaunchKernelGGL(k_camera_trace<true>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                                c->store, grid, c->qs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
             HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
-            hipLaunchKernelGGL(k_merge_wave, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid,
-                               c->qs, c->dMergeOut, c->dStats);
+            /* K4a: counting sort of the queries by base-cell bucket (reuses the grid-build scratch) */
+            const int nb = c->P.nCells + 1;
+            HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+            HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+            hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->qs,
+                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dCellCount);
+            if (launch_scan<int>(c, c->dCellCount, nb, c->dQueryStart, NULL, 1)) return -1;
+            hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->qs, (const int *)c->dQueryKey,
+                               (const int *)c->dQueryStart, c->dCellFill, c->qsSorted);
+            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
+            /* K4 */
+            hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid,
+                               c->qsSorted, c->dMergeOut, c->dStats);
             HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
         } else {
             hipLaunchKernelGGL(k_camera_trace<false>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                                c->store, grid, c->qs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
             HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
             HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
         }
         hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
@@ -549,8 +570,10 @@ int vcm_get_stats(vcm_ctx *c, vcm_stats *out)
         if (hipEventElapsedTime(&ms, c->ev[EV_LIGHT_K0], c->ev[EV_LIGHT_K1]) == hipSuccess) out->msLightKernel = ms;
         if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_GRID], c->ev[EV_CAMERA_K1]) == hipSuccess)
             out->msCameraKernel = ms;
-        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_MERGE_K1]) == hipSuccess)
+        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_SORT_K1], c->ev[EV_MERGE_K1]) == hipSuccess)
             out->msMergeKernel = ms;
+        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_SORT_K1]) == hipSuccess)
+            out->msQuerySort = ms;
     }
     c->lastStats = *out;
     return 0;

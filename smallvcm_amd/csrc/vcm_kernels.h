@@ -6,7 +6,8 @@
 //                         hash-grid build with vertices SORTED BY CELL
 //   K3  k_camera_trace    camera sub-paths: emission, direct illumination,
 //                         vertex connection, scattering; merge queries queued
-//   K4  k_merge_wave      range-merge of the queued queries, one wave per query
+//   K4a k_query_count/scatter  counting sort of the queries by base-cell bucket
+//   K4  k_merge_lane      range-merge of the sorted queries, one lane per query
 //   K5  k_resolve         Framebuffer::AddColor of the camera colours
 //
 // Execution model: one lane per sub-path.  K1/K3 are persistent: each wave
@@ -127,101 +128,84 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     flush_stats(ls, gstats);
 }
 
-/* ---------------- K4: range-merge, one WAVE per query -------------------- */
+/* ---------------- K4a: sort the merge queries by base cell ---------------- */
+/* Counting sort of the queued queries on the hash bucket of the cell that
+ * contains the query point (hashgrid.hxx:124-131).  Queries of one bucket end
+ * up adjacent, so the lanes of a wave walk the same cell lists: loads become
+ * broadcasts served by L1/L2 and all lanes run the same number of steps.  The
+ * order inside a bucket is arbitrary (atomics) and does not matter: every
+ * query writes its own (pathLength, path) slot. */
+__device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
+{
+    const V3 bmin = ld3(hdr->bboxMin), bmax = ld3(hdr->bboxMax);
+    const V3 distMin = queryPos - bmin;
+    const V3 distMax = bmax - queryPos;
+    if (distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f || distMin.z < 0.f || distMax.z < 0.f)
+        return P.nCells;   /* outside the photon bbox: no work, own bucket */
+    const V3 cellPt = P.invCellSize * distMin;
+    return grid_cell_hash(int(floorf(cellPt.x)), int(floorf(cellPt.y)), int(floorf(cellPt.z)), P.nCells);
+}
+
+__global__ void k_query_count(IterParams P, QueryStore qs, const GridHeader *__restrict__ hdr, int *key, int *bucketCount)
+{
+    const int nQ = *qs.count;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
+        const F4 r0 = qs.q0[q];
+        const int k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
+        key[q] = k;
+        atomicAdd(&bucketCount[k], 1);
+    }
+}
+
+__global__ void k_query_scatter(QueryStore qs, const int *__restrict__ key, const int *__restrict__ bucketStart,
+                                int *bucketFill, QueryStore out)
+{
+    const int nQ = *qs.count;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
+        const int k = key[q];
+        const int pos = bucketStart[k] + atomicAdd(&bucketFill[k], 1);
+        out.q0[pos] = qs.q0[q];
+        out.q1[pos] = qs.q1[q];
+        out.q2[pos] = qs.q2[q];
+        out.q3[pos] = qs.q3[q];
+    }
+}
+
+/* ---------------- K4: range-merge of the queued queries -------------------- */
 /* HashGrid::Process + RangeQuery::Process (hashgrid.hxx:110-169,
- * vertexcm.hxx:130-169) for the queries the camera pass queued.
- *
- * The query is wave-uniform: its 8 hashed cell ranges are found once, their
- * concatenation (the reference's visiting order, duplicates included) is
- * strided over by the 64 lanes, so candidate positions are read as
- * contiguous 16-byte elements of the cell-sorted array and every lane runs
- * the same number of steps.  Each lane sums the photons it accepted (in index
- * order), the 64 partial sums are combined by an xor-butterfly (a fixed
- * order: results are deterministic, but not the reference's left-to-right
- * order), and lane 0 stores  throughput * vmNormalization * contrib
- * (vertexcm.hxx:534) into the slot (pathLength, path). */
+ * vertexcm.hxx:130-169).  One lane per query (merge_query): a wave keeps 64
+ * dependent-load chains in flight, and because the queries arrive sorted by
+ * base-cell bucket (K4a) its lanes read the same cell lists -- broadcast
+ * loads, equal trip counts.  The per-query sum is in the reference's order
+ * (:157-168); lane stores throughput * vmNormalization * contrib (:534) into
+ * the slot (pathLength, path).
+ * (A wave-per-query mapping was measured too: 17 ms vs 6 ms for this one at
+ * 2048^2 -- one query per wave exposes its 4 dependent memory round trips.) */
 #define VCM_MERGE_BLOCK 256
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK)
-k_merge_wave(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, QueryStore qs, F4 *mergeOut,
+k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, QueryStore qs, F4 *mergeOut,
              unsigned long long *gstats)
 {
     const vcm_scene_desc &sc = *scp;
     const int nQ = *qs.count;
-    const int nWaves = gridDim.x * (VCM_MERGE_BLOCK / VCM_WAVE);
-    const int wave = (blockIdx.x * VCM_MERGE_BLOCK + threadIdx.x) / VCM_WAVE;
-    const int lane = (int)lane_id();
-    const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
-    uint32_t nCand = 0, nAcc = 0;
-    for (int q0 = wave; q0 < nQ; q0 += nWaves) {
-        const int q = __builtin_amdgcn_readfirstlane(q0);
-        const F4 r0 = qs.q0[q], r1 = qs.q1[q], r2 = qs.q2[q], r3 = qs.q3[q];
-        const V3 queryPos = mk3(r0.x, r0.y, r0.z);
-        const uint32_t lp = f2u(r0.w);
-        const uint32_t pathLength = f2u(r1.w) & 0xffu;
-        Bsdf bsdf;
-        bsdf_restore(bsdf, mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z), (int)((f2u(r1.w) >> 8) & 0xffu), sc);
-        SubPathState st;   /* only the fields RangeQuery::Process reads */
-        st.pathLength = pathLength; st.dVCM = r2.w; st.dVM = r3.w;
-        const V3 throughput = mk3(r3.x, r3.y, r3.z);
-
-        /* hashgrid.hxx:116-155 */
-        const V3 distMin = queryPos - bmin;
-        const V3 distMax = bmax - queryPos;
-        const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
-                              distMin.z < 0.f || distMax.z < 0.f);
-        const V3 cellPt = P.invCellSize * distMin;
-        const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
-        const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
-        const V3 fractCoord = cellPt - coordF;
-        const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
-        const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
-        const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
-        int lo[8], cum[9];
-        cum[0] = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
-            int a = 0, b = 0;
-            if (inside) { a = g.cellStart[cell]; b = g.cellStart[cell + 1]; }
-            lo[j] = __builtin_amdgcn_readfirstlane(a);
-            cum[j + 1] = cum[j] + __builtin_amdgcn_readfirstlane(b - a);
-        }
-        const int total = cum[8];
-        V3 part = sp3(0.f);
-        for (int base = 0; base < total; base += VCM_WAVE) {
-            const int i = base + lane;
-            if (i < total) {
-                int idx = lo[7] + (i - cum[7]);
-#pragma unroll
-                for (int j = 6; j >= 0; j--) idx = (i < cum[j + 1]) ? lo[j] + (i - cum[j]) : idx;
-                const F4 a = g.g0[idx];
-                const float distSqr = lensqr(queryPos - mk3(a.x, a.y, a.z));
-                nCand++;
-                if (distSqr <= P.radiusSqr) {   /* :165 */
-                    nAcc++;
-                    const F4 b = g.g1[idx];
-                    const F4 c = g.g2[idx];
-                    const float dVM = g.g3[idx];
-                    merge_photon(sc, P, bsdf, st, f2u(a.w), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM, part);
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            part.x = part.x + __shfl_xor(part.x, o, 64);
-            part.y = part.y + __shfl_xor(part.y, o, 64);
-            part.z = part.z + __shfl_xor(part.z, o, 64);
-        }
-        if (lane == 0) {
-            const V3 v = throughput * P.vmNormalization * part;   /* :534 */
-            mergeOut[(size_t)(pathLength - 1u) * (size_t)P.nLocal + lp] = mk4(v.x, v.y, v.z, 0.f);
+    __shared__ uint32_t accQ[VCM_MERGE_Q * VCM_MERGE_BLOCK];
+    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK;
+    LaneStats ls; lane_stats_zero(ls);
+    const int stride = gridDim.x * VCM_MERGE_BLOCK;
+    for (int base = blockIdx.x * VCM_MERGE_BLOCK; base < nQ; base += stride) {
+        const int q = base + threadIdx.x;
+        if (q < nQ) {
+            const F4 r0 = qs.q0[q], r1 = qs.q1[q], r2 = qs.q2[q], r3 = qs.q3[q];
+            Bsdf bsdf;
+            bsdf_restore(bsdf, mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z), (int)((f2u(r1.w) >> 8) & 0xffu), sc);
+            SubPathState st;
+            st.pathLength = f2u(r1.w) & 0xffu; st.dVCM = r2.w; st.dVM = r3.w;
+            const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(r0.x, r0.y, r0.z), ls, ms);
+            const V3 v = mk3(r3.x, r3.y, r3.z) * P.vmNormalization * contrib;   /* :534 */
+            mergeOut[(size_t)(st.pathLength - 1u) * (size_t)P.nLocal + f2u(r0.w)] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
-    {
-        unsigned long long c = wave_sum_u32(nCand & 0xffffu) + ((unsigned long long)wave_sum_u32(nCand >> 16) << 16);
-        unsigned long long a = wave_sum_u32(nAcc & 0xffffu) + ((unsigned long long)wave_sum_u32(nAcc >> 16) << 16);
-        if (lane == 0) { if (c) atomicAdd(&gstats[STAT_MERGE_CANDIDATES], c); if (a) atomicAdd(&gstats[STAT_MERGE_ACCEPTED], a); }
-    }
+    flush_stats(ls, gstats);
 }
 
 /* ---------------- K5: Framebuffer::AddColor of camera colours ----------- */
