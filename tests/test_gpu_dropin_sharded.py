@@ -1,0 +1,156 @@
+"""GPU tests of the two host bindings of the C-ABI:
+  * the C++ drop-in: the reference's UNCHANGED smallvcm.cxx + config.hxx built
+    over smallvcm_amd/dropin/vertexcm.hxx (prebuilt: dropin/smallvcm);
+  * the sharded host (ShardedVertexCM + vcm_create_sharded / export / import),
+    here with 2-4 ranks as threads on ONE GPU and an in-process stand-in for
+    the collectives (RCCL itself needs one GPU per rank)."""
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from smallvcm_amd.renderer import HipBackend, ShardedVertexCM, VertexCM, cornell_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "smallvcm_amd", "dropin", "smallvcm")
+
+
+def _rgbe(fb):
+    """Framebuffer::SaveHDR (reference src/framebuffer.hxx:219-251)"""
+    v = fb.max(axis=2)
+    out = np.zeros(fb.shape[:2] + (4,), np.uint8)
+    ok = v >= 1e-32
+    m, e = np.frexp(v.astype(np.float32))
+    scale = np.where(ok, (m.astype(np.float32) * np.float32(256.0) / np.where(ok, v, 1)).astype(np.float32), 0).astype(np.float32)
+    out[..., :3] = (fb * scale[..., None]).astype(np.uint8)
+    out[..., 3] = np.where(ok, e + 128, 0).astype(np.uint8)
+    out[~ok] = 0
+    return out
+
+
+def _read_hdr(path):
+    raw = open(path, "rb").read()
+    head, _, body = raw.partition(b"\n\n")
+    dims, _, pix = body.partition(b"\n")
+    t = dims.split()
+    h, w = int(t[1]), int(t[3])
+    return np.frombuffer(pix, np.uint8).reshape(h, w, 4)
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs a SmallVCM checkout)")
+@pytest.mark.parametrize("algo,name", [(2, "bpm"), (4, "vcm")])
+def test_reference_driver_over_dropin(tmp_path, algo, name):
+    out = str(tmp_path / ("img_%s.hdr" % name))
+    r = subprocess.run([DROPIN, "-s", "1", "-a", name, "-i", "1", "-o", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "done in" in r.stdout
+    img = _read_hdr(out)
+    # the same render through the Python host: 512x512 (config.hxx:237), seed 1234 (:234), maxPathLength 10 (:235)
+    v = VertexCM(cornell_scene(1, 512, 512), algo, 0.003, 0.75, 1234)
+    v.mMaxPathLength, v.mMinPathLength = 10, 0
+    v.RunIteration(0)
+    mine = _rgbe(v.GetFramebuffer())
+    v.close()
+    d = np.abs(img.astype(np.int32) - mine.astype(np.int32))
+    if algo == 2:
+        assert d.max() == 0
+    else:   # light splats: atomic order may move a mantissa byte by one
+        assert (d[..., :3].max() <= 1) and (d[..., 3].max() <= 1) and (d > 0).mean() < 1e-3
+
+
+def test_no_gpu_error_path_is_loud(tmp_path):
+    if not os.path.exists(DROPIN):
+        pytest.skip("drop-in binary not built")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    r = subprocess.run([DROPIN, "-s", "1", "-a", "vcm", "-i", "1", "-o", str(tmp_path / "x.hdr")], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "no HIP device" in (r.stdout + r.stderr)
+
+
+class _ThreadCollectives:
+    """all_gather_into_tensor / all_reduce for ranks that are threads of one process."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, world):
+        import torch
+        self.torch = torch
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.tls = threading.local()
+
+    def bind(self, rank):
+        self.tls.rank = rank
+
+    def _exchange(self, t):
+        self.torch.cuda.current_stream().synchronize()
+        self.slots[self.tls.rank] = t
+        self.bar.wait()
+        parts = list(self.slots)
+        return parts
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        parts = self._exchange(inp)
+        n = inp.numel()
+        for r, p in enumerate(parts):
+            out[r * n:(r + 1) * n].copy_(p)
+        self.torch.cuda.current_stream().synchronize()
+        self.bar.wait()
+
+    def all_reduce(self, t, op=None, group=None):
+        parts = self._exchange(t.clone())
+        acc = parts[0].clone()
+        for p in parts[1:]:
+            acc += p
+        t.copy_(acc)
+        self.torch.cuda.current_stream().synchronize()
+        self.bar.wait()
+
+
+@pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 128, 2), (4, 1, 2, 96, 2), (3, 3, 4, 100, 1)])
+def test_sharded_contexts_equal_single_context(world, sid, algo, res, iters):
+    sc = cornell_scene(sid, res, res)
+    coll = _ThreadCollectives(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            coll.bind(rank)
+            b = HipBackend(sc, algo, 0.003, 0.75, 1234, device=0, rank=rank, world=world)
+            r = ShardedVertexCM(b, rank, world)
+            r.dist = coll
+            r.mMaxPathLength, r.mMinPathLength = 10, 0
+            for it in range(iters):
+                r.RunIteration(it)
+            results[rank] = (r.framebuffer_sum(), b.stats())
+            b.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+            try:
+                coll.bar.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errors, errors
+    one = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    one.mMaxPathLength, one.mMinPathLength = 10, 0
+    for it in range(iters):
+        one.RunIteration(it)
+    ref, st1 = one.framebuffer_sum(), one.stats()
+    one.close()
+    for fb, st in results:
+        assert np.allclose(fb, ref, rtol=2e-6, atol=2e-7)
+        assert st["gridVertices"] == st1["gridVertices"]          # every rank built the full grid
+    assert sum(st["lightVertices"] for _, st in results) == st1["lightVertices"]
+    assert sum(st["mergeAccepted"] for _, st in results) == st1["mergeAccepted"]
+    assert sum(st["connections"] for _, st in results) == st1["connections"]

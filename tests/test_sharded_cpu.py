@@ -1,0 +1,43 @@
+"""Multi-rank host logic (smallvcm_amd.renderer.ShardedVertexCM) on CPU:
+world_size 2 and 3 over gloo, the oracle as compute backend.  Sharding by path
+index + all-gather of the merge records + framebuffer sum must reproduce the
+unsharded result: bit-exact wherever a pixel is written by one rank only."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+from smallvcm_amd.renderer import cornell_scene
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 40, 2), (2, 1, 2, 40, 2), (3, 3, 4, 33, 1), (2, 0, 3, 32, 1)])
+def test_sharded_equals_unsharded(tmp_path, world, sid, algo, res, iters):
+    port = _free_port()
+    out = str(tmp_path / "fb.npy")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(port),
+                               str(sid), str(algo), str(res), str(iters), out]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    fb = np.load(out)
+    o = Oracle(cornell_scene(sid, res, res), algo)
+    for it in range(iters):
+        o.run_iteration(it, 0, 10)
+    ref = o.framebuffer()
+    # per-rank partial sums are added in a different order than the serial loop
+    assert np.allclose(fb, ref, rtol=2e-6, atol=1e-7)
+    if algo == 2:   # no light splats: one writer per pixel (up to jitter-shifted colours)
+        assert (fb == ref).mean() > 0.999
