@@ -37,6 +37,14 @@ def load_library(require_gpu=True):
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("smallvcm_amd: %s not built; the HIP library is the only compute path" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Two HIP runtimes
+        # in one process do not share the GPU ("No HIP GPUs are available" from
+        # whichever comes second), so let torch's copy load first; our library
+        # then binds to the already-loaded libamdhip64 (same SONAME).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, ip, llp, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_float)
         L.vcm_last_error.restype = C.c_char_p
