@@ -124,7 +124,7 @@ def main():
         it += 1
     sync()
     t0 = time.perf_counter()
-    cam_ms, light_ms, total_ms, merge_ms, sort_ms = [], [], [], [], []
+    cam_ms, light_ms, total_ms, merge_ms, sort_ms, conn_ms = [], [], [], [], [], []
     st = None
     for _ in range(args.steps):
         r.RunIteration(it)
@@ -144,6 +144,7 @@ def main():
         cam_ms.append(st["msCameraKernel"])
         merge_ms.append(st["msMergeKernel"])
         sort_ms.append(st["msQuerySort"])
+        conn_ms.append(st["msConnectKernels"])
         light_ms.append(st["msLightKernel"])
         total_ms.append(st["msTotal"])
 
@@ -154,7 +155,8 @@ def main():
         b_iter, b_parts = algorithmic_bytes(st, backend.count, n_paths)
         mean = lambda v: sum(v) / len(v)
         kernels = {"k_light_trace": (mean(light_ms), b_parts["light"]),
-                   "k_camera_trace": (mean(cam_ms), b_parts["camera"]),
+                   "k_camera_trace": (mean(cam_ms), 24 * backend.count),
+                   "k_connect_di+vc": (mean(conn_ms), b_parts["camera"] - 24 * backend.count),
                    "k_merge_lane": (mean(merge_ms), b_parts["merge"])}
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_s, dom_b = kernels[dom][0] / 1e3, kernels[dom][1]
@@ -180,6 +182,7 @@ def main():
                                             "GBs": round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else 0.0}
                                         for k, v in kernels.items()},
                          "query_sort_ms": round(mean(sort_ms), 3),
+                         "connect_kernels_ms": round(mean(conn_ms), 3),
                          "light_kernel_ms": round(sum(light_ms) / len(light_ms), 3),
                          "merge_kernel_ms": round(sum(merge_ms) / len(merge_ms), 3),
                          "scope": "rank 0 shard"},

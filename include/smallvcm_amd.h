@@ -133,7 +133,8 @@ typedef struct vcm_stats {
     float msLight, msGrid, msCamera, msTotal; /* phases: light(+compaction), grid build, camera(+resolve) */
     float msLightKernel, msCameraKernel;      /* k_light_trace / k_camera_trace alone        */
     float msMergeKernel;                      /* k_merge_lane (0 in strict-order mode)       */
-    float msQuerySort;                        /* query counting sort (0 in strict-order mode)*/
+    float msQuerySort;                        /* camera-vertex counting sort (0 in strict mode) */
+    float msConnectKernels;                   /* k_connect_di + k_connect_vc (0 in strict mode) */
     float radius;              /* merge radius of the iteration               */
 } vcm_stats;
 
@@ -163,14 +164,12 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm,
 
 void vcm_destroy(vcm_ctx *ctx);
 
-/* Summation-order mode.  0 (default): merge queries are deferred to their own
- * kernel (queries sorted by cell, one lane each); every control-flow decision, the random-number tape,
- * the light-vertex records and the hash grid are bit-identical to the
- * reference, the per-pixel colour differs from it only by the fp32 rounding of
- * a different (fixed, deterministic) summation order.  1: the merge runs
- * inside the camera path in the reference's order of additions (slower);
- * algorithms without light splats are then bit-exact end to end.
- * The environment variable SMALLVCM_AMD_STRICT_ORDER=1 sets the default. */
+/* Execution mode.  0 (default, "wavefront"): the camera pass only traces and
+ * scatters; direct illumination, vertex connections and merges are evaluated
+ * by dense task kernels and every path's additions are replayed in the
+ * reference's order.  1 ("strict"): everything is evaluated inside the camera
+ * path as the reference does (slower).  Both produce the same bits; the
+ * environment variable SMALLVCM_AMD_STRICT_ORDER=1 sets the default. */
 int vcm_set_strict_order(vcm_ctx *ctx, int on);
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all

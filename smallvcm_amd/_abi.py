@@ -72,7 +72,8 @@ class Stats(C.Structure):
                 ("msLight", C.c_float), ("msGrid", C.c_float),
                 ("msCamera", C.c_float), ("msTotal", C.c_float),
                 ("msLightKernel", C.c_float), ("msCameraKernel", C.c_float),
-                ("msMergeKernel", C.c_float), ("msQuerySort", C.c_float), ("radius", C.c_float)]
+                ("msMergeKernel", C.c_float), ("msQuerySort", C.c_float), ("msConnectKernels", C.c_float),
+                ("radius", C.c_float)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -28,7 +28,7 @@ static int fail(const char *what, const char *detail)
         if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));        \
     } while (0)
 
-enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
+enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_CONNECT_K1, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
 
 struct vcm_ctx {
     vcm_scene_desc scene;
@@ -60,10 +60,9 @@ struct vcm_ctx {
     int *dSortedIndex;                /* debug/parity: grid position -> record index */
     F4 *dCamOut;                      /* nLocal */
     uint32_t *dCamMask;               /* nLocal: path lengths at which a merge query was queued */
-    QueryStore qs;                    /* maxLen*nLocal queries */
-    F4 *dMergeOut;                    /* maxLen*nLocal slots (pathLength, path) */
-    QueryStore qsSorted;              /* queries sorted by base-cell bucket */
-    int *dQueryKey;                   /* maxLen*nLocal */
+    VertexStore vs;                   /* camera vertices + DI/VC tasks of the iteration (wavefront mode) */
+    int *dQueryKey;                   /* per camera vertex: base-cell bucket */
+    int *dSortedVertex;               /* camera vertices sorted by bucket */
     int *dQueryStart;                 /* nCells+2 */
     int allocL;
     bool strictOrder;
@@ -93,8 +92,9 @@ static void free_iteration_buffers(vcm_ctx *c)
     DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll);
     DFREE(c->dCellId); DFREE(c->dUnsorted);
     DFREE(c->dG0); DFREE(c->dG1); DFREE(c->dG2); DFREE(c->dG3); DFREE(c->dSortedIndex);
-    DFREE(c->qs.q0); DFREE(c->qs.q1); DFREE(c->qs.q2); DFREE(c->qs.q3); DFREE(c->dMergeOut);
-    DFREE(c->qsSorted.q0); DFREE(c->qsSorted.q1); DFREE(c->qsSorted.q2); DFREE(c->qsSorted.q3); DFREE(c->dQueryKey);
+    DFREE(c->vs.q0); DFREE(c->vs.q1); DFREE(c->vs.q2); DFREE(c->vs.q3); DFREE(c->vs.q4); DFREE(c->vs.meta);
+    DFREE(c->vs.diTask); DFREE(c->vs.vcTask); DFREE(c->vs.pathVertex); DFREE(c->vs.diOut); DFREE(c->vs.vcOut);
+    DFREE(c->vs.mergeOut); DFREE(c->dQueryKey); DFREE(c->dSortedVertex);
     c->allocS = 0; c->allocL = 0;
 }
 
@@ -124,7 +124,7 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->dCellFill, (size_t)c->N + 2)) return -1;
         if (dalloc(&c->dCamOut, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->dCamMask, (size_t)c->nLocal)) return -1;
-        if (dalloc(&c->qs.count, 1)) return -1;
+        if (dalloc(&c->vs.count, 4)) return -1;
         if (dalloc(&c->dQueryStart, (size_t)c->N + 2)) return -1;
         if (dalloc(&c->dStats, STAT_COUNT)) return -1;
         c->deviceReady = true;
@@ -141,13 +141,16 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->dCellId, allRecs) || dalloc(&c->dUnsorted, allRecs)) return -1;
         if (dalloc(&c->dG0, allRecs) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
             dalloc(&c->dG3, allRecs) || dalloc(&c->dSortedIndex, allRecs)) return -1;
-        const size_t qslots = (size_t)(L > 0 ? L : 1) * (size_t)c->nLocal;
-        if (c->useVM && (dalloc(&c->qs.q0, qslots) || dalloc(&c->qs.q1, qslots) || dalloc(&c->qs.q2, qslots) ||
-                         dalloc(&c->qs.q3, qslots) || dalloc(&c->dMergeOut, qslots) ||
-                         dalloc(&c->qsSorted.q0, qslots) || dalloc(&c->qsSorted.q1, qslots) ||
-                         dalloc(&c->qsSorted.q2, qslots) || dalloc(&c->qsSorted.q3, qslots) ||
-                         dalloc(&c->dQueryKey, qslots))) return -1;
-        c->qsSorted.count = c->qs.count;
+        /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l
+           connects to light vertices of length <= L-1-l, so <= (L-1)(L-2)/2 VC tasks per path */
+        const size_t vslots = (size_t)(L > 0 ? L : 1) * (size_t)c->nLocal;
+        const size_t vcPerPath = (L >= 3) ? (size_t)(L - 1) * (size_t)(L - 2) / 2 : 1;
+        const size_t vcslots = vcPerPath * (size_t)c->nLocal;
+        if (dalloc(&c->vs.q0, vslots) || dalloc(&c->vs.q1, vslots) || dalloc(&c->vs.q2, vslots) ||
+            dalloc(&c->vs.q3, vslots) || dalloc(&c->vs.q4, vslots) || dalloc(&c->vs.meta, vslots) ||
+            dalloc(&c->vs.diTask, vslots) || dalloc(&c->vs.pathVertex, vslots) || dalloc(&c->vs.diOut, vslots) ||
+            dalloc(&c->vs.mergeOut, vslots) || dalloc(&c->vs.vcTask, 2 * vcslots) || dalloc(&c->vs.vcOut, vcslots) ||
+            dalloc(&c->dQueryKey, vslots) || dalloc(&c->dSortedVertex, vslots)) return -1;
         c->allocS = S; c->allocL = L;
     }
     return 0;
@@ -261,7 +264,7 @@ void vcm_destroy(vcm_ctx *c)
         DFREE(c->dScene); DFREE(c->dFb); DFREE(c->store.count); DFREE(c->dRngLight); DFREE(c->dRngCam);
         DFREE(c->dPathStart); DFREE(c->dLocalTotal); DFREE(c->dTileSums); DFREE(c->dHdr);
         DFREE(c->dCellCount); DFREE(c->dCellStart); DFREE(c->dCellFill); DFREE(c->dCamOut); DFREE(c->dStats);
-        DFREE(c->dCamMask); DFREE(c->qs.count); DFREE(c->dQueryStart);
+        DFREE(c->dCamMask); DFREE(c->vs.count); DFREE(c->dQueryStart);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
@@ -320,12 +323,12 @@ int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned max
     P.cellSize = radius * 2.f;                                                /* hashgrid.hxx:47 */
     P.invCellSize = 1.f / P.cellSize;                                         /* :48 */
     P.nCells = c->N;                                                          /* vertexcm.hxx:406 */
-    P.deferMerge = (c->useVM && !c->strictOrder && maxLen <= 31) ? 1 : 0;
+    P.wavefront = (!c->strictOrder && !c->lightTraceOnly && maxLen <= 31) ? 1 : 0;
 
     HIPCHK(hipEventRecord(c->ev[EV_START], c->stream));
     HIPCHK(hipMemsetAsync(c->dStats, 0, STAT_COUNT * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
-    HIPCHK(hipMemsetAsync(c->qs.count, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
     c->inIteration = true;
     c->evValid = false;
@@ -447,33 +450,45 @@ int vcm_trace_camera(vcm_ctx *c)
         GridStore grid;
         grid.cellStart = c->dCellStart; grid.g0 = c->dG0; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
         grid.hdr = c->dHdr;
-        if (c->P.deferMerge) {
-            hipLaunchKernelGGL(k_camera_trace<true>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
-                               c->store, grid, c->qs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+        if (c->P.wavefront) {
+            hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+                               c->store, grid, c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
             HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
-            /* K4a: counting sort of the queries by base-cell bucket (reuses the grid-build scratch) */
-            const int nb = c->P.nCells + 1;
-            HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
-            HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
-            hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->qs,
-                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dCellCount);
-            if (launch_scan<int>(c, c->dCellCount, nb, c->dQueryStart, NULL, 1)) return -1;
-            hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->qs, (const int *)c->dQueryKey,
-                               (const int *)c->dQueryStart, c->dCellFill, c->qsSorted);
-            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
-            /* K4 */
-            hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid,
-                               c->qsSorted, c->dMergeOut, c->dStats);
+            if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
+                hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+                                   c->dStats);
+                hipLaunchKernelGGL(k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+                                   c->store, c->dStats);
+            }
+            HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
+            if (c->useVM) {
+                /* K4a: counting sort of the camera vertices by base-cell bucket (reuses the grid-build scratch) */
+                const int nb = c->P.nCells + 1;
+                HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+                HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+                hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
+                                   (const GridHeader *)c->dHdr, c->dQueryKey, c->dCellCount);
+                if (launch_scan<int>(c, c->dCellCount, nb, c->dQueryStart, NULL, 1)) return -1;
+                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
+                                   (const int *)c->dQueryStart, c->dCellFill, c->dSortedVertex);
+                HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
+                /* K4 */
+                hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid,
+                                   c->vs, (const int *)c->dSortedVertex, c->dStats);
+            } else {
+                HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
+            }
             HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
         } else {
-            hipLaunchKernelGGL(k_camera_trace<false>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
-                               c->store, grid, c->qs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+            hipLaunchKernelGGL(k_camera_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+                               c->store, grid, c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
             HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+            HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
             HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
             HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
         }
         hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
-                           (const uint32_t *)c->dCamMask, (const F4 *)c->dMergeOut, c->dFb);
+                           (const uint32_t *)c->dCamMask, c->vs, c->dFb);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[EV_CAMERA], c->stream));
@@ -572,8 +587,10 @@ int vcm_get_stats(vcm_ctx *c, vcm_stats *out)
             out->msCameraKernel = ms;
         if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_SORT_K1], c->ev[EV_MERGE_K1]) == hipSuccess)
             out->msMergeKernel = ms;
-        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_SORT_K1]) == hipSuccess)
+        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CONNECT_K1], c->ev[EV_SORT_K1]) == hipSuccess)
             out->msQuerySort = ms;
+        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_CONNECT_K1]) == hipSuccess)
+            out->msConnectKernels = ms;
     }
     c->lastStats = *out;
     return 0;

@@ -34,7 +34,7 @@ struct IterParams {
     float lightSubPathCount;
     float cellSize, invCellSize;   /* hashgrid.hxx:47-48 */
     int   nCells;                  /* = N (vertexcm.hxx:406) */
-    int   deferMerge;              /* 1: camera pass emits merge queries for k_merge_wave */
+    int   wavefront;               /* 1: DI / VC / merge deferred to task kernels (default) */
 };
 
 /* device-resident hash-grid header: bbox is reduced on the device */
@@ -70,14 +70,27 @@ struct GridStore {
     const GridHeader *hdr;
 };
 
-/* Merge queries emitted by the camera pass (deferred mode): everything
- * RangeQuery (vertexcm.hxx:109-178) needs from the camera vertex, 64 B. */
-struct QueryStore {
-    F4 *q0;      /* hitpoint.xyz | local path index                    */
-    F4 *q1;      /* isect.normal.xyz | pathLength (bits 0-7), matID (8-15) */
-    F4 *q2;      /* localDirFix.xyz | dVCM                              */
-    F4 *q3;      /* throughput.xyz | dVM                                */
-    int *count;  /* number of queries appended                          */
+/* Camera vertices of one iteration (wavefront mode).  Direct illumination,
+ * vertex connection and merging only ADD to the pixel colour, they never steer
+ * the path (vertexcm.hxx:487-538), so the camera pass appends one 80-byte
+ * record per non-delta vertex plus one task per light connection and dense
+ * kernels evaluate them afterwards; k_resolve then replays the additions of
+ * every path in the reference's order. */
+struct alignas(16) I4 { int x, y, z, w; };
+struct VertexStore {
+    F4 *q0;          /* hitpoint.xyz | local path index                          */
+    F4 *q1;          /* isect.normal.xyz | pathLength (bits 0-7), matID (8-15)   */
+    F4 *q2;          /* localDirFix.xyz | dVCM                                   */
+    F4 *q3;          /* throughput.xyz | dVM                                     */
+    F4 *q4;          /* dVC | the 3 random floats of DirectIllumination (:672-673) */
+    I4 *meta;        /* DI task (-1: none) | first VC task | number of VC tasks | 0 */
+    int *count;      /* [0] vertices  [1] DI tasks  [2] VC tasks                  */
+    int *diTask;     /* DI task -> vertex                                         */
+    int *vcTask;     /* VC task -> (vertex, index j of the light vertex)          */
+    int *pathVertex; /* (pathLength-1)*nLocal + lp -> vertex                      */
+    F4 *diOut;       /* per DI task:  throughput * DirectIllumination()  (:491)   */
+    F4 *vcOut;       /* per VC task:  throughput * lvThroughput * ConnectVertices() (:523) */
+    F4 *mergeOut;    /* per vertex:   throughput * vmNormalization * contrib (:534) */
 };
 
 struct LaneStats {
@@ -784,14 +797,12 @@ VCM_HD V3 get_light_radiance(const vcm_scene_desc &sc, const IterParams &P, cons
 }
 
 /* DirectIllumination :663-738 */
-VCM_HD V3 direct_illumination(const vcm_scene_desc &sc, const IterParams &P, PathRng &rng, const SubPathState &st,
-                              V3 hitpoint, const Bsdf &bsdf, LaneStats &ls)
-{
+VCM_HD V3 direct_illumination(const vcm_scene_desc &sc, const IterParams &P, float rPick, float rx, float ry,
+                              const SubPathState &st, V3 hitpoint, const Bsdf &bsdf, LaneStats &ls)
+{   /* rPick, rx, ry: the three floats drawn at :672-673 */
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;
-    const int lightID = int(rng_float(rng) * lightCount);
-    const float rx = rng_float(rng);
-    const float ry = rng_float(rng);
+    const int lightID = int(rPick * lightCount);
     const vcm_light &light = get_light(sc, lightID);
     V3 directionToLight;
     float distance, directPdfW, emissionPdfW, cosAtLight;
@@ -1001,17 +1012,17 @@ struct CameraPath {
     V3 color;
     int lp;
     float sx, sy;    /* the jittered screen sample (:576) */
-    uint32_t queryMask;   /* deferred mode: bit L set = a merge query was emitted at path length L */
+    uint32_t queryMask;   /* wavefront mode: bit L set = a vertex record was appended at path length L */
 };
 
-/* append slot in the query queue; hipcc aggregates the per-lane atomic into
- * one atomic per wave (ballot + prefix popcount, i.e. v_mbcnt) */
-VCM_HD int queue_slot(int *counter)
+/* reserve n consecutive slots of a device queue; hipcc aggregates the
+ * per-lane atomics of a wave into one (ballot / DPP prefix sum) */
+VCM_HD int queue_reserve(int *counter, int n)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(counter, 1);
+    return atomicAdd(counter, n);
 #else
-    return (*counter)++;
+    const int r = *counter; *counter += n; return r;
 #endif
 }
 
@@ -1050,9 +1061,14 @@ VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, Cam
 }
 
 /* one iteration of the for(;;) at :423-542; returns false when the path ends */
-template <bool DEFER>
+/* MODE 0 ("strict"): everything inside the path, every addition in the
+ *         reference's order as it happens.
+ * MODE 1 ("wavefront", default): the path only traces and scatters; per
+ *         non-delta vertex it appends a VertexStore record and its DI / VC
+ *         tasks.  Returns false when the path ends. */
+template <int MODE>
 VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
-                             const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const QueryStore &qs)
+                             const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const VertexStore &vs)
 {
     SubPathState &st = cp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
@@ -1084,49 +1100,158 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
     }
     if (st.pathLength >= P.maxLen) return false;   /* :482 */
 
-    if (!bsdf.isDelta && P.useVC) {   /* :487-494 */
-        if (st.pathLength + 1 >= P.minLen)
-            cp.color = cp.color + st.throughput * direct_illumination(sc, P, cp.rng, st, hitPoint, bsdf, ls);
-    }
-    if (!bsdf.isDelta && P.useVC) {   /* :498-526: the light path of the same index */
-        const int n = store.count[cp.lp];
-        for (int j = 0; j < n; j++) {
-            const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)cp.lp;
-            const F4 a = store.v0[slot];
-            const uint32_t lvLen = f2u(a.w) & 0xffu;
-            if (lvLen + 1 + st.pathLength < P.minLen) continue;
-            if (lvLen + 1 + st.pathLength > P.maxLen) break;
-            const F4 b = store.v1[slot];
-            const F4 c = store.v2[slot];
-            const F4 d = store.v3[slot];
-            Bsdf lvBsdf;
-            bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
-            cp.color = cp.color + st.throughput * mk3(b.x, b.y, b.z) *
-                       connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, bsdf, hitPoint, st, ls);
-        }
-    }
-    if (!bsdf.isDelta && P.useVM) {   /* :530-538 */
-        ls.mergeQueries++;
-        if (DEFER) {
-            /* the merge only adds to the colour (never steers the path), so it
-               can run later in k_merge_wave; its result comes back through the
-               slot (pathLength, path) and is added by k_resolve */
-            const int qi = queue_slot(qs.count);
-            qs.q0[qi] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
-            qs.q1[qi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z,
-                            u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
-            qs.q2[qi] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
-            qs.q3[qi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
+    if (MODE == 1) {
+        if (!bsdf.isDelta && (P.useVC || P.useVM)) {
+            /* DirectIllumination draws its 3 floats here, in path order (:672-673) */
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            int hasDI = 0;
+            if (P.useVC && st.pathLength + 1 >= P.minLen) {
+                r0 = rng_float(cp.rng); r1 = rng_float(cp.rng); r2 = rng_float(cp.rng);
+                hasDI = 1;
+            }
+            /* the light vertices this camera vertex connects to (:508-521) */
+            uint32_t jmask = 0u;
+            if (P.useVC) {
+                const int n = store.count[cp.lp];
+                for (int j = 0; j < n; j++) {
+                    const uint32_t lvLen = f2u(store.v0[(size_t)j * (size_t)P.nLocal + (size_t)cp.lp].w) & 0xffu;
+                    if (lvLen + 1 + st.pathLength < P.minLen) continue;
+                    if (lvLen + 1 + st.pathLength > P.maxLen) break;
+                    jmask |= 1u << j;
+                }
+            }
+            const int nvc = __builtin_popcount(jmask);
+            const int vi = queue_reserve(&vs.count[0], 1);
+            const int di = hasDI ? queue_reserve(&vs.count[1], 1) : -1;
+            const int vc0 = nvc ? queue_reserve(&vs.count[2], nvc) : 0;
+            vs.q0[vi] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
+            vs.q1[vi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
+            vs.q2[vi] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
+            vs.q3[vi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
+            vs.q4[vi] = mk4(st.dVC, r0, r1, r2);
+            I4 m; m.x = di; m.y = vc0; m.z = nvc; m.w = 0;
+            vs.meta[vi] = m;
+            if (hasDI) vs.diTask[di] = vi;
+            int t = vc0;
+            while (jmask) {
+                const int j = __builtin_ctz(jmask);
+                jmask &= jmask - 1u;
+                vs.vcTask[2 * t] = vi;
+                vs.vcTask[2 * t + 1] = j;
+                t++;
+            }
+            vs.pathVertex[(size_t)(st.pathLength - 1u) * (size_t)P.nLocal + (size_t)cp.lp] = vi;
             cp.queryMask |= 1u << st.pathLength;
-        } else {
+            if (P.useVM) {
+                ls.mergeQueries++;
+                if (P.ppm) return false;   /* :537 */
+            }
+        }
+    } else {
+        if (!bsdf.isDelta && P.useVC) {   /* :487-494 */
+            if (st.pathLength + 1 >= P.minLen) {
+                const float r0 = rng_float(cp.rng), r1 = rng_float(cp.rng), r2 = rng_float(cp.rng);
+                cp.color = cp.color + st.throughput * direct_illumination(sc, P, r0, r1, r2, st, hitPoint, bsdf, ls);
+            }
+        }
+        if (!bsdf.isDelta && P.useVC) {   /* :498-526: the light path of the same index */
+            const int n = store.count[cp.lp];
+            for (int j = 0; j < n; j++) {
+                const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)cp.lp;
+                const F4 a = store.v0[slot];
+                const uint32_t lvLen = f2u(a.w) & 0xffu;
+                if (lvLen + 1 + st.pathLength < P.minLen) continue;
+                if (lvLen + 1 + st.pathLength > P.maxLen) break;
+                const F4 b = store.v1[slot];
+                const F4 c = store.v2[slot];
+                const F4 d = store.v3[slot];
+                Bsdf lvBsdf;
+                bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
+                cp.color = cp.color + st.throughput * mk3(b.x, b.y, b.z) *
+                           connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, bsdf, hitPoint, st, ls);
+            }
+        }
+        if (!bsdf.isDelta && P.useVM) {   /* :530-538 */
+            ls.mergeQueries++;
             const V3 contrib = merge_query(sc, P, grid, bsdf, st, hitPoint, ls, ms);
             cp.color = cp.color + st.throughput * P.vmNormalization * contrib;
+            if (P.ppm) return false;
         }
-        if (P.ppm) return false;
     }
     if (!sample_scattering(sc, P, false, cp.rng, bsdf, hitPoint, st)) return false;
     ++st.pathLength;
     return true;
+}
+
+/* ---- wavefront tasks: the deferred parts of a camera vertex ------------- */
+struct CamVertex {
+    V3 hit, throughput;
+    Bsdf bsdf;
+    SubPathState st;      /* pathLength, dVCM, dVC, dVM are valid */
+    uint32_t lp;
+    float r0, r1, r2;
+};
+VCM_HD void load_cam_vertex(const vcm_scene_desc &sc, const VertexStore &vs, int vi, CamVertex &v)
+{
+    const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi], e = vs.q4[vi];
+    v.hit = mk3(a.x, a.y, a.z);
+    v.lp = f2u(a.w);
+    bsdf_restore(v.bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (int)((f2u(b.w) >> 8) & 0xffu), sc);
+    v.throughput = mk3(d.x, d.y, d.z);
+    v.st.pathLength = f2u(b.w) & 0xffu;
+    v.st.dVCM = c.w; v.st.dVM = d.w; v.st.dVC = e.x;
+    v.st.throughput = v.throughput;
+    v.r0 = e.y; v.r1 = e.z; v.r2 = e.w;
+}
+/* the addend of :491  (color += throughput * DirectIllumination(...)) */
+VCM_HD V3 eval_di_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls)
+{
+    CamVertex v;
+    load_cam_vertex(sc, vs, vi, v);
+    return v.throughput * direct_illumination(sc, P, v.r0, v.r1, v.r2, v.st, v.hit, v.bsdf, ls);
+}
+/* the addend of :523  (color += throughput * lightVertex.mThroughput * ConnectVertices(...)) */
+VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const LightStore &store,
+                       int vi, int j, LaneStats &ls)
+{
+    CamVertex v;
+    load_cam_vertex(sc, vs, vi, v);
+    const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)v.lp;
+    const F4 a = store.v0[slot], b = store.v1[slot], c = store.v2[slot], d = store.v3[slot];
+    Bsdf lvBsdf;
+    bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
+    return v.throughput * mk3(b.x, b.y, b.z) *
+           connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, v.bsdf, v.hit, v.st, ls);
+}
+/* the addend of :534  (color += throughput * mVmNormalization * query.GetContrib()) */
+VCM_HD V3 eval_merge_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
+                          int vi, LaneStats &ls, const MergeScratch &ms)
+{
+    const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+    Bsdf bsdf;
+    bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (int)((f2u(b.w) >> 8) & 0xffu), sc);
+    SubPathState st;
+    st.pathLength = f2u(b.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
+    const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms);
+    return mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
+}
+/* Replays vertexcm.hxx:417-544 for one camera path: colour starts at 0, every
+ * vertex adds its DI term, its VC terms (increasing j), its merge term; the
+ * emission / background term of the last segment comes last (the path ends
+ * there).  Same addends, same order => same bits as the serial reference. */
+VCM_HD V3 replay_path_color(const IterParams &P, const VertexStore &vs, int lp, uint32_t mask, V3 emission)
+{
+    V3 color = sp3(0.f);
+    while (mask) {
+        const int L = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const int vi = vs.pathVertex[(size_t)(L - 1) * (size_t)P.nLocal + (size_t)lp];
+        const I4 m = vs.meta[vi];
+        if (m.x >= 0) { const F4 t = vs.diOut[m.x]; color = color + mk3(t.x, t.y, t.z); }
+        for (int k = 0; k < m.z; k++) { const F4 t = vs.vcOut[m.y + k]; color = color + mk3(t.x, t.y, t.z); }
+        if (P.useVM) { const F4 t = vs.mergeOut[vi]; color = color + mk3(t.x, t.y, t.z); }
+    }
+    return color + emission;
 }
 
 /* Framebuffer::AddColor(screenSample, color) vertexcm.hxx:544, framebuffer.hxx:43-57:

@@ -4,11 +4,14 @@
 //   K1b k_compact_records slot-major store -> contiguous merge records
 //   K2  k_bbox / k_cell_count / scan / k_cell_scatter / k_cell_rank_gather
 //                         hash-grid build with vertices SORTED BY CELL
-//   K3  k_camera_trace    camera sub-paths: emission, direct illumination,
-//                         vertex connection, scattering; merge queries queued
-//   K4a k_query_count/scatter  counting sort of the queries by base-cell bucket
-//   K4  k_merge_lane      range-merge of the sorted queries, one lane per query
-//   K5  k_resolve         Framebuffer::AddColor of the camera colours
+//   K3  k_camera_trace    camera sub-paths: trace, emission, scattering; appends a
+//                         record per non-delta vertex + its DI / VC tasks
+//   K3b k_connect_di      direct illumination tasks (dense, one lane each)
+//   K3c k_connect_vc      vertex connection tasks (dense, one lane each)
+//   K4a k_query_count/scatter  counting sort of the vertices by base-cell bucket
+//   K4  k_merge_lane      range-merge, one lane per camera vertex
+//   K5  k_resolve         replays every path's additions in the reference's order,
+//                         Framebuffer::AddColor
 //
 // Execution model: one lane per sub-path.  K1/K3 are persistent: each wave
 // owns a contiguous chunk of path indices and REFILLS lanes whose path ended
@@ -88,13 +91,12 @@ k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore s
 }
 
 /* ---------------- K3: camera sub-paths (vertexcm.hxx:415-545) ----------- */
-/* DEFER = false: the merge runs inside the path (reference order of every
- *                floating-point addition; "strict" mode);
- * DEFER = true : the path appends a 64-byte query and k_merge_wave does the
- *                range search afterwards (default). */
-template <bool DEFER>
+/* MODE 1 (default, "wavefront"): trace + scatter only; DI / VC / merge become
+ *        records and tasks for K3b / K3c / K4, k_resolve replays the additions;
+ * MODE 0 ("strict"): everything inside the path. */
+template <int MODE>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
-k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, GridStore grid, QueryStore qs,
+k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, GridStore grid, VertexStore vs,
                F4 *camOut, uint32_t *camMask, unsigned char *rngCount, unsigned long long *gstats, int chunk)
 {
     const vcm_scene_desc &sc = *scp;
@@ -103,8 +105,8 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     int next = wave * chunk;
     const int end = min(P.nLocal, next + chunk);
     LaneStats ls; lane_stats_zero(ls);
-    __shared__ uint32_t accQ[DEFER ? 1 : VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
-    MergeScratch ms; ms.q = accQ + (DEFER ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK;
+    __shared__ uint32_t accQ[MODE == 1 ? 1 : VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
+    MergeScratch ms; ms.q = accQ + (MODE == 1 ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK;
     CameraPath path;
     bool alive = false;
     for (;;) {
@@ -116,11 +118,11 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
         next += __popcll(need);
         if (!__any(alive)) break;
         if (alive) {
-            alive = camera_path_step<DEFER>(sc, P, path, store, grid, ls, ms, qs);
+            alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs);
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
-                if (DEFER) camMask[path.lp] = path.queryMask;
+                if (MODE == 1) camMask[path.lp] = path.queryMask;
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
         }
@@ -128,13 +130,46 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     flush_stats(ls, gstats);
 }
 
-/* ---------------- K4a: sort the merge queries by base cell ---------------- */
-/* Counting sort of the queued queries on the hash bucket of the cell that
- * contains the query point (hashgrid.hxx:124-131).  Queries of one bucket end
- * up adjacent, so the lanes of a wave walk the same cell lists: loads become
- * broadcasts served by L1/L2 and all lanes run the same number of steps.  The
- * order inside a bucket is arbitrary (atomics) and does not matter: every
- * query writes its own (pathLength, path) slot. */
+/* ---------------- K3b / K3c: dense connection tasks ----------------------- */
+/* One lane per task; every lane of a wave runs the same code path (a BSDF
+ * evaluation or two and ONE shadow ray), which is what the fused path could
+ * not offer: there the connection loop ran at the trip count of the busiest
+ * lane and at 23 % lane utilisation (profiles/r01b_pmc_*). */
+#define VCM_TASK_BLOCK 256
+__global__ void __launch_bounds__(VCM_TASK_BLOCK)
+k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats)
+{
+    const vcm_scene_desc &sc = *scp;
+    const int n = vs.count[1];
+    LaneStats ls; lane_stats_zero(ls);
+    for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
+        const V3 v = eval_di_task(sc, P, vs, vs.diTask[t], ls);
+        vs.diOut[t] = mk4(v.x, v.y, v.z, 0.f);
+    }
+    flush_stats(ls, gstats);
+}
+
+__global__ void __launch_bounds__(VCM_TASK_BLOCK)
+k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore vs, LightStore store,
+             unsigned long long *gstats)
+{
+    const vcm_scene_desc &sc = *scp;
+    const int n = vs.count[2];
+    LaneStats ls; lane_stats_zero(ls);
+    for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
+        const V3 v = eval_vc_task(sc, P, vs, store, vs.vcTask[2 * t], vs.vcTask[2 * t + 1], ls);
+        vs.vcOut[t] = mk4(v.x, v.y, v.z, 0.f);
+    }
+    flush_stats(ls, gstats);
+}
+
+/* ---------------- K4a: sort the camera vertices by base cell -------------- */
+/* Counting sort (indices only) of the vertex records on the hash bucket of the
+ * cell that contains the query point (hashgrid.hxx:124-131).  Vertices of one
+ * bucket become neighbours in K4, so the lanes of a wave walk the same cell
+ * lists: loads become broadcasts served by L1/L2 and all lanes run the same
+ * number of steps.  The order inside a bucket is arbitrary (atomics) and does
+ * not matter: every vertex has its own output slot. */
 __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
 {
     const V3 bmin = ld3(hdr->bboxMin), bmax = ld3(hdr->bboxMax);
@@ -146,48 +181,43 @@ __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHea
     return grid_cell_hash(int(floorf(cellPt.x)), int(floorf(cellPt.y)), int(floorf(cellPt.z)), P.nCells);
 }
 
-__global__ void k_query_count(IterParams P, QueryStore qs, const GridHeader *__restrict__ hdr, int *key, int *bucketCount)
+__global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__restrict__ hdr, int *key, int *bucketCount)
 {
-    const int nQ = *qs.count;
+    const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
-        const F4 r0 = qs.q0[q];
+        const F4 r0 = vs.q0[q];
         const int k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
         key[q] = k;
         atomicAdd(&bucketCount[k], 1);
     }
 }
 
-__global__ void k_query_scatter(QueryStore qs, const int *__restrict__ key, const int *__restrict__ bucketStart,
-                                int *bucketFill, QueryStore out)
+__global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, const int *__restrict__ bucketStart,
+                                int *bucketFill, int *sortedVertex)
 {
-    const int nQ = *qs.count;
+    const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
         const int k = key[q];
-        const int pos = bucketStart[k] + atomicAdd(&bucketFill[k], 1);
-        out.q0[pos] = qs.q0[q];
-        out.q1[pos] = qs.q1[q];
-        out.q2[pos] = qs.q2[q];
-        out.q3[pos] = qs.q3[q];
+        sortedVertex[bucketStart[k] + atomicAdd(&bucketFill[k], 1)] = q;
     }
 }
 
-/* ---------------- K4: range-merge of the queued queries -------------------- */
+/* ---------------- K4: range-merge of the camera vertices ------------------ */
 /* HashGrid::Process + RangeQuery::Process (hashgrid.hxx:110-169,
- * vertexcm.hxx:130-169).  One lane per query (merge_query): a wave keeps 64
- * dependent-load chains in flight, and because the queries arrive sorted by
- * base-cell bucket (K4a) its lanes read the same cell lists -- broadcast
- * loads, equal trip counts.  The per-query sum is in the reference's order
- * (:157-168); lane stores throughput * vmNormalization * contrib (:534) into
- * the slot (pathLength, path).
+ * vertexcm.hxx:130-169).  One lane per camera vertex (merge_query): a wave
+ * keeps 64 dependent-load chains in flight, and because the vertices arrive
+ * sorted by base-cell bucket (K4a) its lanes read the same cell lists --
+ * broadcast loads, equal trip counts.  The per-query sum is in the reference's
+ * order (:157-168).
  * (A wave-per-query mapping was measured too: 17 ms vs 6 ms for this one at
  * 2048^2 -- one query per wave exposes its 4 dependent memory round trips.) */
 #define VCM_MERGE_BLOCK 256
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK)
-k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, QueryStore qs, F4 *mergeOut,
-             unsigned long long *gstats)
+k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
+             const int *__restrict__ sortedVertex, unsigned long long *gstats)
 {
     const vcm_scene_desc &sc = *scp;
-    const int nQ = *qs.count;
+    const int nQ = vs.count[0];
     __shared__ uint32_t accQ[VCM_MERGE_Q * VCM_MERGE_BLOCK];
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK;
     LaneStats ls; lane_stats_zero(ls);
@@ -195,14 +225,9 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
     for (int base = blockIdx.x * VCM_MERGE_BLOCK; base < nQ; base += stride) {
         const int q = base + threadIdx.x;
         if (q < nQ) {
-            const F4 r0 = qs.q0[q], r1 = qs.q1[q], r2 = qs.q2[q], r3 = qs.q3[q];
-            Bsdf bsdf;
-            bsdf_restore(bsdf, mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z), (int)((f2u(r1.w) >> 8) & 0xffu), sc);
-            SubPathState st;
-            st.pathLength = f2u(r1.w) & 0xffu; st.dVCM = r2.w; st.dVM = r3.w;
-            const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(r0.x, r0.y, r0.z), ls, ms);
-            const V3 v = mk3(r3.x, r3.y, r3.z) * P.vmNormalization * contrib;   /* :534 */
-            mergeOut[(size_t)(st.pathLength - 1u) * (size_t)P.nLocal + f2u(r0.w)] = mk4(v.x, v.y, v.z, 0.f);
+            const int vi = sortedVertex[q];
+            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms);
+            vs.mergeOut[vi] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -212,10 +237,9 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
 /* vertexcm.hxx:544 adds colour p to the pixel of its jittered sample, in path
  * order.  Pixel q can receive from paths q-resX-1, q-resX, q-1, q (ascending
  * = the reference's order); light splats of the iteration are already in.
- * Deferred mode: a path's colour = its non-merge terms (camOut) + its merge
- * terms in increasing path length. */
+ * Wavefront mode: a path's colour is rebuilt by replay_path_color. */
 __global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, const uint32_t *__restrict__ camMask,
-                          const F4 *__restrict__ mergeOut, float *fb)
+                          VertexStore vs, float *fb)
 {
     const int lastQ = min(P.N, P.p0 + P.nLocal + P.resX + 1);
     for (int q = P.p0 + blockIdx.x * blockDim.x + threadIdx.x; q < lastQ; q += gridDim.x * blockDim.x) {
@@ -229,15 +253,7 @@ __global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, const uin
             const F4 c = camOut[lp];
             if ((int)f2u(c.w) != q) continue;
             V3 col = mk3(c.x, c.y, c.z);
-            if (P.deferMerge) {
-                uint32_t m = camMask[lp];
-                while (m) {
-                    const int L = __ffs((int)m) - 1;
-                    m &= m - 1u;
-                    const F4 t = mergeOut[(size_t)(L - 1) * (size_t)P.nLocal + lp];
-                    col = col + mk3(t.x, t.y, t.z);
-                }
-            }
+            if (P.wavefront) col = replay_path_color(P, vs, lp, camMask[lp], col);
             r = r + col.x; g = g + col.y; b = b + col.z;
             touched = true;
         }

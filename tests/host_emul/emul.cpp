@@ -148,8 +148,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             uint32_t q[VCM_MERGE_Q];
             MergeScratch ms; ms.q = q; ms.stride = 1;
             camera_path_begin(e.sc, P, path, lp);
-            QueryStore qs; memset(&qs, 0, sizeof(qs));
-            while (camera_path_step<false>(e.sc, P, path, store, grid, e.ls, ms, qs)) {}
+            VertexStore vs; memset(&vs, 0, sizeof(vs));
+            while (camera_path_step<0>(e.sc, P, path, store, grid, e.ls, ms, vs)) {}
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;
         }

@@ -2,7 +2,8 @@
 the unmodified reference (oracle/_ref, replaying the GPU's random-number tape).
 
 Bars
-  * algorithms without light splats (bpm, ppm): framebuffer BIT-EXACT;
+  * algorithms without light splats (bpm, ppm): framebuffer BIT-EXACT, in the
+    default wavefront mode and in strict mode;
   * vcm / bpt / lt: light splats are fp32 atomic adds whose order is not
     defined; everything else is bit-exact, so the framebuffer may differ from
     the serial order only by fp32 rounding of the per-pixel splat sum:
@@ -29,9 +30,10 @@ def _rmse(a, b):
 
 
 def _check_fb(gpu, ref, algo, strict=True):
-    """strict order + no light splats: bit-exact.  Otherwise only fp32 summation
-    order differs (atomic splats; deferred merges summed by a fixed tree)."""
-    if strict and algo not in SPLAT_ALGOS:
+    """No light splats: bit-exact in BOTH modes (the wavefront mode replays every
+    path's additions in the reference's order).  With splats only the fp32
+    order of the atomic adds differs."""
+    if algo not in SPLAT_ALGOS:
         assert np.array_equal(gpu, ref)
     else:
         assert np.all(np.abs(gpu - ref) <= 2e-5 * np.abs(ref) + 2e-7), float(np.abs(gpu - ref).max())
@@ -73,7 +75,7 @@ CASES = [(sid, algo, 64, 1, 0, 10) for sid in range(4) for algo in range(5)] + [
     (1, 4, 64, 1, 0, 2), (2, 3, 100, 1, 0, 10), (1, 4, 8, 1, 0, 10), (1, 2, 130, 3, 0, 5)]
 
 
-@pytest.mark.parametrize("strict", [False, True], ids=["deferred", "strict"])
+@pytest.mark.parametrize("strict", [False, True], ids=["wavefront", "strict"])
 @pytest.mark.parametrize("sid,algo,res,nit,mn,mx", CASES)
 def test_hip_equals_oracle(sid, algo, res, nit, mn, mx, strict):
     sc = cornell_scene(sid, res, res)
@@ -105,7 +107,7 @@ def test_hip_equals_oracle(sid, algo, res, nit, mn, mx, strict):
 
 @pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not shipped")
 @pytest.mark.parametrize("sid,algo,res,nit", [(1, 4, 128, 2), (3, 4, 128, 1), (0, 2, 96, 1), (2, 1, 96, 2), (1, 3, 96, 1)])
-@pytest.mark.parametrize("strict", [False, True], ids=["deferred", "strict"])
+@pytest.mark.parametrize("strict", [False, True], ids=["wavefront", "strict"])
 def test_hip_equals_unmodified_reference(sid, algo, res, nit, strict):
     """The GPU's tape replayed into the unmodified reference build."""
     mask = SCENE_CONFIGS[sid]
