@@ -143,9 +143,11 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
             dalloc(&c->dG3, allRecs) || dalloc(&c->dSortedIndex, allRecs)) return -1;
         /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l
            connects to light vertices of length <= L-1-l, so <= (L-1)(L-2)/2 VC tasks per path */
-        const size_t vslots = (size_t)(L > 0 ? L : 1) * (size_t)c->nLocal;
+        /* + one partly used block per wave (holes) */
+        const size_t maxWaves = (size_t)256 * 32;
+        const size_t vslots = (size_t)(L > 0 ? L : 1) * (size_t)c->nLocal + maxWaves * VCM_QBLOCK_VERTEX;
         const size_t vcPerPath = (L >= 3) ? (size_t)(L - 1) * (size_t)(L - 2) / 2 : 1;
-        const size_t vcslots = vcPerPath * (size_t)c->nLocal;
+        const size_t vcslots = vcPerPath * (size_t)c->nLocal + maxWaves * VCM_QBLOCK_VC;
         if (dalloc(&c->vs.q0, vslots) || dalloc(&c->vs.q1, vslots) || dalloc(&c->vs.q2, vslots) ||
             dalloc(&c->vs.q3, vslots) || dalloc(&c->vs.q4, vslots) || dalloc(&c->vs.meta, vslots) ||
             dalloc(&c->vs.diTask, vslots) || dalloc(&c->vs.pathVertex, vslots) || dalloc(&c->vs.diOut, vslots) ||

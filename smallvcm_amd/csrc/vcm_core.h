@@ -1015,13 +1015,56 @@ struct CameraPath {
     uint32_t queryMask;   /* wavefront mode: bit L set = a vertex record was appended at path length L */
 };
 
-/* reserve n consecutive slots of a device queue; hipcc aggregates the
- * per-lane atomics of a wave into one (ballot / DPP prefix sum) */
-VCM_HD int queue_reserve(int *counter, int n)
+/* ---- wave-level block allocator for the device queues --------------------
+ * A single hot counter word sustains only ~88 returning atomics per
+ * microsecond on MI355X, and the camera pass appends ~30 M items per
+ * iteration.  So a wave takes BLOCKS of slots from the global counter (one
+ * atomic per block) and hands slots to its lanes with ballot + prefix
+ * popcount; the unused tail of a block is filled with hole markers that the
+ * consumers skip.  On the host build (one lane) it degenerates to a counter. */
+#define VCM_QBLOCK_VERTEX 512
+#define VCM_QBLOCK_DI     512
+#define VCM_QBLOCK_VC     2048
+struct WaveQueue { int base, left; };
+
+VCM_HD uint32_t lanes_below_mask_popc(unsigned long long m)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(counter, n);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 #else
+    (void)m; return 0u;
+#endif
+}
+/* n in [0,15] items for this lane (only active lanes call): returns the lane's
+ * first slot; refills the wave's block from *counter when it runs out.
+ * holeFill(first, count, rank, nActive) must mark slots [first, first+count) as
+ * holes; it is called by the nActive active lanes, rank = 0..nActive-1. */
+template <typename HoleFill>
+VCM_HD int wave_queue_alloc(WaveQueue &wq, int *counter, int blockSize, int n, HoleFill holeFill)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+        const unsigned long long m = __ballot((n >> bit) & 1);
+        prefix += (int)lanes_below_mask_popc(m) << bit;
+        total += __popcll(m) << bit;
+    }
+    if (total > wq.left) {   /* wave-uniform */
+        const unsigned long long act = __ballot(1);
+        const int rank = (int)lanes_below_mask_popc(act);
+        holeFill(wq.base, wq.left, rank, (int)__popcll(act));
+        int nb = 0;
+        if (rank == 0) nb = atomicAdd(counter, blockSize);
+        wq.base = __shfl(nb, __ffsll((long long)act) - 1, 64);
+        wq.left = blockSize;
+    }
+    const int idx = wq.base + prefix;
+    wq.base += total;
+    wq.left -= total;
+    return idx;
+#else
+    (void)wq; (void)blockSize; (void)holeFill;
     const int r = *counter; *counter += n; return r;
 #endif
 }
@@ -1066,9 +1109,12 @@ VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, Cam
  * MODE 1 ("wavefront", default): the path only traces and scatters; per
  *         non-delta vertex it appends a VertexStore record and its DI / VC
  *         tasks.  Returns false when the path ends. */
+struct CameraWaveQueues { WaveQueue v, di, vc; };   /* wave-uniform allocator state of K3 */
+
 template <int MODE>
 VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
-                             const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const VertexStore &vs)
+                             const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const VertexStore &vs,
+                             CameraWaveQueues &wqs)
 {
     SubPathState &st = cp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
@@ -1121,15 +1167,19 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
                 }
             }
             const int nvc = __builtin_popcount(jmask);
-            const int vi = queue_reserve(&vs.count[0], 1);
-            const int di = hasDI ? queue_reserve(&vs.count[1], 1) : -1;
-            const int vc0 = nvc ? queue_reserve(&vs.count[2], nvc) : 0;
+            const int vi = wave_queue_alloc(wqs.v, &vs.count[0], VCM_QBLOCK_VERTEX, 1,
+                [&](int first, int cnt, int rank, int na) {
+                    for (int i = rank; i < cnt; i += na) vs.q0[first + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu)); });
+            const int di = wave_queue_alloc(wqs.di, &vs.count[1], VCM_QBLOCK_DI, hasDI,
+                [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.diTask[first + i] = -1; });
+            const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], VCM_QBLOCK_VC, nvc,
+                [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.vcTask[2 * (first + i)] = -1; });
             vs.q0[vi] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
             vs.q1[vi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
             vs.q2[vi] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
             vs.q3[vi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
             vs.q4[vi] = mk4(st.dVC, r0, r1, r2);
-            I4 m; m.x = di; m.y = vc0; m.z = nvc; m.w = 0;
+            I4 m; m.x = hasDI ? di : -1; m.y = vc0; m.z = nvc; m.w = 0;
             vs.meta[vi] = m;
             if (hasDI) vs.diTask[di] = vi;
             int t = vc0;
@@ -1225,14 +1275,18 @@ VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const Vert
 }
 /* the addend of :534  (color += throughput * mVmNormalization * query.GetContrib()) */
 VCM_HD V3 eval_merge_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
-                          int vi, LaneStats &ls, const MergeScratch &ms)
+                          int vi, LaneStats &ls, const MergeScratch &ms, bool hole)
 {
-    const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+    const F4 a = vs.q0[vi];
+    F4 b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+    if (hole) { b = mk4(0.f, 0.f, 1.f, u2f(1u)); c = mk4(0.f, 0.f, 1.f, 0.f); d = mk4(0.f, 0.f, 0.f, 0.f); }
     Bsdf bsdf;
     bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (int)((f2u(b.w) >> 8) & 0xffu), sc);
     SubPathState st;
     st.pathLength = f2u(b.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
-    const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms);
+    /* a hole queries a point outside every bbox: all 8 cell ranges are empty */
+    const V3 qp = hole ? sp3(-3e38f) : mk3(a.x, a.y, a.z);
+    const V3 contrib = merge_query(sc, P, g, bsdf, st, qp, ls, ms);
     return mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
 }
 /* Replays vertexcm.hxx:417-544 for one camera path: colour starts at 0, every

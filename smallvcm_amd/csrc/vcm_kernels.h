@@ -107,6 +107,8 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     LaneStats ls; lane_stats_zero(ls);
     __shared__ uint32_t accQ[MODE == 1 ? 1 : VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
     MergeScratch ms; ms.q = accQ + (MODE == 1 ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK;
+    CameraWaveQueues wqs;
+    wqs.v.base = wqs.v.left = wqs.di.base = wqs.di.left = wqs.vc.base = wqs.vc.left = 0;
     CameraPath path;
     bool alive = false;
     for (;;) {
@@ -118,7 +120,7 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
         next += __popcll(need);
         if (!__any(alive)) break;
         if (alive) {
-            alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs);
+            alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs);
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
@@ -126,6 +128,11 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
         }
+    }
+    if (MODE == 1) {   /* mark the unused tails of this wave's last blocks as holes */
+        for (int i = (int)lane; i < wqs.v.left; i += VCM_WAVE) vs.q0[wqs.v.base + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+        for (int i = (int)lane; i < wqs.di.left; i += VCM_WAVE) vs.diTask[wqs.di.base + i] = -1;
+        for (int i = (int)lane; i < wqs.vc.left; i += VCM_WAVE) vs.vcTask[2 * (wqs.vc.base + i)] = -1;
     }
     flush_stats(ls, gstats);
 }
@@ -143,7 +150,9 @@ k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
     const int n = vs.count[1];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
-        const V3 v = eval_di_task(sc, P, vs, vs.diTask[t], ls);
+        const int vi = vs.diTask[t];
+        if (vi < 0) continue;   /* hole */
+        const V3 v = eval_di_task(sc, P, vs, vi, ls);
         vs.diOut[t] = mk4(v.x, v.y, v.z, 0.f);
     }
     flush_stats(ls, gstats);
@@ -157,7 +166,9 @@ k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
     const int n = vs.count[2];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
-        const V3 v = eval_vc_task(sc, P, vs, store, vs.vcTask[2 * t], vs.vcTask[2 * t + 1], ls);
+        const int vi = vs.vcTask[2 * t];
+        if (vi < 0) continue;   /* hole */
+        const V3 v = eval_vc_task(sc, P, vs, store, vi, vs.vcTask[2 * t + 1], ls);
         vs.vcOut[t] = mk4(v.x, v.y, v.z, 0.f);
     }
     flush_stats(ls, gstats);
@@ -186,7 +197,8 @@ __global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__
     const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
         const F4 r0 = vs.q0[q];
-        const int k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
+        const int k = (f2u(r0.w) == 0xffffffffu) ? P.nCells   /* hole: the no-work bucket */
+                                                 : query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
         key[q] = k;
         atomicAdd(&bucketCount[k], 1);
     }
@@ -226,8 +238,10 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
         const int q = base + threadIdx.x;
         if (q < nQ) {
             const int vi = sortedVertex[q];
-            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms);
-            vs.mergeOut[vi] = mk4(v.x, v.y, v.z, 0.f);
+            const bool hole = f2u(vs.q0[vi].w) == 0xffffffffu;
+            /* holes run an empty query so that the wave-synchronous loops stay convergent */
+            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms, hole);
+            if (!hole) vs.mergeOut[vi] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);

@@ -149,7 +149,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             MergeScratch ms; ms.q = q; ms.stride = 1;
             camera_path_begin(e.sc, P, path, lp);
             VertexStore vs; memset(&vs, 0, sizeof(vs));
-            while (camera_path_step<0>(e.sc, P, path, store, grid, e.ls, ms, vs)) {}
+            CameraWaveQueues wqs; memset(&wqs, 0, sizeof(wqs));
+            while (camera_path_step<0>(e.sc, P, path, store, grid, e.ls, ms, vs, wqs)) {}
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;
         }
