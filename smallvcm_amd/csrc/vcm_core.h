@@ -1025,7 +1025,10 @@ struct CameraPath {
 #define VCM_QBLOCK_VERTEX 512
 #define VCM_QBLOCK_DI     512
 #define VCM_QBLOCK_VC     2048
-struct WaveQueue { int base, left; };
+/* allocator state of ONE wave: {next free slot, slots left in the block}.  It
+ * lives in LDS (one pair per wave and queue): the allocation runs in divergent
+ * code, so a register copy would go stale in the lanes that sit a call out. */
+struct WaveQueue { volatile int *p; };
 
 VCM_HD uint32_t lanes_below_mask_popc(unsigned long long m)
 {
@@ -1040,9 +1043,11 @@ VCM_HD uint32_t lanes_below_mask_popc(unsigned long long m)
  * holeFill(first, count, rank, nActive) must mark slots [first, first+count) as
  * holes; it is called by the nActive active lanes, rank = 0..nActive-1. */
 template <typename HoleFill>
-VCM_HD int wave_queue_alloc(WaveQueue &wq, int *counter, int blockSize, int n, HoleFill holeFill)
+VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, int n, HoleFill holeFill)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long act = __ballot(1);
+    const int rank = (int)lanes_below_mask_popc(act);
     int prefix = 0, total = 0;
 #pragma unroll
     for (int bit = 0; bit < 4; bit++) {
@@ -1050,19 +1055,16 @@ VCM_HD int wave_queue_alloc(WaveQueue &wq, int *counter, int blockSize, int n, H
         prefix += (int)lanes_below_mask_popc(m) << bit;
         total += __popcll(m) << bit;
     }
-    if (total > wq.left) {   /* wave-uniform */
-        const unsigned long long act = __ballot(1);
-        const int rank = (int)lanes_below_mask_popc(act);
-        holeFill(wq.base, wq.left, rank, (int)__popcll(act));
+    int base = wq.p[0], left = wq.p[1];   /* same values in every active lane */
+    if (total > left) {   /* wave-uniform */
+        holeFill(base, left, rank, (int)__popcll(act));
         int nb = 0;
         if (rank == 0) nb = atomicAdd(counter, blockSize);
-        wq.base = __shfl(nb, __ffsll((long long)act) - 1, 64);
-        wq.left = blockSize;
+        base = __shfl(nb, __ffsll((long long)act) - 1, 64);
+        left = blockSize;
     }
-    const int idx = wq.base + prefix;
-    wq.base += total;
-    wq.left -= total;
-    return idx;
+    if (rank == 0) { wq.p[0] = base + total; wq.p[1] = left - total; }
+    return base + prefix;
 #else
     (void)wq; (void)blockSize; (void)holeFill;
     const int r = *counter; *counter += n; return r;

@@ -107,8 +107,11 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     LaneStats ls; lane_stats_zero(ls);
     __shared__ uint32_t accQ[MODE == 1 ? 1 : VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
     MergeScratch ms; ms.q = accQ + (MODE == 1 ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK;
+    __shared__ int wqState[(VCM_TRACE_BLOCK / VCM_WAVE) * 6];   /* per wave: 3 queues x {next, left} */
+    int *myState = wqState + (threadIdx.x / VCM_WAVE) * 6;
+    if (lane < 6) myState[lane] = 0;
     CameraWaveQueues wqs;
-    wqs.v.base = wqs.v.left = wqs.di.base = wqs.di.left = wqs.vc.base = wqs.vc.left = 0;
+    wqs.v.p = myState; wqs.di.p = myState + 2; wqs.vc.p = myState + 4;
     CameraPath path;
     bool alive = false;
     for (;;) {
@@ -130,9 +133,10 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
         }
     }
     if (MODE == 1) {   /* mark the unused tails of this wave's last blocks as holes */
-        for (int i = (int)lane; i < wqs.v.left; i += VCM_WAVE) vs.q0[wqs.v.base + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
-        for (int i = (int)lane; i < wqs.di.left; i += VCM_WAVE) vs.diTask[wqs.di.base + i] = -1;
-        for (int i = (int)lane; i < wqs.vc.left; i += VCM_WAVE) vs.vcTask[2 * (wqs.vc.base + i)] = -1;
+        const int vb = wqs.v.p[0], vl = wqs.v.p[1], db = wqs.di.p[0], dl = wqs.di.p[1], cb = wqs.vc.p[0], cl = wqs.vc.p[1];
+        for (int i = (int)lane; i < vl; i += VCM_WAVE) vs.q0[vb + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+        for (int i = (int)lane; i < dl; i += VCM_WAVE) vs.diTask[db + i] = -1;
+        for (int i = (int)lane; i < cl; i += VCM_WAVE) vs.vcTask[2 * (cb + i)] = -1;
     }
     flush_stats(ls, gstats);
 }

@@ -149,7 +149,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             MergeScratch ms; ms.q = q; ms.stride = 1;
             camera_path_begin(e.sc, P, path, lp);
             VertexStore vs; memset(&vs, 0, sizeof(vs));
-            CameraWaveQueues wqs; memset(&wqs, 0, sizeof(wqs));
+            int wqState[6] = {0, 0, 0, 0, 0, 0};
+            CameraWaveQueues wqs; wqs.v.p = wqState; wqs.di.p = wqState + 2; wqs.vc.p = wqState + 4;
             while (camera_path_step<0>(e.sc, P, path, store, grid, e.ls, ms, vs, wqs)) {}
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;
