@@ -465,7 +465,7 @@ int vcm_trace_camera(vcm_ctx *c)
             HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
             if (c->useVM) {
                 /* K4a: counting sort of the camera vertices by base-cell bucket (reuses the grid-build scratch) */
-                const int nb = c->P.nCells + 1;
+                const int nb = c->P.nCells;
                 HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
                 HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
                 hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
@@ -476,7 +476,7 @@ int vcm_trace_camera(vcm_ctx *c)
                 HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
                 /* K4 */
                 hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid,
-                                   c->vs, (const int *)c->dSortedVertex, c->dStats);
+                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats);
             } else {
                 HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
             }

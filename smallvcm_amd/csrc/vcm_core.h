@@ -1277,18 +1277,14 @@ VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const Vert
 }
 /* the addend of :534  (color += throughput * mVmNormalization * query.GetContrib()) */
 VCM_HD V3 eval_merge_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
-                          int vi, LaneStats &ls, const MergeScratch &ms, bool hole)
+                          int vi, LaneStats &ls, const MergeScratch &ms)
 {
-    const F4 a = vs.q0[vi];
-    F4 b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
-    if (hole) { b = mk4(0.f, 0.f, 1.f, u2f(1u)); c = mk4(0.f, 0.f, 1.f, 0.f); d = mk4(0.f, 0.f, 0.f, 0.f); }
+    const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
     Bsdf bsdf;
     bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (int)((f2u(b.w) >> 8) & 0xffu), sc);
     SubPathState st;
     st.pathLength = f2u(b.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
-    /* a hole queries a point outside every bbox: all 8 cell ranges are empty */
-    const V3 qp = hole ? sp3(-3e38f) : mk3(a.x, a.y, a.z);
-    const V3 contrib = merge_query(sc, P, g, bsdf, st, qp, ls, ms);
+    const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms);
     return mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
 }
 /* Replays vertexcm.hxx:417-544 for one camera path: colour starts at 0, every

@@ -191,20 +191,25 @@ __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHea
     const V3 distMin = queryPos - bmin;
     const V3 distMax = bmax - queryPos;
     if (distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f || distMin.z < 0.f || distMax.z < 0.f)
-        return P.nCells;   /* outside the photon bbox: no work, own bucket */
+        return -1;   /* outside the photon bbox: HashGrid::Process returns at once (:116-122) */
     const V3 cellPt = P.invCellSize * distMin;
     return grid_cell_hash(int(floorf(cellPt.x)), int(floorf(cellPt.y)), int(floorf(cellPt.z)), P.nCells);
 }
 
+/* holes and out-of-bbox vertices are not sorted at all (key -1): they would all
+ * land in one bucket, i.e. on one atomic word */
 __global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__restrict__ hdr, int *key, int *bucketCount)
 {
     const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
         const F4 r0 = vs.q0[q];
-        const int k = (f2u(r0.w) == 0xffffffffu) ? P.nCells   /* hole: the no-work bucket */
-                                                 : query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
+        int k = -1;
+        if (f2u(r0.w) != 0xffffffffu) {
+            k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
+            if (k < 0) vs.mergeOut[q] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query: contrib = 0 */
+        }
         key[q] = k;
-        atomicAdd(&bucketCount[k], 1);
+        if (k >= 0) atomicAdd(&bucketCount[k], 1);
     }
 }
 
@@ -214,7 +219,7 @@ __global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, con
     const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
         const int k = key[q];
-        sortedVertex[bucketStart[k] + atomicAdd(&bucketFill[k], 1)] = q;
+        if (k >= 0) sortedVertex[bucketStart[k] + atomicAdd(&bucketFill[k], 1)] = q;
     }
 }
 
@@ -230,10 +235,10 @@ __global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, con
 #define VCM_MERGE_BLOCK 256
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK)
 k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
-             const int *__restrict__ sortedVertex, unsigned long long *gstats)
+             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats)
 {
     const vcm_scene_desc &sc = *scp;
-    const int nQ = vs.count[0];
+    const int nQ = *nSorted;
     __shared__ uint32_t accQ[VCM_MERGE_Q * VCM_MERGE_BLOCK];
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK;
     LaneStats ls; lane_stats_zero(ls);
@@ -242,10 +247,8 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
         const int q = base + threadIdx.x;
         if (q < nQ) {
             const int vi = sortedVertex[q];
-            const bool hole = f2u(vs.q0[vi].w) == 0xffffffffu;
-            /* holes run an empty query so that the wave-synchronous loops stay convergent */
-            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms, hole);
-            if (!hole) vs.mergeOut[vi] = mk4(v.x, v.y, v.z, 0.f);
+            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms);
+            vs.mergeOut[vi] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
