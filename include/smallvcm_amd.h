@@ -183,12 +183,15 @@ int vcm_set_stream(vcm_ctx *ctx, void *hipStream);
 int vcm_run_iteration(vcm_ctx *ctx, int iteration, unsigned minLen, unsigned maxLen);
 
 /* Phase-level entry points: vcm_run_iteration == begin, trace_light,
- * build_grid, trace_camera, end.  A multi-GPU host puts the all-gather of the
- * light-vertex records between trace_light and build_grid. */
+ * build_grid, trace_camera, merge, end.  A multi-GPU host puts the all-gather
+ * of the light-vertex records between trace_light and build_grid; in the
+ * default (wavefront) mode vcm_trace_camera does not need the grid, so it may
+ * run BEFORE vcm_build_grid, overlapping the all-gather. */
 int vcm_begin_iteration(vcm_ctx *ctx, int iteration, unsigned minLen, unsigned maxLen); /* :288-316 */
 int vcm_trace_light(vcm_ctx *ctx);   /* :321-396, then compaction into merge records */
 int vcm_build_grid(vcm_ctx *ctx);    /* :403-408 -> hashgrid.hxx:41-107 */
-int vcm_trace_camera(vcm_ctx *ctx);  /* :415-545 */
+int vcm_trace_camera(vcm_ctx *ctx);  /* :415-545 (wavefront mode: all but the merge :530-538) */
+int vcm_merge(vcm_ctx *ctx);         /* :530-538 for every camera vertex, then AddColor :544 */
 int vcm_end_iteration(vcm_ctx *ctx); /* :547 */
 
 /* Local merge records of this rank after vcm_trace_light: device pointer to

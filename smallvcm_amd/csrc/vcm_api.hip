@@ -28,7 +28,8 @@ static int fail(const char *what, const char *detail)
         if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));        \
     } while (0)
 
-enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID, EV_CAMERA_K1, EV_CONNECT_K1, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
+enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID_K0, EV_GRID, EV_CAMERA_K0, EV_CAMERA_K1, EV_CONNECT_K1,
+       EV_MERGE_K0, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
 
 struct vcm_ctx {
     vcm_scene_desc scene;
@@ -51,8 +52,10 @@ struct vcm_ctx {
     int *dLocalTotal;                 /* 1 */
     int *dTileSums;                   /* scan scratch */
     float *dRecordsLocal;             /* S*nLocal records */
+    int *dSlotOfVertex;               /* S*nLocal: dense vertex index -> slot in the light store */
     float *dRecordsAll;               /* S*N records (multi-rank only) */
     bool importedRecords;
+    bool gridBuilt, cameraTraced, merged;
     GridHeader *dHdr;
     int *dCellCount, *dCellStart, *dCellFill;   /* nCells+1 each */
     int *dCellId, *dUnsorted;         /* per record */
@@ -89,7 +92,7 @@ template <typename T> static int dalloc(T **p, size_t n)
 static void free_iteration_buffers(vcm_ctx *c)
 {
     DFREE(c->store.v0); DFREE(c->store.v1); DFREE(c->store.v2); DFREE(c->store.v3); DFREE(c->store.v4);
-    DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll);
+    DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll); DFREE(c->dSlotOfVertex);
     DFREE(c->dCellId); DFREE(c->dUnsorted);
     DFREE(c->dG0); DFREE(c->dG1); DFREE(c->dG2); DFREE(c->dG3); DFREE(c->dSortedIndex);
     DFREE(c->vs.q0); DFREE(c->vs.q1); DFREE(c->vs.q2); DFREE(c->vs.q3); DFREE(c->vs.q4); DFREE(c->vs.meta);
@@ -137,6 +140,7 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->store.v0, slots) || dalloc(&c->store.v1, slots) || dalloc(&c->store.v2, slots) ||
             dalloc(&c->store.v3, slots) || dalloc(&c->store.v4, slots)) return -1;
         if (dalloc(&c->dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
+        if (dalloc(&c->dSlotOfVertex, slots)) return -1;
         if (c->world > 1 && dalloc(&c->dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
         if (dalloc(&c->dCellId, allRecs) || dalloc(&c->dUnsorted, allRecs)) return -1;
         if (dalloc(&c->dG0, allRecs) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
@@ -332,6 +336,7 @@ int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned max
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
+    c->gridBuilt = c->cameraTraced = c->merged = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -344,16 +349,26 @@ int vcm_trace_light(vcm_ctx *c)
     int blocks, chunk;
     trace_launch_shape(c->nLocal, &blocks, &chunk);
     HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K0], c->stream));
-    hipLaunchKernelGGL(k_light_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                       c->dFb, c->dRngLight, c->dStats, chunk);
+    const bool wf = !c->strictOrder;
+    if (wf)
+        hipLaunchKernelGGL(k_light_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
+                           c->dFb, c->dRngLight, c->dStats, chunk);
+    else
+        hipLaunchKernelGGL(k_light_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
+                           c->dFb, c->dRngLight, c->dStats, chunk);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K1], c->stream));
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
        record array in the reference's vertex order */
     if (launch_scan<unsigned char>(c, c->store.count, c->nLocal, c->dPathStart, c->dLocalTotal, 0)) return -1;
-    if (c->useVM) {
+    if (c->useVM || wf) {
         hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
-                           c->dRecordsLocal);
+                           c->dRecordsLocal, c->dSlotOfVertex);
+        HIPCHK(hipGetLastError());
+    }
+    if (wf && (c->useVC || c->lightTraceOnly)) {   /* K1c */
+        hipLaunchKernelGGL(k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
+                           (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dStats);
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
@@ -418,6 +433,8 @@ int vcm_build_grid(vcm_ctx *c)
 {   /* vertexcm.hxx:403-408 -> HashGrid::Build hashgrid.hxx:41-107 */
     if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
     if (use_device(c)) return -1;
+    HIPCHK(hipEventRecord(c->ev[EV_GRID_K0], c->stream));
+    c->gridBuilt = true;
     if (c->useVM) {
         const float *recs = c->importedRecords ? c->dRecordsAll : c->dRecordsLocal;
         const int nCells = c->P.nCells;
@@ -425,7 +442,7 @@ int vcm_build_grid(vcm_ctx *c)
         HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
         HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr);
-        hipLaunchKernelGGL(k_bbox, g, b, 0, c->stream, recs, c->dHdr);
+        hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, c->stream, recs, c->dHdr);
         hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr);
         hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
                            c->dCellCount);
@@ -442,64 +459,86 @@ int vcm_build_grid(vcm_ctx *c)
     return 0;
 }
 
+static GridStore grid_of(vcm_ctx *c)
+{
+    GridStore grid;
+    grid.cellStart = c->dCellStart; grid.g0 = c->dG0; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
+    grid.hdr = c->dHdr;
+    return grid;
+}
+
 int vcm_trace_camera(vcm_ctx *c)
-{   /* vertexcm.hxx:415-545 */
+{   /* vertexcm.hxx:415-545 without the merge (:530-538) in wavefront mode */
     if (!c || !c->inIteration) return fail("vcm_trace_camera", "no iteration in progress");
     if (use_device(c)) return -1;
-    if (!c->lightTraceOnly) {
-        int blocks, chunk;
-        trace_launch_shape(c->nLocal, &blocks, &chunk);
-        GridStore grid;
-        grid.cellStart = c->dCellStart; grid.g0 = c->dG0; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
-        grid.hdr = c->dHdr;
-        if (c->P.wavefront) {
-            hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
-                               c->store, grid, c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
-            HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
-            if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
-                hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
-                                   c->dStats);
-                hipLaunchKernelGGL(k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
-                                   c->store, c->dStats);
-            }
-            HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
-            if (c->useVM) {
-                /* K4a: counting sort of the camera vertices by base-cell bucket (reuses the grid-build scratch) */
-                const int nb = c->P.nCells;
-                HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
-                HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
-                hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
-                                   (const GridHeader *)c->dHdr, c->dQueryKey, c->dCellCount);
-                if (launch_scan<int>(c, c->dCellCount, nb, c->dQueryStart, NULL, 1)) return -1;
-                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
-                                   (const int *)c->dQueryStart, c->dCellFill, c->dSortedVertex);
-                HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
-                /* K4 */
-                hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid,
-                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats);
-            } else {
-                HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
-            }
-            HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
-        } else {
-            hipLaunchKernelGGL(k_camera_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
-                               c->store, grid, c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
-            HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
-            HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
-            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
-            HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
+    c->cameraTraced = true;
+    if (c->lightTraceOnly) return 0;
+    int blocks, chunk;
+    trace_launch_shape(c->nLocal, &blocks, &chunk);
+    HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K0], c->stream));
+    if (c->P.wavefront) {
+        /* K3: needs the light-vertex store, NOT the hash grid */
+        hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+                           c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+        if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
+            hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+                               c->dStats);
+            hipLaunchKernelGGL(k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+                               c->store, c->dStats);
         }
+        HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
+    } else {
+        if (c->useVM && !c->gridBuilt) return fail("vcm_trace_camera", "strict mode merges inside the camera pass: call vcm_build_grid first");
+        hipLaunchKernelGGL(k_camera_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+                           c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+        HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vcm_merge(vcm_ctx *c)
+{   /* vertexcm.hxx:530-538 for all camera vertices, then :544 */
+    if (!c || !c->inIteration) return fail("vcm_merge", "no iteration in progress");
+    if (!c->cameraTraced) return fail("vcm_merge", "call vcm_trace_camera first");
+    if (use_device(c)) return -1;
+    if (!c->lightTraceOnly) {
+        HIPCHK(hipEventRecord(c->ev[EV_MERGE_K0], c->stream));
+        if (c->P.wavefront && c->useVM) {
+            if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
+            /* K4a: counting sort of the camera vertices by base-cell bucket (reuses the grid-build scratch) */
+            const int nb = c->P.nCells;
+            HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+            HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+            hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
+                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dCellCount);
+            if (launch_scan<int>(c, c->dCellCount, nb, c->dQueryStart, NULL, 1)) return -1;
+            hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
+                               (const int *)c->dQueryStart, c->dCellFill, c->dSortedVertex);
+            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
+            /* K4 */
+            hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                               c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats);
+        } else {
+            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
+        }
+        HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
+        /* K5 */
         hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[EV_CAMERA], c->stream));
+    c->merged = true;
     return 0;
 }
 
 int vcm_end_iteration(vcm_ctx *c)
 {
     if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
+    if (!c->merged) return fail("vcm_end_iteration", "vcm_merge has not run");
     c->iterations++;   /* :547 */
     c->inIteration = false;
     c->evValid = true;
@@ -515,6 +554,7 @@ int vcm_run_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLe
     if (vcm_trace_light(c)) return -1;
     if (vcm_build_grid(c)) return -1;
     if (vcm_trace_camera(c)) return -1;
+    if (vcm_merge(c)) return -1;
     return vcm_end_iteration(c);
 }
 
@@ -581,18 +621,18 @@ int vcm_get_stats(vcm_ctx *c, vcm_stats *out)
     if (c->evValid) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_LIGHT]) == hipSuccess) out->msLight = ms;
-        if (hipEventElapsedTime(&ms, c->ev[EV_LIGHT], c->ev[EV_GRID]) == hipSuccess) out->msGrid = ms;
-        if (hipEventElapsedTime(&ms, c->ev[EV_GRID], c->ev[EV_CAMERA]) == hipSuccess) out->msCamera = ms;
+        if (hipEventElapsedTime(&ms, c->ev[EV_GRID_K0], c->ev[EV_GRID]) == hipSuccess) out->msGrid = ms;
         if (hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_CAMERA]) == hipSuccess) out->msTotal = ms;
         if (hipEventElapsedTime(&ms, c->ev[EV_LIGHT_K0], c->ev[EV_LIGHT_K1]) == hipSuccess) out->msLightKernel = ms;
-        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_GRID], c->ev[EV_CAMERA_K1]) == hipSuccess)
-            out->msCameraKernel = ms;
-        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_SORT_K1], c->ev[EV_MERGE_K1]) == hipSuccess)
-            out->msMergeKernel = ms;
-        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CONNECT_K1], c->ev[EV_SORT_K1]) == hipSuccess)
-            out->msQuerySort = ms;
-        if (!c->lightTraceOnly && hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_CONNECT_K1]) == hipSuccess)
-            out->msConnectKernels = ms;
+        if (!c->lightTraceOnly) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, c->ev[EV_CAMERA_K0], c->ev[EV_CONNECT_K1]) == hipSuccess &&
+                hipEventElapsedTime(&b, c->ev[EV_MERGE_K0], c->ev[EV_CAMERA]) == hipSuccess) out->msCamera = a + b;
+            if (hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K0], c->ev[EV_CAMERA_K1]) == hipSuccess) out->msCameraKernel = ms;
+            if (hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_CONNECT_K1]) == hipSuccess) out->msConnectKernels = ms;
+            if (hipEventElapsedTime(&ms, c->ev[EV_MERGE_K0], c->ev[EV_SORT_K1]) == hipSuccess) out->msQuerySort = ms;
+            if (hipEventElapsedTime(&ms, c->ev[EV_SORT_K1], c->ev[EV_MERGE_K1]) == hipSuccess) out->msMergeKernel = ms;
+        }
     }
     c->lastStats = *out;
     return 0;

@@ -736,7 +736,10 @@ VCM_HD void light_path_begin(const vcm_scene_desc &sc, const IterParams &P, Ligh
     generate_light_sample(sc, P, lp.rng, lp.st);
 }
 
-/* one iteration of the for(;;) at :328-393; returns false when the path ends */
+/* one iteration of the for(;;) at :328-393; returns false when the path ends.
+ * MODE 1 (wavefront): ConnectToCamera (:380-384) is left to k_connect_camera,
+ * which runs it for every stored vertex. */
+template <int MODE>
 VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, LightPath &lp, const LightStore &store,
                             float *fb, LaneStats &ls)
 {
@@ -756,7 +759,7 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
         st.dVC  /= mis(fabsf(bsdf.localDirFix.z));
         st.dVM  /= mis(fabsf(bsdf.localDirFix.z));
     }
-    if (!bsdf.isDelta && (P.useVC || P.useVM)) {   /* :364-377 */
+    if (!bsdf.isDelta && (P.useVC || P.useVM || (MODE == 1 && P.lightTraceOnly))) {   /* :364-377 */
         const size_t slot = (size_t)lp.nStored * (size_t)P.nLocal + (size_t)lp.lp;
         const V3 wdir = to_world(bsdf.frame, bsdf.localDirFix);   /* WorldDirFix bsdf.hxx:264 */
         store.v0[slot] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
@@ -767,13 +770,28 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
         lp.nStored++;
         ls.stored++;
     }
-    if (!bsdf.isDelta && (P.useVC || P.lightTraceOnly)) {   /* :380-384 */
+    if (MODE == 0 && !bsdf.isDelta && (P.useVC || P.lightTraceOnly)) {   /* :380-384 */
         if (st.pathLength + 1 >= P.minLen) connect_to_camera(sc, P, st, hitPoint, bsdf, fb, ls);
     }
     if (st.pathLength + 2 > P.maxLen) return false;   /* :387 */
     if (!sample_scattering(sc, P, true, lp.rng, bsdf, hitPoint, st)) return false;
     ++st.pathLength;
     return true;
+}
+
+/* ConnectToCamera (:380-384, :862-933) for a STORED light vertex (wavefront mode) */
+VCM_HD void connect_stored_vertex_to_camera(const vcm_scene_desc &sc, const IterParams &P, const LightStore &store,
+                                            size_t slot, float *fb, LaneStats &ls)
+{
+    const F4 a = store.v0[slot], b = store.v1[slot], c = store.v2[slot], d = store.v3[slot];
+    SubPathState st;
+    st.pathLength = f2u(a.w) & 0xffu;
+    if (!(st.pathLength + 1 >= P.minLen)) return;
+    st.throughput = mk3(b.x, b.y, b.z);
+    st.dVCM = b.w; st.dVC = c.w; st.dVM = d.w;
+    Bsdf bsdf;
+    bsdf_restore(bsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
+    connect_to_camera(sc, P, st, mk3(a.x, a.y, a.z), bsdf, fb, ls);
 }
 
 /* ================= camera sub-path (vertexcm.hxx:415-545) ============= */

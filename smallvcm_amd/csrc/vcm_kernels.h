@@ -58,6 +58,7 @@ __device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long l
 }
 
 /* ---------------- K1: light sub-paths (vertexcm.hxx:321-396) ------------ */
+template <int MODE>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
 k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, float *fb,
               unsigned char *rngCount, unsigned long long *gstats, int chunk)
@@ -80,7 +81,7 @@ k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore s
         next += __popcll(need);
         if (!__any(alive)) break;
         if (alive) {
-            alive = light_path_step(sc, P, path, store, fb, ls);
+            alive = light_path_step<MODE>(sc, P, path, store, fb, ls);
             if (!alive) {
                 store.count[path.lp] = (unsigned char)path.nStored;   /* mPathEnds :395 */
                 rngCount[path.lp] = (unsigned char)path.rng.k;
@@ -356,7 +357,8 @@ k_scan_apply(const T *__restrict__ in, int n, const int *__restrict__ tileOffset
  * (vertexcm.hxx:130-169): pos, WorldDirFix, throughput, dVCM, dVM,
  * ContinuationProb, pathLength.  Record order = the reference's
  * mLightVertices order (path-major, then bounce). */
-__global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records)
+__global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
+                                  int *slotOfVertex)
 {
     const long long total = (long long)P.S * P.nLocal;
     for (long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x; slot < total;
@@ -364,14 +366,33 @@ __global__ void k_compact_records(IterParams P, LightStore store, const int *__r
         const int j = (int)(slot / P.nLocal);
         const int lp = (int)(slot - (long long)j * P.nLocal);
         if (j >= (int)store.count[lp]) continue;
+        const int vtx = pathStart[lp] + j;
+        slotOfVertex[vtx] = (int)slot;   /* dense vertex list for k_connect_camera */
+        if (!P.useVM) continue;
         const F4 a = store.v0[slot], b = store.v1[slot], d = store.v3[slot], e = store.v4[slot];
-        float *r = records + (size_t)(pathStart[lp] + j) * VCM_MERGE_RECORD_FLOATS;
+        float *r = records + (size_t)vtx * VCM_MERGE_RECORD_FLOATS;
         r[0] = a.x; r[1] = a.y; r[2] = a.z;
         r[3] = e.x; r[4] = e.y; r[5] = e.z;
         r[6] = b.x; r[7] = b.y; r[8] = b.z;
         r[9] = b.w; r[10] = d.w; r[11] = e.w;
         r[12] = u2f(f2u(a.w) & 0xffu);
     }
+}
+
+/* ---------------- K1c: connect every stored light vertex to the camera ---- */
+/* vertexcm.hxx:380-384 / :862-933, one lane per stored vertex (dense list):
+ * BSDF evaluation, MIS weight, one shadow ray, fp32 atomic splat. */
+__global__ void __launch_bounds__(256)
+k_connect_camera(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store,
+                 const int *__restrict__ slotOfVertex, const int *__restrict__ nVertices, float *fb,
+                 unsigned long long *gstats)
+{
+    const vcm_scene_desc &sc = *scp;
+    const int n = *nVertices;
+    LaneStats ls; lane_stats_zero(ls);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        connect_stored_vertex_to_camera(sc, P, store, (size_t)slotOfVertex[i], fb, ls);
+    flush_stats(ls, gstats);
 }
 
 __global__ void k_set_counts(GridHeader *hdr, const int *localTotal, int useLocalAsGlobal, int globalTotal)
@@ -396,8 +417,9 @@ __global__ void k_grid_init(GridHeader *hdr)
     if (threadIdx.x < 3) { hdr->bboxMinU[threadIdx.x] = 0xffffffffu; hdr->bboxMaxU[threadIdx.x] = 0u; }
 }
 
-__global__ void k_bbox(const float *__restrict__ records, GridHeader *hdr)
-{   /* :50-61 */
+__global__ void __launch_bounds__(256) k_bbox(const float *__restrict__ records, GridHeader *hdr)
+{   /* :50-61.  min/max are exact and order-free; one atomic set per BLOCK (wave shuffle, then LDS):
+       per-wave atomics on six hot words cost 0.5 ms at 8192 waves */
     const int n = hdr->nRecords;
     uint32_t mn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, mx[3] = { 0u, 0u, 0u };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -409,6 +431,8 @@ __global__ void k_bbox(const float *__restrict__ records, GridHeader *hdr)
             mx[c] = max(mx[c], k);
         }
     }
+    __shared__ uint32_t smn[4][3], smx[4][3];
+    const int w = threadIdx.x / VCM_WAVE;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
 #pragma unroll
@@ -416,7 +440,15 @@ __global__ void k_bbox(const float *__restrict__ records, GridHeader *hdr)
             mn[c] = min(mn[c], (uint32_t)__shfl_xor((int)mn[c], o, 64));
             mx[c] = max(mx[c], (uint32_t)__shfl_xor((int)mx[c], o, 64));
         }
-        if (lane_id() == 0) { atomicMin(&hdr->bboxMinU[c], mn[c]); atomicMax(&hdr->bboxMaxU[c], mx[c]); }
+        if (lane_id() == 0) { smn[w][c] = mn[c]; smx[w][c] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        const uint32_t a = min(min(smn[0][c], smn[1][c]), min(smn[2][c], smn[3][c]));
+        const uint32_t b = max(max(smx[0][c], smx[1][c]), max(smx[2][c], smx[3][c]));
+        atomicMin(&hdr->bboxMinU[c], a);
+        atomicMax(&hdr->bboxMaxU[c], b);
     }
 }
 

@@ -60,7 +60,7 @@ def load_library(require_gpu=True):
         L.vcm_set_strict_order.argtypes = [vp, C.c_int]
         L.vcm_run_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
         L.vcm_begin_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
-        for n in ("vcm_trace_light", "vcm_build_grid", "vcm_trace_camera", "vcm_end_iteration", "vcm_synchronize",
+        for n in ("vcm_trace_light", "vcm_build_grid", "vcm_trace_camera", "vcm_merge", "vcm_end_iteration", "vcm_synchronize",
                   "vcm_clear_framebuffer", "vcm_iterations"):
             getattr(L, n).argtypes = [vp]
         L.vcm_light_records.argtypes = [vp, C.POINTER(vp), llp]
@@ -151,8 +151,9 @@ class HipBackend:
             pass
 
     def set_strict_order(self, on):
-        """True: merges inside the camera path, reference order of additions (bit-exact, slower)."""
+        """True: DI / VC / merge inside the camera path as the reference does (slower, same bits)."""
         _check(self.L, self.L.vcm_set_strict_order(self.ctx, 1 if on else 0), "vcm_set_strict_order")
+        self.camera_before_grid = not on
 
     def set_stream(self, stream_handle):
         _check(self.L, self.L.vcm_set_stream(self.ctx, stream_handle), "vcm_set_stream")
@@ -168,6 +169,12 @@ class HipBackend:
 
     def trace_camera(self):
         _check(self.L, self.L.vcm_trace_camera(self.ctx), "vcm_trace_camera")
+
+    def merge(self):
+        _check(self.L, self.L.vcm_merge(self.ctx), "vcm_merge")
+
+    #: the camera trace needs only the local light vertices (not the grid) unless strict mode is on
+    camera_before_grid = True
 
     def end(self):
         _check(self.L, self.L.vcm_end_iteration(self.ctx), "vcm_end_iteration")
@@ -318,6 +325,7 @@ class ShardedVertexCM:
         b, dist = self.backend, self.dist
         b.begin(aIteration, self.mMinPathLength, self.mMaxPathLength)
         b.trace_light()
+        work = None
         if self.world > 1:
             n_local = b.local_record_count()
             # 1) counts (tiny all-gather)
@@ -327,7 +335,8 @@ class ShardedVertexCM:
             dist.all_gather_into_tensor(cnts, cnt, group=self.group)
             counts = [int(x) for x in cnts.tolist()]
             stride = max(max(counts), 1)
-            # 2) records, padded to the largest shard
+            # 2) records, padded to the largest shard; asynchronous: the camera
+            #    trace below does not need the other ranks' vertices
             need = stride * VCM_MERGE_RECORD_FLOATS
             if self._local is None or self._local.numel() < need:
                 self._local = b.new_tensor(need)
@@ -335,10 +344,18 @@ class ShardedVertexCM:
             local = self._local[:need]
             gathered = self._gather[:need * self.world]
             b.export_records(local, n_local)
-            dist.all_gather_into_tensor(gathered, local, group=self.group)
+            overlap = getattr(b, "camera_before_grid", False)
+            work = dist.all_gather_into_tensor(gathered, local, group=self.group, async_op=overlap)
+        early = work is not None and getattr(b, "camera_before_grid", False)
+        if early:
+            b.trace_camera()            # overlaps the all-gather
+            work.wait()
+        if self.world > 1:
             b.import_records(gathered, counts, stride)
         b.build_grid()
-        b.trace_camera()
+        if not early:
+            b.trace_camera()
+        b.merge()
         b.end()
 
     def WasUsed(self):

@@ -95,7 +95,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     for (int lp = 0; lp < e.nLocal; lp++) {
         LightPath path;
         light_path_begin(e.sc, P, path, lp);
-        while (light_path_step(e.sc, P, path, store, e.fb.data(), e.ls)) {}
+        while (light_path_step<0>(e.sc, P, path, store, e.fb.data(), e.ls)) {}
         e.count[lp] = (unsigned char)path.nStored;
         e.rngL[lp] = (unsigned char)path.rng.k;
     }

@@ -38,8 +38,13 @@ class OracleBackend:
     def build_grid(self):
         self.o.build_grid()
 
+    camera_before_grid = False   # the oracle's camera pass merges inline
+
     def trace_camera(self):
         self.o.trace_camera()
+
+    def merge(self):
+        pass
 
     def end(self):
         self.o.end()

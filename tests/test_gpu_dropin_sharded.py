@@ -94,13 +94,18 @@ class _ThreadCollectives:
         parts = list(self.slots)
         return parts
 
-    def all_gather_into_tensor(self, out, inp, group=None):
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
         parts = self._exchange(inp)
         n = inp.numel()
         for r, p in enumerate(parts):
             out[r * n:(r + 1) * n].copy_(p)
         self.torch.cuda.current_stream().synchronize()
         self.bar.wait()
+        return self._Done()
 
     def all_reduce(self, t, op=None, group=None):
         parts = self._exchange(t.clone())
