@@ -768,7 +768,7 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
         store.v3[slot] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
         store.v4[slot] = mk4(wdir.x, wdir.y, wdir.z, bsdf.contProb);
         lp.nStored++;
-        ls.stored++;
+        if (P.useVC || P.useVM) ls.stored++;   /* the reference stores nothing in light-trace mode (:364) */
     }
     if (MODE == 0 && !bsdf.isDelta && (P.useVC || P.lightTraceOnly)) {   /* :380-384 */
         if (st.pathLength + 1 >= P.minLen) connect_to_camera(sc, P, st, hitPoint, bsdf, fb, ls);
