@@ -930,8 +930,84 @@ VCM_HD bool wave_any(bool x)
 #define VCM_MERGE_UNROLL 4
 struct MergeScratch { uint32_t *q; int stride; };
 
-VCM_HD void merge_drain(const vcm_scene_desc &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
-                        const SubPathState &st, const MergeScratch &ms, int qn, V3 &contrib)
+/* Everything of RangeQuery::Process (vertexcm.hxx:130-169) and of the camera
+ * BSDF::Evaluate (bsdf.hxx:128-153, :393-446) that does not depend on the
+ * photon, computed once per query.  The per-photon part below performs the
+ * remaining operations of the reference in the same order on the same values,
+ * so the sum is bit-identical to evaluating bsdf_evaluate()/merge_photon() per
+ * photon (the material would otherwise be re-fetched with a lane-varying index
+ * for every accepted photon). */
+struct MergeEval {
+    Frame frame;
+    V3 refl;              /* ReflectLocal(mLocalDirFix), bsdf.hxx:423 */
+    V3 diffuseVal;        /* mDiffuseReflectance * INV_PI_F, :411 */
+    V3 rho;               /* mPhongReflectance * (n+2) * 0.5 * INV_PI_F, :442-443 */
+    float ldfz;
+    float diffProb, phongProb, phongExp;
+    float revPdfDiffuse;  /* diffProb * max(0, mLocalDirFix.z * INV_PI_F), :408 */
+    float camContProb;
+    float camTerm;        /* mCameraState.dVCM * mMisVcWeightFactor, vertexcm.hxx:160 */
+    float camdVM;
+    uint32_t pathLength;
+    bool cosOk;           /* !(mLocalDirFix.z < EPS_COSINE) */
+};
+VCM_HD void merge_eval_setup(MergeEval &e, const vcm_scene_desc &sc, const IterParams &P, const Bsdf &b,
+                             const SubPathState &st)
+{
+    const vcm_material &m = sc.materials[b.matID];
+    e.frame = b.frame;
+    e.refl = reflect_local(b.localDirFix);
+    e.diffuseVal = ld3(m.diffuse) * VCM_INV_PI_F;
+    e.rho = ld3(m.phong) * (m.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;
+    e.ldfz = b.localDirFix.z;
+    e.diffProb = b.diffProb; e.phongProb = b.phongProb; e.phongExp = m.phongExp;
+    e.revPdfDiffuse = b.diffProb * smax(0.f, b.localDirFix.z * VCM_INV_PI_F);
+    e.camContProb = b.contProb;
+    e.camTerm = st.dVCM * P.misVcWeightFactor;
+    e.camdVM = st.dVM;
+    e.pathLength = st.pathLength;
+    e.cosOk = !(b.localDirFix.z < VCM_EPS_COSINE);
+}
+VCM_HD void merge_eval_photon(const MergeEval &e, const IterParams &P, uint32_t lvLen, V3 lightDirection,
+                              float lvContProb, V3 lvThroughput, float lvdVCM, float lvdVM, V3 &contrib)
+{
+    if ((lvLen + e.pathLength > P.maxLen) || (lvLen + e.pathLength < P.minLen)) return;   /* :133-135 */
+    /* BSDF::Evaluate */
+    const V3 gen = to_local(e.frame, lightDirection);
+    if (gen.z * e.ldfz < 0.f) return;                       /* zero factor -> :145 */
+    float dirPdf = 0.f, revPdf = 0.f;
+    V3 result = sp3(0.f);
+    const bool ok = e.cosOk && !(gen.z < VCM_EPS_COSINE);   /* :402, :423 */
+    V3 d = sp3(0.f);
+    if (e.diffProb != 0.f && ok) {                          /* EvaluateDiffuse */
+        dirPdf += e.diffProb * smax(0.f, gen.z * VCM_INV_PI_F);
+        revPdf += e.revPdfDiffuse;
+        d = e.diffuseVal;
+    }
+    result = result + d;
+    V3 ph = sp3(0.f);
+    if (e.phongProb != 0.f && ok) {                         /* EvaluatePhong */
+        const float dot_R_Wi = dot(e.refl, gen);
+        if (!(dot_R_Wi <= VCM_EPS_PHONG)) {
+            const float pw = dm_powf(dot_R_Wi, e.phongExp);
+            const float pdfW = e.phongProb * ((e.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
+            dirPdf += pdfW;
+            revPdf += pdfW;
+            ph = e.rho * pw;
+        }
+    }
+    result = result + ph;
+    if (iszero(result)) return;                              /* :145-146 */
+    dirPdf *= e.camContProb;                                 /* :148 */
+    revPdf *= lvContProb;                                    /* :153 */
+    const float wLight = lvdVCM * P.misVcWeightFactor + lvdVM * mis(dirPdf);     /* :156-157 */
+    const float wCamera = e.camTerm + e.camdVM * mis(revPdf);                    /* :160-161 */
+    const float misWeight = P.ppm ? 1.f : 1.f / (wLight + 1.f + wCamera);        /* :164-166 */
+    contrib = contrib + misWeight * result * lvThroughput;                       /* :168 */
+}
+
+VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval &e, const MergeScratch &ms, int qn,
+                        V3 &contrib)
 {
     for (int k = 0; k < VCM_MERGE_Q; k++) {
         if (!wave_any(k < qn)) break;
@@ -941,8 +1017,7 @@ VCM_HD void merge_drain(const vcm_scene_desc &sc, const IterParams &P, const Gri
             const F4 b = g.g1[idx];
             const F4 c = g.g2[idx];
             const float dVM = g.g3[idx];
-            merge_photon(sc, P, cameraBsdf, st, f2u(lenBits), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM,
-                         contrib);
+            merge_eval_photon(e, P, f2u(lenBits), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM, contrib);
         }
     }
 }
@@ -976,6 +1051,8 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
     const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
     const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
     const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+    MergeEval ev;
+    merge_eval_setup(ev, sc, P, cameraBsdf, st);
     int qn = 0;
     for (int j = 0; j < 8; j++) {
         int lo = 0, hi = 0;
@@ -1015,12 +1092,12 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
             }
             lo = (lo + VCM_MERGE_UNROLL < hi) ? lo + VCM_MERGE_UNROLL : hi;
             if (wave_any(qn > VCM_MERGE_Q - VCM_MERGE_UNROLL)) {
-                merge_drain(sc, P, g, cameraBsdf, st, ms, qn, contrib);
+                merge_drain(P, g, ev, ms, qn, contrib);
                 qn = 0;
             }
         }
     }
-    merge_drain(sc, P, g, cameraBsdf, st, ms, qn, contrib);
+    merge_drain(P, g, ev, ms, qn, contrib);
     return contrib;
 }
 

@@ -55,7 +55,8 @@ VCM_HD V3 operator/(V3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 VCM_HD V3 operator-(V3 a) { return mk3(-a.x, -a.y, -a.z); }
 /* Dot: math.hxx:138-139 -- T res(0); res += a_i*b_i in order */
 VCM_HD float dot(V3 a, V3 b) { float r = 0.f; r += a.x * b.x; r += a.y * b.y; r += a.z * b.z; return r; }
-VCM_HD float lensqr(V3 a) { return dot(a, a); }
+/* Dot(a,a): the leading "0 +" of Dot is a bitwise no-op here (a.x*a.x is never -0) */
+VCM_HD float lensqr(V3 a) { float r = a.x * a.x; r += a.y * a.y; r += a.z * a.z; return r; }
 VCM_HD bool iszero(V3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
 VCM_HD float vmax3(V3 a) { float r = a.x; r = smax(r, a.y); r = smax(r, a.z); return r; }
 /* Cross: math.hxx:154-162 */
