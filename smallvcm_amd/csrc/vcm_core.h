@@ -925,7 +925,8 @@ VCM_HD bool wave_any(bool x)
 }
 
 /* Per-lane queue of accepted photon indices, in LDS on the device:
- * entry k of this lane is q[k * stride]. */
+ * entry k of this lane is q[k * stride], k = 0..VCM_MERGE_Q (the last row is a
+ * write-only dummy for rejected candidates). */
 #define VCM_MERGE_Q 16
 #define VCM_MERGE_UNROLL 4
 struct MergeScratch { uint32_t *q; int stride; };
@@ -971,39 +972,37 @@ VCM_HD void merge_eval_setup(MergeEval &e, const vcm_scene_desc &sc, const IterP
 VCM_HD void merge_eval_photon(const MergeEval &e, const IterParams &P, uint32_t lvLen, V3 lightDirection,
                               float lvContProb, V3 lvThroughput, float lvdVCM, float lvdVM, V3 &contrib)
 {
-    if ((lvLen + e.pathLength > P.maxLen) || (lvLen + e.pathLength < P.minLen)) return;   /* :133-135 */
-    /* BSDF::Evaluate */
-    const V3 gen = to_local(e.frame, lightDirection);
-    if (gen.z * e.ldfz < 0.f) return;                       /* zero factor -> :145 */
-    float dirPdf = 0.f, revPdf = 0.f;
-    V3 result = sp3(0.f);
-    const bool ok = e.cosOk && !(gen.z < VCM_EPS_COSINE);   /* :402, :423 */
-    V3 d = sp3(0.f);
-    if (e.diffProb != 0.f && ok) {                          /* EvaluateDiffuse */
-        dirPdf += e.diffProb * smax(0.f, gen.z * VCM_INV_PI_F);
-        revPdf += e.revPdfDiffuse;
-        d = e.diffuseVal;
-    }
-    result = result + d;
+    /* written with selects instead of early returns: on the GPU every early
+       return is an exec-mask save/branch/restore; the values and the order of
+       the operations are those of the reference */
+    const V3 gen = to_local(e.frame, lightDirection);                                   /* bsdf.hxx:140 */
+    const bool valid = !((lvLen + e.pathLength > P.maxLen) || (lvLen + e.pathLength < P.minLen))   /* :133-135 */
+                       && !(gen.z * e.ldfz < 0.f);                                      /* bsdf.hxx:142 */
+    const bool ok = e.cosOk && !(gen.z < VCM_EPS_COSINE);                               /* :402, :423 */
+    const bool dOn = valid && ok && (e.diffProb != 0.f);
+    /* EvaluateDiffuse: the pdfs start at 0, "0 + x" with x >= 0 is x */
+    float dirPdf = dOn ? e.diffProb * smax(0.f, gen.z * VCM_INV_PI_F) : 0.f;
+    float revPdf = dOn ? e.revPdfDiffuse : 0.f;
+    V3 result = sp3(0.f) + (dOn ? e.diffuseVal : sp3(0.f));
+    /* EvaluatePhong */
+    const float dot_R_Wi = dot(e.refl, gen);
     V3 ph = sp3(0.f);
-    if (e.phongProb != 0.f && ok) {                         /* EvaluatePhong */
-        const float dot_R_Wi = dot(e.refl, gen);
-        if (!(dot_R_Wi <= VCM_EPS_PHONG)) {
-            const float pw = dm_powf(dot_R_Wi, e.phongExp);
-            const float pdfW = e.phongProb * ((e.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
-            dirPdf += pdfW;
-            revPdf += pdfW;
-            ph = e.rho * pw;
-        }
+    if (valid && ok && (e.phongProb != 0.f) && !(dot_R_Wi <= VCM_EPS_PHONG)) {
+        const float pw = dm_powf(dot_R_Wi, e.phongExp);
+        const float pdfW = e.phongProb * ((e.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
+        dirPdf += pdfW;
+        revPdf += pdfW;
+        ph = e.rho * pw;
     }
     result = result + ph;
-    if (iszero(result)) return;                              /* :145-146 */
-    dirPdf *= e.camContProb;                                 /* :148 */
-    revPdf *= lvContProb;                                    /* :153 */
-    const float wLight = lvdVCM * P.misVcWeightFactor + lvdVM * mis(dirPdf);     /* :156-157 */
-    const float wCamera = e.camTerm + e.camdVM * mis(revPdf);                    /* :160-161 */
-    const float misWeight = P.ppm ? 1.f : 1.f / (wLight + 1.f + wCamera);        /* :164-166 */
-    contrib = contrib + misWeight * result * lvThroughput;                       /* :168 */
+    if (valid && !iszero(result)) {                                                     /* :145-146 */
+        dirPdf *= e.camContProb;                                                        /* :148 */
+        revPdf *= lvContProb;                                                           /* :153 */
+        const float wLight = lvdVCM * P.misVcWeightFactor + lvdVM * mis(dirPdf);        /* :156-157 */
+        const float wCamera = e.camTerm + e.camdVM * mis(revPdf);                       /* :160-161 */
+        const float misWeight = P.ppm ? 1.f : 1.f / (wLight + 1.f + wCamera);           /* :164-166 */
+        contrib = contrib + misWeight * result * lvThroughput;                          /* :168 */
+    }
 }
 
 VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval &e, const MergeScratch &ms, int qn,
@@ -1064,6 +1063,7 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
             lo = g.cellStart[cell];
             hi = g.cellStart[cell + 1];
         }
+        ls.mergeCandidates += (uint32_t)(hi - lo);   /* one distance test per entry (:162-165) */
         while (wave_any(lo < hi)) {
             F4 a[VCM_MERGE_UNROLL];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1075,28 +1075,27 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
                 ci = (ci < 0) ? 0 : ci;
                 a[u] = g.g0[ci];
             }
+            /* branch-free: a rejected (or out-of-range) candidate writes its index to the
+               dummy row VCM_MERGE_Q of the lane's queue and does not advance qn */
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
             for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
                 const int idx = lo + u;
-                if (idx < hi) {
-                    const float distSqr = lensqr(queryPos - mk3(a[u].x, a[u].y, a[u].z));
-                    ls.mergeCandidates++;
-                    if (distSqr <= P.radiusSqr) {   /* :165 */
-                        ms.q[qn * ms.stride] = (uint32_t)idx;
-                        qn++;
-                        ls.mergeAccepted++;
-                    }
-                }
+                const float distSqr = lensqr(queryPos - mk3(a[u].x, a[u].y, a[u].z));
+                const bool acc = (idx < hi) & (distSqr <= P.radiusSqr);   /* :165 */
+                ms.q[(acc ? qn : VCM_MERGE_Q) * ms.stride] = (uint32_t)idx;
+                qn += acc ? 1 : 0;
             }
             lo = (lo + VCM_MERGE_UNROLL < hi) ? lo + VCM_MERGE_UNROLL : hi;
             if (wave_any(qn > VCM_MERGE_Q - VCM_MERGE_UNROLL)) {
+                ls.mergeAccepted += (uint32_t)qn;
                 merge_drain(P, g, ev, ms, qn, contrib);
                 qn = 0;
             }
         }
     }
+    ls.mergeAccepted += (uint32_t)qn;
     merge_drain(P, g, ev, ms, qn, contrib);
     return contrib;
 }

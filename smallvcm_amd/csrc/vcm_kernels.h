@@ -106,7 +106,7 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     int next = wave * chunk;
     const int end = min(P.nLocal, next + chunk);
     LaneStats ls; lane_stats_zero(ls);
-    __shared__ uint32_t accQ[MODE == 1 ? 1 : VCM_MERGE_Q * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
+    __shared__ uint32_t accQ[MODE == 1 ? 1 : (VCM_MERGE_Q + 1) * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
     MergeScratch ms; ms.q = accQ + (MODE == 1 ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK;
     __shared__ int wqState[(VCM_TRACE_BLOCK / VCM_WAVE) * 6];   /* per wave: 3 queues x {next, left} */
     int *myState = wqState + (threadIdx.x / VCM_WAVE) * 6;
@@ -240,7 +240,7 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
 {
     const vcm_scene_desc &sc = *scp;
     const int nQ = *nSorted;
-    __shared__ uint32_t accQ[VCM_MERGE_Q * VCM_MERGE_BLOCK];
+    __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_MERGE_BLOCK];
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK;
     LaneStats ls; lane_stats_zero(ls);
     const int stride = gridDim.x * VCM_MERGE_BLOCK;

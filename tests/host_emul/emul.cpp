@@ -145,7 +145,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
         e.camOut.assign((size_t)e.nLocal, mk4(0, 0, 0, 0));
         for (int lp = 0; lp < e.nLocal; lp++) {
             CameraPath path;
-            uint32_t q[VCM_MERGE_Q];
+            uint32_t q[VCM_MERGE_Q + 1];
             MergeScratch ms; ms.q = q; ms.stride = 1;
             camera_path_begin(e.sc, P, path, lp);
             VertexStore vs; memset(&vs, 0, sizeof(vs));
