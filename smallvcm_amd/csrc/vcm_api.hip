@@ -143,7 +143,7 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->dSlotOfVertex, slots)) return -1;
         if (c->world > 1 && dalloc(&c->dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
         if (dalloc(&c->dCellId, allRecs) || dalloc(&c->dUnsorted, allRecs)) return -1;
-        if (dalloc(&c->dG0, allRecs) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
+        if (dalloc(&c->dG0, allRecs + VCM_MERGE_UNROLL) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
             dalloc(&c->dG3, allRecs) || dalloc(&c->dSortedIndex, allRecs)) return -1;
         /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l
            connects to light vertices of length <= L-1-l, so <= (L-1)(L-2)/2 VC tasks per path */

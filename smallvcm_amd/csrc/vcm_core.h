@@ -1069,12 +1069,9 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (int u = 0; u < VCM_MERGE_UNROLL; u++) {   /* 4 independent loads in flight */
-                int ci = lo + u;
-                ci = (ci < hi) ? ci : hi - 1;
-                ci = (ci < 0) ? 0 : ci;
-                a[u] = g.g0[ci];
-            }
+            /* 4 independent loads in flight; entries past hi are read but never used
+               (the array is padded by VCM_MERGE_UNROLL elements), so one address serves all 4 */
+            for (int u = 0; u < VCM_MERGE_UNROLL; u++) a[u] = g.g0[lo + u];
             /* branch-free: a rejected (or out-of-range) candidate writes its index to the
                dummy row VCM_MERGE_Q of the lane's queue and does not advance qn */
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -25,7 +25,7 @@ from ._abi import (SceneDesc, Stats, SCENE_CONFIGS, VCM_MERGE_RECORD_FLOATS, ALG
                    ALGO_BPT, ALGO_VCM)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmallvcm_amd.so")
+LIB_PATH = os.environ.get("SMALLVCM_AMD_LIB") or os.path.join(_HERE, "csrc", "libsmallvcm_amd.so")
 
 _lib = None
 

@@ -114,7 +114,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     e.hdr.nRecords = n;
     for (int c = 0; c < 3; c++) { e.hdr.bboxMin[c] = 1e36f; e.hdr.bboxMax[c] = -1e36f; }
     e.cellStart.assign((size_t)P.nCells + 1, 0);
-    e.g0.assign((size_t)n, mk4(0, 0, 0, 0)); e.g1 = e.g0; e.g2 = e.g0; e.g3.assign((size_t)n, 0.f);
+    e.g0.assign((size_t)n + VCM_MERGE_UNROLL, mk4(0, 0, 0, 0)); e.g1 = e.g0; e.g2 = e.g0; e.g3.assign((size_t)n, 0.f);
     if (e.useVM) {
         for (int i = 0; i < n; i++)
             for (int c = 0; c < 3; c++) {
