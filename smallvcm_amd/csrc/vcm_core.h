@@ -1005,19 +1005,31 @@ VCM_HD void merge_eval_photon(const MergeEval &e, const IterParams &P, uint32_t 
     }
 }
 
+struct MergePhoton { float lenBits; F4 b, c; float dVM; };
+VCM_HD void merge_photon_load(const GridStore &g, const MergeScratch &ms, int k, int qn, MergePhoton &p)
+{
+    /* lanes without an entry k read photon 0 (always allocated); the value is not used */
+    const uint32_t idx = (k < qn) ? ms.q[k * ms.stride] : 0u;
+    p.lenBits = g.g0[idx].w;
+    p.b = g.g1[idx];
+    p.c = g.g2[idx];
+    p.dVM = g.g3[idx];
+}
 VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval &e, const MergeScratch &ms, int qn,
                         V3 &contrib)
 {
+    /* software-pipelined: the loads of entry k+1 are in flight while entry k is evaluated */
+    if (!wave_any(0 < qn)) return;
+    MergePhoton cur, nxt;
+    merge_photon_load(g, ms, 0, qn, cur);
     for (int k = 0; k < VCM_MERGE_Q; k++) {
-        if (!wave_any(k < qn)) break;
-        if (k < qn) {
-            const uint32_t idx = ms.q[k * ms.stride];
-            const float lenBits = g.g0[idx].w;
-            const F4 b = g.g1[idx];
-            const F4 c = g.g2[idx];
-            const float dVM = g.g3[idx];
-            merge_eval_photon(e, P, f2u(lenBits), mk3(b.x, b.y, b.z), b.w, mk3(c.x, c.y, c.z), c.w, dVM, contrib);
-        }
+        const bool more = wave_any(k + 1 < qn);
+        if (more) merge_photon_load(g, ms, k + 1, qn, nxt);
+        if (k < qn)
+            merge_eval_photon(e, P, f2u(cur.lenBits), mk3(cur.b.x, cur.b.y, cur.b.z), cur.b.w,
+                              mk3(cur.c.x, cur.c.y, cur.c.z), cur.c.w, cur.dVM, contrib);
+        if (!more) break;
+        cur = nxt;
     }
 }
 
