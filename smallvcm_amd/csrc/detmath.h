@@ -144,5 +144,33 @@ VCM_HD float dm_powf(float xf, float yf)
     return (float)(q * scale);
 }
 
+/* dm_powf for call sites where the exponent is a material constant (the Phong
+ * exponent): if every active lane of the wave holds the same small integer
+ * exponent, the binary exponentiation is driven by SCALAR control flow -- only
+ * the ~log2(n)+popcount(n) binary64 multiplies remain as vector work, instead
+ * of a per-lane loop with selects.  Same multiplication sequence as dm_powf,
+ * hence the same bits; any other case falls back to dm_powf. */
+VCM_HD float dm_powf_wave(float xf, float yf)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yf)));
+    if (y0 >= 1.0f && y0 <= 256.0f && y0 == floorf(y0) && __all(yf == y0)) {   /* wave-uniform */
+        unsigned n = (unsigned)y0;
+        double b = (double)xf, r = 1.0;
+        for (;;) {
+            if (n & 1u) r = r * b;
+            n >>= 1;
+            if (n == 0u) break;
+            b = b * b;
+        }
+        float res = (float)r;
+        res = (xf == 1.0f) ? 1.0f : res;
+        res = !(xf > 0.0f) ? 0.0f : res;
+        return res;
+    }
+#endif
+    return dm_powf(xf, yf);
+}
+
 } // namespace vcm
 #endif

@@ -153,7 +153,7 @@ VCM_HD V3 sample_power_cos_hemisphere(float sx, float sy, float power)
 VCM_HD float power_cos_hemisphere_pdf(V3 n, V3 d, float power)
 {   /* :105-113 */
     const float cosTheta = smax(0.f, dot(n, d));
-    return (power + 1.f) * dm_powf(cosTheta, power) * (VCM_INV_PI_F * 0.5f);
+    return (power + 1.f) * dm_powf_wave(cosTheta, power) * (VCM_INV_PI_F * 0.5f);
 }
 VCM_HD void sample_concentric_disc(float sx, float sy, float &ox, float &oy)
 {   /* :119-160 */
@@ -364,7 +364,7 @@ VCM_HD V3 bsdf_eval_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *d
     if (dot_R_Wi <= VCM_EPS_PHONG) return sp3(0.f);
     /* pow(dot_R_Wi, n) is needed by the pdf (PowerCosHemispherePdfW, whose
        cosTheta = max(0, dot) == dot here) and by the value: evaluate once */
-    const float pw = dm_powf(dot_R_Wi, m.phongExp);
+    const float pw = dm_powf_wave(dot_R_Wi, m.phongExp);
     if (dirPdf || revPdf) {
         const float pdfW = b.phongProb * ((m.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
         if (dirPdf) *dirPdf += pdfW;
@@ -447,7 +447,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const vcm_scene_desc &sc, bool fixIsLight, 
         const float dot_R_Wi = dot(refl, gen);
         if (dot_R_Wi <= VCM_EPS_PHONG) return sp3(0.f);
         /* PdfPhong(:309) and the value (:317) use the same pow */
-        const float pw = dm_powf(dot_R_Wi, m.phongExp);
+        const float pw = dm_powf_wave(dot_R_Wi, m.phongExp);
         if (b.phongProb != 0.f)
             pdfW += ((m.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f)) * b.phongProb;
         const V3 rho = ld3(m.phong) * (m.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;
@@ -925,8 +925,8 @@ VCM_HD bool wave_any(bool x)
 }
 
 /* Per-lane queue of accepted photon indices, in LDS on the device:
- * entry k of this lane is q[k * stride], k = 0..VCM_MERGE_Q (the last row is a
- * write-only dummy for rejected candidates). */
+ * entry k of this lane is q[k * stride], k = 0..VCM_MERGE_Q (one spare row: the
+ * scan writes every candidate at the tail and only advances it on acceptance). */
 #define VCM_MERGE_Q 16
 #define VCM_MERGE_UNROLL 4
 struct MergeScratch { uint32_t *q; int stride; };
@@ -988,7 +988,7 @@ VCM_HD void merge_eval_photon(const MergeEval &e, const IterParams &P, uint32_t 
     const float dot_R_Wi = dot(e.refl, gen);
     V3 ph = sp3(0.f);
     if (valid && ok && (e.phongProb != 0.f) && !(dot_R_Wi <= VCM_EPS_PHONG)) {
-        const float pw = dm_powf(dot_R_Wi, e.phongExp);
+        const float pw = dm_powf_wave(dot_R_Wi, e.phongExp);
         const float pdfW = e.phongProb * ((e.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
         dirPdf += pdfW;
         revPdf += pdfW;
@@ -1084,8 +1084,8 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
             /* 4 independent loads in flight; entries past hi are read but never used
                (the array is padded by VCM_MERGE_UNROLL elements), so one address serves all 4 */
             for (int u = 0; u < VCM_MERGE_UNROLL; u++) a[u] = g.g0[lo + u];
-            /* branch-free: a rejected (or out-of-range) candidate writes its index to the
-               dummy row VCM_MERGE_Q of the lane's queue and does not advance qn */
+            /* branch-free: every candidate writes its index at the queue tail, only an
+               accepted one advances the tail (qn <= VCM_MERGE_Q, row VCM_MERGE_Q is spare) */
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -1093,7 +1093,7 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
                 const int idx = lo + u;
                 const float distSqr = lensqr(queryPos - mk3(a[u].x, a[u].y, a[u].z));
                 const bool acc = (idx < hi) & (distSqr <= P.radiusSqr);   /* :165 */
-                ms.q[(acc ? qn : VCM_MERGE_Q) * ms.stride] = (uint32_t)idx;
+                ms.q[qn * ms.stride] = (uint32_t)idx;
                 qn += acc ? 1 : 0;
             }
             lo = (lo + VCM_MERGE_UNROLL < hi) ? lo + VCM_MERGE_UNROLL : hi;
