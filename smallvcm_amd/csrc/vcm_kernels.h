@@ -360,22 +360,23 @@ k_scan_apply(const T *__restrict__ in, int n, const int *__restrict__ tileOffset
 __global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
                                   int *slotOfVertex)
 {
-    const long long total = (long long)P.S * P.nLocal;
-    for (long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x; slot < total;
-         slot += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(slot / P.nLocal);
-        const int lp = (int)(slot - (long long)j * P.nLocal);
-        if (j >= (int)store.count[lp]) continue;
-        const int vtx = pathStart[lp] + j;
-        slotOfVertex[vtx] = (int)slot;   /* dense vertex list for k_connect_camera */
-        if (!P.useVM) continue;
-        const F4 a = store.v0[slot], b = store.v1[slot], d = store.v3[slot], e = store.v4[slot];
-        float *r = records + (size_t)vtx * VCM_MERGE_RECORD_FLOATS;
-        r[0] = a.x; r[1] = a.y; r[2] = a.z;
-        r[3] = e.x; r[4] = e.y; r[5] = e.z;
-        r[6] = b.x; r[7] = b.y; r[8] = b.z;
-        r[9] = b.w; r[10] = d.w; r[11] = e.w;
-        r[12] = u2f(f2u(a.w) & 0xffu);
+    /* one lane per light path: slot reads are coalesced across the wave for every j (slot-major store) */
+    for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < P.nLocal; lp += gridDim.x * blockDim.x) {
+        const int n = (int)store.count[lp];
+        const int base = pathStart[lp];
+        for (int j = 0; j < n; j++) {
+            const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)lp;
+            const int vtx = base + j;
+            slotOfVertex[vtx] = (int)slot;   /* dense vertex list for k_connect_camera */
+            if (!P.useVM) continue;
+            const F4 a = store.v0[slot], b = store.v1[slot], d = store.v3[slot], e = store.v4[slot];
+            float *r = records + (size_t)vtx * VCM_MERGE_RECORD_FLOATS;
+            r[0] = a.x; r[1] = a.y; r[2] = a.z;
+            r[3] = e.x; r[4] = e.y; r[5] = e.z;
+            r[6] = b.x; r[7] = b.y; r[8] = b.z;
+            r[9] = b.w; r[10] = d.w; r[11] = e.w;
+            r[12] = u2f(f2u(a.w) & 0xffu);
+        }
     }
 }
 
