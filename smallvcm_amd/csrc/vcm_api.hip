@@ -66,7 +66,7 @@ struct vcm_ctx {
     VertexStore vs;                   /* camera vertices + DI/VC tasks of the iteration (wavefront mode) */
     int *dQueryKey;                   /* per camera vertex: base-cell bucket */
     int *dSortedVertex;               /* camera vertices sorted by bucket */
-    int *dQueryStart;                 /* nCells+2 */
+    int *dQueryStart, *dQueryCount, *dQueryFill;   /* VCM_QSORT_BUCKETS+2 each */
     int allocL;
     bool strictOrder;
     unsigned long long *dStats;
@@ -118,7 +118,8 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         HIPCHK(hipMemset(c->dRngCam, 0, (size_t)c->nLocal));
         if (dalloc(&c->dPathStart, (size_t)c->nLocal + 1)) return -1;
         if (dalloc(&c->dLocalTotal, 1)) return -1;
-        const size_t maxScan = (size_t)(c->N > c->nLocal ? c->N : c->nLocal) + 1;
+        size_t maxScan = (size_t)(c->N > c->nLocal ? c->N : c->nLocal) + 1;
+        if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
         if (dalloc(&c->dTileSums, maxScan / VCM_SCAN_TILE + 2)) return -1;
         if (dalloc(&c->dHdr, 1)) return -1;
         HIPCHK(hipMemset(c->dHdr, 0, sizeof(GridHeader)));
@@ -128,7 +129,8 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->dCamOut, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->dCamMask, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->vs.count, 4)) return -1;
-        if (dalloc(&c->dQueryStart, (size_t)c->N + 2)) return -1;
+        if (dalloc(&c->dQueryStart, (size_t)VCM_QSORT_BUCKETS + 2) || dalloc(&c->dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||
+            dalloc(&c->dQueryFill, (size_t)VCM_QSORT_BUCKETS + 2)) return -1;
         if (dalloc(&c->dStats, STAT_COUNT)) return -1;
         c->deviceReady = true;
     }
@@ -270,7 +272,7 @@ void vcm_destroy(vcm_ctx *c)
         DFREE(c->dScene); DFREE(c->dFb); DFREE(c->store.count); DFREE(c->dRngLight); DFREE(c->dRngCam);
         DFREE(c->dPathStart); DFREE(c->dLocalTotal); DFREE(c->dTileSums); DFREE(c->dHdr);
         DFREE(c->dCellCount); DFREE(c->dCellStart); DFREE(c->dCellFill); DFREE(c->dCamOut); DFREE(c->dStats);
-        DFREE(c->dCamMask); DFREE(c->vs.count); DFREE(c->dQueryStart);
+        DFREE(c->dCamMask); DFREE(c->vs.count); DFREE(c->dQueryStart); DFREE(c->dQueryCount); DFREE(c->dQueryFill);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
@@ -508,15 +510,15 @@ int vcm_merge(vcm_ctx *c)
         HIPCHK(hipEventRecord(c->ev[EV_MERGE_K0], c->stream));
         if (c->P.wavefront && c->useVM) {
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
-            /* K4a: counting sort of the camera vertices by base-cell bucket (reuses the grid-build scratch) */
-            const int nb = c->P.nCells;
-            HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
-            HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+            /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
+            const int nb = VCM_QSORT_BUCKETS;
+            HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+            HIPCHK(hipMemsetAsync(c->dQueryFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
             hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
-                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dCellCount);
-            if (launch_scan<int>(c, c->dCellCount, nb, c->dQueryStart, NULL, 1)) return -1;
+                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryCount);
+            if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
             hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
-                               (const int *)c->dQueryStart, c->dCellFill, c->dSortedVertex);
+                               (const int *)c->dQueryStart, c->dQueryFill, c->dSortedVertex);
             HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
             /* K4 */
             hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),

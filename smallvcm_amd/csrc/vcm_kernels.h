@@ -180,12 +180,27 @@ k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
 }
 
 /* ---------------- K4a: sort the camera vertices by base cell -------------- */
-/* Counting sort (indices only) of the vertex records on the hash bucket of the
- * cell that contains the query point (hashgrid.hxx:124-131).  Vertices of one
- * bucket become neighbours in K4, so the lanes of a wave walk the same cell
- * lists: loads become broadcasts served by L1/L2 and all lanes run the same
- * number of steps.  The order inside a bucket is arbitrary (atomics) and does
- * not matter: every vertex has its own output slot. */
+/* Counting sort (indices only) of the vertex records on the Morton code of the
+ * cell that contains the query point (hashgrid.hxx:124-131).  Same cell =>
+ * same key, so the lanes of a wave walk the same cell lists (broadcast loads,
+ * equal trip counts); neighbouring keys are neighbouring cells, so consecutive
+ * waves share most of their 8-cell neighbourhoods and find them in L2 -- with
+ * the hash bucket as key (first version) consecutive waves were spatially
+ * unrelated and K4 re-fetched ~10x the photon data from HBM.  The order inside
+ * a key is arbitrary (atomics) and does not matter: every vertex has its own
+ * output slot. */
+#define VCM_QSORT_BITS 8                       /* per axis */
+#define VCM_QSORT_BUCKETS (1 << (3 * VCM_QSORT_BITS))
+
+__device__ __forceinline__ uint32_t morton_part(uint32_t x)
+{   /* spreads the low 8 bits: abcdefgh -> a00b00c00d00e00f00g00h */
+    x &= 0xffu;
+    x = (x | (x << 8)) & 0x0000f00fu;
+    x = (x | (x << 4)) & 0x000c30c3u;
+    x = (x | (x << 2)) & 0x00249249u;
+    return x;
+}
+
 __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
 {
     const V3 bmin = ld3(hdr->bboxMin), bmax = ld3(hdr->bboxMax);
@@ -193,8 +208,15 @@ __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHea
     const V3 distMax = bmax - queryPos;
     if (distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f || distMin.z < 0.f || distMax.z < 0.f)
         return -1;   /* outside the photon bbox: HashGrid::Process returns at once (:116-122) */
+    /* coarsen until the grid extent fits 8 bits per axis (wave-uniform) */
+    const V3 ext = P.invCellSize * (bmax - bmin);
+    const uint32_t maxc = (uint32_t)fmaxf(fmaxf(ext.x, ext.y), fmaxf(ext.z, 0.f));
+    int shift = 0;
+    while ((maxc >> shift) >= (1u << VCM_QSORT_BITS)) shift++;
     const V3 cellPt = P.invCellSize * distMin;
-    return grid_cell_hash(int(floorf(cellPt.x)), int(floorf(cellPt.y)), int(floorf(cellPt.z)), P.nCells);
+    const uint32_t cx = (uint32_t)floorf(cellPt.x) >> shift, cy = (uint32_t)floorf(cellPt.y) >> shift,
+                   cz = (uint32_t)floorf(cellPt.z) >> shift;
+    return (int)(morton_part(cx) | (morton_part(cy) << 1) | (morton_part(cz) << 2));
 }
 
 /* holes and out-of-bbox vertices are not sorted at all (key -1): they would all
@@ -243,9 +265,17 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
     __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_MERGE_BLOCK];
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK;
     LaneStats ls; lane_stats_zero(ls);
-    const int stride = gridDim.x * VCM_MERGE_BLOCK;
-    for (int base = blockIdx.x * VCM_MERGE_BLOCK; base < nQ; base += stride) {
-        const int q = base + threadIdx.x;
+    /* every block takes a CONTIGUOUS range of the sorted vertices, and the blocks of one XCD
+       (block b runs on XCD b % 8) take neighbouring ranges: one XCD's L2 then serves one region of
+       space.  Only locality depends on this mapping, never the result. */
+    const int nBlocks = (int)gridDim.x;
+    const int perXcd = (nBlocks + 7) / 8;
+    const int logical = ((int)blockIdx.x % 8) * perXcd + (int)blockIdx.x / 8;
+    const int batches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
+    const int perBlock = (batches + perXcd * 8 - 1) / (perXcd * 8);
+    const int firstBatch = logical * perBlock;
+    for (int bt = firstBatch; bt < firstBatch + perBlock && bt < batches; bt++) {
+        const int q = bt * VCM_MERGE_BLOCK + (int)threadIdx.x;
         if (q < nQ) {
             const int vi = sortedVertex[q];
             const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms);
