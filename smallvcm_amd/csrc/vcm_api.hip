@@ -44,7 +44,7 @@ struct vcm_ctx {
     bool deviceReady;
     int allocS;
 
-    vcm_scene_desc *dScene;
+    vcm_scene_desc *dScene;           /* first member of a device-resident SceneDev */
     float *dFb;                       /* N*3, running sum */
     LightStore store;                 /* S*nLocal slots */
     unsigned char *dRngLight, *dRngCam;
@@ -107,8 +107,16 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
     if (!c->deviceReady) {
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-        if (dalloc(&c->dScene, 1)) return -1;
-        HIPCHK(hipMemcpy(c->dScene, &c->scene, sizeof(vcm_scene_desc), hipMemcpyHostToDevice));
+        {
+            SceneDev *sd = new SceneDev();
+            scene_dev_build(c->scene, *sd);
+            SceneDev *dsd = NULL;
+            if (dalloc(&dsd, 1)) { delete sd; return -1; }
+            hipError_t e = hipMemcpy(dsd, sd, sizeof(SceneDev), hipMemcpyHostToDevice);
+            delete sd;
+            if (e != hipSuccess) return fail("hipMemcpy(scene)", hipGetErrorString(e));
+            c->dScene = &dsd->sc;
+        }
         if (dalloc(&c->dFb, (size_t)c->N * 3)) return -1;
         HIPCHK(hipMemset(c->dFb, 0, (size_t)c->N * 3 * sizeof(float)));
         if (dalloc(&c->store.count, (size_t)c->nLocal)) return -1;
@@ -182,7 +190,9 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk)
     /* persistent waves: enough to fill 256 CUs several times over, each wave
        owning a contiguous chunk of paths (>= 64) */
     int waves = (nLocal + VCM_WAVE - 1) / VCM_WAVE;
-    const int maxWaves = 256 * 32;
+    static const char *tw = getenv("SMALLVCM_AMD_TRACE_WAVES");
+    /* 4096 = 16 waves per CU: measured best (fewer, longer-lived waves leave fewer partly used queue blocks) */
+    const int maxWaves = (tw && atoi(tw) > 0) ? atoi(tw) : 256 * 16;
     if (waves > maxWaves) waves = maxWaves;
     if (waves < 1) waves = 1;
     const int wavesPerBlock = VCM_TRACE_BLOCK / VCM_WAVE;

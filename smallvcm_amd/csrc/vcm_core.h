@@ -120,6 +120,75 @@ VCM_HD void fb_atomic_add(float *addr, float v)
 struct Ray { V3 org, dir; float tmin; };
 struct Isect { float dist; int matID; int lightID; V3 normal; };
 
+/* ---- two-wide fp32 (packed v_pk_mul_f32 / v_pk_add_f32 on gfx950: IEEE per half,
+ *      twice the scalar fp32 rate; never fused, the build has -ffp-contract=off) */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float f2 __attribute__((ext_vector_type(2)));
+VCM_HD f2 f2_mk(float a, float b) { f2 r = { a, b }; return r; }
+VCM_HD float f2_get(f2 a, int i) { return i ? a.y : a.x; }
+#else
+struct f2 { float x, y; };
+VCM_HD f2 f2_mk(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+VCM_HD float f2_get(f2 a, int i) { return i ? a.y : a.x; }
+VCM_HD f2 operator+(f2 a, f2 b) { return f2_mk(a.x + b.x, a.y + b.y); }
+VCM_HD f2 operator-(f2 a, f2 b) { return f2_mk(a.x - b.x, a.y - b.y); }
+VCM_HD f2 operator*(f2 a, f2 b) { return f2_mk(a.x * b.x, a.y * b.y); }
+#endif
+VCM_HD f2 f2_ld(const float *p) { return f2_mk(p[0], p[1]); }
+VCM_HD f2 f2_sp(float a) { return f2_mk(a, a); }
+/* Dot for both halves, same order as vcm::dot (T res(0); res += ...) */
+VCM_HD f2 f2_dot(f2 ax, f2 ay, f2 az, f2 bx, f2 by, f2 bz)
+{
+    f2 r = f2_sp(0.f);
+    r = r + ax * bx; r = r + ay * by; r = r + az * bz;
+    return r;
+}
+
+/* Device-side scene: the C-ABI description plus the primitive list regrouped
+ * for the intersection loop -- consecutive triangles of GeometryList::mGeometry
+ * (geometry.hxx:104) in PAIRS whose fields are interleaved {tri a, tri b}, so a
+ * wave-uniform scalar load of 8 bytes feeds both halves of a packed operation.
+ * List order is preserved (closest-hit ties go to the first primitive). */
+struct alignas(8) TriPair {
+    float p0x[2], p0y[2], p0z[2], p1x[2], p1y[2], p1z[2], p2x[2], p2y[2], p2z[2], nx[2], ny[2], nz[2];
+    int matID[2];
+    int valid1;   /* 0: the pair holds only one triangle */
+    int pad;
+};
+struct PrimOp { int kind; int index; };   /* kind 0: TriPair pairs[index]; kind 1: sphere sc.prims[index] */
+struct SceneDev {
+    vcm_scene_desc sc;   /* must stay the first member (scene_dev()) */
+    int nOps, pad0;
+    PrimOp ops[VCM_MAX_PRIMS];
+    TriPair pairs[VCM_MAX_PRIMS];
+};
+/* every vcm_scene_desc the device functions see is the first member of a SceneDev */
+VCM_HD const SceneDev &scene_dev(const vcm_scene_desc &sc) { return *reinterpret_cast<const SceneDev *>(&sc); }
+
+inline void scene_dev_build(const vcm_scene_desc &sc, SceneDev &sd)
+{
+    __builtin_memset(&sd, 0, sizeof(sd));
+    sd.sc = sc;
+    int nPairs = 0;
+    for (int i = 0; i < sc.nPrims; ) {
+        PrimOp &op = sd.ops[sd.nOps++];
+        if (sc.prims[i].type != VCM_PRIM_TRIANGLE) { op.kind = 1; op.index = i; i++; continue; }
+        op.kind = 0; op.index = nPairs;
+        TriPair &tp = sd.pairs[nPairs++];
+        const bool two = (i + 1 < sc.nPrims) && sc.prims[i + 1].type == VCM_PRIM_TRIANGLE;
+        for (int h = 0; h < 2; h++) {
+            const vcm_prim &t = sc.prims[(h == 1 && two) ? i + 1 : i];
+            tp.p0x[h] = t.p0[0]; tp.p0y[h] = t.p0[1]; tp.p0z[h] = t.p0[2];
+            tp.p1x[h] = t.p1[0]; tp.p1y[h] = t.p1[1]; tp.p1z[h] = t.p1[2];
+            tp.p2x[h] = t.p2[0]; tp.p2y[h] = t.p2[1]; tp.p2z[h] = t.p2[2];
+            tp.nx[h] = t.n[0]; tp.ny[h] = t.n[1]; tp.nz[h] = t.n[2];
+            tp.matID[h] = t.matID;
+        }
+        tp.valid1 = two ? 1 : 0;
+        i += two ? 2 : 1;
+    }
+}
+
 /* ---- utils.hxx ---------------------------------------------------- */
 VCM_HD float luminance(V3 c)
 {   /* :36-41 */
@@ -261,18 +330,55 @@ VCM_HD bool sph_intersect(const vcm_prim &s, const Ray &ray, Isect &res)
     res.normal = normalize(to + sp3(resT) * ray.dir);
     return true;
 }
-VCM_HD bool prim_intersect(const vcm_prim &p, const Ray &ray, Isect &res)
+/* Triangle::Intersect (:125-156) for the two triangles of a pair: the edge
+ * functions and the plane distance of both are evaluated with packed
+ * operations, then the two closest-hit updates are applied in list order
+ * (exactly what two consecutive calls of tri_intersect do). */
+VCM_HD bool tri_pair_intersect(const TriPair &t, const Ray &ray, Isect &res)
 {
-    return (p.type == VCM_PRIM_TRIANGLE) ? tri_intersect(p, ray, res) : sph_intersect(p, ray, res);
+    const f2 ox = f2_sp(ray.org.x), oy = f2_sp(ray.org.y), oz = f2_sp(ray.org.z);
+    const f2 dx = f2_sp(ray.dir.x), dy = f2_sp(ray.dir.y), dz = f2_sp(ray.dir.z);
+    const f2 aox = f2_ld(t.p0x) - ox, aoy = f2_ld(t.p0y) - oy, aoz = f2_ld(t.p0z) - oz;
+    const f2 box = f2_ld(t.p1x) - ox, boy = f2_ld(t.p1y) - oy, boz = f2_ld(t.p1z) - oz;
+    const f2 cox = f2_ld(t.p2x) - ox, coy = f2_ld(t.p2y) - oy, coz = f2_ld(t.p2z) - oz;
+    /* v0 = Cross(co, bo), v1 = Cross(bo, ao), v2 = Cross(ao, co)  (math.hxx:154-162) */
+    const f2 v0x = coy * boz - coz * boy, v0y = coz * box - cox * boz, v0z = cox * boy - coy * box;
+    const f2 v1x = boy * aoz - boz * aoy, v1y = boz * aox - box * aoz, v1z = box * aoy - boy * aox;
+    const f2 v2x = aoy * coz - aoz * coy, v2y = aoz * cox - aox * coz, v2z = aox * coy - aoy * cox;
+    const f2 v0d = f2_dot(v0x, v0y, v0z, dx, dy, dz);
+    const f2 v1d = f2_dot(v1x, v1y, v1z, dx, dy, dz);
+    const f2 v2d = f2_dot(v2x, v2y, v2z, dx, dy, dz);
+    const f2 nx = f2_ld(t.nx), ny = f2_ld(t.ny), nz = f2_ld(t.nz);
+    const f2 num = f2_dot(nx, ny, nz, aox, aoy, aoz);
+    const f2 den = f2_dot(nx, ny, nz, dx, dy, dz);
+    bool anyHit = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int h = 0; h < 2; h++) {
+        const float a = f2_get(v0d, h), b = f2_get(v1d, h), c = f2_get(v2d, h);
+        const bool inside = ((a < 0.f) && (b < 0.f) && (c < 0.f)) || ((a >= 0.f) && (b >= 0.f) && (c >= 0.f));
+        const float distance = f2_get(num, h) / f2_get(den, h);
+        if ((h == 0 || t.valid1) && inside && (distance > ray.tmin) && (distance < res.dist)) {
+            res.normal = mk3(f2_get(nx, h), f2_get(ny, h), f2_get(nz, h));
+            res.matID = t.matID[h];
+            res.dist = distance;
+            anyHit = true;
+        }
+    }
+    return anyHit;
 }
 /* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78):
- * brute force over <= 22 primitives; the index is wave-uniform, so the
- * primitive data comes in through scalar loads. */
+ * brute force over <= 22 primitives in list order; the op index is wave-uniform,
+ * so the primitive data comes in through scalar loads. */
 VCM_HD bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res)
 {
+    const SceneDev &sd = scene_dev(sc);
     bool any = false;
-    for (int i = 0; i < sc.nPrims; i++) {
-        const bool hit = prim_intersect(sc.prims[i], ray, res);
+    for (int i = 0; i < sd.nOps; i++) {
+        const PrimOp op = sd.ops[i];
+        const bool hit = (op.kind == 0) ? tri_pair_intersect(sd.pairs[op.index], ray, res)
+                                        : sph_intersect(sc.prims[op.index], ray, res);
         if (hit) any = hit;
     }
     if (any) res.lightID = sc.mat2light[res.matID];
@@ -281,15 +387,23 @@ VCM_HD bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res
 /* Scene::Occluded scene.hxx:72-85 (+ GeometryList::IntersectP geometry.hxx:80-91) */
 VCM_HD bool scene_occluded(const vcm_scene_desc &sc, V3 point, V3 dir, float tmax)
 {
+    const SceneDev &sd = scene_dev(sc);
     Ray ray;
     ray.org = point + dir * VCM_EPS_RAY;
     ray.dir = dir;
     ray.tmin = 0;
     Isect isect;
     isect.dist = tmax - 2 * VCM_EPS_RAY;
+    isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
     bool occluded = false;
-    for (int i = 0; i < sc.nPrims; i++)
-        if (!occluded && prim_intersect(sc.prims[i], ray, isect)) occluded = true;
+    for (int i = 0; i < sd.nOps; i++) {
+        const PrimOp op = sd.ops[i];
+        if (!occluded) {
+            const bool hit = (op.kind == 0) ? tri_pair_intersect(sd.pairs[op.index], ray, isect)
+                                            : sph_intersect(sc.prims[op.index], ray, isect);
+            if (hit) occluded = true;
+        }
+    }
     return occluded;
 }
 

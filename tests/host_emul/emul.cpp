@@ -11,7 +11,7 @@
 using namespace vcm;
 
 struct Emul {
-    vcm_scene_desc sc;
+    SceneDev sd;   /* e.sd.sc is what the device functions see */
     bool useVM, useVC, lightTraceOnly, ppm;
     float baseRadius, radiusAlpha;
     int seed, iterations;
@@ -31,7 +31,7 @@ void *emul_create(const vcm_scene_desc *scene, int algorithm, float radiusFactor
                   int rank, int world)
 {
     Emul *e = new Emul();
-    e->sc = *scene;
+    scene_dev_build(*scene, e->sd);
     e->useVM = e->useVC = e->lightTraceOnly = e->ppm = false;
     switch (algorithm) {
     case VCM_ALGO_LIGHT_TRACE: e->lightTraceOnly = true; break;
@@ -94,8 +94,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     /* K1 */
     for (int lp = 0; lp < e.nLocal; lp++) {
         LightPath path;
-        light_path_begin(e.sc, P, path, lp);
-        while (light_path_step<0>(e.sc, P, path, store, e.fb.data(), e.ls)) {}
+        light_path_begin(e.sd.sc, P, path, lp);
+        while (light_path_step<0>(e.sd.sc, P, path, store, e.fb.data(), e.ls)) {}
         e.count[lp] = (unsigned char)path.nStored;
         e.rngL[lp] = (unsigned char)path.rng.k;
     }
@@ -147,11 +147,11 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             CameraPath path;
             uint32_t q[VCM_MERGE_Q + 1];
             MergeScratch ms; ms.q = q; ms.stride = 1;
-            camera_path_begin(e.sc, P, path, lp);
+            camera_path_begin(e.sd.sc, P, path, lp);
             VertexStore vs; memset(&vs, 0, sizeof(vs));
             int wqState[6] = {0, 0, 0, 0, 0, 0};
             CameraWaveQueues wqs; wqs.v.p = wqState; wqs.di.p = wqState + 2; wqs.vc.p = wqState + 4;
-            while (camera_path_step<0>(e.sc, P, path, store, grid, e.ls, ms, vs, wqs)) {}
+            while (camera_path_step<0>(e.sd.sc, P, path, store, grid, e.ls, ms, vs, wqs)) {}
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;
         }
