@@ -53,6 +53,7 @@ struct vcm_ctx {
     int *dTileSums;                   /* scan scratch */
     float *dRecordsLocal;             /* S*nLocal records */
     int *dSlotOfVertex;               /* S*nLocal: dense vertex index -> slot in the light store */
+    F4 *dSplat;                       /* S*nLocal: splat of each light vertex (rgb | pixel) */
     float *dRecordsAll;               /* S*N records (multi-rank only) */
     bool importedRecords;
     bool gridBuilt, cameraTraced, merged;
@@ -92,7 +93,7 @@ template <typename T> static int dalloc(T **p, size_t n)
 static void free_iteration_buffers(vcm_ctx *c)
 {
     DFREE(c->store.v0); DFREE(c->store.v1); DFREE(c->store.v2); DFREE(c->store.v3); DFREE(c->store.v4);
-    DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll); DFREE(c->dSlotOfVertex);
+    DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll); DFREE(c->dSlotOfVertex); DFREE(c->dSplat);
     DFREE(c->dCellId); DFREE(c->dUnsorted);
     DFREE(c->dG0); DFREE(c->dG1); DFREE(c->dG2); DFREE(c->dG3); DFREE(c->dSortedIndex);
     DFREE(c->vs.q0); DFREE(c->vs.q1); DFREE(c->vs.q2); DFREE(c->vs.q3); DFREE(c->vs.q4); DFREE(c->vs.meta);
@@ -137,7 +138,8 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->dCamOut, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->dCamMask, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->vs.count, 4)) return -1;
-        if (dalloc(&c->dQueryStart, (size_t)VCM_QSORT_BUCKETS + 2) || dalloc(&c->dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||
+        const size_t qsN = ((size_t)c->N > (size_t)VCM_QSORT_BUCKETS ? (size_t)c->N : (size_t)VCM_QSORT_BUCKETS) + 2;   /* also pixStart of K1d */
+        if (dalloc(&c->dQueryStart, qsN) || dalloc(&c->dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||
             dalloc(&c->dQueryFill, (size_t)VCM_QSORT_BUCKETS + 2)) return -1;
         if (dalloc(&c->dStats, STAT_COUNT)) return -1;
         c->deviceReady = true;
@@ -150,7 +152,7 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         if (dalloc(&c->store.v0, slots) || dalloc(&c->store.v1, slots) || dalloc(&c->store.v2, slots) ||
             dalloc(&c->store.v3, slots) || dalloc(&c->store.v4, slots)) return -1;
         if (dalloc(&c->dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
-        if (dalloc(&c->dSlotOfVertex, slots)) return -1;
+        if (dalloc(&c->dSlotOfVertex, slots) || dalloc(&c->dSplat, slots)) return -1;
         if (c->world > 1 && dalloc(&c->dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
         if (dalloc(&c->dCellId, allRecs) || dalloc(&c->dUnsorted, allRecs)) return -1;
         if (dalloc(&c->dG0, allRecs + VCM_MERGE_UNROLL) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
@@ -378,9 +380,19 @@ int vcm_trace_light(vcm_ctx *c)
                            c->dRecordsLocal, c->dSlotOfVertex);
         HIPCHK(hipGetLastError());
     }
-    if (wf && (c->useVC || c->lightTraceOnly)) {   /* K1c */
+    if (wf && (c->useVC || c->lightTraceOnly)) {
+        /* K1c + K1d; scratch shared with the grid build / query sort, which run later */
+        int *pixCount = c->dCellCount, *pixFill = c->dCellFill, *pixStart = c->dQueryStart, *list = c->dUnsorted;
+        HIPCHK(hipMemsetAsync(pixCount, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
+        HIPCHK(hipMemsetAsync(pixFill, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
-                           (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dStats);
+                           (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
+                           c->dStats);
+        if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
+        hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, c->stream, (const F4 *)c->dSplat,
+                           (const int *)c->dLocalTotal, (const int *)pixStart, pixFill, list);
+        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const F4 *)c->dSplat,
+                           (const int *)pixStart, (const int *)list, c->dFb);
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);

@@ -798,9 +798,13 @@ VCM_HD void generate_light_sample(const vcm_scene_desc &sc, const IterParams &P,
 
 /* ConnectToCamera :862-933; the splat is an atomic add (Framebuffer::AddColor
  * framebuffer.hxx:43-57 on an arbitrary pixel) */
+/* splatOut == NULL: the splat is an fp32 atomic add on fb (strict mode);
+ * otherwise *splatOut receives (contrib.rgb, pixel) -- pixel -1 when nothing is
+ * splatted -- and k_splat_apply adds the splats of a pixel in vertex order. */
 VCM_HD void connect_to_camera(const vcm_scene_desc &sc, const IterParams &P, const SubPathState &st, V3 hitpoint,
-                              const Bsdf &bsdf, float *fb, LaneStats &ls)
+                              const Bsdf &bsdf, float *fb, LaneStats &ls, F4 *splatOut = 0)
 {
+    if (splatOut) *splatOut = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
     const vcm_camera &cam = sc.camera;
     V3 directionToCamera = ld3(cam.position) - hitpoint;
     if (dot(ld3(cam.forward), -directionToCamera) <= 0.f) return;
@@ -827,10 +831,14 @@ VCM_HD void connect_to_camera(const vcm_scene_desc &sc, const IterParams &P, con
         ls.shadowRays++;
         if (scene_occluded(sc, hitpoint, directionToCamera, distance)) return;
         const int x = int(ip.x), y = int(ip.y);
-        float *px = fb + (size_t)(x + y * P.resX) * 3;
-        fb_atomic_add(px + 0, contrib.x);
-        fb_atomic_add(px + 1, contrib.y);
-        fb_atomic_add(px + 2, contrib.z);
+        if (splatOut) {
+            *splatOut = mk4(contrib.x, contrib.y, contrib.z, u2f((uint32_t)(x + y * P.resX)));
+        } else {
+            float *px = fb + (size_t)(x + y * P.resX) * 3;
+            fb_atomic_add(px + 0, contrib.x);
+            fb_atomic_add(px + 1, contrib.y);
+            fb_atomic_add(px + 2, contrib.z);
+        }
         ls.lightSplats++;
     }
 }
@@ -895,17 +903,18 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
 
 /* ConnectToCamera (:380-384, :862-933) for a STORED light vertex (wavefront mode) */
 VCM_HD void connect_stored_vertex_to_camera(const vcm_scene_desc &sc, const IterParams &P, const LightStore &store,
-                                            size_t slot, float *fb, LaneStats &ls)
+                                            size_t slot, float *fb, LaneStats &ls, F4 *splatOut)
 {
     const F4 a = store.v0[slot], b = store.v1[slot], c = store.v2[slot], d = store.v3[slot];
     SubPathState st;
     st.pathLength = f2u(a.w) & 0xffu;
+    *splatOut = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
     if (!(st.pathLength + 1 >= P.minLen)) return;
     st.throughput = mk3(b.x, b.y, b.z);
     st.dVCM = b.w; st.dVC = c.w; st.dVM = d.w;
     Bsdf bsdf;
     bsdf_restore(bsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
-    connect_to_camera(sc, P, st, mk3(a.x, a.y, a.z), bsdf, fb, ls);
+    connect_to_camera(sc, P, st, mk3(a.x, a.y, a.z), bsdf, fb, ls, splatOut);
 }
 
 /* ================= camera sub-path (vertexcm.hxx:415-545) ============= */

@@ -406,19 +406,60 @@ __global__ void k_compact_records(IterParams P, LightStore store, const int *__r
 }
 
 /* ---------------- K1c: connect every stored light vertex to the camera ---- */
-/* vertexcm.hxx:380-384 / :862-933, one lane per stored vertex (dense list):
- * BSDF evaluation, MIS weight, one shadow ray, fp32 atomic splat. */
+/* vertexcm.hxx:380-384 / :862-933, one lane per stored vertex (dense list, which
+ * is the reference's vertex order): BSDF evaluation, MIS weight, one shadow
+ * ray.  The splat is NOT added here: Framebuffer::AddColor (:931) runs in
+ * vertex order in the reference, and fp32 addition does not commute with
+ * rounding, so the splats are written out and K1d adds them per pixel in that
+ * order -- bit-identical to the serial loop and reproducible from run to run
+ * (fp32 atomics gave an RMSE of 5e-9 and a different image every run). */
 __global__ void __launch_bounds__(256)
 k_connect_camera(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store,
-                 const int *__restrict__ slotOfVertex, const int *__restrict__ nVertices, float *fb,
-                 unsigned long long *gstats)
+                 const int *__restrict__ slotOfVertex, const int *__restrict__ nVertices, float *fb, F4 *splat,
+                 int *pixCount, unsigned long long *gstats)
 {
     const vcm_scene_desc &sc = *scp;
     const int n = *nVertices;
     LaneStats ls; lane_stats_zero(ls);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        connect_stored_vertex_to_camera(sc, P, store, (size_t)slotOfVertex[i], fb, ls);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        F4 sp;
+        connect_stored_vertex_to_camera(sc, P, store, (size_t)slotOfVertex[i], fb, ls, &sp);
+        splat[i] = sp;
+        if (f2u(sp.w) != 0xffffffffu) atomicAdd(&pixCount[f2u(sp.w)], 1);
+    }
     flush_stats(ls, gstats);
+}
+
+/* ---------------- K1d: ordered application of the light splats ------------ */
+__global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restrict__ nVertices,
+                                const int *__restrict__ pixStart, int *pixFill, int *list)
+{
+    const int n = *nVertices;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t pix = f2u(splat[i].w);
+        if (pix != 0xffffffffu) list[pixStart[pix] + atomicAdd(&pixFill[pix], 1)] = i;
+    }
+}
+
+/* one lane per pixel: its splats in increasing vertex index (selection by
+ * repeated minimum: a pixel holds 1.7 splats on average) */
+__global__ void k_splat_apply(int N, const F4 *__restrict__ splat, const int *__restrict__ pixStart,
+                              const int *__restrict__ list, float *fb)
+{
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
+        const int lo = pixStart[p], hi = pixStart[p + 1];
+        if (lo == hi) continue;
+        float r = fb[(size_t)p * 3 + 0], g = fb[(size_t)p * 3 + 1], b = fb[(size_t)p * 3 + 2];
+        int last = -1;
+        for (int k = lo; k < hi; k++) {
+            int best = 0x7fffffff;
+            for (int q = lo; q < hi; q++) { const int v = list[q]; best = (v > last && v < best) ? v : best; }
+            const F4 s = splat[best];
+            r = r + s.x; g = g + s.y; b = b + s.z;   /* framebuffer.hxx:56 */
+            last = best;
+        }
+        fb[(size_t)p * 3 + 0] = r; fb[(size_t)p * 3 + 1] = g; fb[(size_t)p * 3 + 2] = b;
+    }
 }
 
 __global__ void k_set_counts(GridHeader *hdr, const int *localTotal, int useLocalAsGlobal, int globalTotal)
