@@ -167,9 +167,10 @@ void vcm_destroy(vcm_ctx *ctx);
 /* Execution mode.  0 (default, "wavefront"): the camera pass only traces and
  * scatters; direct illumination, vertex connections and merges are evaluated
  * by dense task kernels and every path's additions are replayed in the
- * reference's order.  1 ("strict"): everything is evaluated inside the camera
- * path as the reference does (slower).  Both produce the same bits; the
- * environment variable SMALLVCM_AMD_STRICT_ORDER=1 sets the default. */
+ * reference's order, light splats included: bit-identical to the reference for
+ * every algorithm.  1 ("strict"): everything is evaluated inside the paths as
+ * the reference does (about 2x slower; light splats are fp32 atomics there).
+ * The environment variable SMALLVCM_AMD_STRICT_ORDER=1 sets the default. */
 int vcm_set_strict_order(vcm_ctx *ctx, int on);
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all
