@@ -11,12 +11,15 @@
 #include <string.h>
 #include <string>
 #include <new>
+#include <mutex>
+#include <atomic>
 
 #include "vcm_kernels.h"
 
 using namespace vcm;
 
 static thread_local std::string g_err;
+static thread_local bool g_hipFailed;   /* the last failure on this thread came from the HIP runtime */
 static int fail(const char *what, const char *detail)
 {
     g_err = std::string(what) + ": " + (detail ? detail : "");
@@ -25,13 +28,59 @@ static int fail(const char *what, const char *detail)
 #define HIPCHK(expr)                                                            \
     do {                                                                        \
         hipError_t e_ = (expr);                                                 \
-        if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));        \
+        if (e_ != hipSuccess) { g_hipFailed = true; return fail(#expr, hipGetErrorString(e_)); } \
     } while (0)
 
 enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID_K0, EV_GRID, EV_CAMERA_K0, EV_CAMERA_K1, EV_CONNECT_K1,
        EV_MERGE_K0, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
 
-struct vcm_ctx {
+/* Iteration scratch: everything that is dead once an iteration has been
+ * resolved into the framebuffer.  It lives in a per-device ARENA shared by all
+ * contexts of the process: the reference's render() creates one renderer per
+ * host core and runs them concurrently (smallvcm.cxx:66, :82-108) -- 256
+ * private copies (1.2 GB each at 512^2, 18 GB at 2048^2) do not fit in HBM.  A
+ * context borrows the arena from vcm_begin_iteration to vcm_end_iteration
+ * (host mutex); consecutive borrowers are ordered on the GPU by an event, the
+ * host never waits for the device. */
+struct Scratch {
+    LightStore store;                 /* S*nLocal slots (+ count[nLocal]) */
+    int *dPathStart;                  /* nLocal+1 */
+    int *dLocalTotal;                 /* 1 */
+    int *dTileSums;                   /* scan scratch */
+    float *dRecordsLocal;             /* S*nLocal records */
+    int *dSlotOfVertex;               /* S*nLocal: dense vertex index -> slot in the light store */
+    F4 *dSplat;                       /* S*nLocal: splat of each light vertex (rgb | pixel) */
+    float *dRecordsAll;               /* S*N records (multi-rank only) */
+    int *dCellCount, *dCellStart, *dCellFill;   /* N+2 each */
+    int *dCellId, *dUnsorted;         /* per record */
+    F4 *dG0, *dG1, *dG2; float *dG3;
+    int *dSortedIndex;                /* parity: grid position -> record index */
+    F4 *dCamOut;                      /* nLocal */
+    uint32_t *dCamMask;               /* nLocal: path lengths at which a vertex record was appended */
+    VertexStore vs;                   /* camera vertices + DI/VC tasks (wavefront mode) */
+    int *dQueryKey;                   /* per camera vertex: sort key */
+    int *dSortedVertex;               /* camera vertices sorted by key */
+    int *dQueryStart, *dQueryCount, *dQueryFill;   /* VCM_QSORT_BUCKETS+2 each (dQueryStart also >= N+2) */
+};
+
+struct vcm_ctx;
+struct Arena {
+    std::mutex mtx;                   /* held by the context between begin and end */
+    int device;
+    Scratch s;
+    size_t capLocal, capN; int capS, capL; bool capSharded;
+    bool allocated;
+    hipEvent_t lastUse; bool eventReady, lastValid;
+    vcm_ctx *lastUser;
+    int users;                        /* live contexts on this device */
+    bool shared;                      /* registry arena (false: private to one sharded context) */
+    std::atomic<unsigned long long> ownerThread;   /* host thread holding mtx, 0 = none */
+};
+static std::atomic<unsigned long long> g_threadCounter{0};
+static thread_local unsigned long long g_threadId = 0;
+static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_threadCounter; return g_threadId; }
+
+struct vcm_ctx : Scratch {
     vcm_scene_desc scene;
     bool useVM, useVC, lightTraceOnly, ppm;
     float baseRadius, radiusAlpha;
@@ -42,36 +91,18 @@ struct vcm_ctx {
     hipStream_t stream;
     bool ownStream;
     bool deviceReady;
-    int allocS;
+    Arena *arena; bool holdsArena;
 
+    /* per context: survives the iteration */
     vcm_scene_desc *dScene;           /* first member of a device-resident SceneDev */
-    float *dFb;                       /* N*3, running sum */
-    LightStore store;                 /* S*nLocal slots */
-    unsigned char *dRngLight, *dRngCam;
-    int *dPathStart;                  /* nLocal */
-    int *dLocalTotal;                 /* 1 */
-    int *dTileSums;                   /* scan scratch */
-    float *dRecordsLocal;             /* S*nLocal records */
-    int *dSlotOfVertex;               /* S*nLocal: dense vertex index -> slot in the light store */
-    F4 *dSplat;                       /* S*nLocal: splat of each light vertex (rgb | pixel) */
-    float *dRecordsAll;               /* S*N records (multi-rank only) */
-    bool importedRecords;
-    bool gridBuilt, cameraTraced, merged;
+    float *dFb;                       /* N*3, running sum (mFramebuffer, renderer.hxx:68) */
+    unsigned char *dRngLight, *dRngCam;   /* the random-number tape of the last iteration */
     GridHeader *dHdr;
-    int *dCellCount, *dCellStart, *dCellFill;   /* nCells+1 each */
-    int *dCellId, *dUnsorted;         /* per record */
-    F4 *dG0, *dG1, *dG2; float *dG3;
-    int *dSortedIndex;                /* debug/parity: grid position -> record index */
-    F4 *dCamOut;                      /* nLocal */
-    uint32_t *dCamMask;               /* nLocal: path lengths at which a merge query was queued */
-    VertexStore vs;                   /* camera vertices + DI/VC tasks of the iteration (wavefront mode) */
-    int *dQueryKey;                   /* per camera vertex: base-cell bucket */
-    int *dSortedVertex;               /* camera vertices sorted by bucket */
-    int *dQueryStart, *dQueryCount, *dQueryFill;   /* VCM_QSORT_BUCKETS+2 each */
-    int allocL;
-    bool strictOrder;
     unsigned long long *dStats;
 
+    bool importedRecords;
+    bool gridBuilt, cameraTraced, merged;
+    bool strictOrder;
     IterParams P;
     bool inIteration;
     hipEvent_t ev[EV_COUNT];
@@ -90,19 +121,141 @@ template <typename T> static int dalloc(T **p, size_t n)
 }
 #define DFREE(p) do { if (p) { (void)hipFree(p); p = NULL; } } while (0)
 
-static void free_iteration_buffers(vcm_ctx *c)
+/* ---- arena -------------------------------------------------------------- */
+static std::mutex g_arenaRegistryMutex;
+static Arena *g_arenas[64];
+
+static Arena *arena_new(int device, bool shared)
 {
-    DFREE(c->store.v0); DFREE(c->store.v1); DFREE(c->store.v2); DFREE(c->store.v3); DFREE(c->store.v4);
-    DFREE(c->dRecordsLocal); DFREE(c->dRecordsAll); DFREE(c->dSlotOfVertex); DFREE(c->dSplat);
-    DFREE(c->dCellId); DFREE(c->dUnsorted);
-    DFREE(c->dG0); DFREE(c->dG1); DFREE(c->dG2); DFREE(c->dG3); DFREE(c->dSortedIndex);
-    DFREE(c->vs.q0); DFREE(c->vs.q1); DFREE(c->vs.q2); DFREE(c->vs.q3); DFREE(c->vs.q4); DFREE(c->vs.meta);
-    DFREE(c->vs.diTask); DFREE(c->vs.vcTask); DFREE(c->vs.pathVertex); DFREE(c->vs.diOut); DFREE(c->vs.vcOut);
-    DFREE(c->vs.mergeOut); DFREE(c->dQueryKey); DFREE(c->dSortedVertex);
-    c->allocS = 0; c->allocL = 0;
+    Arena *a = new Arena();
+    a->device = device;
+    memset((void *)&a->s, 0, sizeof(Scratch));
+    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
+    a->allocated = false; a->eventReady = a->lastValid = false; a->lastUser = NULL; a->users = 0;
+    a->shared = shared; a->ownerThread = 0;
+    return a;
+}
+/* single-rank contexts share the device's arena; a sharded context (one process per GPU, its
+   iteration spans host-side collectives) gets a private one */
+static Arena *arena_get(int device, bool shared)
+{
+    if (device < 0 || device >= 64) return NULL;
+    if (!shared) return arena_new(device, false);
+    std::lock_guard<std::mutex> g(g_arenaRegistryMutex);
+    if (!g_arenas[device]) g_arenas[device] = arena_new(device, true);
+    return g_arenas[device];
 }
 
-static int ensure_device(vcm_ctx *c, int S, int L = 0)
+static void arena_free_buffers(Arena *a)
+{
+    Scratch &s = a->s;
+    DFREE(s.store.v0); DFREE(s.store.v1); DFREE(s.store.v2); DFREE(s.store.v3); DFREE(s.store.v4); DFREE(s.store.count);
+    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums);
+    DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
+    DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellFill); DFREE(s.dCellId); DFREE(s.dUnsorted);
+    DFREE(s.dG0); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
+    DFREE(s.dCamOut); DFREE(s.dCamMask);
+    DFREE(s.vs.q0); DFREE(s.vs.q1); DFREE(s.vs.q2); DFREE(s.vs.q3); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
+    DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.pathVertex); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
+    DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryFill);
+    a->allocated = false;
+    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
+}
+
+/* called with a->mtx held; grows the arena to what this context needs */
+static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sharded)
+{
+    if (!a->eventReady) { HIPCHK(hipEventCreateWithFlags(&a->lastUse, hipEventDisableTiming)); a->eventReady = true; }
+    if (a->allocated && nLocal <= a->capLocal && N <= a->capN && S <= a->capS && L <= a->capL && (!sharded || a->capSharded))
+        return 0;
+    HIPCHK(hipDeviceSynchronize());   /* rare: another context's kernels may still use the old buffers */
+    const size_t cl = nLocal > a->capLocal ? nLocal : a->capLocal, cn = N > a->capN ? N : a->capN;
+    const int cs = S > a->capS ? S : a->capS, cL = L > a->capL ? L : a->capL;
+    const bool sh = sharded || a->capSharded;
+    arena_free_buffers(a);
+    a->lastValid = false;
+    Scratch &s = a->s;
+    const size_t slots = (size_t)cs * cl;
+    const size_t allRecs = (size_t)cs * cn;
+    if (dalloc(&s.store.v0, slots) || dalloc(&s.store.v1, slots) || dalloc(&s.store.v2, slots) ||
+        dalloc(&s.store.v3, slots) || dalloc(&s.store.v4, slots) || dalloc(&s.store.count, cl)) return -1;
+    if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
+    size_t maxScan = (cn > cl ? cn : cl) + 1;
+    if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
+    if (dalloc(&s.dTileSums, maxScan / VCM_SCAN_TILE + 2)) return -1;
+    if (dalloc(&s.dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
+    if (dalloc(&s.dSlotOfVertex, slots) || dalloc(&s.dSplat, slots)) return -1;
+    if (sh && dalloc(&s.dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
+    if (dalloc(&s.dCellCount, cn + 2) || dalloc(&s.dCellStart, cn + 2) || dalloc(&s.dCellFill, cn + 2)) return -1;
+    if (dalloc(&s.dCellId, allRecs) || dalloc(&s.dUnsorted, allRecs)) return -1;
+    if (dalloc(&s.dG0, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
+        dalloc(&s.dG3, allRecs) || dalloc(&s.dSortedIndex, allRecs)) return -1;
+    if (dalloc(&s.dCamOut, cl) || dalloc(&s.dCamMask, cl) || dalloc(&s.vs.count, 4)) return -1;
+    /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l connects to
+       light vertices of length <= L-1-l, so <= (L-1)(L-2)/2 VC tasks per path; + one partly used
+       block per wave (holes) */
+    const size_t maxWaves = (size_t)256 * 32;
+    const size_t vslots = (size_t)(cL > 0 ? cL : 1) * cl + maxWaves * VCM_QBLOCK_VERTEX;
+    const size_t vcPerPath = (cL >= 3) ? (size_t)(cL - 1) * (size_t)(cL - 2) / 2 : 1;
+    const size_t vcslots = vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
+    if (dalloc(&s.vs.q0, vslots) || dalloc(&s.vs.q1, vslots) || dalloc(&s.vs.q2, vslots) ||
+        dalloc(&s.vs.q3, vslots) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
+        dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.pathVertex, vslots) || dalloc(&s.vs.diOut, vslots) ||
+        dalloc(&s.vs.mergeOut, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
+        dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;
+    const size_t qsN = (cn > (size_t)VCM_QSORT_BUCKETS ? cn : (size_t)VCM_QSORT_BUCKETS) + 2;   /* also pixStart of K1d */
+    if (dalloc(&s.dQueryStart, qsN) || dalloc(&s.dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||
+        dalloc(&s.dQueryFill, (size_t)VCM_QSORT_BUCKETS + 2)) return -1;
+    a->capLocal = cl; a->capN = cn; a->capS = cs; a->capL = cL; a->capSharded = sh;
+    a->allocated = true;
+    return 0;
+}
+
+/* borrow the device's arena for one iteration */
+static int arena_acquire(vcm_ctx *c, int S, int L)
+{
+    Arena *a = c->arena;
+    if (a->ownerThread.load() == this_thread_id())
+        return fail("vcm_begin_iteration", "this thread is already inside an iteration of another context on this "
+                                           "device: single-rank contexts share the iteration scratch, end that iteration first");
+    a->mtx.lock();
+    a->ownerThread = this_thread_id();
+    c->holdsArena = true;
+    if (arena_ensure(a, (size_t)c->nLocal, (size_t)c->N, S, L, c->world > 1)) return -1;
+    *static_cast<Scratch *>(c) = a->s;
+    if (a->lastValid && a->lastUser != c) HIPCHK(hipStreamWaitEvent(c->stream, a->lastUse, 0));
+    return 0;
+}
+static void arena_release(vcm_ctx *c, bool recordEvent)
+{
+    if (!c->holdsArena) return;
+    Arena *a = c->arena;
+    if (recordEvent && a->eventReady && hipEventRecord(a->lastUse, c->stream) == hipSuccess) { a->lastValid = true; a->lastUser = c; }
+    c->holdsArena = false;
+    a->ownerThread = 0;
+    a->mtx.unlock();
+}
+/* error inside an iteration: give the arena back so that other contexts do not dead-lock */
+static int abort_iteration(vcm_ctx *c, int rc)
+{
+    if (rc != 0 && g_hipFailed && c && c->holdsArena) {
+        (void)hipStreamSynchronize(c->stream);
+        c->inIteration = false;
+        arena_release(c, false);
+    }
+    return rc;
+}
+
+/* the scratch of the last iteration is readable until another context borrows the arena */
+static int scratch_readable(vcm_ctx *c, const char *what)
+{
+    if (!c || !c->deviceReady || (!c->inIteration && c->iterations == 0)) return fail(what, "no iteration has run");
+    if (!c->holdsArena && c->arena->lastUser != c)
+        return fail(what, "the iteration scratch has since been used by another context of this device");
+    return 0;
+}
+
+static int ensure_device(vcm_ctx *c)
 {
     if (use_device(c)) return -1;
     if (!c->deviceReady) {
@@ -120,56 +273,15 @@ static int ensure_device(vcm_ctx *c, int S, int L = 0)
         }
         if (dalloc(&c->dFb, (size_t)c->N * 3)) return -1;
         HIPCHK(hipMemset(c->dFb, 0, (size_t)c->N * 3 * sizeof(float)));
-        if (dalloc(&c->store.count, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->dRngLight, (size_t)c->nLocal)) return -1;
         if (dalloc(&c->dRngCam, (size_t)c->nLocal)) return -1;
         HIPCHK(hipMemset(c->dRngLight, 0, (size_t)c->nLocal));
         HIPCHK(hipMemset(c->dRngCam, 0, (size_t)c->nLocal));
-        if (dalloc(&c->dPathStart, (size_t)c->nLocal + 1)) return -1;
-        if (dalloc(&c->dLocalTotal, 1)) return -1;
-        size_t maxScan = (size_t)(c->N > c->nLocal ? c->N : c->nLocal) + 1;
-        if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
-        if (dalloc(&c->dTileSums, maxScan / VCM_SCAN_TILE + 2)) return -1;
         if (dalloc(&c->dHdr, 1)) return -1;
         HIPCHK(hipMemset(c->dHdr, 0, sizeof(GridHeader)));
-        if (dalloc(&c->dCellCount, (size_t)c->N + 2)) return -1;
-        if (dalloc(&c->dCellStart, (size_t)c->N + 1)) return -1;
-        if (dalloc(&c->dCellFill, (size_t)c->N + 2)) return -1;
-        if (dalloc(&c->dCamOut, (size_t)c->nLocal)) return -1;
-        if (dalloc(&c->dCamMask, (size_t)c->nLocal)) return -1;
-        if (dalloc(&c->vs.count, 4)) return -1;
-        const size_t qsN = ((size_t)c->N > (size_t)VCM_QSORT_BUCKETS ? (size_t)c->N : (size_t)VCM_QSORT_BUCKETS) + 2;   /* also pixStart of K1d */
-        if (dalloc(&c->dQueryStart, qsN) || dalloc(&c->dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||
-            dalloc(&c->dQueryFill, (size_t)VCM_QSORT_BUCKETS + 2)) return -1;
         if (dalloc(&c->dStats, STAT_COUNT)) return -1;
+        HIPCHK(hipMemset(c->dStats, 0, STAT_COUNT * sizeof(unsigned long long)));
         c->deviceReady = true;
-    }
-    if (S > 0 && (c->allocS != S || c->allocL != L)) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        free_iteration_buffers(c);
-        const size_t slots = (size_t)S * (size_t)c->nLocal;
-        const size_t allRecs = (size_t)S * (size_t)c->N;
-        if (dalloc(&c->store.v0, slots) || dalloc(&c->store.v1, slots) || dalloc(&c->store.v2, slots) ||
-            dalloc(&c->store.v3, slots) || dalloc(&c->store.v4, slots)) return -1;
-        if (dalloc(&c->dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
-        if (dalloc(&c->dSlotOfVertex, slots) || dalloc(&c->dSplat, slots)) return -1;
-        if (c->world > 1 && dalloc(&c->dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
-        if (dalloc(&c->dCellId, allRecs) || dalloc(&c->dUnsorted, allRecs)) return -1;
-        if (dalloc(&c->dG0, allRecs + VCM_MERGE_UNROLL) || dalloc(&c->dG1, allRecs) || dalloc(&c->dG2, allRecs) ||
-            dalloc(&c->dG3, allRecs) || dalloc(&c->dSortedIndex, allRecs)) return -1;
-        /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l
-           connects to light vertices of length <= L-1-l, so <= (L-1)(L-2)/2 VC tasks per path */
-        /* + one partly used block per wave (holes) */
-        const size_t maxWaves = (size_t)256 * 32;
-        const size_t vslots = (size_t)(L > 0 ? L : 1) * (size_t)c->nLocal + maxWaves * VCM_QBLOCK_VERTEX;
-        const size_t vcPerPath = (L >= 3) ? (size_t)(L - 1) * (size_t)(L - 2) / 2 : 1;
-        const size_t vcslots = vcPerPath * (size_t)c->nLocal + maxWaves * VCM_QBLOCK_VC;
-        if (dalloc(&c->vs.q0, vslots) || dalloc(&c->vs.q1, vslots) || dalloc(&c->vs.q2, vslots) ||
-            dalloc(&c->vs.q3, vslots) || dalloc(&c->vs.q4, vslots) || dalloc(&c->vs.meta, vslots) ||
-            dalloc(&c->vs.diTask, vslots) || dalloc(&c->vs.pathVertex, vslots) || dalloc(&c->vs.diOut, vslots) ||
-            dalloc(&c->vs.mergeOut, vslots) || dalloc(&c->vs.vcTask, 2 * vcslots) || dalloc(&c->vs.vcOut, vcslots) ||
-            dalloc(&c->dQueryKey, vslots) || dalloc(&c->dSortedVertex, vslots)) return -1;
-        c->allocS = S; c->allocL = L;
     }
     return 0;
 }
@@ -262,6 +374,9 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     c->p0 = (int)((long long)c->N * rank / worldSize);
     c->nLocal = (int)((long long)c->N * (rank + 1) / worldSize) - c->p0;
     c->ownStream = true;
+    c->arena = arena_get(device, worldSize == 1);
+    if (!c->arena) { delete c; fail("vcm_create", "device index out of range"); return NULL; }
+    { std::lock_guard<std::mutex> g(c->arena->mtx); c->arena->users++; }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
     return c;
@@ -280,11 +395,25 @@ void vcm_destroy(vcm_ctx *c)
     if (c->deviceReady) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
-        free_iteration_buffers(c);
-        DFREE(c->dScene); DFREE(c->dFb); DFREE(c->store.count); DFREE(c->dRngLight); DFREE(c->dRngCam);
-        DFREE(c->dPathStart); DFREE(c->dLocalTotal); DFREE(c->dTileSums); DFREE(c->dHdr);
-        DFREE(c->dCellCount); DFREE(c->dCellStart); DFREE(c->dCellFill); DFREE(c->dCamOut); DFREE(c->dStats);
-        DFREE(c->dCamMask); DFREE(c->vs.count); DFREE(c->dQueryStart); DFREE(c->dQueryCount); DFREE(c->dQueryFill);
+    }
+    arena_release(c, false);
+    if (c->arena) {
+        Arena *a = c->arena;
+        std::lock_guard<std::mutex> g(a->mtx);
+        if (a->lastUser == c) { a->lastUser = NULL; }   /* the event stays valid: its work was synchronised above */
+        if (--a->users == 0 && a->allocated) {
+            (void)hipSetDevice(a->device);
+            (void)hipDeviceSynchronize();
+            arena_free_buffers(a);
+            a->lastValid = false;
+        }
+    }
+    if (c->arena && !c->arena->shared) {
+        if (c->arena->eventReady) (void)hipEventDestroy(c->arena->lastUse);
+        delete c->arena;
+    }
+    if (c->deviceReady) {
+        DFREE(c->dScene); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStats);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
@@ -313,14 +442,15 @@ int vcm_set_stream(vcm_ctx *c, void *hipStream)
     return 0;
 }
 
-int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)
+static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)
 {   /* vertexcm.hxx:288-316 */
     if (!c) return fail("vcm_begin_iteration", "ctx is NULL");
     if (c->inIteration) return fail("vcm_begin_iteration", "previous iteration not ended");
     if (maxLen > 255) return fail("vcm_begin_iteration", "maxPathLength > 255 unsupported (8-bit vertex counts)");
     const int S = (maxLen >= 2) ? (int)maxLen - 1 : 1;
     const int L = (maxLen >= 1) ? (int)maxLen : 1;
-    if (ensure_device(c, S, L)) return -1;
+    if (ensure_device(c)) return -1;
+    if (arena_acquire(c, S, L)) { g_hipFailed = true; return abort_iteration(c, -1); }
 
     IterParams &P = c->P;
     memset(&P, 0, sizeof(P));
@@ -356,7 +486,7 @@ int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned max
     return 0;
 }
 
-int vcm_trace_light(vcm_ctx *c)
+static int vcm_trace_light_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:321-396 */
     if (!c || !c->inIteration) return fail("vcm_trace_light", "no iteration in progress");
     if (use_device(c)) return -1;
@@ -403,7 +533,7 @@ int vcm_trace_light(vcm_ctx *c)
 
 int vcm_light_records(vcm_ctx *c, void **devPtr, long long *count)
 {
-    if (!c || !c->deviceReady) return fail("vcm_light_records", "no iteration has run");
+    if (scratch_readable(c, "vcm_light_records")) return -1;
     if (use_device(c)) return -1;
     int n = 0;
     HIPCHK(hipMemcpyAsync(&n, c->dLocalTotal, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -415,7 +545,8 @@ int vcm_light_records(vcm_ctx *c, void **devPtr, long long *count)
 
 int vcm_export_light_records(vcm_ctx *c, void *dstDev, long long count)
 {
-    if (!c || !c->deviceReady || !dstDev) return fail("vcm_export_light_records", "bad argument");
+    if (!dstDev) return fail("vcm_export_light_records", "bad argument");
+    if (scratch_readable(c, "vcm_export_light_records")) return -1;
     if (use_device(c)) return -1;
     if (count > 0)
         HIPCHK(hipMemcpyAsync(dstDev, c->dRecordsLocal, (size_t)count * VCM_MERGE_RECORD_FLOATS * sizeof(float),
@@ -426,12 +557,12 @@ int vcm_export_light_records(vcm_ctx *c, void *dstDev, long long count)
 int vcm_export_framebuffer(vcm_ctx *c, void *dstDev)
 {
     if (!c || !dstDev) return fail("vcm_export_framebuffer", "bad argument");
-    if (ensure_device(c, 0)) return -1;
+    if (ensure_device(c)) return -1;
     HIPCHK(hipMemcpyAsync(dstDev, c->dFb, (size_t)c->N * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
-int vcm_import_light_records(vcm_ctx *c, const void *devPtr, const long long *counts, int nSeg, long long strideRecords)
+static int vcm_import_light_records_impl(vcm_ctx *c, const void *devPtr, const long long *counts, int nSeg, long long strideRecords)
 {
     if (!c || !c->inIteration) return fail("vcm_import_light_records", "no iteration in progress");
     if (c->world <= 1 || !c->dRecordsAll) return fail("vcm_import_light_records", "context is not sharded");
@@ -440,7 +571,7 @@ int vcm_import_light_records(vcm_ctx *c, const void *devPtr, const long long *co
     const size_t recBytes = VCM_MERGE_RECORD_FLOATS * sizeof(float);
     for (int s = 0; s < nSeg; s++) {
         if (counts[s] < 0) return fail("vcm_import_light_records", "negative count");
-        if (total + counts[s] > (long long)c->allocS * c->N) return fail("vcm_import_light_records", "too many records");
+        if (total + counts[s] > (long long)c->arena->capS * (long long)c->arena->capN) return fail("vcm_import_light_records", "too many records");
         if (counts[s] > 0)
             HIPCHK(hipMemcpyAsync((char *)c->dRecordsAll + (size_t)total * recBytes,
                                   (const char *)devPtr + (size_t)s * (size_t)strideRecords * recBytes,
@@ -453,7 +584,7 @@ int vcm_import_light_records(vcm_ctx *c, const void *devPtr, const long long *co
     return 0;
 }
 
-int vcm_build_grid(vcm_ctx *c)
+static int vcm_build_grid_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:403-408 -> HashGrid::Build hashgrid.hxx:41-107 */
     if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
     if (use_device(c)) return -1;
@@ -491,7 +622,7 @@ static GridStore grid_of(vcm_ctx *c)
     return grid;
 }
 
-int vcm_trace_camera(vcm_ctx *c)
+static int vcm_trace_camera_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:415-545 without the merge (:530-538) in wavefront mode */
     if (!c || !c->inIteration) return fail("vcm_trace_camera", "no iteration in progress");
     if (use_device(c)) return -1;
@@ -523,7 +654,7 @@ int vcm_trace_camera(vcm_ctx *c)
     return 0;
 }
 
-int vcm_merge(vcm_ctx *c)
+static int vcm_merge_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:530-538 for all camera vertices, then :544 */
     if (!c || !c->inIteration) return fail("vcm_merge", "no iteration in progress");
     if (!c->cameraTraced) return fail("vcm_merge", "call vcm_trace_camera first");
@@ -559,6 +690,22 @@ int vcm_merge(vcm_ctx *c)
     return 0;
 }
 
+/* a HIP failure inside a phase ends the iteration and returns the arena */
+int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)
+{
+    g_hipFailed = false;
+    return abort_iteration(c, vcm_begin_iteration_impl(c, iteration, minLen, maxLen));
+}
+int vcm_import_light_records(vcm_ctx *c, const void *devPtr, const long long *counts, int nSeg, long long strideRecords)
+{
+    g_hipFailed = false;
+    return abort_iteration(c, vcm_import_light_records_impl(c, devPtr, counts, nSeg, strideRecords));
+}
+int vcm_trace_light(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_trace_light_impl(c)); }
+int vcm_build_grid(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_build_grid_impl(c)); }
+int vcm_trace_camera(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_trace_camera_impl(c)); }
+int vcm_merge(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_merge_impl(c)); }
+
 int vcm_end_iteration(vcm_ctx *c)
 {
     if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
@@ -566,6 +713,7 @@ int vcm_end_iteration(vcm_ctx *c)
     c->iterations++;   /* :547 */
     c->inIteration = false;
     c->evValid = true;
+    arena_release(c, true);
     return 0;
 }
 
@@ -604,7 +752,7 @@ int vcm_read_framebuffer(vcm_ctx *c, float *rgbHost)
 int vcm_framebuffer_device(vcm_ctx *c, void **devPtr)
 {
     if (!c || !devPtr) return fail("vcm_framebuffer_device", "NULL argument");
-    if (ensure_device(c, 0)) return -1;
+    if (ensure_device(c)) return -1;
     *devPtr = c->dFb;
     return 0;
 }
@@ -687,7 +835,7 @@ int vcm_local_path_range(vcm_ctx *c, int *first, int *count)
  * (grid position -> record index, nRecords ints), bbox (6 floats) */
 int vcm_debug_read_grid(vcm_ctx *c, int *cellStart, int *sortedIndex, float *bbox6, long long *nRecords)
 {
-    if (!c || !c->deviceReady) return fail("vcm_debug_read_grid", "no iteration has run");
+    if (scratch_readable(c, "vcm_debug_read_grid")) return -1;
     if (use_device(c)) return -1;
     GridHeader hdr;
     HIPCHK(hipMemcpy(&hdr, c->dHdr, sizeof(hdr), hipMemcpyDeviceToHost));
@@ -702,7 +850,7 @@ int vcm_debug_read_grid(vcm_ctx *c, int *cellStart, int *sortedIndex, float *bbo
 /* local merge records of the last iteration, host copy (count from vcm_light_records) */
 int vcm_debug_read_records(vcm_ctx *c, float *out, long long count)
 {
-    if (!c || !c->deviceReady) return fail("vcm_debug_read_records", "no iteration has run");
+    if (scratch_readable(c, "vcm_debug_read_records")) return -1;
     if (use_device(c)) return -1;
     if (count > 0)
         HIPCHK(hipMemcpy(out, c->dRecordsLocal, (size_t)count * VCM_MERGE_RECORD_FLOATS * sizeof(float), hipMemcpyDeviceToHost));

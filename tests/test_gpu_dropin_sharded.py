@@ -156,3 +156,76 @@ def test_sharded_contexts_equal_single_context(world, sid, algo, res, iters):
     assert sum(st["lightVertices"] for _, st in results) == st1["lightVertices"]
     assert sum(st["mergeAccepted"] for _, st in results) == st1["mergeAccepted"]
     assert sum(st["connections"] for _, st in results) == st1["connections"]
+
+
+# ---- many renderers on one device: the shared iteration-scratch arena -------------------------------------------
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs a SmallVCM checkout)")
+def test_reference_driver_time_mode_uses_every_host_core(tmp_path):
+    """`-t` makes render() run one renderer per host core concurrently (smallvcm.cxx:66, :82-108): on the GPU
+    box that is 256 contexts on one device, which only fit because the iteration scratch is shared."""
+    out = str(tmp_path / "img_t.hdr")
+    r = subprocess.run([DROPIN, "-s", "1", "-a", "vcm", "-t", "2", "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "done in" in r.stdout
+    img = _read_hdr(out).astype(np.int32)
+    assert img.shape[:2] == (512, 512) and img[..., 3].max() > 0
+    # more iterations of the same estimator: close to a 1-iteration render, pixel for pixel on average
+    v = VertexCM(cornell_scene(1, 512, 512), 4, 0.003, 0.75, 1234)
+    v.mMaxPathLength, v.mMinPathLength = 10, 0
+    for i in range(4):
+        v.RunIteration(i)
+    mine = v.GetFramebuffer()
+    v.close()
+    rgb = img[..., :3] * np.exp2(img[..., 3:4] - 136.0) * (img[..., 3:4] > 0)
+    assert abs(rgb.mean() - mine.mean()) < 0.05 * mine.mean()
+
+
+def test_concurrent_contexts_share_scratch_and_stay_exact():
+    """8 host threads, each with its own context on device 0, iterate concurrently; every image must equal the
+    image of the same renderer run alone (the arena hand-over is ordered on the GPU by an event)."""
+    sc = cornell_scene(1, 96, 80)
+    seeds = [1234 + 7 * i for i in range(8)]
+
+    def render(seed, iters=3):
+        v = VertexCM(sc, 4, 0.003, 0.75, seed)
+        v.mMaxPathLength, v.mMinPathLength = 10, 0
+        for it in range(iters):
+            v.RunIteration(it)
+        fb = v.framebuffer_sum()
+        v.close()
+        return fb
+
+    alone = [render(s) for s in seeds]
+    together, errors = [None] * len(seeds), []
+
+    def run(i):
+        try:
+            together[i] = render(seeds[i])
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(seeds))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errors, errors
+    for a, b in zip(alone, together):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_interleaving_two_iterations_on_one_thread_is_refused_not_deadlocked():
+    sc = cornell_scene(0, 32, 32)
+    a = HipBackend(sc, 4, 0.003, 0.75, 1)
+    b = HipBackend(sc, 4, 0.003, 0.75, 2)
+    a.begin(0, 0, 10)
+    with pytest.raises(RuntimeError, match="already inside an iteration"):
+        b.begin(0, 0, 10)
+    a.trace_light(); a.build_grid(); a.trace_camera(); a.merge(); a.end()
+    b.begin(0, 0, 10)
+    b.trace_light(); b.build_grid(); b.trace_camera(); b.merge(); b.end()
+    # the scratch now belongs to b's last iteration: a's records are gone, and saying so beats returning b's
+    with pytest.raises(RuntimeError, match="used by another context"):
+        a.records()
+    assert b.records().shape[0] > 0
+    a.close(); b.close()
