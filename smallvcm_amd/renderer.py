@@ -377,3 +377,76 @@ class ShardedVertexCM:
         if self.mIterations > 0:
             fb = fb * np.float32(1.0 / self.mIterations)
         return fb
+
+
+def static_schedule(n_iterations, n_threads, tid):
+    """The iterations OpenMP's default `schedule(static)` gives thread `tid` of the reference's
+    `#pragma omp parallel for` (src/smallvcm.cxx:98-108): contiguous blocks, the first
+    n_iterations % n_threads threads get one more."""
+    q, r = divmod(int(n_iterations), int(n_threads))
+    lo = tid * q + min(tid, r)
+    return range(lo, lo + q + (1 if tid < r else 0))
+
+
+class RenderFarm:
+    """The reference's render() (src/smallvcm.cxx:52-151) over the GPUs of one node.
+
+    The reference creates one renderer per host thread, seed mBaseSeed + i (:66-72), hands each a
+    block of iterations (:98-108), and averages the used renderers' framebuffers (:116-142).  Here a
+    "thread" is a GROUP of `shards` ranks: the world of W ranks (one per GPU) is cut into
+    R = W / shards replica groups; group g is one ShardedVertexCM with seed base + g whose `shards`
+    ranks split the paths of every iteration (RCCL all-gather of the light vertices inside the group).
+    shards = W is one renderer across all GPUs (minimum latency per iteration), shards = 1 is one
+    renderer per GPU (no per-iteration communication); the image is the same estimator either way.
+    The only world-wide collective is the framebuffer reduce at read-out.
+
+    backend_factory(seed, shard_rank, shard_world) -> backend with HipBackend's phase interface.
+    """
+
+    def __init__(self, backend_factory, base_seed, rank, world, shards=None, dist=None):
+        if dist is None:
+            import torch.distributed as dist
+        shards = world if shards is None else int(shards)
+        if shards < 1 or world % shards:
+            raise ValueError("world size %d is not a multiple of %d shards" % (world, shards))
+        self.dist, self.rank, self.world, self.shards = dist, rank, world, shards
+        self.replicas = world // shards
+        self.replica, self.shard = rank // shards, rank % shards
+        self.group = None
+        if world > 1 and 1 < shards < world:
+            # every rank creates every group, in the same order (torch.distributed contract)
+            for g in range(self.replicas):
+                grp = dist.new_group(ranks=list(range(g * shards, (g + 1) * shards)))
+                if g == self.replica:
+                    self.group = grp
+        self.backend = backend_factory(base_seed + self.replica, self.shard, shards)
+        self.renderer = ShardedVertexCM(self.backend, self.shard, shards, group=self.group)
+        self.renderer.dist = dist
+
+    def set_path_lengths(self, min_len, max_len):
+        self.renderer.mMinPathLength, self.renderer.mMaxPathLength = min_len, max_len   # smallvcm.cxx:70-71
+
+    def render(self, n_iterations):
+        """smallvcm.cxx:98-108 (iterations based loop)"""
+        for it in static_schedule(n_iterations, self.replicas, self.replica):
+            self.renderer.RunIteration(it)
+
+    def framebuffer(self):
+        """smallvcm.cxx:116-142: mean over the used renderers of (running sum / own iterations).
+        One all_reduce over the whole world: the shards of a renderer hold partial sums of it."""
+        b, dist = self.backend, self.dist
+        with b.stream_context():
+            t = b.new_tensor(b.N * 3)
+            b.export_framebuffer(t)
+            used = t.new_tensor([1.0 if (self.renderer.WasUsed() and self.shard == 0) else 0.0])
+            if self.renderer.WasUsed():
+                t *= 1.0 / self.renderer.mIterations                                    # renderer.hxx:53-54
+            else:
+                t.zero_()
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                dist.all_reduce(used, op=dist.ReduceOp.SUM)
+            n_used = max(float(used.cpu()[0]), 1.0)
+            t *= 1.0 / n_used                                                           # smallvcm.cxx:142
+            out = t.cpu()
+        return out.numpy().reshape(b.resy, b.resx, 3)

@@ -1,6 +1,7 @@
 """Worker for tests/test_sharded_cpu.py: one rank of ShardedVertexCM over gloo,
 computing with the ORACLE as backend (test infrastructure; the product backend
-is HipBackend).  Usage: sharded_worker.py rank world port scene algo res iters out.npy"""
+is HipBackend).  Usage: sharded_worker.py rank world port scene algo res iters out.npy [shards]
+With `shards` the rank is one member of a RenderFarm (world/shards replica groups)."""
 import contextlib
 import os
 import sys
@@ -15,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle_lib import Oracle  # noqa: E402
 from smallvcm_amd._abi import VCM_MERGE_RECORD_FLOATS  # noqa: E402
-from smallvcm_amd.renderer import ShardedVertexCM, cornell_scene  # noqa: E402
+from smallvcm_amd.renderer import RenderFarm, ShardedVertexCM, cornell_scene  # noqa: E402
 
 
 class OracleBackend:
@@ -74,11 +75,18 @@ def main():
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = cornell_scene(sid, res, res)
-    r = ShardedVertexCM(OracleBackend(sc, algo, rank, world), rank, world)
-    r.mMaxPathLength, r.mMinPathLength = 10, 0
-    for it in range(iters):
-        r.RunIteration(it)
-    fb = r.framebuffer_sum()
+    if len(sys.argv) > 9:
+        farm = RenderFarm(lambda seed, s, S: OracleBackend(sc, algo, s, S, seed=seed), 1234, rank, world,
+                          shards=int(sys.argv[9]), dist=dist)
+        farm.set_path_lengths(0, 10)
+        farm.render(iters)
+        fb = farm.framebuffer()
+    else:
+        r = ShardedVertexCM(OracleBackend(sc, algo, rank, world), rank, world)
+        r.mMaxPathLength, r.mMinPathLength = 10, 0
+        for it in range(iters):
+            r.RunIteration(it)
+        fb = r.framebuffer_sum()
     if rank == 0:
         np.save(out, fb)
     dist.barrier()

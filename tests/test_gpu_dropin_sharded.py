@@ -11,7 +11,7 @@ import threading
 import numpy as np
 import pytest
 
-from smallvcm_amd.renderer import HipBackend, ShardedVertexCM, VertexCM, cornell_scene
+from smallvcm_amd.renderer import HipBackend, RenderFarm, ShardedVertexCM, VertexCM, cornell_scene, static_schedule
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -68,50 +68,61 @@ def test_no_gpu_error_path_is_loud(tmp_path):
 
 
 class _ThreadCollectives:
-    """all_gather_into_tensor / all_reduce for ranks that are threads of one process."""
+    """all_gather_into_tensor / all_reduce / new_group for ranks that are threads of one process."""
 
     class ReduceOp:
         SUM = "sum"
+
+    class _Group:
+        def __init__(self, ranks):
+            self.ranks = list(ranks)
+            self.bar = threading.Barrier(len(self.ranks))
+            self.slots = [None] * len(self.ranks)
 
     def __init__(self, world):
         import torch
         self.torch = torch
         self.world = world
-        self.bar = threading.Barrier(world)
-        self.slots = [None] * world
+        self.all = self._Group(range(world))
+        self.bar = self.all.bar
+        self.groups, self.lock = {}, threading.Lock()
         self.tls = threading.local()
 
     def bind(self, rank):
         self.tls.rank = rank
 
-    def _exchange(self, t):
+    def new_group(self, ranks):
+        with self.lock:
+            return self.groups.setdefault(tuple(ranks), self._Group(ranks))
+
+    def _exchange(self, t, group):
+        g = group or self.all
         self.torch.cuda.current_stream().synchronize()
-        self.slots[self.tls.rank] = t
-        self.bar.wait()
-        parts = list(self.slots)
-        return parts
+        g.slots[g.ranks.index(self.tls.rank)] = t
+        g.bar.wait()
+        return g, list(g.slots)
 
     class _Done:
         def wait(self):
             return True
 
     def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
-        parts = self._exchange(inp)
+        g, parts = self._exchange(inp, group)
         n = inp.numel()
         for r, p in enumerate(parts):
             out[r * n:(r + 1) * n].copy_(p)
         self.torch.cuda.current_stream().synchronize()
-        self.bar.wait()
+        g.bar.wait()
         return self._Done()
 
     def all_reduce(self, t, op=None, group=None):
-        parts = self._exchange(t.clone())
+        g, parts = self._exchange(t.clone(), group)
         acc = parts[0].clone()
         for p in parts[1:]:
             acc += p
         t.copy_(acc)
         self.torch.cuda.current_stream().synchronize()
-        self.bar.wait()
+        g.bar.wait()
 
 
 @pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 128, 2), (4, 1, 2, 96, 2), (3, 3, 4, 100, 1)])
@@ -229,3 +240,59 @@ def test_interleaving_two_iterations_on_one_thread_is_refused_not_deadlocked():
         a.records()
     assert b.records().shape[0] > 0
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("world,shards,algo,res,iters", [(4, 2, 4, 96, 5), (3, 1, 4, 64, 4)])
+def test_render_farm_on_one_gpu(world, shards, algo, res, iters):
+    """RenderFarm (replica groups x path shards) with threads as ranks: equals the mean of the group renderers run
+    alone with seeds base + g over their static-schedule iteration blocks (smallvcm.cxx:61-142)."""
+    sc = cornell_scene(1, res, res)
+    coll = _ThreadCollectives(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            coll.bind(rank)
+            farm = RenderFarm(lambda seed, s, S: HipBackend(sc, algo, 0.003, 0.75, seed, device=0, rank=s, world=S),
+                              1234, rank, world, shards=shards, dist=coll)
+            farm.set_path_lengths(0, 10)
+            farm.render(iters)
+            results[rank] = farm.framebuffer()
+            farm.backend.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+            for g in [coll.all] + list(coll.groups.values()):
+                g.bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errors, errors
+    replicas = world // shards
+    total = np.zeros((res, res, 3), np.float64)
+    for g in range(replicas):
+        its = static_schedule(iters, replicas, g)
+        v = VertexCM(sc, algo, 0.003, 0.75, 1234 + g)
+        v.mMaxPathLength, v.mMinPathLength = 10, 0
+        for it in its:
+            v.RunIteration(it)
+        total += v.GetFramebuffer().astype(np.float64)
+        v.close()
+    ref = (total / replicas).astype(np.float32)
+    for fb in results:
+        assert np.allclose(fb, ref, rtol=3e-6, atol=2e-7)
+
+
+def test_rccl_plumbing_with_one_rank():
+    """see tests/nccl_single_rank.py"""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_single_rank.py"), str(port)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

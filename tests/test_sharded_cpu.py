@@ -41,3 +41,39 @@ def test_sharded_equals_unsharded(tmp_path, world, sid, algo, res, iters):
     assert np.allclose(fb, ref, rtol=2e-6, atol=1e-7)
     if algo == 2:   # no light splats: one writer per pixel (up to jitter-shifted colours)
         assert (fb == ref).mean() > 0.999
+
+
+@pytest.mark.parametrize("world,shards,sid,algo,res,iters", [(4, 2, 1, 4, 32, 5), (2, 1, 1, 4, 32, 3), (3, 1, 3, 2, 24, 2),
+                                                             (2, 2, 1, 4, 32, 2)])
+def test_render_farm_equals_the_reference_render_loop(tmp_path, world, shards, sid, algo, res, iters):
+    """RenderFarm = render() of src/smallvcm.cxx:52-151 with one "thread" per replica group: renderer g has seed
+    base + g, runs the static-schedule block of iterations, the used renderers' means are averaged."""
+    from smallvcm_amd.renderer import static_schedule
+    port = _free_port()
+    out = str(tmp_path / "fb.npy")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(port),
+                               str(sid), str(algo), str(res), str(iters), out, str(shards)]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    fb = np.load(out)
+    replicas = world // shards
+    total, used = np.zeros((res, res, 3), np.float64), 0
+    for g in range(replicas):
+        its = static_schedule(iters, replicas, g)
+        if len(its) == 0:
+            continue
+        o = Oracle(cornell_scene(sid, res, res), algo, seed=1234 + g)   # smallvcm.cxx:68
+        for it in its:
+            o.run_iteration(it, 0, 10)
+        total += o.framebuffer().astype(np.float64) / len(its)          # renderer.hxx:53-54
+        used += 1
+    ref = (total / used).astype(np.float32)                             # smallvcm.cxx:142
+    assert used == min(replicas, iters)
+    assert np.allclose(fb, ref, rtol=3e-6, atol=1e-7)
+
+
+def test_static_schedule_is_openmp_static():
+    from smallvcm_amd.renderer import static_schedule
+    assert [list(static_schedule(10, 4, t)) for t in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    assert [len(static_schedule(2, 4, t)) for t in range(4)] == [1, 1, 0, 0]
+    assert sorted(i for t in range(7) for i in static_schedule(23, 7, t)) == list(range(23))
