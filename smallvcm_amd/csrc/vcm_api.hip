@@ -51,7 +51,7 @@ struct Scratch {
     int *dSlotOfVertex;               /* S*nLocal: dense vertex index -> slot in the light store */
     F4 *dSplat;                       /* S*nLocal: splat of each light vertex (rgb | pixel) */
     float *dRecordsAll;               /* S*N records (multi-rank only) */
-    int *dCellCount, *dCellStart, *dCellFill;   /* N+2 each */
+    int *dCellCount, *dCellStart;     /* N+2 each */
     int *dCellId, *dUnsorted;         /* per record */
     F4 *dG0, *dG1, *dG2; float *dG3;
     int *dSortedIndex;                /* parity: grid position -> record index */
@@ -60,7 +60,8 @@ struct Scratch {
     VertexStore vs;                   /* camera vertices + DI/VC tasks (wavefront mode) */
     int *dQueryKey;                   /* per camera vertex: sort key */
     int *dSortedVertex;               /* camera vertices sorted by key */
-    int *dQueryStart, *dQueryCount, *dQueryFill;   /* VCM_QSORT_BUCKETS+2 each (dQueryStart also >= N+2) */
+    int *dQueryStart, *dQueryCount;   /* VCM_QSORT_BUCKETS+2 each (dQueryStart also >= N+2) */
+    int *dQueryArrival;               /* per camera vertex: its place inside its bucket */
 };
 
 struct vcm_ctx;
@@ -101,7 +102,7 @@ struct vcm_ctx : Scratch {
     unsigned long long *dStats;
 
     bool importedRecords;
-    bool gridBuilt, cameraTraced, merged;
+    bool gridBuilt, cameraTraced, merged, splatsPending;
     bool strictOrder;
     IterParams P;
     bool inIteration;
@@ -152,12 +153,12 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.store.v0); DFREE(s.store.v1); DFREE(s.store.v2); DFREE(s.store.v3); DFREE(s.store.v4); DFREE(s.store.count);
     DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
-    DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellFill); DFREE(s.dCellId); DFREE(s.dUnsorted);
+    DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
     DFREE(s.dG0); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
     DFREE(s.vs.q0); DFREE(s.vs.q1); DFREE(s.vs.q2); DFREE(s.vs.q3); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
     DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.pathVertex); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
-    DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryFill);
+    DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryArrival);
     a->allocated = false;
     a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
 }
@@ -186,7 +187,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dSlotOfVertex, slots) || dalloc(&s.dSplat, slots)) return -1;
     if (sh && dalloc(&s.dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
-    if (dalloc(&s.dCellCount, cn + 2) || dalloc(&s.dCellStart, cn + 2) || dalloc(&s.dCellFill, cn + 2)) return -1;
+    if (dalloc(&s.dCellCount, cn + 2) || dalloc(&s.dCellStart, cn + 2)) return -1;
     if (dalloc(&s.dCellId, allRecs) || dalloc(&s.dUnsorted, allRecs)) return -1;
     if (dalloc(&s.dG0, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
         dalloc(&s.dG3, allRecs) || dalloc(&s.dSortedIndex, allRecs)) return -1;
@@ -205,7 +206,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
         dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;
     const size_t qsN = (cn > (size_t)VCM_QSORT_BUCKETS ? cn : (size_t)VCM_QSORT_BUCKETS) + 2;   /* also pixStart of K1d */
     if (dalloc(&s.dQueryStart, qsN) || dalloc(&s.dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||
-        dalloc(&s.dQueryFill, (size_t)VCM_QSORT_BUCKETS + 2)) return -1;
+        dalloc(&s.dQueryArrival, vslots)) return -1;
     a->capLocal = cl; a->capN = cn; a->capS = cs; a->capL = cL; a->capSharded = sh;
     a->allocated = true;
     return 0;
@@ -480,9 +481,34 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = false;
     c->inIteration = true;
     c->evValid = false;
+    return 0;
+}
+
+/* K1c + K1d: connect every light vertex to the camera and add the splats in the reference's
+ * order (vertexcm.hxx:373-378 -> :863-934).  A sharded context defers this until the host has
+ * started the all-gather of the light records (they are complete after K1b), so that the
+ * exchange overlaps it; it must run before the grid build, whose scratch it borrows. */
+static int flush_light_splats(vcm_ctx *c)
+{
+    if (!c->splatsPending) return 0;
+    c->splatsPending = false;
+    {
+        /* scratch shared with the grid build / query sort, which run later */
+        int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart, *list = c->dUnsorted;
+        HIPCHK(hipMemsetAsync(pixCount, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
+                           (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
+                           arrival, c->dStats);
+        if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
+        hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, c->stream, (const F4 *)c->dSplat,
+                           (const int *)c->dLocalTotal, (const int *)pixStart, (const int *)arrival, list);
+        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const F4 *)c->dSplat,
+                           (const int *)pixStart, (const int *)list, c->dFb);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -511,19 +537,8 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         HIPCHK(hipGetLastError());
     }
     if (wf && (c->useVC || c->lightTraceOnly)) {
-        /* K1c + K1d; scratch shared with the grid build / query sort, which run later */
-        int *pixCount = c->dCellCount, *pixFill = c->dCellFill, *pixStart = c->dQueryStart, *list = c->dUnsorted;
-        HIPCHK(hipMemsetAsync(pixCount, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
-        HIPCHK(hipMemsetAsync(pixFill, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
-                           (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
-                           c->dStats);
-        if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
-        hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, c->stream, (const F4 *)c->dSplat,
-                           (const int *)c->dLocalTotal, (const int *)pixStart, pixFill, list);
-        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const F4 *)c->dSplat,
-                           (const int *)pixStart, (const int *)list, c->dFb);
-        HIPCHK(hipGetLastError());
+        c->splatsPending = true;
+        if (c->world == 1 && flush_light_splats(c)) return -1;
     }
     hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
     HIPCHK(hipGetLastError());
@@ -588,6 +603,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:403-408 -> HashGrid::Build hashgrid.hxx:41-107 */
     if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
     if (use_device(c)) return -1;
+    if (flush_light_splats(c)) return -1;
     HIPCHK(hipEventRecord(c->ev[EV_GRID_K0], c->stream));
     c->gridBuilt = true;
     if (c->useVM) {
@@ -595,16 +611,15 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         const int nCells = c->P.nCells;
         const dim3 g(2048), b(256);
         HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
-        HIPCHK(hipMemsetAsync(c->dCellFill, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr);
         hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, c->stream, recs, c->dHdr);
         hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr);
         hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
-                           c->dCellCount);
+                           c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount);
         HIPCHK(hipGetLastError());
         if (launch_scan<int>(c, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
         hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
-                           (const int *)c->dCellStart, c->dCellFill, c->dUnsorted);
+                           (const int *)c->dSortedIndex, (const int *)c->dCellStart, c->dUnsorted);
         hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, c->stream, (const GridHeader *)c->dHdr, recs,
                            (const int *)c->dCellId, (const int *)c->dCellStart, (const int *)c->dUnsorted, c->dG0,
                            c->dG1, c->dG2, c->dG3, c->dSortedIndex);
@@ -626,6 +641,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:415-545 without the merge (:530-538) in wavefront mode */
     if (!c || !c->inIteration) return fail("vcm_trace_camera", "no iteration in progress");
     if (use_device(c)) return -1;
+    if (flush_light_splats(c)) return -1;
     c->cameraTraced = true;
     if (c->lightTraceOnly) return 0;
     int blocks, chunk;
@@ -666,12 +682,11 @@ static int vcm_merge_impl(vcm_ctx *c)
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
             const int nb = VCM_QSORT_BUCKETS;
             HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
-            HIPCHK(hipMemsetAsync(c->dQueryFill, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
             hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
-                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryCount);
+                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount);
             if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
             hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
-                               (const int *)c->dQueryStart, c->dQueryFill, c->dSortedVertex);
+                               (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
             HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
             /* K4 */
             hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),

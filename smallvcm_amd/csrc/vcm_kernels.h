@@ -221,7 +221,8 @@ __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHea
 
 /* holes and out-of-bbox vertices are not sorted at all (key -1): they would all
  * land in one bucket, i.e. on one atomic word */
-__global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__restrict__ hdr, int *key, int *bucketCount)
+__global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__restrict__ hdr, int *key, int *arrival,
+                              int *bucketCount)
 {
     const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
@@ -232,17 +233,18 @@ __global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__
             if (k < 0) vs.mergeOut[q] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query: contrib = 0 */
         }
         key[q] = k;
-        if (k >= 0) atomicAdd(&bucketCount[k], 1);
+        /* the value the atomic returns is the vertex's place in its bucket: the scatter needs no second atomic */
+        if (k >= 0) arrival[q] = atomicAdd(&bucketCount[k], 1);
     }
 }
 
-__global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, const int *__restrict__ bucketStart,
-                                int *bucketFill, int *sortedVertex)
+__global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, const int *__restrict__ arrival,
+                                const int *__restrict__ bucketStart, int *sortedVertex)
 {
     const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
         const int k = key[q];
-        if (k >= 0) sortedVertex[bucketStart[k] + atomicAdd(&bucketFill[k], 1)] = q;
+        if (k >= 0) sortedVertex[bucketStart[k] + arrival[q]] = q;
     }
 }
 
@@ -416,7 +418,7 @@ __global__ void k_compact_records(IterParams P, LightStore store, const int *__r
 __global__ void __launch_bounds__(256)
 k_connect_camera(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store,
                  const int *__restrict__ slotOfVertex, const int *__restrict__ nVertices, float *fb, F4 *splat,
-                 int *pixCount, unsigned long long *gstats)
+                 int *pixCount, int *arrival, unsigned long long *gstats)
 {
     const vcm_scene_desc &sc = *scp;
     const int n = *nVertices;
@@ -425,19 +427,19 @@ k_connect_camera(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStor
         F4 sp;
         connect_stored_vertex_to_camera(sc, P, store, (size_t)slotOfVertex[i], fb, ls, &sp);
         splat[i] = sp;
-        if (f2u(sp.w) != 0xffffffffu) atomicAdd(&pixCount[f2u(sp.w)], 1);
+        if (f2u(sp.w) != 0xffffffffu) arrival[i] = atomicAdd(&pixCount[f2u(sp.w)], 1);
     }
     flush_stats(ls, gstats);
 }
 
 /* ---------------- K1d: ordered application of the light splats ------------ */
 __global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restrict__ nVertices,
-                                const int *__restrict__ pixStart, int *pixFill, int *list)
+                                const int *__restrict__ pixStart, const int *__restrict__ arrival, int *list)
 {
     const int n = *nVertices;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t pix = f2u(splat[i].w);
-        if (pix != 0xffffffffu) list[pixStart[pix] + atomicAdd(&pixFill[pix], 1)] = i;
+        if (pix != 0xffffffffu) list[pixStart[pix] + arrival[i]] = i;
     }
 }
 
@@ -534,7 +536,7 @@ __global__ void k_bbox_finalize(GridHeader *hdr)
 }
 
 __global__ void k_cell_count(IterParams P, const float *__restrict__ records, const GridHeader *__restrict__ hdr,
-                             int *cellId, int *cellCount)
+                             int *cellId, int *arrival, int *cellCount)
 {   /* :67-71 */
     const int n = hdr->nRecords;
     const V3 bmin = ld3(hdr->bboxMin);
@@ -542,18 +544,17 @@ __global__ void k_cell_count(IterParams P, const float *__restrict__ records, co
         const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
         const int cell = grid_cell_of_point(mk3(r[0], r[1], r[2]), bmin, P.invCellSize, P.nCells);
         cellId[i] = cell;
-        atomicAdd(&cellCount[cell], 1);
+        arrival[i] = atomicAdd(&cellCount[cell], 1);
     }
 }
 
 __global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__restrict__ cellId,
-                               const int *__restrict__ cellStart, int *cellFill, int *unsorted)
+                               const int *__restrict__ arrival, const int *__restrict__ cellStart, int *unsorted)
 {   /* :83-88, but in arbitrary order inside a cell; k_cell_rank_gather restores the order */
     const int n = hdr->nRecords;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int cell = cellId[i];
-        const int pos = cellStart[cell] + atomicAdd(&cellFill[cell], 1);
-        unsorted[pos] = i;
+        unsorted[cellStart[cell] + arrival[i]] = i;
     }
 }
 
