@@ -1242,7 +1242,10 @@ void oracle_build_grid(void *h)
 
 /* rowStride > 1 traces only pixel rows y % rowStride == 0 (bounded CPU
    baseline sample for bench.py); 1 = the full pass. */
-void oracle_trace_camera_rows(void *h, int rowStride)
+/* rows y with (y mod rowStride) < rowWidth only: a bounded sample of the camera pass for the CPU baseline
+ * (bench.py) and for full-size parity checks.  A pixel of row y collects the colours of paths of rows y-1
+ * and y (jittered AddColor), so with rowWidth >= 2 the rows with (y mod rowStride) in [1, rowWidth) are complete. */
+void oracle_trace_camera_window(void *h, int rowStride, int rowWidth)
 {   /* vertexcm.hxx:415-545 */
     Oracle &o = *(Oracle *)h;
     if (o.lightTraceOnly) return;
@@ -1258,7 +1261,7 @@ void oracle_trace_camera_rows(void *h, int rowStride)
         const int b = c * CH, e = std::min(nLocal, b + CH);
         for (int lp = b; lp < e; lp++) {
             const int p = o.p0 + lp;
-            if (rowStride > 1 && ((p / o.resX) % rowStride) != 0) continue;
+            if (rowStride > 1 && ((p / o.resX) % rowStride) >= rowWidth) continue;
             trace_camera_path(o, p, o.camCounts[lp], cst[c]);
         }
     }
@@ -1273,7 +1276,8 @@ void oracle_trace_camera_rows(void *h, int rowStride)
         px[2] = px[2] + o.camColor[(size_t)lp * 3 + 2];
     }
 }
-void oracle_trace_camera(void *h) { oracle_trace_camera_rows(h, 1); }
+void oracle_trace_camera_rows(void *h, int rowStride) { oracle_trace_camera_window(h, rowStride, 1); }
+void oracle_trace_camera(void *h) { oracle_trace_camera_window(h, 1, 1); }
 
 void oracle_end_iteration(void *h) { ((Oracle *)h)->iterations++; }   /* :547 */
 

@@ -40,6 +40,7 @@ def oracle():
         L.oracle_begin_iteration.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
         L.oracle_run_iteration.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
         L.oracle_trace_camera_rows.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_trace_camera_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.oracle_light_record_count.argtypes = [C.c_void_p]
         L.oracle_light_record_count.restype = C.c_longlong
         L.oracle_export_light_records.argtypes = [C.c_void_p, _fp]
@@ -98,8 +99,9 @@ class Oracle:
     def build_grid(self):
         self.L.oracle_build_grid(self.h)
 
-    def trace_camera(self, row_stride=1):
-        self.L.oracle_trace_camera_rows(self.h, row_stride)
+    def trace_camera(self, row_stride=1, row_width=1):
+        """camera paths of the pixel rows y with y % row_stride < row_width"""
+        self.L.oracle_trace_camera_window(self.h, row_stride, row_width)
 
     def end(self):
         self.L.oracle_end_iteration(self.h)

@@ -159,3 +159,37 @@ def test_full_size_properties_2048():
     lc, cc = r.backend.rng_counts()
     assert lc.min() >= 5 and lc.max() <= 5 + 9 * 4 and cc.min() >= 2 and cc.max() <= 2 + 10 * 7
     r.close()
+
+
+@pytest.mark.parametrize("sid,algo,res,stride", [(1, 4, 2048, 32), (1, 2, 2048, 64), (3, 4, 1024, 16)],
+                         ids=["s1-vcm-2048", "s1-bpm-2048", "s3-vcm-1024"])
+def test_full_size_rows_equal_oracle(sid, algo, res, stride):
+    """BASELINE.json's GPU configs at their FULL size against the oracle, bit for bit, on a sample of pixel rows:
+    the oracle (all host cores) runs the complete light pass + grid build and the camera paths of two adjacent
+    rows out of every `stride`; the second row of each pair then holds every contribution it gets in the
+    reference (light splats from anywhere, camera colours of rows y-1 and y)."""
+    import os
+    sc = cornell_scene(sid, res, res)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r.mMaxPathLength, r.mMinPathLength = 10, 0
+    r.RunIteration(0)
+    fb = r.framebuffer_sum()
+    st = r.stats()
+    lc, _ = r.backend.rng_counts()
+    r.close()
+    o = oracle_lib.Oracle(sc, algo, threads=os.cpu_count() or 1)
+    o.begin(0, 0, 10)
+    o.trace_light()
+    o.build_grid()
+    o.trace_camera(row_stride=stride, row_width=2)
+    o.end()
+    ref = o.framebuffer()
+    ost = o.stats()
+    rows = np.arange(1, res, stride)
+    assert len(rows) >= 8
+    assert np.array_equal(fb[rows].view(np.uint32), ref[rows].view(np.uint32))
+    assert fb[rows].max() > 0
+    for k in ("lightVertices", "lightRays", "lightSplats"):   # the light pass ran in full on both sides
+        assert st[k] == ost[k], k
+    olc, _ = o.counts()
+    assert np.array_equal(lc, olc)
