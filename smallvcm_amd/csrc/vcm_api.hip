@@ -53,7 +53,7 @@ struct Scratch {
     float *dRecordsAll;               /* S*N records (multi-rank only) */
     int *dCellCount, *dCellStart;     /* N+2 each */
     int *dCellId, *dUnsorted;         /* per record */
-    F4 *dG0, *dG1, *dG2; float *dG3;
+    float *dGx, *dGy, *dGz; F4 *dG1, *dG2; F2 *dG3;
     int *dSortedIndex;                /* parity: grid position -> record index */
     F4 *dCamOut;                      /* nLocal */
     uint32_t *dCamMask;               /* nLocal: path lengths at which a vertex record was appended */
@@ -154,7 +154,7 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
-    DFREE(s.dG0); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
+    DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
     DFREE(s.vs.q0); DFREE(s.vs.q1); DFREE(s.vs.q2); DFREE(s.vs.q3); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
     DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.pathVertex); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
@@ -189,7 +189,8 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (sh && dalloc(&s.dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dCellCount, cn + 2) || dalloc(&s.dCellStart, cn + 2)) return -1;
     if (dalloc(&s.dCellId, allRecs) || dalloc(&s.dUnsorted, allRecs)) return -1;
-    if (dalloc(&s.dG0, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
+    if (dalloc(&s.dGx, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dGy, allRecs + VCM_MERGE_UNROLL) ||
+        dalloc(&s.dGz, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
         dalloc(&s.dG3, allRecs) || dalloc(&s.dSortedIndex, allRecs)) return -1;
     if (dalloc(&s.dCamOut, cl) || dalloc(&s.dCamMask, cl) || dalloc(&s.vs.count, 4)) return -1;
     /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l connects to
@@ -621,8 +622,8 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
                            (const int *)c->dSortedIndex, (const int *)c->dCellStart, c->dUnsorted);
         hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, c->stream, (const GridHeader *)c->dHdr, recs,
-                           (const int *)c->dCellId, (const int *)c->dCellStart, (const int *)c->dUnsorted, c->dG0,
-                           c->dG1, c->dG2, c->dG3, c->dSortedIndex);
+                           (const int *)c->dCellId, (const int *)c->dCellStart, (const int *)c->dUnsorted, c->dGx,
+                           c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[EV_GRID], c->stream));
@@ -632,7 +633,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
 static GridStore grid_of(vcm_ctx *c)
 {
     GridStore grid;
-    grid.cellStart = c->dCellStart; grid.g0 = c->dG0; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
+    grid.cellStart = c->dCellStart; grid.gx = c->dGx; grid.gy = c->dGy; grid.gz = c->dGz; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
     grid.hdr = c->dHdr;
     return grid;
 }

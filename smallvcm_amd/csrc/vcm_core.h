@@ -61,12 +61,15 @@ struct LightStore {
 
 /* Hash grid, vertices sorted by cell (replaces mIndices indirection,
  * hashgrid.hxx:83-88): cell c = [cellStart[c], cellStart[c+1]) */
+struct alignas(8) F2 { float x, y; };
 struct GridStore {
     const int *cellStart;   /* nCells+1 */
-    const F4 *g0;           /* position.xyz | pathLength bits */
+    const float *gx, *gy, *gz;   /* position, one array per axis (padded by VCM_MERGE_UNROLL): the distance
+                                    test reads nothing else, and consecutive candidates of a cell arrive as the
+                                    two halves of a packed fp32 operand */
     const F4 *g1;           /* WorldDirFix.xyz | light ContinuationProb */
     const F4 *g2;           /* throughput.xyz | dVCM */
-    const float *g3;        /* dVM */
+    const F2 *g3;           /* dVM | pathLength bits */
     const GridHeader *hdr;
 };
 
@@ -1133,10 +1136,11 @@ VCM_HD void merge_photon_load(const GridStore &g, const MergeScratch &ms, int k,
 {
     /* lanes without an entry k read photon 0 (always allocated); the value is not used */
     const uint32_t idx = (k < qn) ? ms.q[k * ms.stride] : 0u;
-    p.lenBits = g.g0[idx].w;
+    const F2 t = g.g3[idx];
+    p.lenBits = t.y;
     p.b = g.g1[idx];
     p.c = g.g2[idx];
-    p.dVM = g.g3[idx];
+    p.dVM = t.x;
 }
 VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval &e, const MergeScratch &ms, int qn,
                         V3 &contrib)
@@ -1188,25 +1192,44 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
     MergeEval ev;
     merge_eval_setup(ev, sc, P, cameraBsdf, st);
     int qn = 0;
+    /* the range of cell j+1 is fetched while cell j is scanned: one dependent memory round trip per cell less */
+    int nlo = 0, nhi = 0;
+    if (inside) {
+        const int cell = grid_cell_hash(px, py, pz, P.nCells);
+        nlo = g.cellStart[cell];
+        nhi = g.cellStart[cell + 1];
+    }
     for (int j = 0; j < 8; j++) {
-        int lo = 0, hi = 0;
-        if (inside) {
-            const int cx = (j & 4) ? pxo : px;
-            const int cy = (j & 2) ? pyo : py;
-            const int cz = (j & 1) ? pzo : pz;
+        int lo = nlo, hi = nhi;
+        if (inside && j < 7) {
+            const int k = j + 1;
+            const int cx = (k & 4) ? pxo : px;
+            const int cy = (k & 2) ? pyo : py;
+            const int cz = (k & 1) ? pzo : pz;
             const int cell = grid_cell_hash(cx, cy, cz, P.nCells);
-            lo = g.cellStart[cell];
-            hi = g.cellStart[cell + 1];
+            nlo = g.cellStart[cell];
+            nhi = g.cellStart[cell + 1];
         }
         ls.mergeCandidates += (uint32_t)(hi - lo);   /* one distance test per entry (:162-165) */
         while (wave_any(lo < hi)) {
-            F4 a[VCM_MERGE_UNROLL];
+            /* entries past hi are read but never used (the arrays are padded by VCM_MERGE_UNROLL elements), so
+               one address serves all 4.  LenSqr of (query - position), hashgrid.hxx:162, math.hxx:107. */
+            float distSqr[VCM_MERGE_UNROLL];
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
+            {   /* 3 x 16-byte loads; two candidates per packed operation (IEEE per half, same operation order) */
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                const f4u X = *(const f4u *)(g.gx + lo), Y = *(const f4u *)(g.gy + lo), Z = *(const f4u *)(g.gz + lo);
+                const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
+                const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
+                const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
+                const f2 da = dxa * dxa + dya * dya + dza * dza;
+                const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
+                distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
+            }
+#else
+            for (int u = 0; u < VCM_MERGE_UNROLL; u++)
+                distSqr[u] = lensqr(queryPos - mk3(g.gx[lo + u], g.gy[lo + u], g.gz[lo + u]));
 #endif
-            /* 4 independent loads in flight; entries past hi are read but never used
-               (the array is padded by VCM_MERGE_UNROLL elements), so one address serves all 4 */
-            for (int u = 0; u < VCM_MERGE_UNROLL; u++) a[u] = g.g0[lo + u];
             /* branch-free: every candidate writes its index at the queue tail, only an
                accepted one advances the tail (qn <= VCM_MERGE_Q, row VCM_MERGE_Q is spare) */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1214,8 +1237,7 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
 #endif
             for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
                 const int idx = lo + u;
-                const float distSqr = lensqr(queryPos - mk3(a[u].x, a[u].y, a[u].z));
-                const bool acc = (idx < hi) & (distSqr <= P.radiusSqr);   /* :165 */
+                const bool acc = (idx < hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
                 ms.q[qn * ms.stride] = (uint32_t)idx;
                 qn += acc ? 1 : 0;
             }

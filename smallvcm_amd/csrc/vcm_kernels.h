@@ -258,6 +258,8 @@ __global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, con
  * (A wave-per-query mapping was measured too: 17 ms vs 6 ms for this one at
  * 2048^2 -- one query per wave exposes its 4 dependent memory round trips.) */
 #define VCM_MERGE_BLOCK 256
+/* 104 VGPRs = 4 waves/SIMD.  Forcing 5 / 6 / 8 waves (amdgpu_waves_per_eu) was measured: 5.66 / 6.9 / 10.8 ms
+ * against 5.4 ms on the same box -- the spills cost more than the occupancy buys. */
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK)
 k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
              const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats)
@@ -566,7 +568,8 @@ __global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__
  * mIndices indirection. */
 __global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, const float *__restrict__ records,
                                    const int *__restrict__ cellId, const int *__restrict__ cellStart,
-                                   const int *__restrict__ unsorted, F4 *g0, F4 *g1, F4 *g2, float *g3, int *sortedIndex)
+                                   const int *__restrict__ unsorted, float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3,
+                                   int *sortedIndex)
 {
     const int n = hdr->nRecords;
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
@@ -577,10 +580,11 @@ __global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, const flo
         for (int q = lo; q < hi; q++) rank += (unsorted[q] < i) ? 1 : 0;
         const int dst = lo + rank;
         const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
-        g0[dst] = mk4(r[0], r[1], r[2], r[12]);
+        gx[dst] = r[0]; gy[dst] = r[1]; gz[dst] = r[2];
         g1[dst] = mk4(r[3], r[4], r[5], r[11]);
         g2[dst] = mk4(r[6], r[7], r[8], r[9]);
-        g3[dst] = r[10];
+        F2 t; t.x = r[10]; t.y = r[12];
+        g3[dst] = t;
         if (sortedIndex) sortedIndex[dst] = i;
     }
 }

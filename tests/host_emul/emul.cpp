@@ -17,8 +17,9 @@ struct Emul {
     int seed, iterations;
     int resX, resY, N, p0, nLocal;
     IterParams P;
-    std::vector<F4> v0, v1, v2, v3, v4, g0, g1, g2, camOut;
-    std::vector<float> g3, fb, records;
+    std::vector<F4> v0, v1, v2, v3, v4, g1, g2, camOut;
+    std::vector<F2> g3;
+    std::vector<float> gx, gy, gz, fb, records;
     std::vector<unsigned char> count, rngL, rngC;
     std::vector<int> cellStart;
     GridHeader hdr;
@@ -114,7 +115,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     e.hdr.nRecords = n;
     for (int c = 0; c < 3; c++) { e.hdr.bboxMin[c] = 1e36f; e.hdr.bboxMax[c] = -1e36f; }
     e.cellStart.assign((size_t)P.nCells + 1, 0);
-    e.g0.assign((size_t)n + VCM_MERGE_UNROLL, mk4(0, 0, 0, 0)); e.g1 = e.g0; e.g2 = e.g0; e.g3.assign((size_t)n, 0.f);
+    e.gx.assign((size_t)n + VCM_MERGE_UNROLL, 0.f); e.gy = e.gx; e.gz = e.gx;
+    e.g1.assign((size_t)n + 1, mk4(0, 0, 0, 0)); e.g2 = e.g1; { F2 z; z.x = z.y = 0.f; e.g3.assign((size_t)n + 1, z); }
     if (e.useVM) {
         for (int i = 0; i < n; i++)
             for (int c = 0; c < 3; c++) {
@@ -132,14 +134,14 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
         for (int i = 0; i < n; i++) {
             const float *r = &e.records[(size_t)i * 13];
             const int dst = fill[cell[i]]++;
-            e.g0[dst] = mk4(r[0], r[1], r[2], r[12]);
+            e.gx[dst] = r[0]; e.gy[dst] = r[1]; e.gz[dst] = r[2];
             e.g1[dst] = mk4(r[3], r[4], r[5], r[11]);
             e.g2[dst] = mk4(r[6], r[7], r[8], r[9]);
-            e.g3[dst] = r[10];
+            e.g3[dst].x = r[10]; e.g3[dst].y = r[12];
         }
     }
     /* K3 */
-    GridStore grid; grid.cellStart = e.cellStart.data(); grid.g0 = e.g0.data(); grid.g1 = e.g1.data();
+    GridStore grid; grid.cellStart = e.cellStart.data(); grid.gx = e.gx.data(); grid.gy = e.gy.data(); grid.gz = e.gz.data(); grid.g1 = e.g1.data();
     grid.g2 = e.g2.data(); grid.g3 = e.g3.data(); grid.hdr = &e.hdr;
     if (!e.lightTraceOnly) {
         e.camOut.assign((size_t)e.nLocal, mk4(0, 0, 0, 0));
