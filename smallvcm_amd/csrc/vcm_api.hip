@@ -102,7 +102,7 @@ struct vcm_ctx : Scratch {
     unsigned long long *dStats;
 
     bool importedRecords;
-    bool gridBuilt, cameraTraced, merged, splatsPending;
+    bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid;
     bool strictOrder;
     IterParams P;
     bool inIteration;
@@ -150,7 +150,7 @@ static Arena *arena_get(int device, bool shared)
 static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
-    DFREE(s.store.v0); DFREE(s.store.v1); DFREE(s.store.v2); DFREE(s.store.v3); DFREE(s.store.v4); DFREE(s.store.count);
+    DFREE(s.store.v); DFREE(s.store.count);
     DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
@@ -178,8 +178,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
-    if (dalloc(&s.store.v0, slots) || dalloc(&s.store.v1, slots) || dalloc(&s.store.v2, slots) ||
-        dalloc(&s.store.v3, slots) || dalloc(&s.store.v4, slots) || dalloc(&s.store.count, cl)) return -1;
+    if (dalloc(&s.store.v, slots * VCM_LV_FIELDS) || dalloc(&s.store.count, cl)) return -1;
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
@@ -482,7 +481,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -533,8 +532,11 @@ static int vcm_trace_light_impl(vcm_ctx *c)
        record array in the reference's vertex order */
     if (launch_scan<unsigned char>(c, c->store.count, c->nLocal, c->dPathStart, c->dLocalTotal, 0)) return -1;
     if (c->useVM || wf) {
+        /* a sharded renderer ships the records to the other ranks; a single-rank one builds its grid straight
+           from the store and materialises them only when somebody asks (ensure_records) */
+        c->recordsValid = c->useVM && c->world > 1;
         hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
-                           c->dRecordsLocal, c->dSlotOfVertex);
+                           c->dRecordsLocal, c->dSlotOfVertex, c->recordsValid ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     if (wf && (c->useVC || c->lightTraceOnly)) {
@@ -547,11 +549,23 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     return 0;
 }
 
+/* materialise the 13-float merge records of the local light vertices (reference order) if K1b skipped them */
+static int ensure_records(vcm_ctx *c)
+{
+    if (c->recordsValid || !c->useVM) return 0;
+    hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
+                       c->dRecordsLocal, c->dSlotOfVertex, 1);
+    HIPCHK(hipGetLastError());
+    c->recordsValid = true;
+    return 0;
+}
+
 int vcm_light_records(vcm_ctx *c, void **devPtr, long long *count)
 {
     if (scratch_readable(c, "vcm_light_records")) return -1;
     if (use_device(c)) return -1;
     int n = 0;
+    if (devPtr && ensure_records(c)) return -1;
     HIPCHK(hipMemcpyAsync(&n, c->dLocalTotal, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (devPtr) *devPtr = c->dRecordsLocal;
@@ -564,6 +578,7 @@ int vcm_export_light_records(vcm_ctx *c, void *dstDev, long long count)
     if (!dstDev) return fail("vcm_export_light_records", "bad argument");
     if (scratch_readable(c, "vcm_export_light_records")) return -1;
     if (use_device(c)) return -1;
+    if (ensure_records(c)) return -1;
     if (count > 0)
         HIPCHK(hipMemcpyAsync(dstDev, c->dRecordsLocal, (size_t)count * VCM_MERGE_RECORD_FLOATS * sizeof(float),
                               hipMemcpyDeviceToDevice, c->stream));
@@ -608,7 +623,10 @@ static int vcm_build_grid_impl(vcm_ctx *c)
     HIPCHK(hipEventRecord(c->ev[EV_GRID_K0], c->stream));
     c->gridBuilt = true;
     if (c->useVM) {
-        const float *recs = c->importedRecords ? c->dRecordsAll : c->dRecordsLocal;
+        VertexSource recs;
+        recs.records = c->importedRecords ? c->dRecordsAll : (c->recordsValid ? c->dRecordsLocal : NULL);
+        recs.store = c->store;
+        recs.slotOfVertex = c->dSlotOfVertex;
         const int nCells = c->P.nCells;
         const dim3 g(2048), b(256);
         HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
@@ -868,6 +886,8 @@ int vcm_debug_read_records(vcm_ctx *c, float *out, long long count)
 {
     if (scratch_readable(c, "vcm_debug_read_records")) return -1;
     if (use_device(c)) return -1;
+    if (ensure_records(c)) return -1;
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (count > 0)
         HIPCHK(hipMemcpy(out, c->dRecordsLocal, (size_t)count * VCM_MERGE_RECORD_FLOATS * sizeof(float), hipMemcpyDeviceToHost));
     return 0;

@@ -46,18 +46,23 @@ struct GridHeader {
     int   pad[2];
 };
 
-/* Light-vertex store, slot-major SoA: vertex j of local path lp lives at
- * [j * nLocal + lp] so that a wave (64 consecutive paths at the same bounce)
- * writes 64 consecutive 16-byte elements.  Replaces the AoS
- * std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
+/* Light-vertex store: vertex j of local path lp lives in slot [j * nLocal + lp], a record of five
+ * 16-byte fields (80 B).  K1 writes slot-major, so a wave (64 consecutive paths at the same bounce) fills one
+ * contiguous 5 KB region; the consumers that GATHER a vertex (vertex connection K3c, the cell-sorted copy
+ * of the grid build) find all of it in one or two cache lines.  (Five separate arrays -- SoA -- were
+ * measured: the gathers then touch five lines per vertex, k_cell_rank_gather 1.16 ms instead of 0.6.)
+ * Replaces the AoS std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
+#define VCM_LV_FIELDS 5
 struct LightStore {
-    F4 *v0;   /* hitpoint.xyz | pathLength (bits 0-7) , matID (bits 8-15)   */
-    F4 *v1;   /* throughput.xyz | dVCM                                       */
-    F4 *v2;   /* isect.normal.xyz | dVC                                      */
-    F4 *v3;   /* localDirFix.xyz | dVM                                       */
-    F4 *v4;   /* WorldDirFix().xyz | ContinuationProb()                      */
+    F4 *v;    /* [slot * 5 + k]:
+                 k=0 hitpoint.xyz | pathLength (bits 0-7) , matID (bits 8-15)
+                 k=1 throughput.xyz | dVCM
+                 k=2 isect.normal.xyz | dVC
+                 k=3 localDirFix.xyz | dVM
+                 k=4 WorldDirFix().xyz | ContinuationProb()                  */
     unsigned char *count;   /* stored vertices per local path (mPathEnds, :395) */
 };
+VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return s.v[slot * VCM_LV_FIELDS + (size_t)k]; }
 
 /* Hash grid, vertices sorted by cell (replaces mIndices indirection,
  * hashgrid.hxx:83-88): cell c = [cellStart[c], cellStart[c+1]) */
@@ -887,11 +892,11 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
     if (!bsdf.isDelta && (P.useVC || P.useVM || (MODE == 1 && P.lightTraceOnly))) {   /* :364-377 */
         const size_t slot = (size_t)lp.nStored * (size_t)P.nLocal + (size_t)lp.lp;
         const V3 wdir = to_world(bsdf.frame, bsdf.localDirFix);   /* WorldDirFix bsdf.hxx:264 */
-        store.v0[slot] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
-        store.v1[slot] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVCM);
-        store.v2[slot] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, st.dVC);
-        store.v3[slot] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
-        store.v4[slot] = mk4(wdir.x, wdir.y, wdir.z, bsdf.contProb);
+        lv(store, slot, 0) = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
+        lv(store, slot, 1) = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVCM);
+        lv(store, slot, 2) = mk4(isect.normal.x, isect.normal.y, isect.normal.z, st.dVC);
+        lv(store, slot, 3) = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
+        lv(store, slot, 4) = mk4(wdir.x, wdir.y, wdir.z, bsdf.contProb);
         lp.nStored++;
         if (P.useVC || P.useVM) ls.stored++;   /* the reference stores nothing in light-trace mode (:364) */
     }
@@ -908,7 +913,7 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
 VCM_HD void connect_stored_vertex_to_camera(const vcm_scene_desc &sc, const IterParams &P, const LightStore &store,
                                             size_t slot, float *fb, LaneStats &ls, F4 *splatOut)
 {
-    const F4 a = store.v0[slot], b = store.v1[slot], c = store.v2[slot], d = store.v3[slot];
+    const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), c = lv(store, slot, 2), d = lv(store, slot, 3);
     SubPathState st;
     st.pathLength = f2u(a.w) & 0xffu;
     *splatOut = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
@@ -1410,7 +1415,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
             if (P.useVC) {
                 const int n = store.count[cp.lp];
                 for (int j = 0; j < n; j++) {
-                    const uint32_t lvLen = f2u(store.v0[(size_t)j * (size_t)P.nLocal + (size_t)cp.lp].w) & 0xffu;
+                    const uint32_t lvLen = f2u(lv(store, (size_t)j * (size_t)P.nLocal + (size_t)cp.lp, 0).w) & 0xffu;
                     if (lvLen + 1 + st.pathLength < P.minLen) continue;
                     if (lvLen + 1 + st.pathLength > P.maxLen) break;
                     jmask |= 1u << j;
@@ -1458,13 +1463,13 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
             const int n = store.count[cp.lp];
             for (int j = 0; j < n; j++) {
                 const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)cp.lp;
-                const F4 a = store.v0[slot];
+                const F4 a = lv(store, slot, 0);
                 const uint32_t lvLen = f2u(a.w) & 0xffu;
                 if (lvLen + 1 + st.pathLength < P.minLen) continue;
                 if (lvLen + 1 + st.pathLength > P.maxLen) break;
-                const F4 b = store.v1[slot];
-                const F4 c = store.v2[slot];
-                const F4 d = store.v3[slot];
+                const F4 b = lv(store, slot, 1);
+                const F4 c = lv(store, slot, 2);
+                const F4 d = lv(store, slot, 3);
                 Bsdf lvBsdf;
                 bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
                 cp.color = cp.color + st.throughput * mk3(b.x, b.y, b.z) *
@@ -1517,7 +1522,7 @@ VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const Vert
     CamVertex v;
     load_cam_vertex(sc, vs, vi, v);
     const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)v.lp;
-    const F4 a = store.v0[slot], b = store.v1[slot], c = store.v2[slot], d = store.v3[slot];
+    const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), c = lv(store, slot, 2), d = lv(store, slot, 3);
     Bsdf lvBsdf;
     bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
     return v.throughput * mk3(b.x, b.y, b.z) *

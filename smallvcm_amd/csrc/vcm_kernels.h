@@ -387,7 +387,7 @@ k_scan_apply(const T *__restrict__ in, int n, const int *__restrict__ tileOffset
  * ContinuationProb, pathLength.  Record order = the reference's
  * mLightVertices order (path-major, then bounce). */
 __global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
-                                  int *slotOfVertex)
+                                  int *slotOfVertex, int writeRecords)
 {
     /* one lane per light path: slot reads are coalesced across the wave for every j (slot-major store) */
     for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < P.nLocal; lp += gridDim.x * blockDim.x) {
@@ -397,8 +397,8 @@ __global__ void k_compact_records(IterParams P, LightStore store, const int *__r
             const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)lp;
             const int vtx = base + j;
             slotOfVertex[vtx] = (int)slot;   /* dense vertex list for k_connect_camera */
-            if (!P.useVM) continue;
-            const F4 a = store.v0[slot], b = store.v1[slot], d = store.v3[slot], e = store.v4[slot];
+            if (!writeRecords) continue;
+            const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), d = lv(store, slot, 3), e = lv(store, slot, 4);
             float *r = records + (size_t)vtx * VCM_MERGE_RECORD_FLOATS;
             r[0] = a.x; r[1] = a.y; r[2] = a.z;
             r[3] = e.x; r[4] = e.y; r[5] = e.z;
@@ -483,18 +483,34 @@ __device__ __forceinline__ float float_from_order_key(uint32_t k)
     return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+/* Where the grid build reads the light vertices from: the contiguous 13-float merge records (a sharded
+ * renderer: the all-gathered array) or, for a single-rank renderer, the slot-major store of K1 itself through
+ * the dense vertex -> slot table -- the records are then never materialised (0.6 ms at 2048^2). */
+struct VertexSource {
+    const float *records;      /* NULL: read the store */
+    LightStore store;
+    const int *slotOfVertex;
+};
+__device__ __forceinline__ V3 source_position(const VertexSource &src, int i)
+{
+    if (src.records) { const float *r = src.records + (size_t)i * VCM_MERGE_RECORD_FLOATS; return mk3(r[0], r[1], r[2]); }
+    const F4 a = lv(src.store, src.slotOfVertex[i], 0);
+    return mk3(a.x, a.y, a.z);
+}
+
 __global__ void k_grid_init(GridHeader *hdr)
 {
     if (threadIdx.x < 3) { hdr->bboxMinU[threadIdx.x] = 0xffffffffu; hdr->bboxMaxU[threadIdx.x] = 0u; }
 }
 
-__global__ void __launch_bounds__(256) k_bbox(const float *__restrict__ records, GridHeader *hdr)
+__global__ void __launch_bounds__(256) k_bbox(VertexSource src, GridHeader *hdr)
 {   /* :50-61.  min/max are exact and order-free; one atomic set per BLOCK (wave shuffle, then LDS):
        per-wave atomics on six hot words cost 0.5 ms at 8192 waves */
     const int n = hdr->nRecords;
     uint32_t mn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, mx[3] = { 0u, 0u, 0u };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
+        const V3 pos = source_position(src, i);
+        const float r[3] = { pos.x, pos.y, pos.z };
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const uint32_t k = float_order_key(r[c]);
@@ -537,14 +553,13 @@ __global__ void k_bbox_finalize(GridHeader *hdr)
     }
 }
 
-__global__ void k_cell_count(IterParams P, const float *__restrict__ records, const GridHeader *__restrict__ hdr,
+__global__ void k_cell_count(IterParams P, VertexSource src, const GridHeader *__restrict__ hdr,
                              int *cellId, int *arrival, int *cellCount)
 {   /* :67-71 */
     const int n = hdr->nRecords;
     const V3 bmin = ld3(hdr->bboxMin);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
-        const int cell = grid_cell_of_point(mk3(r[0], r[1], r[2]), bmin, P.invCellSize, P.nCells);
+        const int cell = grid_cell_of_point(source_position(src, i), bmin, P.invCellSize, P.nCells);
         cellId[i] = cell;
         arrival[i] = atomicAdd(&cellCount[cell], 1);
     }
@@ -566,7 +581,7 @@ __global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__
  * cell with a smaller index; the vertex data is then written to its final
  * position, so the query reads contiguous, cell-sorted memory and needs no
  * mIndices indirection. */
-__global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, const float *__restrict__ records,
+__global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, VertexSource src,
                                    const int *__restrict__ cellId, const int *__restrict__ cellStart,
                                    const int *__restrict__ unsorted, float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3,
                                    int *sortedIndex)
@@ -579,11 +594,21 @@ __global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, const flo
         int rank = 0;
         for (int q = lo; q < hi; q++) rank += (unsorted[q] < i) ? 1 : 0;
         const int dst = lo + rank;
-        const float *r = records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
-        gx[dst] = r[0]; gy[dst] = r[1]; gz[dst] = r[2];
-        g1[dst] = mk4(r[3], r[4], r[5], r[11]);
-        g2[dst] = mk4(r[6], r[7], r[8], r[9]);
-        F2 t; t.x = r[10]; t.y = r[12];
+        F2 t;
+        if (src.records) {
+            const float *r = src.records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
+            gx[dst] = r[0]; gy[dst] = r[1]; gz[dst] = r[2];
+            g1[dst] = mk4(r[3], r[4], r[5], r[11]);
+            g2[dst] = mk4(r[6], r[7], r[8], r[9]);
+            t.x = r[10]; t.y = r[12];
+        } else {   /* the same 13 values k_compact_records would have written */
+            const size_t slot = (size_t)src.slotOfVertex[i];
+            const F4 a = lv(src.store, slot, 0), b = lv(src.store, slot, 1), d = lv(src.store, slot, 3), e = lv(src.store, slot, 4);
+            gx[dst] = a.x; gy[dst] = a.y; gz[dst] = a.z;
+            g1[dst] = e;
+            g2[dst] = b;
+            t.x = d.w; t.y = u2f(f2u(a.w) & 0xffu);
+        }
         g3[dst] = t;
         if (sortedIndex) sortedIndex[dst] = i;
     }

@@ -17,7 +17,7 @@ struct Emul {
     int seed, iterations;
     int resX, resY, N, p0, nLocal;
     IterParams P;
-    std::vector<F4> v0, v1, v2, v3, v4, g1, g2, camOut;
+    std::vector<F4> v0 /* the light store, 5 fields per slot */, g1, g2, camOut;
     std::vector<F2> g3;
     std::vector<float> gx, gy, gz, fb, records;
     std::vector<unsigned char> count, rngL, rngC;
@@ -86,11 +86,10 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     P.nCells = e.N;
 
     const size_t slots = (size_t)S * e.nLocal;
-    e.v0.assign(slots, mk4(0, 0, 0, 0)); e.v1 = e.v0; e.v2 = e.v0; e.v3 = e.v0; e.v4 = e.v0;
+    e.v0.assign(slots * VCM_LV_FIELDS, mk4(0, 0, 0, 0));
     e.count.assign((size_t)e.nLocal, 0); e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
     lane_stats_zero(e.ls);
-    LightStore store; store.v0 = e.v0.data(); store.v1 = e.v1.data(); store.v2 = e.v2.data(); store.v3 = e.v3.data();
-    store.v4 = e.v4.data(); store.count = e.count.data();
+    LightStore store; store.v = e.v0.data(); store.count = e.count.data();
 
     /* K1 */
     for (int lp = 0; lp < e.nLocal; lp++) {
@@ -105,7 +104,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     for (int lp = 0; lp < e.nLocal; lp++)
         for (int j = 0; j < e.count[lp]; j++) {
             const size_t slot = (size_t)j * e.nLocal + lp;
-            const F4 a = e.v0[slot], b = e.v1[slot], d = e.v3[slot], w = e.v4[slot];
+            const F4 a = e.v0[slot * VCM_LV_FIELDS + 0], b = e.v0[slot * VCM_LV_FIELDS + 1], d = e.v0[slot * VCM_LV_FIELDS + 3],
+                     w = e.v0[slot * VCM_LV_FIELDS + 4];
             const float r[13] = { a.x, a.y, a.z, w.x, w.y, w.z, b.x, b.y, b.z, b.w, d.w, w.w, u2f(f2u(a.w) & 0xffu) };
             e.records.insert(e.records.end(), r, r + 13);
         }
