@@ -24,10 +24,10 @@ VCM_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 #endif
 }
 
+/* The stream is random-access (float k = word k&3 of block k>>2), so a path keeps only its position. */
 struct PathRng {
     uint32_t key0, key1, path, kind;
     uint32_t k;               /* floats drawn so far */
-    uint32_t b0, b1, b2, b3;  /* current block */
 };
 
 VCM_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -51,18 +51,50 @@ VCM_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 VCM_HD void rng_init(PathRng &r, uint32_t seed, uint32_t localIter, uint32_t path, uint32_t kind)
 {
     r.key0 = seed; r.key1 = localIter; r.path = path; r.kind = kind; r.k = 0;
-    r.b0 = r.b1 = r.b2 = r.b3 = 0;
 }
 
+/* open interval (0,1): (2k+1) * 2^-24 with k = top 23 bits; exact 0 would make
+   AreaLight::Emit return a zero pdf (lights.hxx:178-186) -> inf throughput -> NaN */
+VCM_HD float rng_word_to_float(uint32_t w) { return (float)(((w >> 9) << 1) | 1u) * (1.0f / 16777216.0f); }
+
+/* Floats k0 .. k0+n-1 of the path's stream, n <= 5, WITHOUT advancing it.  On the GPU what matters is where
+ * Philox runs: a per-float "refill when the block is used up" puts a 100-instruction generator behind a
+ * divergent branch at every draw (a wave step of the camera kernel executed it at 6 sites, each for a
+ * quarter of its lanes).  Here the two blocks that can hold the n floats are generated unconditionally, by
+ * all lanes, at one site per bounce step.  n floats from word offset o <= 3 reach word o+n-1 <= 7. */
+VCM_HD void rng_peek(const PathRng &r, uint32_t k0, float *out, int n)
+{
+    uint32_t w[8];
+    const uint32_t blk = k0 >> 2;
+    philox4x32_10(r.path, r.kind, blk, 0u, r.key0, r.key1, w[0], w[1], w[2], w[3]);
+    philox4x32_10(r.path, r.kind, blk + 1u, 0u, r.key0, r.key1, w[4], w[5], w[6], w[7]);
+    const uint32_t o = k0 & 3u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < n; j++) {
+        const uint32_t a = w[j], b = w[j + 1], c = w[j + 2], d = w[j + 3];   /* select, no dynamic indexing */
+        out[j] = rng_word_to_float(o == 0u ? a : o == 1u ? b : o == 2u ? c : d);
+    }
+}
+/* the same when the floats are known to lie in ONE block (k0 & 3) + n <= 4, e.g. the first draws of a path */
+VCM_HD void rng_peek_block(const PathRng &r, uint32_t k0, float *out, int n)
+{
+    uint32_t w[4];
+    philox4x32_10(r.path, r.kind, k0 >> 2, 0u, r.key0, r.key1, w[0], w[1], w[2], w[3]);
+    const uint32_t o = k0 & 3u;
+    for (int j = 0; j < n; j++) {
+        const uint32_t i = o + (uint32_t)j;
+        out[j] = rng_word_to_float(i == 0u ? w[0] : i == 1u ? w[1] : i == 2u ? w[2] : w[3]);
+    }
+}
+/* one float, sequential interface (tests, spec kernels; the path code uses rng_peek) */
 VCM_HD float rng_float(PathRng &r)
 {
-    const uint32_t i = r.k & 3u;
-    if (i == 0u) philox4x32_10(r.path, r.kind, r.k >> 2, 0u, r.key0, r.key1, r.b0, r.b1, r.b2, r.b3);
-    const uint32_t w = (i == 0u) ? r.b0 : (i == 1u) ? r.b1 : (i == 2u) ? r.b2 : r.b3;
+    float f;
+    rng_peek_block(r, r.k, &f, 1);
     r.k++;
-    /* open interval (0,1): (2k+1) * 2^-24 with k = top 23 bits; exact 0 would make
-       AreaLight::Emit return a zero pdf (lights.hxx:178-186) -> inf throughput -> NaN */
-    return (float)(((w >> 9) << 1) | 1u) * (1.0f / 16777216.0f);
+    return f;
 }
 
 } // namespace vcm

@@ -743,9 +743,12 @@ VCM_HD float mis(float pdf) { return pdf; }   /* :553-557 (balance heuristic) */
 VCM_HD bool sample_scattering(const vcm_scene_desc &sc, const IterParams &P, bool lightSample, PathRng &rng,
                               const Bsdf &bsdf, V3 hitPoint, SubPathState &st)
 {
-    const float r0 = rng_float(rng);
-    const float r1 = rng_float(rng);
-    const float r2 = rng_float(rng);
+    /* the 3 floats of BSDF::Sample (:944) and the Russian-roulette float (:964), which only counts as drawn if
+       the sample is non-zero: 4 consecutive floats, generated at one site */
+    float rnd[4];
+    rng_peek(rng, rng.k, rnd, 4);
+    rng.k += 3u;
+    const float r0 = rnd[0], r1 = rnd[1], r2 = rnd[2];
     float bsdfDirPdfW, cosThetaOut;
     uint32_t sampledEvent;
     const V3 bsdfFactor = bsdf_sample(bsdf, sc, lightSample, r0, r1, r2, st.direction, bsdfDirPdfW, cosThetaOut,
@@ -754,7 +757,8 @@ VCM_HD bool sample_scattering(const vcm_scene_desc &sc, const IterParams &P, boo
     float bsdfRevPdfW = bsdfDirPdfW;
     if ((sampledEvent & kSpecular) == 0) bsdfRevPdfW = bsdf_pdf(bsdf, sc, st.direction, true);
     const float contProb = bsdf.contProb;
-    if (rng_float(rng) > contProb) return false;
+    rng.k += 1u;
+    if (rnd[3] > contProb) return false;
     bsdfDirPdfW *= contProb;
     bsdfRevPdfW *= contProb;
     if (sampledEvent & kSpecular) {
@@ -780,11 +784,14 @@ VCM_HD void generate_light_sample(const vcm_scene_desc &sc, const IterParams &P,
 {
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;
-    const int lightID = int(rng_float(rng) * lightCount);
-    const float dx = rng_float(rng);
-    const float dy = rng_float(rng);
-    const float px = rng_float(rng);
-    const float py = rng_float(rng);
+    float rnd[5];   /* :822-824 */
+    rng_peek(rng, rng.k, rnd, 5);
+    rng.k += 5u;
+    const int lightID = int(rnd[0] * lightCount);
+    const float dx = rnd[1];
+    const float dy = rnd[2];
+    const float px = rnd[3];
+    const float py = rnd[4];
     const vcm_light &light = get_light(sc, lightID);
     float emissionPdfW, directPdfA, cosLight;
     st.throughput = light_emit(light, sc, dx, dy, px, py, st.origin, st.direction, emissionPdfW, directPdfA, cosLight);
@@ -1335,8 +1342,11 @@ VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, Cam
     rng_init(cp.rng, P.seed, P.localIter, (uint32_t)pathIdx, 1u);
     const int x = pathIdx % P.resX;
     const int y = pathIdx / P.resX;
-    const float jx = rng_float(cp.rng);
-    const float jy = rng_float(cp.rng);
+    float jit[2];   /* :576, the first two floats of the path */
+    rng_peek_block(cp.rng, 0u, jit, 2);
+    cp.rng.k = 2u;
+    const float jx = jit[0];
+    const float jy = jit[1];
     cp.sx = float(x) + jx;
     cp.sy = float(y) + jy;
     const V3 worldRaster = transform_point(cam.rasterToWorld, mk3(cp.sx, cp.sy, 0.f));
@@ -1403,11 +1413,13 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
 
     if (MODE == 1) {
         if (!bsdf.isDelta && (P.useVC || P.useVM)) {
-            /* DirectIllumination draws its 3 floats here, in path order (:672-673) */
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            /* DirectIllumination draws its 3 floats here, in path order (:672-673): the task records WHERE in
+               the path's stream they are and K3b generates them */
+            uint32_t diK = 0u;
             int hasDI = 0;
             if (P.useVC && st.pathLength + 1 >= P.minLen) {
-                r0 = rng_float(cp.rng); r1 = rng_float(cp.rng); r2 = rng_float(cp.rng);
+                diK = cp.rng.k;
+                cp.rng.k += 3u;
                 hasDI = 1;
             }
             /* the light vertices this camera vertex connects to (:508-521) */
@@ -1433,7 +1445,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
             vs.q1[vi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
             vs.q2[vi] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
             vs.q3[vi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
-            vs.q4[vi] = mk4(st.dVC, r0, r1, r2);
+            vs.q4[vi] = mk4(st.dVC, u2f(diK), 0.f, 0.f);
             I4 m; m.x = hasDI ? di : -1; m.y = vc0; m.z = nvc; m.w = 0;
             vs.meta[vi] = m;
             if (hasDI) vs.diTask[di] = vi;
@@ -1455,8 +1467,10 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
     } else {
         if (!bsdf.isDelta && P.useVC) {   /* :487-494 */
             if (st.pathLength + 1 >= P.minLen) {
-                const float r0 = rng_float(cp.rng), r1 = rng_float(cp.rng), r2 = rng_float(cp.rng);
-                cp.color = cp.color + st.throughput * direct_illumination(sc, P, r0, r1, r2, st, hitPoint, bsdf, ls);
+                float rnd[3];
+                rng_peek(cp.rng, cp.rng.k, rnd, 3);
+                cp.rng.k += 3u;
+                cp.color = cp.color + st.throughput * direct_illumination(sc, P, rnd[0], rnd[1], rnd[2], st, hitPoint, bsdf, ls);
             }
         }
         if (!bsdf.isDelta && P.useVC) {   /* :498-526: the light path of the same index */
@@ -1494,7 +1508,7 @@ struct CamVertex {
     Bsdf bsdf;
     SubPathState st;      /* pathLength, dVCM, dVC, dVM are valid */
     uint32_t lp;
-    float r0, r1, r2;
+    uint32_t diK;         /* position of DirectIllumination's 3 floats in the path's random stream */
 };
 VCM_HD void load_cam_vertex(const vcm_scene_desc &sc, const VertexStore &vs, int vi, CamVertex &v)
 {
@@ -1506,14 +1520,18 @@ VCM_HD void load_cam_vertex(const vcm_scene_desc &sc, const VertexStore &vs, int
     v.st.pathLength = f2u(b.w) & 0xffu;
     v.st.dVCM = c.w; v.st.dVM = d.w; v.st.dVC = e.x;
     v.st.throughput = v.throughput;
-    v.r0 = e.y; v.r1 = e.z; v.r2 = e.w;
+    v.diK = f2u(e.y);
 }
 /* the addend of :491  (color += throughput * DirectIllumination(...)) */
 VCM_HD V3 eval_di_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls)
 {
     CamVertex v;
     load_cam_vertex(sc, vs, vi, v);
-    return v.throughput * direct_illumination(sc, P, v.r0, v.r1, v.r2, v.st, v.hit, v.bsdf, ls);
+    PathRng rng;
+    rng_init(rng, P.seed, P.localIter, (uint32_t)(P.p0 + (int)v.lp), 1u);
+    float rnd[3];
+    rng_peek(rng, v.diK, rnd, 3);
+    return v.throughput * direct_illumination(sc, P, rnd[0], rnd[1], rnd[2], v.st, v.hit, v.bsdf, ls);
 }
 /* the addend of :523  (color += throughput * lightVertex.mThroughput * ConnectVertices(...)) */
 VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const LightStore &store,
