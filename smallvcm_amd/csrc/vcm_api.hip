@@ -708,8 +708,10 @@ static int vcm_merge_impl(vcm_ctx *c)
                                (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
             HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
             /* K4 */
+            static int mergeChunk = 0;
+            if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
             hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
-                               c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats);
+                               c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk);
         } else {
             HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
         }

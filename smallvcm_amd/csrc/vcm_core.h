@@ -1065,7 +1065,9 @@ VCM_HD bool wave_any(bool x)
 /* Per-lane queue of accepted photon indices, in LDS on the device:
  * entry k of this lane is q[k * stride], k = 0..VCM_MERGE_Q (one spare row: the
  * scan writes every candidate at the tail and only advances it on acceptance). */
+#ifndef VCM_MERGE_Q
 #define VCM_MERGE_Q 16
+#endif
 #define VCM_MERGE_UNROLL 4
 struct MergeScratch { uint32_t *q; int stride; };
 
@@ -1223,21 +1225,28 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
             nhi = g.cellStart[cell + 1];
         }
         ls.mergeCandidates += (uint32_t)(hi - lo);   /* one distance test per entry (:162-165) */
+        /* entries past hi are read but never used (the arrays are padded by VCM_MERGE_UNROLL elements), so one
+           address serves all 4 candidates of a step.  LenSqr of (query - position), hashgrid.hxx:162, math.hxx:107. */
+#if defined(__HIP_DEVICE_COMPILE__)
+        /* 3 x 16-byte loads per step, software-pipelined: the candidates of step s+1 are in flight while step s
+           is tested; two candidates per packed operation (IEEE per half, same operation order) */
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
+        f4u X = *(const f4u *)(g.gx + lo), Y = *(const f4u *)(g.gy + lo), Z = *(const f4u *)(g.gz + lo);
+#endif
         while (wave_any(lo < hi)) {
-            /* entries past hi are read but never used (the arrays are padded by VCM_MERGE_UNROLL elements), so
-               one address serves all 4.  LenSqr of (query - position), hashgrid.hxx:162, math.hxx:107. */
+            const int nextLo = (lo + VCM_MERGE_UNROLL < hi) ? lo + VCM_MERGE_UNROLL : hi;
             float distSqr[VCM_MERGE_UNROLL];
 #if defined(__HIP_DEVICE_COMPILE__)
-            {   /* 3 x 16-byte loads; two candidates per packed operation (IEEE per half, same operation order) */
-                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                const f4u X = *(const f4u *)(g.gx + lo), Y = *(const f4u *)(g.gy + lo), Z = *(const f4u *)(g.gz + lo);
-                const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
+            const f4u Xn = *(const f4u *)(g.gx + nextLo), Yn = *(const f4u *)(g.gy + nextLo), Zn = *(const f4u *)(g.gz + nextLo);
+            {
                 const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
                 const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
                 const f2 da = dxa * dxa + dya * dya + dza * dza;
                 const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
                 distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
             }
+            X = Xn; Y = Yn; Z = Zn;
 #else
             for (int u = 0; u < VCM_MERGE_UNROLL; u++)
                 distSqr[u] = lensqr(queryPos - mk3(g.gx[lo + u], g.gy[lo + u], g.gz[lo + u]));
@@ -1253,7 +1262,7 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
                 ms.q[qn * ms.stride] = (uint32_t)idx;
                 qn += acc ? 1 : 0;
             }
-            lo = (lo + VCM_MERGE_UNROLL < hi) ? lo + VCM_MERGE_UNROLL : hi;
+            lo = nextLo;
             if (wave_any(qn > VCM_MERGE_Q - VCM_MERGE_UNROLL)) {
                 ls.mergeAccepted += (uint32_t)qn;
                 merge_drain(P, g, ev, ms, qn, contrib);

@@ -262,19 +262,27 @@ __global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, con
  * against 5.4 ms on the same box -- the spills cost more than the occupancy buys. */
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK)
 k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
-             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats)
+             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk)
 {
     const vcm_scene_desc &sc = *scp;
     const int nQ = *nSorted;
     __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_MERGE_BLOCK];
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK;
     LaneStats ls; lane_stats_zero(ls);
-    /* batches are dealt round-robin to the blocks: dense regions (many photons per cell) are spread
-       over all CUs.  (Contiguous ranges per block / per XCD were measured: better L2 locality but a
-       long tail from the blocks that own the dense regions, 6.8 ms vs 5.2 ms.) */
-    const int stride = gridDim.x * VCM_MERGE_BLOCK;
-    for (int base = blockIdx.x * VCM_MERGE_BLOCK; base < nQ; base += stride) {
-        const int q = base + (int)threadIdx.x;
+    /* XCD-aware dealing of the sorted queries.  A batch = 256 consecutive queries of the Morton order, a chunk =
+       `chunk` consecutive batches = one compact region of the scene.  Workgroup i runs on XCD i mod 8 (round-robin
+       dispatch), and each XCD has its own L2: chunk c goes to XCD c mod 8 and is shared out among that XCD's
+       workgroups, so the photons of a region are fetched into ONE L2 and reused by the neighbouring queries, while
+       dense regions (many photons per cell), which span many chunks, are still spread over all XCDs.  (Measured
+       alternatives: batches round-robin over all workgroups -- every L2 streams the whole photon set; one
+       contiguous range per XCD -- a long tail from the XCDs that own the dense regions, 6.8 ms.) */
+    const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
+    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
+    for (int t = wgOfXcd;; t += wgPerXcd) {
+        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
+        if ((t / chunk) * 8 * chunk >= nBatches) break;   /* every chunk row of this XCD is past the end */
+        if (b >= nBatches) continue;
+        const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
         if (q < nQ) {
             const int vi = sortedVertex[q];
             const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms);
