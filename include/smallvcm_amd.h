@@ -113,7 +113,11 @@ enum {
     VCM_ALGO_PPM = 1,
     VCM_ALGO_BPM = 2,
     VCM_ALGO_BPT = 3,
-    VCM_ALGO_VCM = 4
+    VCM_ALGO_VCM = 4,
+    /* the reference's two other renderers behind the same interface (AbstractRenderer, renderer.hxx:33-70;
+       created at config.hxx:118-121).  radiusFactor / radiusAlpha are ignored. */
+    VCM_ALGO_PATH_TRACE = 5,                   /* PathTracer  src/pathtracer.hxx:45-215 */
+    VCM_ALGO_EYE_LIGHT = 6                     /* EyeLight    src/eyelight.hxx:46-77 */
 };
 
 /* Per-iteration workload counters (what SURVEY.md section 8(d) calls N_LV, C, A, K, S)

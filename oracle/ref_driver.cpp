@@ -192,7 +192,16 @@ int ref_run_tape(unsigned boxMask, int resX, int resY, int vcmAlgo,
 {
     Scene *scene = make_scene(boxMask, resX, resY);
     const int N = resX * resY;
-    VertexCM *r = new VertexCM(*scene, (VertexCM::AlgorithmType)vcmAlgo, radiusFactor, radiusAlpha, seed);
+    /* vcmAlgo 0..4 = VertexCM::AlgorithmType; 5 = PathTracer, 6 = EyeLight (created as config.hxx:118-121 does) */
+    AbstractRenderer *r;
+    bool lightTraceOnly = false;
+    if (vcmAlgo == 5) r = new PathTracer(*scene, seed);
+    else if (vcmAlgo == 6) r = new EyeLight(*scene, seed);
+    else {
+        VertexCM *v = new VertexCM(*scene, (VertexCM::AlgorithmType)vcmAlgo, radiusFactor, radiusAlpha, seed);
+        lightTraceOnly = v->mLightTraceOnly;
+        r = v;
+    }
     r->mMaxPathLength = maxLen;   /* src/smallvcm.cxx:70-71 */
     r->mMinPathLength = minLen;
     int bad = 0;
@@ -206,7 +215,7 @@ int ref_run_tape(unsigned boxMask, int resX, int resY, int vcmAlgo,
         g_tape.key[1] = (uint32_t)i;
         long long expect = 0;
         for (int p = 0; p < N; p++) expect += g_tape.counts[0][p];
-        if (!r->mLightTraceOnly) for (int p = 0; p < N; p++) expect += g_tape.counts[1][p];
+        if (!lightTraceOnly) for (int p = 0; p < N; p++) expect += g_tape.counts[1][p];
         r->RunIteration(firstIteration + i);
         if (g_tape.overrun || g_tape.consumed != expect) bad = 1;
         total += g_tape.consumed;

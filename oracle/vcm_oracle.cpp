@@ -266,6 +266,8 @@ struct Splat { int pixel; V3 c; };
 struct Oracle {
     vcm_scene_desc sc;
     bool useVM, useVC, lightTraceOnly, ppm;
+    int renderer;               /* 0 VertexCM, 1 PathTracer (pathtracer.hxx), 2 EyeLight (eyelight.hxx) */
+    int iteration;              /* aIteration of the current RunIteration */
     float baseRadius, radiusAlpha;
     int seed;
     int rank, world;
@@ -1095,6 +1097,154 @@ static void trace_camera_path(Oracle &o, int pathIdx, unsigned char &rngCount, v
     rngCount = (unsigned char)rng.k;
 }
 
+/* ================= PathTracer::RunIteration, src/pathtracer.hxx:45-215 ================= */
+static inline float mis2(float samplePdf, float otherPdf) { return mis(samplePdf) / (mis(samplePdf) + mis(otherPdf)); }  /* :226-231 */
+static inline float pdf_a_to_w(float pdfA, float dist, float cosThere) { return pdfA * osqr(dist) / std::abs(cosThere); }  /* utils.hxx:253-259 */
+
+static void store_path_colour(Oracle &o, int lp, float sx, float sy, V3 color, bool add)
+{   /* Framebuffer::AddColor(sample, color), deferred: the caller adds in pixel-loop order */
+    const vcm_camera &cam = o.sc.camera;
+    int target = -1;
+    if (add && !(sx < 0 || sx >= cam.resolution[0]) && !(sy < 0 || sy >= cam.resolution[1]))
+        target = int(sx) + int(sy) * o.resX;
+    o.camTarget[lp] = target;
+    o.camColor[(size_t)lp * 3 + 0] = color.x;
+    o.camColor[(size_t)lp * 3 + 1] = color.y;
+    o.camColor[(size_t)lp * 3 + 2] = color.z;
+}
+
+static void trace_pt_path(Oracle &o, int pixID, unsigned char &rngCount, vcm_stats &stats)
+{
+    const vcm_scene_desc &sc = o.sc;
+    const vcm_camera &cam = sc.camera;
+    PathRngRef rng;
+    path_rng_init_ref(&rng, (uint32_t)o.seed, (uint32_t)o.iterations, (uint32_t)pixID, 1u);
+    const int lightCount = sc.nLights;                 /* :48-49 */
+    const float lightPickProb = 1.f / lightCount;
+    const int x = pixID % o.resX, y = pixID / o.resX;  /* :56-57 */
+    const float jx = path_rng_float_ref(&rng);
+    const float jy = path_rng_float_ref(&rng);
+    const float sx = float(x) + jx, sy = float(y) + jy;   /* :59 */
+    Ray ray;                                            /* Camera::GenerateRay camera.hxx:108-117 */
+    ray.org = ld3(cam.position);
+    ray.dir = normalize(transform_point(cam.rasterToWorld, mk(sx, sy, 0)) - ray.org);
+    ray.tmin = 0;
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp(0);
+    V3 pathWeight = sp(1), color = sp(0);
+    unsigned pathLength = 1;
+    bool lastSpecular = true;
+    float lastPdfW = 1;
+    for (;; ++pathLength) {
+        stats.cameraRays++;
+        if (!scene_intersect(sc, ray, isect)) {          /* :73-97 */
+            if (pathLength < o.minLen) break;
+            if (sc.backgroundLight < 0) break;
+            float directPdfW;
+            const V3 contrib = light_get_radiance(sc.lights[sc.backgroundLight], sc, ray.dir, sp(0), &directPdfW, NULL);
+            if (iszero(contrib)) break;
+            float misWeight = 1.f;
+            if (pathLength > 1 && !lastSpecular) misWeight = mis2(lastPdfW, directPdfW * lightPickProb);
+            color = color + pathWeight * misWeight * contrib;
+            break;
+        }
+        const V3 hitPoint = ray.org + ray.dir * isect.dist;   /* :99-100 */
+        isect.dist += O_EPS_RAY;
+        Bsdf bsdf;
+        bsdf_setup(bsdf, ray, isect, sc);
+        if (bsdf.matID < 0) break;
+        if (isect.lightID >= 0) {                        /* :107-129 */
+            if (pathLength < o.minLen) break;
+            const vcm_light &light = get_light(sc, isect.lightID);
+            float directPdfA;
+            const V3 contrib = light_get_radiance(light, sc, ray.dir, hitPoint, &directPdfA, NULL);
+            if (iszero(contrib)) break;
+            float misWeight = 1.f;
+            if (pathLength > 1 && !lastSpecular) {
+                const float directPdfW = pdf_a_to_w(directPdfA, isect.dist, bsdf.localDirFix.z);
+                misWeight = mis2(lastPdfW, directPdfW * lightPickProb);
+            }
+            color = color + pathWeight * misWeight * contrib;
+            break;
+        }
+        if (pathLength >= o.maxLen) break;               /* :131 */
+        if (bsdf.contProb == 0) break;                   /* :134 */
+        if (!bsdf.isDelta && pathLength + 1 >= o.minLen) {   /* :138-179 */
+            const int lightID = int(path_rng_float_ref(&rng) * lightCount);
+            const vcm_light &light = get_light(sc, lightID);
+            const float rx = path_rng_float_ref(&rng);
+            const float ry = path_rng_float_ref(&rng);
+            V3 directionToLight;
+            float distance, directPdfW;
+            const V3 radiance = light_illuminate(light, sc, hitPoint, rx, ry, directionToLight, distance, directPdfW, NULL, NULL);
+            if (!iszero(radiance)) {
+                float bsdfPdfW, cosThetaOut;
+                const V3 factor = bsdf_evaluate(bsdf, sc, directionToLight, cosThetaOut, &bsdfPdfW, NULL);
+                if (!iszero(factor)) {
+                    float weight = 1.f;
+                    if (!light_is_delta(light)) {
+                        const float contProb = bsdf.contProb;
+                        bsdfPdfW *= contProb;
+                        weight = mis2(directPdfW * lightPickProb, bsdfPdfW);
+                    }
+                    const V3 contrib = (weight * cosThetaOut / (lightPickProb * directPdfW)) * (radiance * factor);
+                    stats.shadowRays++;
+                    if (!scene_occluded(sc, hitPoint, directionToLight, distance)) color = color + pathWeight * contrib;
+                }
+            }
+        }
+        {   /* :182-212 */
+            const float r0 = path_rng_float_ref(&rng);
+            const float r1 = path_rng_float_ref(&rng);
+            const float r2 = path_rng_float_ref(&rng);
+            float pdf, cosThetaOut;
+            unsigned sampledEvent;
+            const V3 factor = bsdf_sample(bsdf, sc, false, mk(r0, r1, r2), ray.dir, pdf, cosThetaOut, sampledEvent);
+            if (iszero(factor)) break;
+            const float contProb = bsdf.contProb;
+            lastSpecular = (sampledEvent & kSpecular) != 0;
+            lastPdfW = pdf * contProb;
+            if (contProb < 1.f) {
+                if (path_rng_float_ref(&rng) > contProb) break;
+                pdf *= contProb;
+            }
+            pathWeight = pathWeight * (factor * (cosThetaOut / pdf));
+            ray.org = hitPoint + O_EPS_RAY * ray.dir;
+            ray.tmin = 0.f;
+            isect.dist = 1e36f;
+        }
+    }
+    store_path_colour(o, pixID - o.p0, sx, sy, color, true);   /* :214 */
+    rngCount = (unsigned char)rng.k;
+}
+
+/* ================= EyeLight::RunIteration, src/eyelight.hxx:46-77 ================= */
+static void trace_eyelight_path(Oracle &o, int pixID, unsigned char &rngCount, vcm_stats &stats)
+{
+    const vcm_scene_desc &sc = o.sc;
+    const vcm_camera &cam = sc.camera;
+    PathRngRef rng;
+    path_rng_init_ref(&rng, (uint32_t)o.seed, (uint32_t)o.iterations, (uint32_t)pixID, 1u);
+    const int x = pixID % o.resX, y = pixID / o.resX;
+    float jx = 0.5f, jy = 0.5f;
+    if (o.iteration != 1) { jx = path_rng_float_ref(&rng); jy = path_rng_float_ref(&rng); }   /* :60-61 */
+    const float sx = float(x) + jx, sy = float(y) + jy;
+    Ray ray;
+    ray.org = ld3(cam.position);
+    ray.dir = normalize(transform_point(cam.rasterToWorld, mk(sx, sy, 0)) - ray.org);
+    ray.tmin = 0;
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp(0);
+    stats.cameraRays++;
+    V3 color = sp(0);
+    bool hit = false;
+    if (scene_intersect(sc, ray, isect)) {               /* :67-76 */
+        const float dotLN = dot(isect.normal, -ray.dir);
+        color = (dotLN > 0) ? sp(dotLN) : mk(-dotLN, 0, 0);
+        hit = true;
+    }
+    store_path_colour(o, pixID - o.p0, sx, sy, color, hit);
+    rngCount = (unsigned char)rng.k;
+}
+
 static void add_stats(vcm_stats &a, const vcm_stats &b)
 {
     a.lightRays += b.lightRays; a.cameraRays += b.cameraRays; a.shadowRays += b.shadowRays;
@@ -1113,12 +1263,15 @@ void *oracle_create(const vcm_scene_desc *scene, int algorithm, float radiusFact
     Oracle *o = new Oracle();
     o->sc = *scene;
     o->useVM = o->useVC = o->lightTraceOnly = o->ppm = false;
+    o->renderer = 0; o->iteration = 0;
     switch (algorithm) {
     case VCM_ALGO_LIGHT_TRACE: o->lightTraceOnly = true; break;
     case VCM_ALGO_PPM: o->ppm = true; o->useVM = true; break;
     case VCM_ALGO_BPM: o->useVM = true; break;
     case VCM_ALGO_BPT: o->useVC = true; break;
     case VCM_ALGO_VCM: o->useVC = true; o->useVM = true; break;
+    case VCM_ALGO_PATH_TRACE: o->renderer = 1; break;   /* config.hxx:120-121 */
+    case VCM_ALGO_EYE_LIGHT: o->renderer = 2; break;    /* config.hxx:118-119 */
     default: break;
     }
     if (o->ppm) {   /* :246-278 */
@@ -1162,6 +1315,7 @@ void oracle_begin_iteration(void *h, int iteration, unsigned minLen, unsigned ma
 {   /* vertexcm.hxx:288-316 */
     Oracle &o = *(Oracle *)h;
     o.minLen = minLen; o.maxLen = maxLen;
+    o.iteration = iteration;
     o.lightSubPathCount = float(o.resX * o.resY);
     float radius = o.baseRadius;
     radius /= dmr_powf(float(iteration + 1), 0.5f * (1 - o.radiusAlpha));
@@ -1183,6 +1337,7 @@ void oracle_trace_light(void *h)
 {   /* vertexcm.hxx:321-396 over the local path range; chunked so that the
        OpenMP variant produces exactly the serial result */
     Oracle &o = *(Oracle *)h;
+    if (o.renderer) return;   /* PathTracer / EyeLight: no light pass */
     const int nLocal = o.p1 - o.p0;
     const int CH = 1024;
     const int nChunks = (nLocal + CH - 1) / CH;
@@ -1262,7 +1417,9 @@ void oracle_trace_camera_window(void *h, int rowStride, int rowWidth)
         for (int lp = b; lp < e; lp++) {
             const int p = o.p0 + lp;
             if (rowStride > 1 && ((p / o.resX) % rowStride) >= rowWidth) continue;
-            trace_camera_path(o, p, o.camCounts[lp], cst[c]);
+            if (o.renderer == 1) trace_pt_path(o, p, o.camCounts[lp], cst[c]);
+            else if (o.renderer == 2) trace_eyelight_path(o, p, o.camCounts[lp], cst[c]);
+            else trace_camera_path(o, p, o.camCounts[lp], cst[c]);
         }
     }
     for (int c = 0; c < nChunks; c++) add_stats(o.st, cst[c]);

@@ -15,8 +15,9 @@ LIGHT_AREA, LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_BACKGROUND = 0, 1, 2, 3
 
 # VertexCM::AlgorithmType (reference src/vertexcm.hxx:182-204)
 ALGO_LIGHT_TRACE, ALGO_PPM, ALGO_BPM, ALGO_BPT, ALGO_VCM = 0, 1, 2, 3, 4
+ALGO_PATH_TRACE, ALGO_EYE_LIGHT = 5, 6        # PathTracer (src/pathtracer.hxx), EyeLight (src/eyelight.hxx)
 ALGO_BY_NAME = {"lt": ALGO_LIGHT_TRACE, "ppm": ALGO_PPM, "bpm": ALGO_BPM,
-                "bpt": ALGO_BPT, "vcm": ALGO_VCM}
+                "bpt": ALGO_BPT, "vcm": ALGO_VCM, "pt": ALGO_PATH_TRACE, "el": ALGO_EYE_LIGHT}
 
 f3 = C.c_float * 3
 

@@ -84,6 +84,7 @@ static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_t
 struct vcm_ctx : Scratch {
     vcm_scene_desc scene;
     bool useVM, useVC, lightTraceOnly, ppm;
+    int renderer;                     /* 0 VertexCM family, 1 PathTracer, 2 EyeLight */
     float baseRadius, radiusAlpha;
     int seed, device, rank, world;
     int resX, resY, N, p0, nLocal;
@@ -349,6 +350,8 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     case VCM_ALGO_BPM: c->useVM = true; break;
     case VCM_ALGO_BPT: c->useVC = true; break;
     case VCM_ALGO_VCM: c->useVC = true; c->useVM = true; break;
+    case VCM_ALGO_PATH_TRACE: c->renderer = 1; break;   /* PathTracer(scene, seed), config.hxx:120-121 */
+    case VCM_ALGO_EYE_LIGHT: c->renderer = 2; break;    /* EyeLight(scene, seed), config.hxx:118-119 */
     default: delete c; fail("vcm_create", "unknown algorithm"); return NULL;
     }
     if (c->ppm) {   /* PPM -> BPM downgrade :246-278 */
@@ -448,8 +451,9 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     if (!c) return fail("vcm_begin_iteration", "ctx is NULL");
     if (c->inIteration) return fail("vcm_begin_iteration", "previous iteration not ended");
     if (maxLen > 255) return fail("vcm_begin_iteration", "maxPathLength > 255 unsupported (8-bit vertex counts)");
-    const int S = (maxLen >= 2) ? (int)maxLen - 1 : 1;
-    const int L = (maxLen >= 1) ? (int)maxLen : 1;
+    /* light-vertex slots per path / camera vertices per path; PathTracer and EyeLight store neither */
+    const int S = c->renderer ? 1 : ((maxLen >= 2) ? (int)maxLen - 1 : 1);
+    const int L = c->renderer ? 1 : ((maxLen >= 1) ? (int)maxLen : 1);
     if (ensure_device(c)) return -1;
     if (arena_acquire(c, S, L)) { g_hipFailed = true; return abort_iteration(c, -1); }
 
@@ -474,7 +478,9 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     P.cellSize = radius * 2.f;                                                /* hashgrid.hxx:47 */
     P.invCellSize = 1.f / P.cellSize;                                         /* :48 */
     P.nCells = c->N;                                                          /* vertexcm.hxx:406 */
-    P.wavefront = (!c->strictOrder && !c->lightTraceOnly && maxLen <= 31) ? 1 : 0;
+    P.wavefront = (!c->strictOrder && !c->lightTraceOnly && !c->renderer && maxLen <= 31) ? 1 : 0;
+    P.renderer = c->renderer;
+    P.iteration = iteration;
 
     HIPCHK(hipEventRecord(c->ev[EV_START], c->stream));
     HIPCHK(hipMemsetAsync(c->dStats, 0, STAT_COUNT * sizeof(unsigned long long), c->stream));
@@ -516,6 +522,15 @@ static int vcm_trace_light_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:321-396 */
     if (!c || !c->inIteration) return fail("vcm_trace_light", "no iteration in progress");
     if (use_device(c)) return -1;
+    if (c->renderer) {   /* PathTracer / EyeLight have no light pass */
+        HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K0], c->stream));
+        HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K1], c->stream));
+        HIPCHK(hipMemsetAsync(c->dLocalTotal, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev[EV_LIGHT], c->stream));
+        return 0;
+    }
     int blocks, chunk;
     trace_launch_shape(c->nLocal, &blocks, &chunk);
     HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K0], c->stream));
@@ -666,6 +681,18 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     int blocks, chunk;
     trace_launch_shape(c->nLocal, &blocks, &chunk);
     HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K0], c->stream));
+    if (c->renderer) {   /* PathTracer / EyeLight: colour + jittered pixel per path; K5 adds them in path order */
+        if (c->renderer == 1)
+            hipLaunchKernelGGL(k_path_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->dCamOut,
+                               c->dRngCam, c->dStats, chunk);
+        else
+            hipLaunchKernelGGL(k_eye_light, dim3(2048), dim3(256), 0, c->stream, c->dScene, c->P, c->dCamOut, c->dRngCam,
+                               c->dStats);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+        HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
+        return 0;
+    }
     if (c->P.wavefront) {
         /* K3: needs the light-vertex store, NOT the hash grid */
         hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,

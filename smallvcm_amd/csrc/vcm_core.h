@@ -35,6 +35,8 @@ struct IterParams {
     float cellSize, invCellSize;   /* hashgrid.hxx:47-48 */
     int   nCells;                  /* = N (vertexcm.hxx:406) */
     int   wavefront;               /* 1: DI / VC / merge deferred to task kernels (default) */
+    int   renderer;                /* 0: VertexCM family; 1: PathTracer (pathtracer.hxx); 2: EyeLight (eyelight.hxx) */
+    int   iteration;               /* aIteration as passed to RunIteration (EyeLight reads it, eyelight.hxx:61) */
 };
 
 /* device-resident hash-grid header: bbox is reduced on the device */
@@ -285,6 +287,11 @@ VCM_HD float uniform_sphere_pdf() { return VCM_INV_PI_F * 0.25f; }   /* :232-236
 VCM_HD float pdf_w_to_a(float pdfW, float dist, float cosThere)
 {   /* :245-251 */
     return pdfW * fabsf(cosThere) / sqr(dist);
+}
+
+VCM_HD float pdf_a_to_w(float pdfA, float dist, float cosThere)
+{   /* :253-259 */
+    return pdfA * sqr(dist) / fabsf(cosThere);
 }
 
 /* ---- geometry.hxx ------------------------------------------------- */
@@ -1584,6 +1591,170 @@ VCM_HD V3 replay_path_color(const IterParams &P, const VertexStore &vs, int lp, 
         if (P.useVM) { const F4 t = vs.mergeOut[vi]; color = color + mk3(t.x, t.y, t.z); }
     }
     return color + emission;
+}
+
+/* ================= PathTracer::RunIteration (pathtracer.hxx:45-215) ================= */
+/* The reference's second renderer (SURVEY section 8(f) "next" #2): same device functions, one lane per
+ * pixel, next-event estimation + BSDF sampling combined with Mis2.  Random floats of a path, in order:
+ * jitter x,y (:59); per vertex [light pick, 2 for Illuminate (:148-154)] if the vertex does NEE, the Sample
+ * triplet (:185), the Russian-roulette float only if contProb < 1 (:201-203). */
+struct PtPath {
+    V3 org, dir;          /* the next ray; the FIRST one starts at the camera without the EPS_RAY offset (:61) */
+    V3 weight, color;
+    uint32_t pathLength, lastSpecular;
+    float lastPdfW;
+    float sx, sy;
+    PathRng rng;
+    int lp;
+};
+VCM_HD float mis2(float samplePdf, float otherPdf) { return mis(samplePdf) / (mis(samplePdf) + mis(otherPdf)); }   /* :226-231 */
+VCM_HD void pt_path_begin(const vcm_scene_desc &sc, const IterParams &P, PtPath &pp, int localPath)
+{
+    const vcm_camera &cam = sc.camera;
+    const int pathIdx = P.p0 + localPath;
+    pp.lp = localPath;
+    rng_init(pp.rng, P.seed, P.localIter, (uint32_t)pathIdx, 1u);
+    float jit[2];
+    rng_peek_block(pp.rng, 0u, jit, 2);
+    pp.rng.k = 2u;
+    pp.sx = float(pathIdx % P.resX) + jit[0];   /* :56-59 */
+    pp.sy = float(pathIdx / P.resX) + jit[1];
+    const V3 worldRaster = transform_point(cam.rasterToWorld, mk3(pp.sx, pp.sy, 0.f));   /* camera.hxx:108-117 */
+    pp.org = ld3(cam.position);
+    pp.dir = normalize(worldRaster - pp.org);
+    pp.weight = sp3(1.f);
+    pp.color = sp3(0.f);
+    pp.pathLength = 1;
+    pp.lastSpecular = 1;
+    pp.lastPdfW = 1.f;
+}
+/* one turn of the for(;; ++pathLength) at :71-213; false when the path ends */
+VCM_HD bool pt_path_step(const vcm_scene_desc &sc, const IterParams &P, PtPath &pp, LaneStats &ls)
+{
+    const int lightCount = sc.nLights;
+    const float lightPickProb = 1.f / lightCount;   /* :48-49 */
+    Ray ray; ray.org = pp.org; ray.dir = pp.dir; ray.tmin = 0;
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    ls.cameraRays++;
+    if (!scene_intersect(sc, ray, isect)) {   /* :73-97 */
+        if (pp.pathLength < P.minLen) return false;
+        if (sc.backgroundLight < 0) return false;
+        float directPdfW = 0.f, emissionPdfW = 0.f;
+        const V3 contrib = light_get_radiance(sc.lights[sc.backgroundLight], sc, ray.dir, directPdfW, emissionPdfW);
+        if (iszero(contrib)) return false;
+        float misWeight = 1.f;
+        if (pp.pathLength > 1 && !pp.lastSpecular) misWeight = mis2(pp.lastPdfW, directPdfW * lightPickProb);
+        pp.color = pp.color + pp.weight * misWeight * contrib;
+        return false;
+    }
+    const V3 hitPoint = ray.org + ray.dir * isect.dist;   /* :99-100 */
+    isect.dist += VCM_EPS_RAY;
+    Bsdf bsdf;
+    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, sc);
+    if (bsdf.matID < 0) return false;
+    if (isect.lightID >= 0) {   /* :107-129 */
+        if (pp.pathLength < P.minLen) return false;
+        const vcm_light &light = get_light(sc, isect.lightID);
+        float directPdfA = 0.f, emissionPdfW = 0.f;
+        const V3 contrib = light_get_radiance(light, sc, ray.dir, directPdfA, emissionPdfW);
+        if (iszero(contrib)) return false;
+        float misWeight = 1.f;
+        if (pp.pathLength > 1 && !pp.lastSpecular) {
+            const float directPdfW = pdf_a_to_w(directPdfA, isect.dist, bsdf.localDirFix.z);   /* CosThetaFix, bsdf.hxx:263 */
+            misWeight = mis2(pp.lastPdfW, directPdfW * lightPickProb);
+        }
+        pp.color = pp.color + pp.weight * misWeight * contrib;
+        return false;
+    }
+    if (pp.pathLength >= P.maxLen) return false;   /* :131 */
+    if (bsdf.contProb == 0.f) return false;        /* :134 */
+    if (!bsdf.isDelta && pp.pathLength + 1 >= P.minLen) {   /* next event estimation :138-179 */
+        float rnd[3];
+        rng_peek(pp.rng, pp.rng.k, rnd, 3);
+        pp.rng.k += 3u;
+        const int lightID = int(rnd[0] * lightCount);
+        const vcm_light &light = get_light(sc, lightID);
+        V3 directionToLight;
+        float distance, directPdfW, emissionPdfW, cosAtLight;
+        const V3 radiance = light_illuminate(light, sc, hitPoint, rnd[1], rnd[2], directionToLight, distance, directPdfW,
+                                             emissionPdfW, cosAtLight);
+        if (!iszero(radiance)) {
+            float bsdfPdfW, cosThetaOut;
+            const V3 factor = bsdf_evaluate(bsdf, sc, directionToLight, cosThetaOut, &bsdfPdfW, NULL);
+            if (!iszero(factor)) {
+                float weight = 1.f;
+                if (!light_is_delta(light)) {
+                    const float contProb = bsdf.contProb;
+                    bsdfPdfW *= contProb;
+                    weight = mis2(directPdfW * lightPickProb, bsdfPdfW);
+                }
+                const V3 contrib = (weight * cosThetaOut / (lightPickProb * directPdfW)) * (radiance * factor);
+                ls.shadowRays++;
+                if (!scene_occluded(sc, hitPoint, directionToLight, distance)) pp.color = pp.color + pp.weight * contrib;
+            }
+        }
+    }
+    {   /* continue the random walk :182-212 */
+        float rnd[4];
+        rng_peek(pp.rng, pp.rng.k, rnd, 4);
+        pp.rng.k += 3u;
+        float pdf, cosThetaOut;
+        uint32_t sampledEvent;
+        V3 newDir;
+        const V3 factor = bsdf_sample(bsdf, sc, false, rnd[0], rnd[1], rnd[2], newDir, pdf, cosThetaOut, sampledEvent);
+        if (iszero(factor)) return false;
+        const float contProb = bsdf.contProb;
+        pp.lastSpecular = (sampledEvent & kSpecular) != 0 ? 1u : 0u;
+        pp.lastPdfW = pdf * contProb;
+        if (contProb < 1.f) {
+            pp.rng.k += 1u;
+            if (rnd[3] > contProb) return false;
+            pdf *= contProb;
+        }
+        pp.weight = pp.weight * (factor * (cosThetaOut / pdf));
+        pp.dir = newDir;
+        pp.org = hitPoint + VCM_EPS_RAY * newDir;   /* :208 */
+    }
+    ++pp.pathLength;
+    return true;
+}
+
+/* ================= EyeLight::RunIteration (eyelight.hxx:46-77) ================= */
+/* returns the colour and the jittered sample; hit = false: nothing is added (:68) */
+VCM_HD bool eyelight_path(const vcm_scene_desc &sc, const IterParams &P, int localPath, V3 &color, float &sx, float &sy,
+                          uint32_t &floatsDrawn, LaneStats &ls)
+{
+    const vcm_camera &cam = sc.camera;
+    const int pathIdx = P.p0 + localPath;
+    float jit[2] = { 0.5f, 0.5f };
+    floatsDrawn = 0u;
+    if (P.iteration != 1) {   /* :60-61: iteration 1 samples the pixel centres and draws nothing */
+        PathRng rng;
+        rng_init(rng, P.seed, P.localIter, (uint32_t)pathIdx, 1u);
+        rng_peek_block(rng, 0u, jit, 2);
+        floatsDrawn = 2u;
+    }
+    sx = float(pathIdx % P.resX) + jit[0];
+    sy = float(pathIdx / P.resX) + jit[1];
+    Ray ray;
+    const V3 worldRaster = transform_point(cam.rasterToWorld, mk3(sx, sy, 0.f));
+    ray.org = ld3(cam.position);
+    ray.dir = normalize(worldRaster - ray.org);
+    ray.tmin = 0;
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    ls.cameraRays++;
+    if (!scene_intersect(sc, ray, isect)) return false;
+    const float dotLN = dot(isect.normal, -ray.dir);   /* :70-75 */
+    color = (dotLN > 0) ? sp3(dotLN) : mk3(-dotLN, 0.f, 0.f);
+    return true;
+}
+
+VCM_HD int raster_target(const IterParams &P, float sx, float sy)
+{   /* Framebuffer::AddColor framebuffer.hxx:43-57 */
+    const float rx = (float)P.resX, ry = (float)P.resY;
+    if (sx < 0 || sx >= rx) return -1;
+    if (sy < 0 || sy >= ry) return -1;
+    return int(sx) + int(sy) * P.resX;
 }
 
 /* Framebuffer::AddColor(screenSample, color) vertexcm.hxx:544, framebuffer.hxx:43-57:

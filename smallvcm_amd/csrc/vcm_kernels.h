@@ -142,6 +142,57 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     flush_stats(ls, gstats);
 }
 
+/* ---------------- PathTracer / EyeLight (pathtracer.hxx:45-215, eyelight.hxx:46-77) ---------------- */
+/* Same shape as K3: persistent waves, one lane per pixel, dead lanes refilled by ballot + prefix popcount.
+ * The colour of a path goes to camOut with the pixel of its jittered sample; k_resolve adds it in path order. */
+__global__ void __launch_bounds__(VCM_TRACE_BLOCK)
+k_path_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
+             unsigned long long *gstats, int chunk)
+{
+    const vcm_scene_desc &sc = *scp;
+    const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
+    const unsigned lane = lane_id();
+    int next = wave * chunk;
+    const int end = min(P.nLocal, next + chunk);
+    LaneStats ls; lane_stats_zero(ls);
+    PtPath path;
+    bool alive = false;
+    for (;;) {
+        const unsigned long long need = __ballot(!alive);
+        if (!alive) {
+            const int idx = next + __popcll(need & ((1ull << lane) - 1ull));
+            if (idx < end) { pt_path_begin(sc, P, path, idx); alive = true; }
+        }
+        next += __popcll(need);
+        if (!__any(alive)) break;
+        if (alive) {
+            alive = pt_path_step(sc, P, path, ls);
+            if (!alive) {
+                camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)raster_target(P, path.sx, path.sy)));
+                rngCount[path.lp] = (unsigned char)path.rng.k;
+            }
+        }
+    }
+    flush_stats(ls, gstats);
+}
+
+__global__ void __launch_bounds__(256)
+k_eye_light(const vcm_scene_desc *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
+            unsigned long long *gstats)
+{
+    const vcm_scene_desc &sc = *scp;
+    LaneStats ls; lane_stats_zero(ls);
+    for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < P.nLocal; lp += gridDim.x * blockDim.x) {
+        V3 color = sp3(0.f);
+        float sx, sy;
+        uint32_t drawn;
+        const bool hit = eyelight_path(sc, P, lp, color, sx, sy, drawn, ls);
+        camOut[lp] = mk4(color.x, color.y, color.z, u2f((uint32_t)(hit ? raster_target(P, sx, sy) : -1)));
+        rngCount[lp] = (unsigned char)drawn;
+    }
+    flush_stats(ls, gstats);
+}
+
 /* ---------------- K3b / K3c: dense connection tasks ----------------------- */
 /* One lane per task; every lane of a wave runs the same code path (a BSDF
  * evaluation or two and ONE shadow ray), which is what the fused path could

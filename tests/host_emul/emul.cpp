@@ -13,6 +13,7 @@ using namespace vcm;
 struct Emul {
     SceneDev sd;   /* e.sd.sc is what the device functions see */
     bool useVM, useVC, lightTraceOnly, ppm;
+    int renderer;
     float baseRadius, radiusAlpha;
     int seed, iterations;
     int resX, resY, N, p0, nLocal;
@@ -34,11 +35,14 @@ void *emul_create(const vcm_scene_desc *scene, int algorithm, float radiusFactor
     Emul *e = new Emul();
     scene_dev_build(*scene, e->sd);
     e->useVM = e->useVC = e->lightTraceOnly = e->ppm = false;
+    e->renderer = 0;
     switch (algorithm) {
     case VCM_ALGO_LIGHT_TRACE: e->lightTraceOnly = true; break;
     case VCM_ALGO_PPM: e->ppm = true; e->useVM = true; break;
     case VCM_ALGO_BPM: e->useVM = true; break;
     case VCM_ALGO_BPT: e->useVC = true; break;
+    case VCM_ALGO_PATH_TRACE: e->renderer = 1; break;
+    case VCM_ALGO_EYE_LIGHT: e->renderer = 2; break;
     default: e->useVC = true; e->useVM = true; break;
     }
     if (e->ppm) {
@@ -85,6 +89,35 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     P.invCellSize = 1.f / P.cellSize;
     P.nCells = e.N;
 
+    P.renderer = e.renderer; P.iteration = iteration;
+    if (e.renderer) {   /* PathTracer / EyeLight: pixel loop, then AddColor in pixel order */
+        e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
+        e.records.clear();
+        lane_stats_zero(e.ls);
+        e.camOut.assign((size_t)e.nLocal, mk4(0, 0, 0, 0));
+        for (int lp = 0; lp < e.nLocal; lp++) {
+            if (e.renderer == 1) {
+                PtPath path;
+                pt_path_begin(e.sd.sc, P, path, lp);
+                while (pt_path_step(e.sd.sc, P, path, e.ls)) {}
+                e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)raster_target(P, path.sx, path.sy)));
+                e.rngC[lp] = (unsigned char)path.rng.k;
+            } else {
+                V3 color = sp3(0.f); float sx, sy; uint32_t drawn;
+                const bool hit = eyelight_path(e.sd.sc, P, lp, color, sx, sy, drawn, e.ls);
+                e.camOut[lp] = mk4(color.x, color.y, color.z, u2f((uint32_t)(hit ? raster_target(P, sx, sy) : -1)));
+                e.rngC[lp] = (unsigned char)drawn;
+            }
+        }
+        for (int lp = 0; lp < e.nLocal; lp++) {
+            const int t = (int)f2u(e.camOut[lp].w);
+            if (t < 0) continue;
+            float *px = &e.fb[(size_t)t * 3];
+            px[0] = px[0] + e.camOut[lp].x; px[1] = px[1] + e.camOut[lp].y; px[2] = px[2] + e.camOut[lp].z;
+        }
+        e.iterations++;
+        return;
+    }
     const size_t slots = (size_t)S * e.nLocal;
     e.v0.assign(slots * VCM_LV_FIELDS, mk4(0, 0, 0, 0));
     e.count.assign((size_t)e.nLocal, 0); e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);

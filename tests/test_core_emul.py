@@ -10,7 +10,7 @@ from smallvcm_amd.renderer import cornell_scene
 
 CASES = [(sid, algo, 48, 1, 0, 10) for sid in range(4) for algo in range(5)] + [
     (1, 4, 96, 2, 0, 10), (3, 4, 64, 2, 2, 6), (1, 4, 32, 1, 0, 1), (1, 4, 32, 1, 0, 2), (0, 4, 32, 2, 5, 5),
-    (2, 2, 40, 1, 0, 3)]
+    (2, 2, 40, 1, 0, 3)] + [(sid, algo, 40, 3, 0, 10) for sid in range(4) for algo in (5, 6)] + [(1, 5, 32, 1, 3, 4)]
 
 
 @pytest.mark.parametrize("sid,algo,res,nit,mn,mx", CASES)

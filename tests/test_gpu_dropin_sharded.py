@@ -58,6 +58,26 @@ def test_reference_driver_over_dropin(tmp_path, algo, name):
     assert d.max() == 0   # deterministic, also with light splats
 
 
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs a SmallVCM checkout)")
+@pytest.mark.parametrize("algo,name", [(5, "pt"), (6, "el")])
+def test_reference_driver_runs_path_tracer_and_eye_light_on_the_gpu(tmp_path, algo, name):
+    """`-a pt` / `-a el` of the unchanged driver over dropin/pathtracer.hxx / eyelight.hxx"""
+    out = str(tmp_path / ("img_%s.hdr" % name))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(["taskset", "-c", "0", DROPIN, "-s", "0", "-a", name, "-i", "2", "-o", out], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = _read_hdr(out)
+    # one host core => render() creates one renderer (smallvcm.cxx:66, :280), seed 1234, iterations 0 and 1
+    v = VertexCM(cornell_scene(0, 512, 512), algo, 0.003, 0.75, 1234)
+    v.mMaxPathLength, v.mMinPathLength = 10, 0
+    v.RunIteration(0)
+    v.RunIteration(1)
+    mine = _rgbe(v.GetFramebuffer())
+    v.close()
+    assert np.array_equal(img, mine)
+
+
 def test_no_gpu_error_path_is_loud(tmp_path):
     if not os.path.exists(DROPIN):
         pytest.skip("drop-in binary not built")

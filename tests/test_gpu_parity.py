@@ -193,3 +193,55 @@ def test_full_size_rows_equal_oracle(sid, algo, res, stride):
         assert st[k] == ost[k], k
     olc, _ = o.counts()
     assert np.array_equal(lc, olc)
+
+
+# ---- the reference's two other renderers on the GPU (SURVEY section 8(f) "next" #2) ----------------------------------
+SIMPLE_CASES = [(sid, algo, 96, 3, 0, 10) for sid in range(4) for algo in (5, 6)] + [
+    (1, 5, 200, 2, 0, 10), (0, 5, 64, 1, 2, 5), (3, 5, 64, 1, 0, 1), (1, 5, 130, 1, 0, 3), (2, 5, 8, 1, 0, 10)]
+
+
+@pytest.mark.parametrize("sid,algo,res,nit,mn,mx", SIMPLE_CASES)
+def test_path_tracer_and_eye_light_equal_oracle_and_reference(sid, algo, res, nit, mn, mx):
+    """PathTracer::RunIteration (pathtracer.hxx:45-215) and EyeLight::RunIteration (eyelight.hxx:46-77) through the
+    same C-ABI (VCM_ALGO_PATH_TRACE / VCM_ALGO_EYE_LIGHT): tape, counters and framebuffer bit-exact against the
+    oracle, and the GPU's tape replayed into the unmodified reference classes gives the same image."""
+    sc = cornell_scene(sid, res, res)
+    o = Oracle(sc, algo, threads=8)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r.mMinPathLength, r.mMaxPathLength = mn, mx
+    lcs, ccs = [], []
+    for it in range(nit):
+        o.run_iteration(it, mn, mx)
+        r.RunIteration(it)
+        lc, cc = r.backend.rng_counts()
+        olc, occ = o.counts()
+        assert lc.max() == 0 and np.array_equal(cc, occ), "camera tape"
+        lcs.append(lc)
+        ccs.append(cc)
+        so, sg = o.stats(), r.stats()
+        for k in ("lightVertices", "cameraRays", "shadowRays", "mergeQueries", "connections", "lightSplats"):
+            assert so[k] == sg[k], (k, so[k], sg[k])
+    fb = r.framebuffer_sum()
+    assert np.array_equal(fb.view(np.uint32), o.framebuffer().view(np.uint32))
+    assert fb.max() > 0 or mx == 1   # maxPathLength 1 sees only directly visible emitters: none in scene 3
+    if oracle_lib.have_ref():
+        ref, consumed, bad = oracle_lib.ref_run_tape(SCENE_CONFIGS[sid], res, res, algo, np.concatenate(lcs),
+                                                     np.concatenate(ccs), n_iter=nit, min_len=mn, max_len=mx)
+        assert bad == 0 and consumed == int(np.concatenate(ccs).sum())
+        assert np.array_equal(fb.view(np.uint32), ref.view(np.uint32))
+    r.close()
+
+
+def test_path_tracer_converges_to_the_vcm_image():
+    """Independent estimators of the same image (the cross-check SURVEY 8(f) asks the GPU path tracer for)."""
+    sc = cornell_scene(1, 128, 128)
+    imgs = {}
+    for algo, n in ((5, 64), (4, 24)):
+        r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+        r.mMaxPathLength = 10
+        for it in range(n):
+            r.RunIteration(it)
+        imgs[algo] = r.GetFramebuffer()
+        r.close()
+    a, b = imgs[5].mean(axis=(0, 1)), imgs[4].mean(axis=(0, 1))
+    assert np.all(np.abs(a - b) < 0.03 * b), (a, b)

@@ -49,7 +49,10 @@ needs_ref = pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref no
 @needs_ref
 @pytest.mark.parametrize("sid,algo,res,nit,mn,mx,threads", [
     (1, 4, 128, 2, 0, 10, 4), (3, 4, 96, 2, 0, 10, 1), (0, 4, 96, 1, 0, 10, 4), (2, 4, 96, 1, 0, 10, 4),
-    (1, 2, 96, 1, 0, 10, 4), (1, 3, 64, 2, 1, 7, 1), (2, 1, 64, 2, 0, 10, 4), (0, 0, 64, 1, 0, 10, 1)])
+    (1, 2, 96, 1, 0, 10, 4), (1, 3, 64, 2, 1, 7, 1), (2, 1, 64, 2, 0, 10, 4), (0, 0, 64, 1, 0, 10, 1),
+    # PathTracer (pathtracer.hxx) and EyeLight (eyelight.hxx; iteration 1 draws no jitter) behind the same interface
+    (0, 5, 96, 2, 0, 10, 4), (1, 5, 96, 1, 0, 10, 4), (2, 5, 64, 1, 0, 10, 1), (3, 5, 96, 2, 0, 10, 4), (1, 5, 64, 1, 2, 5, 1),
+    (0, 6, 64, 3, 0, 10, 4), (3, 6, 64, 2, 0, 10, 1)])
 def test_oracle_matches_live_reference(sid, algo, res, nit, mn, mx, threads):
     mask = SCENE_CONFIGS[sid]
     sc = ref_scene(mask, res, res)
