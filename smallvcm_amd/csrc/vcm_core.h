@@ -295,30 +295,6 @@ VCM_HD float pdf_a_to_w(float pdfA, float dist, float cosThere)
 }
 
 /* ---- geometry.hxx ------------------------------------------------- */
-VCM_HD bool tri_intersect(const vcm_prim &t, const Ray &ray, Isect &res)
-{   /* Triangle::Intersect :125-156 */
-    const V3 ao = ld3(t.p0) - ray.org;
-    const V3 bo = ld3(t.p1) - ray.org;
-    const V3 co = ld3(t.p2) - ray.org;
-    const V3 v0 = cross(co, bo);
-    const V3 v1 = cross(bo, ao);
-    const V3 v2 = cross(ao, co);
-    const float v0d = dot(v0, ray.dir);
-    const float v1d = dot(v1, ray.dir);
-    const float v2d = dot(v2, ray.dir);
-    if (((v0d < 0.f) && (v1d < 0.f) && (v2d < 0.f)) ||
-        ((v0d >= 0.f) && (v1d >= 0.f) && (v2d >= 0.f))) {
-        const V3 n = ld3(t.n);
-        const float distance = dot(n, ao) / dot(n, ray.dir);
-        if ((distance > ray.tmin) && (distance < res.dist)) {
-            res.normal = n;
-            res.matID = t.matID;
-            res.dist = distance;
-            return true;
-        }
-    }
-    return false;
-}
 VCM_HD bool sph_intersect(const vcm_prim &s, const Ray &ray, Isect &res)
 {   /* Sphere::Intersect :198-237.  The discriminant is evaluated in float and
        only then widened (:211); sqrt, q, t0, t1 are double (:216-220). */
@@ -348,7 +324,7 @@ VCM_HD bool sph_intersect(const vcm_prim &s, const Ray &ray, Isect &res)
 /* Triangle::Intersect (:125-156) for the two triangles of a pair: the edge
  * functions and the plane distance of both are evaluated with packed
  * operations, then the two closest-hit updates are applied in list order
- * (exactly what two consecutive calls of tri_intersect do). */
+ * (exactly what two consecutive calls of Triangle::Intersect do). */
 VCM_HD bool tri_pair_intersect(const TriPair &t, const Ray &ray, Isect &res)
 {
     const f2 ox = f2_sp(ray.org.x), oy = f2_sp(ray.org.y), oz = f2_sp(ray.org.z);
@@ -1041,24 +1017,6 @@ VCM_HD int grid_cell_of_point(V3 p, V3 bboxMin, float invCellSize, int nCells)
     return grid_cell_hash(int(fx), int(fy), int(fz), nCells);
 }
 
-/* RangeQuery::Process vertexcm.hxx:130-169 for one accepted photon */
-VCM_HD void merge_photon(const vcm_scene_desc &sc, const IterParams &P, const Bsdf &cameraBsdf,
-                         const SubPathState &st, uint32_t lvLen, V3 lightDirection, float lvContProb,
-                         V3 lvThroughput, float lvdVCM, float lvdVM, V3 &contrib)
-{
-    if ((lvLen + st.pathLength > P.maxLen) || (lvLen + st.pathLength < P.minLen)) return;
-    float cosCamera, cameraBsdfDirPdfW, cameraBsdfRevPdfW;
-    const V3 cameraBsdfFactor = bsdf_evaluate(cameraBsdf, sc, lightDirection, cosCamera, &cameraBsdfDirPdfW,
-                                              &cameraBsdfRevPdfW);
-    if (iszero(cameraBsdfFactor)) return;
-    cameraBsdfDirPdfW *= cameraBsdf.contProb;
-    cameraBsdfRevPdfW *= lvContProb;
-    const float wLight = lvdVCM * P.misVcWeightFactor + lvdVM * mis(cameraBsdfDirPdfW);
-    const float wCamera = st.dVCM * P.misVcWeightFactor + st.dVM * mis(cameraBsdfRevPdfW);
-    const float misWeight = P.ppm ? 1.f : 1.f / (wLight + 1.f + wCamera);
-    contrib = contrib + misWeight * cameraBsdfFactor * lvThroughput;
-}
-
 /* wave-level "any lane" (one lane on the host build) */
 VCM_HD bool wave_any(bool x)
 {
@@ -1082,7 +1040,7 @@ struct MergeScratch { uint32_t *q; int stride; };
  * BSDF::Evaluate (bsdf.hxx:128-153, :393-446) that does not depend on the
  * photon, computed once per query.  The per-photon part below performs the
  * remaining operations of the reference in the same order on the same values,
- * so the sum is bit-identical to evaluating bsdf_evaluate()/merge_photon() per
+ * so the sum is bit-identical to evaluating bsdf_evaluate() per
  * photon (the material would otherwise be re-fetched with a lane-varying index
  * for every accepted photon). */
 struct MergeEval {
