@@ -1,0 +1,151 @@
+// vcm_render.cpp -- a C++ host over the C-ABI alone (include/smallvcm_amd.h; no
+// reference headers, no Python): the driver options the reference's CLI does not
+// expose.  smallvcm.cxx hard-wires 512x512, seed 1234,
+// path lengths 0..10, one renderer per host core and CPU-seconds timing
+// (src/config.hxx:233-240, src/smallvcm.cxx:66, :150); the benchmark and parity
+// configurations need other resolutions, a fixed renderer count, raw fp32
+// output and wall-clock time.
+//
+//   vcm_render -s <scene 0..3> -a <el|pt|lt|ppm|bpm|bpt|vcm> -i <iterations>
+//              [--res W H] [--seed S] [--minlen A] [--maxlen B]
+//              [--renderers R] [--radius-factor F] [--radius-alpha A]
+//              [--device D] [--strict] [--warmup W] [-o out.pfm] [--json]
+//
+// -s / -a / -i keep the meaning they have in the reference's CLI
+// (src/config.hxx:246-395; scenes = g_SceneConfigs[0..3], :146-151).
+// --renderers R reproduces render() (src/smallvcm.cxx:52-151) with R "threads":
+// renderer g has seed S+g and runs the iterations OpenMP's static schedule gives
+// thread g; the image is the mean of the used renderers' means.  -o writes the
+// averaged framebuffer as PFM exactly like Framebuffer::SavePFM
+// (src/framebuffer.hxx:137-146: "PF", "W H", "-1", rows top to bottom).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "smallvcm_amd.h"
+
+static int die(const char *what)
+{
+    fprintf(stderr, "vcm_render: %s: %s\n", what, vcm_last_error());
+    return 2;   // the reference's convention for fatal errors (src/config.hxx:140-141)
+}
+
+static int algorithm_by_acronym(const std::string &a)
+{   // Config::GetAcronym, src/config.hxx:86-91
+    if (a == "el") return VCM_ALGO_EYE_LIGHT;
+    if (a == "pt") return VCM_ALGO_PATH_TRACE;
+    if (a == "lt") return VCM_ALGO_LIGHT_TRACE;
+    if (a == "ppm") return VCM_ALGO_PPM;
+    if (a == "bpm") return VCM_ALGO_BPM;
+    if (a == "bpt") return VCM_ALGO_BPT;
+    if (a == "vcm") return VCM_ALGO_VCM;
+    return -1;
+}
+
+int main(int argc, char **argv)
+{
+    int sceneID = 0, algorithm = VCM_ALGO_VCM, iterations = 1, resX = 512, resY = 512, seed = 1234;   // config.hxx:233-240
+    unsigned minLen = 0, maxLen = 10;
+    int renderers = 1, device = 0, warmup = 0, strict = 0, json = 0;
+    float radiusFactor = 0.003f, radiusAlpha = 0.75f;
+    std::string out, algoName = "vcm";
+    for (int i = 1; i < argc; i++) {
+        const std::string a(argv[i]);
+        auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "vcm_render: %s needs %d argument(s)\n", a.c_str(), n); exit(2); } };
+        if (a == "-s") { need(1); sceneID = atoi(argv[++i]); }
+        else if (a == "-a") { need(1); algoName = argv[++i]; algorithm = algorithm_by_acronym(algoName); }
+        else if (a == "-i") { need(1); iterations = atoi(argv[++i]); }
+        else if (a == "-o") { need(1); out = argv[++i]; }
+        else if (a == "--res") { need(2); resX = atoi(argv[++i]); resY = atoi(argv[++i]); }
+        else if (a == "--seed") { need(1); seed = atoi(argv[++i]); }
+        else if (a == "--minlen") { need(1); minLen = (unsigned)atoi(argv[++i]); }
+        else if (a == "--maxlen") { need(1); maxLen = (unsigned)atoi(argv[++i]); }
+        else if (a == "--renderers") { need(1); renderers = atoi(argv[++i]); }
+        else if (a == "--radius-factor") { need(1); radiusFactor = (float)atof(argv[++i]); }
+        else if (a == "--radius-alpha") { need(1); radiusAlpha = (float)atof(argv[++i]); }
+        else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+        else if (a == "--warmup") { need(1); warmup = atoi(argv[++i]); }
+        else if (a == "--strict") strict = 1;
+        else if (a == "--json") json = 1;
+        else { fprintf(stderr, "vcm_render: unknown option %s (see the header of vcm_render.cpp)\n", a.c_str()); return 2; }
+    }
+    if (algorithm < 0 || sceneID < 0 || sceneID > 3 || iterations < 1 || resX < 1 || resY < 1 || renderers < 1) {
+        fprintf(stderr, "vcm_render: invalid argument\n");
+        return 2;
+    }
+
+    vcm_scene_desc scene;
+    if (vcm_scene_cornell(resX, resY, vcm_scene_config_mask(sceneID), &scene)) return die("vcm_scene_cornell");
+
+    // render(): one renderer per "thread", seed base + i (smallvcm.cxx:61-72)
+    std::vector<vcm_ctx *> r((size_t)renderers, (vcm_ctx *)NULL);
+    for (int g = 0; g < renderers; g++) {
+        r[g] = vcm_create_sharded(&scene, algorithm, radiusFactor, radiusAlpha, seed + g, device, 0, 1);
+        if (!r[g]) return die("vcm_create");
+        if (strict && vcm_set_strict_order(r[g], 1)) return die("vcm_set_strict_order");
+    }
+    // untimed warm-up on a throw-away renderer: allocations, first-launch costs
+    if (warmup > 0) {
+        vcm_ctx *w = vcm_create_sharded(&scene, algorithm, radiusFactor, radiusAlpha, seed, device, 0, 1);
+        if (!w) return die("vcm_create");
+        for (int it = 0; it < warmup; it++) if (vcm_run_iteration(w, it, minLen, maxLen)) return die("vcm_run_iteration");
+        vcm_synchronize(w);
+        vcm_destroy(w);
+    }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    // static schedule of `#pragma omp parallel for` (smallvcm.cxx:98-108): contiguous blocks, the first
+    // iterations % renderers threads get one more
+    const int q = iterations / renderers, rem = iterations % renderers;
+    for (int g = 0; g < renderers; g++) {
+        const int lo = g * q + (g < rem ? g : rem), n = q + (g < rem ? 1 : 0);
+        for (int it = lo; it < lo + n; it++)
+            if (vcm_run_iteration(r[g], it, minLen, maxLen)) return die("vcm_run_iteration");
+    }
+    for (int g = 0; g < renderers; g++) if (vcm_synchronize(r[g])) return die("vcm_synchronize");
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    // accumulate the used renderers: mean of (running sum / own iterations), smallvcm.cxx:116-142
+    const size_t n3 = (size_t)resX * resY * 3;
+    std::vector<float> fb(n3, 0.f), tmp(n3);
+    int used = 0;
+    for (int g = 0; g < renderers; g++) {
+        const int its = vcm_iterations(r[g]);
+        if (its == 0) continue;                       // WasUsed(), renderer.hxx:58
+        if (vcm_read_framebuffer(r[g], tmp.data())) return die("vcm_read_framebuffer");
+        const float s = 1.f / its;                    // renderer.hxx:53-54
+        if (used == 0) for (size_t i = 0; i < n3; i++) fb[i] = tmp[i] * s;
+        else for (size_t i = 0; i < n3; i++) fb[i] = fb[i] + tmp[i] * s;   // Framebuffer::Add, framebuffer.hxx:75-79
+        used++;
+    }
+    const float su = 1.f / used;                      // Framebuffer::Scale, smallvcm.cxx:142
+    for (size_t i = 0; i < n3; i++) fb[i] = fb[i] * su;
+
+    vcm_stats st;
+    memset(&st, 0, sizeof(st));
+    vcm_get_stats(r[0], &st);
+    for (int g = 0; g < renderers; g++) vcm_destroy(r[g]);
+
+    if (!out.empty()) {   // Framebuffer::SavePFM, framebuffer.hxx:137-146
+        FILE *f = fopen(out.c_str(), "wb");
+        if (!f) { fprintf(stderr, "vcm_render: cannot write %s\n", out.c_str()); return 2; }
+        fprintf(f, "PF\n%d %d\n-1\n", resX, resY);
+        fwrite(fb.data(), sizeof(float), n3, f);
+        fclose(f);
+    }
+    double mean[3] = { 0, 0, 0 };
+    for (size_t i = 0; i < n3; i++) mean[i % 3] += fb[i];
+    const double paths = (algorithm == VCM_ALGO_PATH_TRACE || algorithm == VCM_ALGO_EYE_LIGHT ? 1.0 : 2.0) * resX * resY * iterations;
+    if (json)
+        printf("{\"scene\": %d, \"algorithm\": \"%s\", \"res\": [%d, %d], \"iterations\": %d, \"renderers\": %d, \"seed\": %d, "
+               "\"wall_s\": %.6f, \"Mpaths_s\": %.3f, \"image_mean\": [%.6f, %.6f, %.6f], \"last_iteration_ms\": %.3f}\n",
+               sceneID, algoName.c_str(), resX, resY, iterations, renderers, seed, wall, paths / wall / 1e6,
+               mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal);
+    else
+        printf("scene %d, %s, %dx%d, %d iteration(s) on %d renderer(s): %.3f s wall clock, %.2f Mpaths/s\n", sceneID,
+               algoName.c_str(), resX, resY, iterations, renderers, wall, paths / wall / 1e6);
+    return 0;
+}

@@ -316,3 +316,53 @@ def test_rccl_plumbing_with_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_single_rank.py"), str(port)], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- the C++ host over the C-ABI alone (smallvcm_amd/host/vcm_render.cpp) ------------------------------------------
+HOST = os.path.join(ROOT, "smallvcm_amd", "host", "vcm_render")
+
+
+def _read_pfm(path):
+    raw = open(path, "rb").read()
+    a, b, c, data = raw.split(b"\n", 3)
+    w, h = (int(x) for x in b.split())
+    assert a == b"PF" and c == b"-1"   # Framebuffer::SavePFM, framebuffer.hxx:137-146
+    return np.frombuffer(data, np.float32).reshape(h, w, 3)
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="vcm_render not built")
+@pytest.mark.parametrize("name,algo,renderers,iters", [("vcm", 4, 2, 5), ("bpm", 2, 1, 2), ("pt", 5, 3, 4)])
+def test_cpp_host_equals_python_host(tmp_path, name, algo, renderers, iters):
+    """non-square resolution, seed, path-length window and renderer count from the command line; raw fp32 PFM"""
+    import json
+    out = str(tmp_path / "img.pfm")
+    r = subprocess.run([HOST, "-s", "1", "-a", name, "-i", str(iters), "--res", "96", "72", "--seed", "77", "--minlen", "1",
+                        "--maxlen", "6", "--renderers", str(renderers), "-o", out, "--json"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["res"] == [96, 72] and info["Mpaths_s"] > 0
+    img = _read_pfm(out)
+    sc = cornell_scene(1, 96, 72)
+    acc, used = None, 0
+    for g in range(renderers):
+        its = static_schedule(iters, renderers, g)
+        if len(its) == 0:
+            continue
+        v = VertexCM(sc, algo, 0.003, 0.75, 77 + g)
+        v.mMinPathLength, v.mMaxPathLength = 1, 6
+        for it in its:
+            v.RunIteration(it)
+        f = v.framebuffer_sum() * np.float32(1.0 / len(its))
+        acc = f if acc is None else acc + f
+        used += 1
+        v.close()
+    ref = acc * np.float32(1.0 / used)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert abs(info["image_mean"][0] - float(ref[..., 0].mean())) < 1e-4
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="vcm_render not built")
+def test_cpp_host_rejects_bad_arguments():
+    r = subprocess.run([HOST, "-a", "nope"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
