@@ -52,7 +52,8 @@ struct Scratch {
     F4 *dSplat;                       /* S*nLocal: splat of each light vertex (rgb | pixel) */
     float *dRecordsAll;               /* S*N records (multi-rank only) */
     int *dCellCount, *dCellStart;     /* N+2 each */
-    int *dCellId, *dUnsorted;         /* per record */
+    int *dCellId;                     /* per record */
+    I4 *dUnsorted;                    /* per record: {index, slot, cell} list entries, grouped by cell (also K1d scratch) */
     float *dGx, *dGy, *dGz; F4 *dG1, *dG2; F2 *dG3;
     int *dSortedIndex;                /* parity: grid position -> record index */
     F4 *dCamOut;                      /* nLocal */
@@ -158,7 +159,7 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
     DFREE(s.vs.q0); DFREE(s.vs.q1); DFREE(s.vs.q2); DFREE(s.vs.q3); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
-    DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.pathVertex); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
+    DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
     DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryArrival);
     a->allocated = false;
     a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
@@ -202,7 +203,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const size_t vcslots = vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
     if (dalloc(&s.vs.q0, vslots) || dalloc(&s.vs.q1, vslots) || dalloc(&s.vs.q2, vslots) ||
         dalloc(&s.vs.q3, vslots) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
-        dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.pathVertex, vslots) || dalloc(&s.vs.diOut, vslots) ||
+        dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.diOut, vslots) ||
         dalloc(&s.vs.mergeOut, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
         dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;
     const size_t qsN = (cn > (size_t)VCM_QSORT_BUCKETS ? cn : (size_t)VCM_QSORT_BUCKETS) + 2;   /* also pixStart of K1d */
@@ -503,7 +504,7 @@ static int flush_light_splats(vcm_ctx *c)
     c->splatsPending = false;
     {
         /* scratch shared with the grid build / query sort, which run later */
-        int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart, *list = c->dUnsorted;
+        int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart, *list = (int *)c->dUnsorted;
         HIPCHK(hipMemsetAsync(pixCount, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
@@ -653,9 +654,10 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         HIPCHK(hipGetLastError());
         if (launch_scan<int>(c, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
         hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
-                           (const int *)c->dSortedIndex, (const int *)c->dCellStart, c->dUnsorted);
+                           (const int *)c->dSortedIndex, (const int *)c->dCellStart,
+                           recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
         hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, c->stream, (const GridHeader *)c->dHdr, recs,
-                           (const int *)c->dCellId, (const int *)c->dCellStart, (const int *)c->dUnsorted, c->dGx,
+                           (const int *)c->dCellStart, (const I4 *)c->dUnsorted, c->dGx,
                            c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
         HIPCHK(hipGetLastError());
     }
@@ -744,7 +746,7 @@ static int vcm_merge_impl(vcm_ctx *c)
         }
         HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
         /* K5 */
-        hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
+        hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb);
         HIPCHK(hipGetLastError());
     }

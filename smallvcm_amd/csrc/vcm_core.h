@@ -93,15 +93,21 @@ struct VertexStore {
     F4 *q2;          /* localDirFix.xyz | dVCM                                   */
     F4 *q3;          /* throughput.xyz | dVM                                     */
     F4 *q4;          /* dVC | the 3 random floats of DirectIllumination (:672-673) */
-    I4 *meta;        /* DI task (-1: none) | first VC task | number of VC tasks | 0 */
+    I4 *meta;        /* per PATH SLOT: DI task (-1: none) | first VC task | number of VC tasks | 0 */
     int *count;      /* [0] vertices  [1] DI tasks  [2] VC tasks                  */
     int *diTask;     /* DI task -> vertex                                         */
     int *vcTask;     /* VC task -> (vertex, index j of the light vertex)          */
-    int *pathVertex; /* (pathLength-1)*nLocal + lp -> vertex                      */
-    F4 *diOut;       /* per DI task:  throughput * DirectIllumination()  (:491)   */
-    F4 *vcOut;       /* per VC task:  throughput * lvThroughput * ConnectVertices() (:523) */
-    F4 *mergeOut;    /* per vertex:   throughput * vmNormalization * contrib (:534) */
+    /* What k_resolve reads per vertex is indexed by the vertex's PATH SLOT (pathLength-1)*nLocal + lp, not by its
+       queue position: lanes of k_resolve hold neighbouring paths, so these reads coalesce (the queue order is the
+       order in which waves happened to append). */
+    F4 *diOut;       /* per path slot: throughput * DirectIllumination()  (:491)   */
+    F4 *vcOut;       /* per VC task:   throughput * lvThroughput * ConnectVertices() (:523) */
+    F4 *mergeOut;    /* per path slot: throughput * vmNormalization * contrib (:534) */
 };
+VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
+{
+    return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
+}
 
 struct LaneStats {
     uint32_t lightRays, cameraRays, shadowRays, mergeQueries, mergeCandidates, mergeAccepted,
@@ -1421,7 +1427,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
             vs.q3[vi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
             vs.q4[vi] = mk4(st.dVC, u2f(diK), 0.f, 0.f);
             I4 m; m.x = hasDI ? di : -1; m.y = vc0; m.z = nvc; m.w = 0;
-            vs.meta[vi] = m;
+            vs.meta[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = m;
             if (hasDI) vs.diTask[di] = vi;
             int t = vc0;
             while (jmask) {
@@ -1431,7 +1437,6 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
                 vs.vcTask[2 * t + 1] = j;
                 t++;
             }
-            vs.pathVertex[(size_t)(st.pathLength - 1u) * (size_t)P.nLocal + (size_t)cp.lp] = vi;
             cp.queryMask |= 1u << st.pathLength;
             if (P.useVM) {
                 ls.mergeQueries++;
@@ -1497,10 +1502,12 @@ VCM_HD void load_cam_vertex(const vcm_scene_desc &sc, const VertexStore &vs, int
     v.diK = f2u(e.y);
 }
 /* the addend of :491  (color += throughput * DirectIllumination(...)) */
-VCM_HD V3 eval_di_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls)
+VCM_HD V3 eval_di_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls,
+                       size_t &pathSlot)
 {
     CamVertex v;
     load_cam_vertex(sc, vs, vi, v);
+    pathSlot = path_slot(P, v.st.pathLength, v.lp);
     PathRng rng;
     rng_init(rng, P.seed, P.localIter, (uint32_t)(P.p0 + (int)v.lp), 1u);
     float rnd[3];
@@ -1522,9 +1529,10 @@ VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const Vert
 }
 /* the addend of :534  (color += throughput * mVmNormalization * query.GetContrib()) */
 VCM_HD V3 eval_merge_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
-                          int vi, LaneStats &ls, const MergeScratch &ms)
+                          int vi, LaneStats &ls, const MergeScratch &ms, size_t &pathSlot)
 {
     const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+    pathSlot = path_slot(P, f2u(b.w) & 0xffu, f2u(a.w));
     Bsdf bsdf;
     bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (int)((f2u(b.w) >> 8) & 0xffu), sc);
     SubPathState st;
@@ -1542,11 +1550,11 @@ VCM_HD V3 replay_path_color(const IterParams &P, const VertexStore &vs, int lp, 
     while (mask) {
         const int L = __builtin_ctz(mask);
         mask &= mask - 1u;
-        const int vi = vs.pathVertex[(size_t)(L - 1) * (size_t)P.nLocal + (size_t)lp];
-        const I4 m = vs.meta[vi];
-        if (m.x >= 0) { const F4 t = vs.diOut[m.x]; color = color + mk3(t.x, t.y, t.z); }
+        const size_t ps = path_slot(P, (uint32_t)L, (uint32_t)lp);
+        const I4 m = vs.meta[ps];
+        if (m.x >= 0) { const F4 t = vs.diOut[ps]; color = color + mk3(t.x, t.y, t.z); }
         for (int k = 0; k < m.z; k++) { const F4 t = vs.vcOut[m.y + k]; color = color + mk3(t.x, t.y, t.z); }
-        if (P.useVM) { const F4 t = vs.mergeOut[vi]; color = color + mk3(t.x, t.y, t.z); }
+        if (P.useVM) { const F4 t = vs.mergeOut[ps]; color = color + mk3(t.x, t.y, t.z); }
     }
     return color + emission;
 }

@@ -208,8 +208,9 @@ k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
         const int vi = vs.diTask[t];
         if (vi < 0) continue;   /* hole */
-        const V3 v = eval_di_task(sc, P, vs, vi, ls);
-        vs.diOut[t] = mk4(v.x, v.y, v.z, 0.f);
+        size_t ps;
+        const V3 v = eval_di_task(sc, P, vs, vi, ls, ps);
+        vs.diOut[ps] = mk4(v.x, v.y, v.z, 0.f);
     }
     flush_stats(ls, gstats);
 }
@@ -240,7 +241,10 @@ k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
  * unrelated and K4 re-fetched ~10x the photon data from HBM.  The order inside
  * a key is arbitrary (atomics) and does not matter: every vertex has its own
  * output slot. */
-#define VCM_QSORT_BITS 8                       /* per axis */
+#ifndef VCM_QSORT_BITS
+#define VCM_QSORT_BITS 8
+#endif
+//                       /* per axis */
 #define VCM_QSORT_BUCKETS (1 << (3 * VCM_QSORT_BITS))
 
 __device__ __forceinline__ uint32_t morton_part(uint32_t x)
@@ -281,7 +285,8 @@ __global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__
         int k = -1;
         if (f2u(r0.w) != 0xffffffffu) {
             k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
-            if (k < 0) vs.mergeOut[q] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query: contrib = 0 */
+            if (k < 0)   /* empty query: contrib = 0 */
+                vs.mergeOut[path_slot(P, f2u(vs.q1[q].w) & 0xffu, f2u(r0.w))] = mk4(0.f, 0.f, 0.f, 0.f);
         }
         key[q] = k;
         /* the value the atomic returns is the vertex's place in its bucket: the scatter needs no second atomic */
@@ -336,8 +341,9 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
         const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
         if (q < nQ) {
             const int vi = sortedVertex[q];
-            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms);
-            vs.mergeOut[vi] = mk4(v.x, v.y, v.z, 0.f);
+            size_t ps;
+            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms, ps);
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -624,13 +630,17 @@ __global__ void k_cell_count(IterParams P, VertexSource src, const GridHeader *_
     }
 }
 
+/* list entry of a cell: everything k_cell_rank_gather needs about the vertex, in one 16-byte element -- one random
+ * write here instead of three dependent random 4-byte reads (cell id, slot, then the data) per vertex there */
 __global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__restrict__ cellId,
-                               const int *__restrict__ arrival, const int *__restrict__ cellStart, int *unsorted)
+                               const int *__restrict__ arrival, const int *__restrict__ cellStart,
+                               const int *__restrict__ slotOfVertex /* NULL: records */, I4 *unsorted)
 {   /* :83-88, but in arbitrary order inside a cell; k_cell_rank_gather restores the order */
     const int n = hdr->nRecords;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int cell = cellId[i];
-        unsorted[cellStart[cell] + arrival[i]] = i;
+        I4 e; e.x = i; e.y = slotOfVertex ? slotOfVertex[i] : i; e.z = cell; e.w = 0;
+        unsorted[cellStart[cell] + arrival[i]] = e;
     }
 }
 
@@ -641,17 +651,16 @@ __global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__
  * position, so the query reads contiguous, cell-sorted memory and needs no
  * mIndices indirection. */
 __global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, VertexSource src,
-                                   const int *__restrict__ cellId, const int *__restrict__ cellStart,
-                                   const int *__restrict__ unsorted, float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3,
-                                   int *sortedIndex)
+                                   const int *__restrict__ cellStart, const I4 *__restrict__ unsorted,
+                                   float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3, int *sortedIndex)
 {
     const int n = hdr->nRecords;
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
-        const int i = unsorted[pos];
-        const int cell = cellId[i];
+        const I4 me = unsorted[pos];
+        const int i = me.x, cell = me.z;
         const int lo = cellStart[cell], hi = cellStart[cell + 1];
         int rank = 0;
-        for (int q = lo; q < hi; q++) rank += (unsorted[q] < i) ? 1 : 0;
+        for (int q = lo; q < hi; q++) rank += (unsorted[q].x < i) ? 1 : 0;
         const int dst = lo + rank;
         F2 t;
         if (src.records) {
@@ -661,7 +670,7 @@ __global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, VertexSou
             g2[dst] = mk4(r[6], r[7], r[8], r[9]);
             t.x = r[10]; t.y = r[12];
         } else {   /* the same 13 values k_compact_records would have written */
-            const size_t slot = (size_t)src.slotOfVertex[i];
+            const size_t slot = (size_t)me.y;
             const F4 a = lv(src.store, slot, 0), b = lv(src.store, slot, 1), d = lv(src.store, slot, 3), e = lv(src.store, slot, 4);
             gx[dst] = a.x; gy[dst] = a.y; gz[dst] = a.z;
             g1[dst] = e;
