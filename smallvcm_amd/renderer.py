@@ -314,18 +314,32 @@ class ShardedVertexCM:
         self.mIterations = 0
         self._gather = None
         self._local = None
+        self._pending = None
 
     def RunIteration(self, aIteration):
+        self.start_iteration(aIteration)
+        self.finish_iteration()
+
+    # An iteration in two host-side halves, so that a scheduler (RenderFarm) can keep TWO renderers in flight on
+    # the same GPUs: everything here only enqueues work (kernels on the context's stream, the all-gather on RCCL's),
+    # so while one renderer's records cross xGMI the GPU runs the other renderer's kernels.
+    def start_iteration(self, aIteration):
+        """light pass, start of the exchange, and the part of the camera pass that does not need the grid"""
         with self.backend.stream_context():
-            self._run_iteration(aIteration)
+            self._start(aIteration)
+
+    def finish_iteration(self):
+        """wait for the exchange, grid build, merge, resolve"""
+        with self.backend.stream_context():
+            self._finish()
         self.mIterations += 1
 
-    def _run_iteration(self, aIteration):
+    def _start(self, aIteration):
         import torch
         b, dist = self.backend, self.dist
         b.begin(aIteration, self.mMinPathLength, self.mMaxPathLength)
         b.trace_light()
-        work = None
+        work = counts = stride = gathered = None
         if self.world > 1:
             n_local = b.local_record_count()
             # 1) counts (tiny all-gather)
@@ -346,9 +360,16 @@ class ShardedVertexCM:
             b.export_records(local, n_local)
             overlap = getattr(b, "camera_before_grid", False)
             work = dist.all_gather_into_tensor(gathered, local, group=self.group, async_op=overlap)
-        early = work is not None and getattr(b, "camera_before_grid", False)
+        early = getattr(b, "camera_before_grid", False)
         if early:
             b.trace_camera()            # overlaps the all-gather
+        self._pending = (work, counts, stride, gathered, early)
+
+    def _finish(self):
+        b = self.backend
+        work, counts, stride, gathered, early = self._pending
+        self._pending = None
+        if work is not None and early:
             work.wait()
         if self.world > 1:
             b.import_records(gathered, counts, stride)
@@ -393,60 +414,100 @@ class RenderFarm:
 
     The reference creates one renderer per host thread, seed mBaseSeed + i (:66-72), hands each a
     block of iterations (:98-108), and averages the used renderers' framebuffers (:116-142).  Here a
-    "thread" is a GROUP of `shards` ranks: the world of W ranks (one per GPU) is cut into
-    R = W / shards replica groups; group g is one ShardedVertexCM with seed base + g whose `shards`
-    ranks split the paths of every iteration (RCCL all-gather of the light vertices inside the group).
-    shards = W is one renderer across all GPUs (minimum latency per iteration), shards = 1 is one
-    renderer per GPU (no per-iteration communication); the image is the same estimator either way.
-    The only world-wide collective is the framebuffer reduce at read-out.
+    "thread" is a renderer that lives on a GROUP of `shards` ranks: the world of W ranks (one per GPU) is
+    cut into W / shards groups; a renderer's ranks split the paths of every iteration (RCCL all-gather of
+    the light vertices inside the group).  shards = W is one renderer across all GPUs (minimum latency per
+    iteration), shards = 1 is one renderer per GPU (no per-iteration communication); the image is the same
+    estimator either way.  The only world-wide collective is the framebuffer reduce at read-out.
+
+    `inflight` renderers share each group and take turns (default 2 when shards > 1): every call of an
+    iteration half only ENQUEUES work, so while one renderer's 464 MB exchange crosses xGMI the GPUs run the
+    other renderer's kernels -- the exchange is hidden without any second buffer set inside a renderer.
+    Each in-flight renderer has its own process group (its own RCCL communicator): collectives of one
+    communicator execute in order, and the small count exchange of one renderer must not queue behind the
+    large all-gather of the other.  Renderer index = group * inflight + slot; R = (W / shards) * inflight.
 
     backend_factory(seed, shard_rank, shard_world) -> backend with HipBackend's phase interface.
     """
 
-    def __init__(self, backend_factory, base_seed, rank, world, shards=None, dist=None):
+    def __init__(self, backend_factory, base_seed, rank, world, shards=None, dist=None, inflight=None):
         if dist is None:
             import torch.distributed as dist
         shards = world if shards is None else int(shards)
         if shards < 1 or world % shards:
             raise ValueError("world size %d is not a multiple of %d shards" % (world, shards))
-        self.dist, self.rank, self.world, self.shards = dist, rank, world, shards
-        self.replicas = world // shards
-        self.replica, self.shard = rank // shards, rank % shards
-        self.group = None
-        if world > 1 and 1 < shards < world:
-            # every rank creates every group, in the same order (torch.distributed contract)
-            for g in range(self.replicas):
-                grp = dist.new_group(ranks=list(range(g * shards, (g + 1) * shards)))
-                if g == self.replica:
-                    self.group = grp
-        self.backend = backend_factory(base_seed + self.replica, self.shard, shards)
-        self.renderer = ShardedVertexCM(self.backend, self.shard, shards, group=self.group)
-        self.renderer.dist = dist
+        inflight = (2 if shards > 1 else 1) if inflight is None else int(inflight)
+        if inflight < 1:
+            raise ValueError("inflight must be >= 1")
+        self.dist, self.rank, self.world, self.shards, self.inflight = dist, rank, world, shards, inflight
+        self.groups = world // shards
+        self.replicas = self.groups * inflight          # renderers = the reference's "threads"
+        self.group_index, self.shard = rank // shards, rank % shards
+        self.renderers, self.renderer_ids = [], []
+        for g in range(self.groups):
+            for k in range(inflight):
+                grp = None
+                if world > 1 and shards > 1 and (shards < world or inflight > 1):
+                    # every rank creates every group, in the same order (torch.distributed contract)
+                    grp = dist.new_group(ranks=list(range(g * shards, (g + 1) * shards)))
+                if g != self.group_index:
+                    continue
+                rid = g * inflight + k
+                backend = backend_factory(base_seed + rid, self.shard, shards)   # smallvcm.cxx:68
+                r = ShardedVertexCM(backend, self.shard, shards, group=grp)
+                r.dist = dist
+                self.renderers.append(r)
+                self.renderer_ids.append(rid)
+        # first local renderer: what single-renderer callers (bench.py's per-kernel statistics) look at
+        self.renderer, self.backend = self.renderers[0], self.renderers[0].backend
+        self.replica = self.renderer_ids[0]
 
     def set_path_lengths(self, min_len, max_len):
-        self.renderer.mMinPathLength, self.renderer.mMaxPathLength = min_len, max_len   # smallvcm.cxx:70-71
+        for r in self.renderers:
+            r.mMinPathLength, r.mMaxPathLength = min_len, max_len   # smallvcm.cxx:70-71
+
+    def run_iterations(self, per_renderer):
+        """per_renderer[k] = the iteration indices of this rank's k-th renderer, in order.  Round-robin over the
+        in-flight renderers, one iteration half at a time (start all, then finish all)."""
+        for t in range(max(len(x) for x in per_renderer)):
+            live = [(r, its[t]) for r, its in zip(self.renderers, per_renderer) if t < len(its)]
+            for r, it in live:
+                r.start_iteration(it)
+            for r, _ in live:
+                r.finish_iteration()
 
     def render(self, n_iterations):
         """smallvcm.cxx:98-108 (iterations based loop)"""
-        for it in static_schedule(n_iterations, self.replicas, self.replica):
-            self.renderer.RunIteration(it)
+        self.run_iterations([list(static_schedule(n_iterations, self.replicas, rid)) for rid in self.renderer_ids])
 
     def framebuffer(self):
         """smallvcm.cxx:116-142: mean over the used renderers of (running sum / own iterations).
         One all_reduce over the whole world: the shards of a renderer hold partial sums of it."""
-        b, dist = self.backend, self.dist
-        with b.stream_context():
-            t = b.new_tensor(b.N * 3)
-            b.export_framebuffer(t)
-            used = t.new_tensor([1.0 if (self.renderer.WasUsed() and self.shard == 0) else 0.0])
-            if self.renderer.WasUsed():
-                t *= 1.0 / self.renderer.mIterations                                    # renderer.hxx:53-54
-            else:
-                t.zero_()
+        b0, dist = self.backend, self.dist
+        with b0.stream_context():
+            t = b0.new_tensor(b0.N * 3)
+            t.zero_()
+            n_used_local = 0.0
+            for r in self.renderers:
+                if not r.WasUsed():
+                    continue
+                with r.backend.stream_context():
+                    part = r.backend.new_tensor(b0.N * 3)
+                    r.backend.export_framebuffer(part)
+                    part *= 1.0 / r.mIterations                                         # renderer.hxx:53-54
+                    r.backend.synchronize()
+                t += part
+                if self.shard == 0:
+                    n_used_local += 1.0
+            used = t.new_tensor([n_used_local])
             if self.world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 dist.all_reduce(used, op=dist.ReduceOp.SUM)
             n_used = max(float(used.cpu()[0]), 1.0)
             t *= 1.0 / n_used                                                           # smallvcm.cxx:142
             out = t.cpu()
-        return out.numpy().reshape(b.resy, b.resx, 3)
+        return out.numpy().reshape(b0.resy, b0.resx, 3)
+
+    def close(self):
+        for r in self.renderers:
+            r.backend.close()

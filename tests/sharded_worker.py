@@ -1,6 +1,6 @@
 """Worker for tests/test_sharded_cpu.py: one rank of ShardedVertexCM over gloo,
 computing with the ORACLE as backend (test infrastructure; the product backend
-is HipBackend).  Usage: sharded_worker.py rank world port scene algo res iters out.npy [shards]
+is HipBackend).  Usage: sharded_worker.py rank world port scene algo res iters out.npy [shards [inflight]]
 With `shards` the rank is one member of a RenderFarm (world/shards replica groups)."""
 import contextlib
 import os
@@ -64,6 +64,12 @@ class OracleBackend:
         g = gathered.numpy().reshape(len(counts), stride, VCM_MERGE_RECORD_FLOATS)
         self.o.import_records(np.concatenate([g[s, :c] for s, c in enumerate(counts)], axis=0))
 
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass
+
     def export_framebuffer(self, dst):
         dst.copy_(torch.from_numpy(self.o.framebuffer().ravel()))
 
@@ -77,7 +83,7 @@ def main():
     sc = cornell_scene(sid, res, res)
     if len(sys.argv) > 9:
         farm = RenderFarm(lambda seed, s, S: OracleBackend(sc, algo, s, S, seed=seed), 1234, rank, world,
-                          shards=int(sys.argv[9]), dist=dist)
+                          shards=int(sys.argv[9]), dist=dist, inflight=int(sys.argv[10]) if len(sys.argv) > 10 else None)
         farm.set_path_lengths(0, 10)
         farm.render(iters)
         fb = farm.framebuffer()

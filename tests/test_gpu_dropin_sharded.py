@@ -112,8 +112,12 @@ class _ThreadCollectives:
         self.tls.rank = rank
 
     def new_group(self, ranks):
+        """every rank (thread) creates every group in the same order: the n-th call with these ranks is the same
+        communicator on all of them"""
+        seen = self.tls.__dict__.setdefault("created", {})
+        n = seen[tuple(ranks)] = seen.get(tuple(ranks), 0) + 1
         with self.lock:
-            return self.groups.setdefault(tuple(ranks), self._Group(ranks))
+            return self.groups.setdefault((tuple(ranks), n), self._Group(ranks))
 
     def _exchange(self, t, group):
         g = group or self.all
@@ -262,8 +266,9 @@ def test_interleaving_two_iterations_on_one_thread_is_refused_not_deadlocked():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("world,shards,algo,res,iters", [(4, 2, 4, 96, 5), (3, 1, 4, 64, 4)])
-def test_render_farm_on_one_gpu(world, shards, algo, res, iters):
+@pytest.mark.parametrize("world,shards,inflight,algo,res,iters", [(4, 2, 1, 4, 96, 5), (3, 1, 1, 4, 64, 4), (2, 2, 2, 4, 96, 5),
+                                                                  (4, 2, 2, 2, 64, 9)])
+def test_render_farm_on_one_gpu(world, shards, inflight, algo, res, iters):
     """RenderFarm (replica groups x path shards) with threads as ranks: equals the mean of the group renderers run
     alone with seeds base + g over their static-schedule iteration blocks (smallvcm.cxx:61-142)."""
     sc = cornell_scene(1, res, res)
@@ -274,11 +279,11 @@ def test_render_farm_on_one_gpu(world, shards, algo, res, iters):
         try:
             coll.bind(rank)
             farm = RenderFarm(lambda seed, s, S: HipBackend(sc, algo, 0.003, 0.75, seed, device=0, rank=s, world=S),
-                              1234, rank, world, shards=shards, dist=coll)
+                              1234, rank, world, shards=shards, dist=coll, inflight=inflight)
             farm.set_path_lengths(0, 10)
             farm.render(iters)
             results[rank] = farm.framebuffer()
-            farm.backend.close()
+            farm.close()
         except Exception as e:   # noqa: BLE001
             errors.append(repr(e))
             for g in [coll.all] + list(coll.groups.values()):
@@ -290,10 +295,11 @@ def test_render_farm_on_one_gpu(world, shards, algo, res, iters):
     for t in ts:
         t.join(timeout=600)
     assert not errors, errors
-    replicas = world // shards
+    replicas = (world // shards) * inflight
     total = np.zeros((res, res, 3), np.float64)
     for g in range(replicas):
         its = static_schedule(iters, replicas, g)
+        assert len(its) > 0
         v = VertexCM(sc, algo, 0.003, 0.75, 1234 + g)
         v.mMaxPathLength, v.mMinPathLength = 10, 0
         for it in its:

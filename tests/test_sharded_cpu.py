@@ -43,20 +43,25 @@ def test_sharded_equals_unsharded(tmp_path, world, sid, algo, res, iters):
         assert (fb == ref).mean() > 0.999
 
 
-@pytest.mark.parametrize("world,shards,sid,algo,res,iters", [(4, 2, 1, 4, 32, 5), (2, 1, 1, 4, 32, 3), (3, 1, 3, 2, 24, 2),
-                                                             (2, 2, 1, 4, 32, 2)])
-def test_render_farm_equals_the_reference_render_loop(tmp_path, world, shards, sid, algo, res, iters):
-    """RenderFarm = render() of src/smallvcm.cxx:52-151 with one "thread" per replica group: renderer g has seed
-    base + g, runs the static-schedule block of iterations, the used renderers' means are averaged."""
+@pytest.mark.parametrize("world,shards,inflight,sid,algo,res,iters", [
+    (4, 2, 1, 1, 4, 32, 5), (2, 1, 1, 1, 4, 32, 3), (3, 1, 1, 3, 2, 24, 2), (2, 2, 1, 1, 4, 32, 2),
+    (2, 2, 2, 1, 4, 32, 5),     # one pair, two renderers in flight on it
+    (4, 2, 2, 1, 2, 24, 7),     # two pairs x two in flight = 4 renderers, uneven iteration blocks
+    (2, 2, 3, 3, 4, 24, 2)])    # more renderers than iterations: the unused one must not count
+def test_render_farm_equals_the_reference_render_loop(tmp_path, world, shards, inflight, sid, algo, res, iters):
+    """RenderFarm = render() of src/smallvcm.cxx:52-151 with one "thread" per renderer: renderer i has seed
+    base + i, runs the static-schedule block of iterations, the used renderers' means are averaged.  Renderers are
+    spread over groups of `shards` ranks, `inflight` of them taking turns on each group."""
     from smallvcm_amd.renderer import static_schedule
     port = _free_port()
     out = str(tmp_path / "fb.npy")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(port),
-                               str(sid), str(algo), str(res), str(iters), out, str(shards)]) for r in range(world)]
+                               str(sid), str(algo), str(res), str(iters), out, str(shards), str(inflight)])
+             for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     fb = np.load(out)
-    replicas = world // shards
+    replicas = (world // shards) * inflight
     total, used = np.zeros((res, res, 3), np.float64), 0
     for g in range(replicas):
         its = static_schedule(iters, replicas, g)
