@@ -504,7 +504,8 @@ static int flush_light_splats(vcm_ctx *c)
     c->splatsPending = false;
     {
         /* scratch shared with the grid build / query sort, which run later */
-        int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart, *list = (int *)c->dUnsorted;
+        int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart;
+        F4 *list = (F4 *)c->dUnsorted;   /* 16-byte elements, like the cell list it is later used for */
         HIPCHK(hipMemsetAsync(pixCount, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
@@ -512,8 +513,8 @@ static int flush_light_splats(vcm_ctx *c)
         if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
         hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, c->stream, (const F4 *)c->dSplat,
                            (const int *)c->dLocalTotal, (const int *)pixStart, (const int *)arrival, list);
-        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const F4 *)c->dSplat,
-                           (const int *)pixStart, (const int *)list, c->dFb);
+        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const int *)pixStart,
+                           (const F4 *)list, c->dFb);
         HIPCHK(hipGetLastError());
     }
     return 0;

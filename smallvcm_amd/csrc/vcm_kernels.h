@@ -500,32 +500,67 @@ k_connect_camera(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStor
 }
 
 /* ---------------- K1d: ordered application of the light splats ------------ */
+/* the scatter moves the splat VALUE (rgb | vertex index) into its pixel's segment, so that k_splat_apply reads
+ * one contiguous run per pixel instead of gathering 16 bytes per splat from all over the vertex-ordered array */
 __global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restrict__ nVertices,
-                                const int *__restrict__ pixStart, const int *__restrict__ arrival, int *list)
+                                const int *__restrict__ pixStart, const int *__restrict__ arrival, F4 *list)
 {
     const int n = *nVertices;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t pix = f2u(splat[i].w);
-        if (pix != 0xffffffffu) list[pixStart[pix] + arrival[i]] = i;
+        const F4 s = splat[i];
+        const uint32_t pix = f2u(s.w);
+        if (pix != 0xffffffffu) list[pixStart[pix] + arrival[i]] = mk4(s.x, s.y, s.z, u2f((uint32_t)i));
     }
 }
 
-/* one lane per pixel: its splats in increasing vertex index (selection by
- * repeated minimum: a pixel holds 1.7 splats on average) */
-__global__ void k_splat_apply(int N, const F4 *__restrict__ splat, const int *__restrict__ pixStart,
-                              const int *__restrict__ list, float *fb)
+/* one lane per pixel: its splats in increasing vertex index.  A pixel holds 1.7 splats on average and the
+ * kernel is pure latency (the busiest of a wave's 64 pixels has ~7): up to VCM_SPLAT_REG entries are loaded
+ * ONCE, all loads in flight together, and ordered in registers by rank (number of smaller indices); longer
+ * lists take the selection loop. */
+#define VCM_SPLAT_REG 8
+__global__ void k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb)
 {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
         const int lo = pixStart[p], hi = pixStart[p + 1];
-        if (lo == hi) continue;
+        const int k = hi - lo;
+        if (k == 0) continue;
         float r = fb[(size_t)p * 3 + 0], g = fb[(size_t)p * 3 + 1], b = fb[(size_t)p * 3 + 2];
-        int last = -1;
-        for (int k = lo; k < hi; k++) {
-            int best = 0x7fffffff;
-            for (int q = lo; q < hi; q++) { const int v = list[q]; best = (v > last && v < best) ? v : best; }
-            const F4 s = splat[best];
-            r = r + s.x; g = g + s.y; b = b + s.z;   /* framebuffer.hxx:56 */
-            last = best;
+        if (k <= VCM_SPLAT_REG) {
+            F4 e[VCM_SPLAT_REG];
+#pragma unroll
+            for (int j = 0; j < VCM_SPLAT_REG; j++) e[j] = (j < k) ? list[lo + j] : mk4(0.f, 0.f, 0.f, u2f(0x7fffffffu));
+            int rank[VCM_SPLAT_REG];
+#pragma unroll
+            for (int j = 0; j < VCM_SPLAT_REG; j++) {
+                int c = 0;
+#pragma unroll
+                for (int m = 0; m < VCM_SPLAT_REG; m++) c += ((int)f2u(e[m].w) < (int)f2u(e[j].w)) ? 1 : 0;
+                rank[j] = c;   /* indices are distinct, padding sorts last */
+            }
+#pragma unroll
+            for (int t = 0; t < VCM_SPLAT_REG; t++) {
+                if (t < k) {
+                    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+                    for (int j = 0; j < VCM_SPLAT_REG; j++) {
+                        const bool me = rank[j] == t;
+                        sx = me ? e[j].x : sx; sy = me ? e[j].y : sy; sz = me ? e[j].z : sz;
+                    }
+                    r = r + sx; g = g + sy; b = b + sz;   /* framebuffer.hxx:56 */
+                }
+            }
+        } else {
+            int last = -1;
+            for (int t = lo; t < hi; t++) {
+                int best = 0x7fffffff, at = lo;
+                for (int q = lo; q < hi; q++) {
+                    const int v = (int)f2u(list[q].w);
+                    if (v > last && v < best) { best = v; at = q; }
+                }
+                const F4 s = list[at];
+                r = r + s.x; g = g + s.y; b = b + s.z;
+                last = best;
+            }
         }
         fb[(size_t)p * 3 + 0] = r; fb[(size_t)p * 3 + 1] = g; fb[(size_t)p * 3 + 2] = b;
     }
