@@ -1546,15 +1546,28 @@ VCM_HD V3 eval_merge_task(const vcm_scene_desc &sc, const IterParams &P, const V
  * there).  Same addends, same order => same bits as the serial reference. */
 VCM_HD V3 replay_path_color(const IterParams &P, const VertexStore &vs, int lp, uint32_t mask, V3 emission)
 {
+    /* pure latency: per vertex the three slot-indexed loads go out together, the VC addends in batches of 4 */
     V3 color = sp3(0.f);
     while (mask) {
         const int L = __builtin_ctz(mask);
         mask &= mask - 1u;
         const size_t ps = path_slot(P, (uint32_t)L, (uint32_t)lp);
         const I4 m = vs.meta[ps];
-        if (m.x >= 0) { const F4 t = vs.diOut[ps]; color = color + mk3(t.x, t.y, t.z); }
-        for (int k = 0; k < m.z; k++) { const F4 t = vs.vcOut[m.y + k]; color = color + mk3(t.x, t.y, t.z); }
-        if (P.useVM) { const F4 t = vs.mergeOut[ps]; color = color + mk3(t.x, t.y, t.z); }
+        const F4 di = vs.diOut[ps];
+        const F4 mg = P.useVM ? vs.mergeOut[ps] : mk4(0.f, 0.f, 0.f, 0.f);
+        if (m.x >= 0) color = color + mk3(di.x, di.y, di.z);
+        for (int k0 = 0; k0 < m.z; k0 += 4) {
+            F4 t[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int u = 0; u < 4; u++) t[u] = (k0 + u < m.z) ? vs.vcOut[m.y + k0 + u] : mk4(0.f, 0.f, 0.f, 0.f);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int u = 0; u < 4; u++) if (k0 + u < m.z) color = color + mk3(t[u].x, t[u].y, t[u].z);
+        }
+        if (P.useVM) color = color + mk3(mg.x, mg.y, mg.z);
     }
     return color + emission;
 }
