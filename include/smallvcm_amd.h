@@ -226,6 +226,11 @@ int vcm_clear_framebuffer(vcm_ctx *ctx);
 int vcm_iterations(vcm_ctx *ctx); /* AbstractRenderer::mIterations */
 int vcm_synchronize(vcm_ctx *ctx);
 int vcm_get_stats(vcm_ctx *ctx, vcm_stats *out);
+/* The same for an earlier iteration: `ago` = 0 is the last completed one; the counters and the phase times
+ * (stamped on the context's stream by every iteration) of the last 64 iterations are kept on the device, so a
+ * host can run a batch of iterations without reading anything back in between and still get per-iteration
+ * figures afterwards. */
+int vcm_get_stats_at(vcm_ctx *ctx, int ago, vcm_stats *out);
 
 /* Number of random floats each path consumed in the last iteration (local
  * paths of this rank): the "tape" that lets the unmodified reference replay

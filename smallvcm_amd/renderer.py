@@ -70,6 +70,7 @@ def load_library(require_gpu=True):
         L.vcm_read_framebuffer.argtypes = [vp, fp]
         L.vcm_framebuffer_device.argtypes = [vp, C.POINTER(vp)]
         L.vcm_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.vcm_get_stats_at.argtypes = [vp, C.c_int, C.POINTER(Stats)]
         L.vcm_get_rng_counts.argtypes = [vp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
         L.vcm_local_path_range.argtypes = [vp, ip, ip]
         L.vcm_scene_cornell.argtypes = [C.c_int, C.c_int, C.c_uint, C.POINTER(SceneDesc)]
@@ -222,6 +223,12 @@ class HipBackend:
         s = Stats()
         _check(self.L, self.L.vcm_get_stats(self.ctx, C.byref(s)), "vcm_get_stats")
         return s.asdict()
+
+    def stats_at(self, ago):
+        """counters and phase times of the iteration `ago` iterations before the last completed one (<= 63)"""
+        st = Stats()
+        _check(self.L, self.L.vcm_get_stats_at(self.ctx, int(ago), C.byref(st)), "vcm_get_stats_at")
+        return st.asdict()
 
     def rng_counts(self):
         a = np.zeros(self.count, np.uint8)
