@@ -31,6 +31,8 @@ static int fail(const char *what, const char *detail)
         if (e_ != hipSuccess) { g_hipFailed = true; return fail(#expr, hipGetErrorString(e_)); } \
     } while (0)
 
+#define VCM_STAMP_RING 64   /* iterations of phase timestamps and counters kept on the device */
+#define VCM_STAT_SLOTS (STAT_COUNT + 1)   /* + the number of vertices in the grid */
 enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID_K0, EV_GRID, EV_CAMERA_K0, EV_CAMERA_K1, EV_CONNECT_K1,
        EV_MERGE_K0, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
 
@@ -101,7 +103,11 @@ struct vcm_ctx : Scratch {
     float *dFb;                       /* N*3, running sum (mFramebuffer, renderer.hxx:68) */
     unsigned char *dRngLight, *dRngCam;   /* the random-number tape of the last iteration */
     GridHeader *dHdr;
-    unsigned long long *dStats;
+    unsigned long long *dStats;       /* the current iteration's slot of dStatsRing */
+    unsigned long long *dStatsRing;   /* VCM_STAMP_RING x VCM_STAT_SLOTS: counters of the last iterations */
+    unsigned long long *dStamps;      /* VCM_STAMP_RING x EV_COUNT device wall-clock readings */
+    float radiusRing[VCM_STAMP_RING];
+    double stampKHz;
 
     bool importedRecords;
     bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid;
@@ -282,10 +288,30 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipMemset(c->dRngCam, 0, (size_t)c->nLocal));
         if (dalloc(&c->dHdr, 1)) return -1;
         HIPCHK(hipMemset(c->dHdr, 0, sizeof(GridHeader)));
-        if (dalloc(&c->dStats, STAT_COUNT)) return -1;
-        HIPCHK(hipMemset(c->dStats, 0, STAT_COUNT * sizeof(unsigned long long)));
+        if (dalloc(&c->dStatsRing, (size_t)VCM_STAMP_RING * VCM_STAT_SLOTS)) return -1;
+        HIPCHK(hipMemset(c->dStatsRing, 0, (size_t)VCM_STAMP_RING * VCM_STAT_SLOTS * sizeof(unsigned long long)));
+        c->dStats = c->dStatsRing;
+        if (dalloc(&c->dStamps, (size_t)VCM_STAMP_RING * EV_COUNT)) return -1;
+        HIPCHK(hipMemset(c->dStamps, 0, (size_t)VCM_STAMP_RING * EV_COUNT * sizeof(unsigned long long)));
+        { int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device)); c->stampKHz = khz > 0 ? (double)khz : 100000.0; }
         c->deviceReady = true;
     }
+    return 0;
+}
+
+/* Phase / kernel boundaries of every iteration are marked twice on the context's stream: a HIP event, and the
+ * device's constant-rate wall clock read by a one-lane kernel.  Both give the same intervals (checked:
+ * SMALLVCM_AMD_TIMING=events makes vcm_get_stats report the events); the stamps are kept for the last
+ * VCM_STAMP_RING iterations, so a host can run a batch of iterations back to back and ask for per-iteration
+ * figures afterwards -- reading back between iterations lets the GPU idle and return at a lower clock, which
+ * made kernel times come out 10-20 % longer than in the batch. */
+static __global__ void k_stamp(unsigned long long *t) { *t = wall_clock64(); }
+static __global__ void k_note_grid_vertices(const GridHeader *hdr, unsigned long long *out) { *out = (unsigned long long)hdr->nRecords; }
+static int mark(vcm_ctx *c, int ev)
+{
+    HIPCHK(hipEventRecord(c->ev[ev], c->stream));
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, c->stream, c->dStamps + (size_t)(c->iterations % VCM_STAMP_RING) * EV_COUNT + ev);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -418,7 +444,7 @@ void vcm_destroy(vcm_ctx *c)
         delete c->arena;
     }
     if (c->deviceReady) {
-        DFREE(c->dScene); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStats);
+        DFREE(c->dScene); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
@@ -483,8 +509,10 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     P.renderer = c->renderer;
     P.iteration = iteration;
 
-    HIPCHK(hipEventRecord(c->ev[EV_START], c->stream));
-    HIPCHK(hipMemsetAsync(c->dStats, 0, STAT_COUNT * sizeof(unsigned long long), c->stream));
+    if (mark(c, EV_START)) return -1;
+    c->dStats = c->dStatsRing + (size_t)(c->iterations % VCM_STAMP_RING) * VCM_STAT_SLOTS;
+    c->radiusRing[c->iterations % VCM_STAMP_RING] = radius;
+    HIPCHK(hipMemsetAsync(c->dStats, 0, VCM_STAT_SLOTS * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
@@ -525,17 +553,17 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     if (!c || !c->inIteration) return fail("vcm_trace_light", "no iteration in progress");
     if (use_device(c)) return -1;
     if (c->renderer) {   /* PathTracer / EyeLight have no light pass */
-        HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K0], c->stream));
-        HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K1], c->stream));
+        if (mark(c, EV_LIGHT_K0)) return -1;
+        if (mark(c, EV_LIGHT_K1)) return -1;
         HIPCHK(hipMemsetAsync(c->dLocalTotal, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev[EV_LIGHT], c->stream));
+        if (mark(c, EV_LIGHT)) return -1;
         return 0;
     }
     int blocks, chunk;
     trace_launch_shape(c->nLocal, &blocks, &chunk);
-    HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K0], c->stream));
+    if (mark(c, EV_LIGHT_K0)) return -1;
     const bool wf = !c->strictOrder;
     if (wf)
         hipLaunchKernelGGL(k_light_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
@@ -544,7 +572,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         hipLaunchKernelGGL(k_light_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
                            c->dFb, c->dRngLight, c->dStats, chunk);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[EV_LIGHT_K1], c->stream));
+    if (mark(c, EV_LIGHT_K1)) return -1;
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
        record array in the reference's vertex order */
     if (launch_scan<unsigned char>(c, c->store.count, c->nLocal, c->dPathStart, c->dLocalTotal, 0)) return -1;
@@ -562,7 +590,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     }
     hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[EV_LIGHT], c->stream));
+    if (mark(c, EV_LIGHT)) return -1;
     return 0;
 }
 
@@ -637,7 +665,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
     if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
     if (use_device(c)) return -1;
     if (flush_light_splats(c)) return -1;
-    HIPCHK(hipEventRecord(c->ev[EV_GRID_K0], c->stream));
+    if (mark(c, EV_GRID_K0)) return -1;
     c->gridBuilt = true;
     if (c->useVM) {
         VertexSource recs;
@@ -660,9 +688,10 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, c->stream, (const GridHeader *)c->dHdr, recs,
                            (const int *)c->dCellStart, (const I4 *)c->dUnsorted, c->dGx,
                            c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
+        hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, c->stream, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev[EV_GRID], c->stream));
+    if (mark(c, EV_GRID)) return -1;
     return 0;
 }
 
@@ -683,7 +712,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     if (c->lightTraceOnly) return 0;
     int blocks, chunk;
     trace_launch_shape(c->nLocal, &blocks, &chunk);
-    HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K0], c->stream));
+    if (mark(c, EV_CAMERA_K0)) return -1;
     if (c->renderer) {   /* PathTracer / EyeLight: colour + jittered pixel per path; K5 adds them in path order */
         if (c->renderer == 1)
             hipLaunchKernelGGL(k_path_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->dCamOut,
@@ -692,28 +721,28 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             hipLaunchKernelGGL(k_eye_light, dim3(2048), dim3(256), 0, c->stream, c->dScene, c->P, c->dCamOut, c->dRngCam,
                                c->dStats);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
-        HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
+        if (mark(c, EV_CAMERA_K1)) return -1;
+        if (mark(c, EV_CONNECT_K1)) return -1;
         return 0;
     }
     if (c->P.wavefront) {
         /* K3: needs the light-vertex store, NOT the hash grid */
         hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
-        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
+        if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
             hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats);
             hipLaunchKernelGGL(k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->store, c->dStats);
         }
-        HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
+        if (mark(c, EV_CONNECT_K1)) return -1;
     } else {
         if (c->useVM && !c->gridBuilt) return fail("vcm_trace_camera", "strict mode merges inside the camera pass: call vcm_build_grid first");
         hipLaunchKernelGGL(k_camera_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
-        HIPCHK(hipEventRecord(c->ev[EV_CAMERA_K1], c->stream));
-        HIPCHK(hipEventRecord(c->ev[EV_CONNECT_K1], c->stream));
+        if (mark(c, EV_CAMERA_K1)) return -1;
+        if (mark(c, EV_CONNECT_K1)) return -1;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -725,7 +754,7 @@ static int vcm_merge_impl(vcm_ctx *c)
     if (!c->cameraTraced) return fail("vcm_merge", "call vcm_trace_camera first");
     if (use_device(c)) return -1;
     if (!c->lightTraceOnly) {
-        HIPCHK(hipEventRecord(c->ev[EV_MERGE_K0], c->stream));
+        if (mark(c, EV_MERGE_K0)) return -1;
         if (c->P.wavefront && c->useVM) {
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
@@ -736,22 +765,22 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
             hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
                                (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
-            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
+            if (mark(c, EV_SORT_K1)) return -1;
             /* K4 */
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
             hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
                                c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk);
         } else {
-            HIPCHK(hipEventRecord(c->ev[EV_SORT_K1], c->stream));
+            if (mark(c, EV_SORT_K1)) return -1;
         }
-        HIPCHK(hipEventRecord(c->ev[EV_MERGE_K1], c->stream));
+        if (mark(c, EV_MERGE_K1)) return -1;
         /* K5 */
         hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev[EV_CAMERA], c->stream));
+    if (mark(c, EV_CAMERA)) return -1;
     c->merged = true;
     return 0;
 }
@@ -834,19 +863,24 @@ int vcm_clear_framebuffer(vcm_ctx *c)
 
 int vcm_iterations(vcm_ctx *c) { return c ? c->iterations : 0; }
 
-int vcm_get_stats(vcm_ctx *c, vcm_stats *out)
+/* counters and phase times of the iteration that ended `ago` iterations before the last one (0 = the last) */
+int vcm_get_stats_at(vcm_ctx *c, int ago, vcm_stats *out)
 {
     if (!c || !out) return fail("vcm_get_stats", "NULL argument");
     memset(out, 0, sizeof(*out));
     if (!c->deviceReady) return 0;
+    if (ago < 0 || ago >= VCM_STAMP_RING) return fail("vcm_get_stats_at", "only the last 64 iterations are kept");
     if (use_device(c)) return -1;
-    unsigned long long h[STAT_COUNT];
-    GridHeader hdr;
-    HIPCHK(hipMemcpyAsync(h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&hdr, c->dHdr, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+    /* inside an iteration the current slot is the newest; otherwise the last completed one */
+    const int newest = c->inIteration ? c->iterations : c->iterations - 1;
+    if (newest < 0) return 0;
+    if (newest - ago < 0) return fail("vcm_get_stats_at", "no such iteration");
+    const int slot = (newest - ago) % VCM_STAMP_RING;
+    unsigned long long h[VCM_STAT_SLOTS];
+    HIPCHK(hipMemcpyAsync(h, c->dStatsRing + (size_t)slot * VCM_STAT_SLOTS, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     out->lightVertices = (long long)h[STAT_STORED];
-    out->gridVertices = c->useVM ? hdr.nRecords : 0;
+    out->gridVertices = (long long)h[STAT_COUNT];
     out->lightRays = (long long)h[STAT_LIGHT_RAYS];
     out->cameraRays = (long long)h[STAT_CAMERA_RAYS];
     out->shadowRays = (long long)h[STAT_SHADOW_RAYS];
@@ -855,26 +889,35 @@ int vcm_get_stats(vcm_ctx *c, vcm_stats *out)
     out->mergeAccepted = (long long)h[STAT_MERGE_ACCEPTED];
     out->connections = (long long)h[STAT_CONNECTIONS];
     out->lightSplats = (long long)h[STAT_LIGHT_SPLATS];
-    out->radius = c->P.radius;
-    if (c->evValid) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_LIGHT]) == hipSuccess) out->msLight = ms;
-        if (hipEventElapsedTime(&ms, c->ev[EV_GRID_K0], c->ev[EV_GRID]) == hipSuccess) out->msGrid = ms;
-        if (hipEventElapsedTime(&ms, c->ev[EV_START], c->ev[EV_CAMERA]) == hipSuccess) out->msTotal = ms;
-        if (hipEventElapsedTime(&ms, c->ev[EV_LIGHT_K0], c->ev[EV_LIGHT_K1]) == hipSuccess) out->msLightKernel = ms;
+    out->radius = c->radiusRing[slot];
+    if (!c->inIteration) {
+        static int useEvents = -1;
+        if (useEvents < 0) { const char *e = getenv("SMALLVCM_AMD_TIMING"); useEvents = (e && !strcmp(e, "events")) ? 1 : 0; }
+        unsigned long long t[EV_COUNT];
+        HIPCHK(hipMemcpy(t, c->dStamps + (size_t)slot * EV_COUNT, sizeof(t), hipMemcpyDeviceToHost));
+        const bool ev = useEvents && ago == 0 && c->evValid;   /* the events only remember the last iteration */
+        auto span = [&](int a, int b) -> float {
+            float ms = 0;
+            if (ev) { if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) ms = 0; }
+            else ms = (float)((double)(t[b] - t[a]) / c->stampKHz);
+            return ms;
+        };
+        out->msLight = span(EV_START, EV_LIGHT);
+        out->msGrid = span(EV_GRID_K0, EV_GRID);
+        out->msTotal = span(EV_START, EV_CAMERA);
+        out->msLightKernel = span(EV_LIGHT_K0, EV_LIGHT_K1);
         if (!c->lightTraceOnly) {
-            float a = 0, b = 0;
-            if (hipEventElapsedTime(&a, c->ev[EV_CAMERA_K0], c->ev[EV_CONNECT_K1]) == hipSuccess &&
-                hipEventElapsedTime(&b, c->ev[EV_MERGE_K0], c->ev[EV_CAMERA]) == hipSuccess) out->msCamera = a + b;
-            if (hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K0], c->ev[EV_CAMERA_K1]) == hipSuccess) out->msCameraKernel = ms;
-            if (hipEventElapsedTime(&ms, c->ev[EV_CAMERA_K1], c->ev[EV_CONNECT_K1]) == hipSuccess) out->msConnectKernels = ms;
-            if (hipEventElapsedTime(&ms, c->ev[EV_MERGE_K0], c->ev[EV_SORT_K1]) == hipSuccess) out->msQuerySort = ms;
-            if (hipEventElapsedTime(&ms, c->ev[EV_SORT_K1], c->ev[EV_MERGE_K1]) == hipSuccess) out->msMergeKernel = ms;
+            out->msCamera = span(EV_CAMERA_K0, EV_CONNECT_K1) + span(EV_MERGE_K0, EV_CAMERA);
+            out->msCameraKernel = span(EV_CAMERA_K0, EV_CAMERA_K1);
+            out->msConnectKernels = span(EV_CAMERA_K1, EV_CONNECT_K1);
+            out->msQuerySort = span(EV_MERGE_K0, EV_SORT_K1);
+            out->msMergeKernel = span(EV_SORT_K1, EV_MERGE_K1);
         }
     }
-    c->lastStats = *out;
+    if (ago == 0) c->lastStats = *out;
     return 0;
 }
+int vcm_get_stats(vcm_ctx *c, vcm_stats *out) { return vcm_get_stats_at(c, 0, out); }
 
 int vcm_get_rng_counts(vcm_ctx *c, unsigned char *lightCounts, unsigned char *cameraCounts)
 {
