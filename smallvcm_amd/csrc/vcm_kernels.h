@@ -235,7 +235,7 @@ k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
 /* Counting sort (indices only) of the vertex records on the Morton code of the
  * cell that contains the query point (hashgrid.hxx:124-131).  Same cell =>
  * same key, so the lanes of a wave walk the same cell lists (broadcast loads,
- * equal trip counts); neighbouring keys are neighbouring cells, so consecutive
+ * equal trip counts); neighbouring keys are neighbouring cells of a row, so consecutive
  * waves share most of their 8-cell neighbourhoods and find them in L2 -- with
  * the hash bucket as key (first version) consecutive waves were spatially
  * unrelated and K4 re-fetched ~10x the photon data from HBM.  The order inside
@@ -247,13 +247,24 @@ k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
 //                       /* per axis */
 #define VCM_QSORT_BUCKETS (1 << (3 * VCM_QSORT_BITS))
 
-__device__ __forceinline__ uint32_t morton_part(uint32_t x)
-{   /* spreads the low 8 bits: abcdefgh -> a00b00c00d00e00f00g00h */
-    x &= 0xffu;
-    x = (x | (x << 8)) & 0x0000f00fu;
-    x = (x | (x << 4)) & 0x000c30c3u;
-    x = (x | (x << 2)) & 0x00249249u;
-    return x;
+/* Bucket index of a cell: row-major over the cells the photon bbox spans, with per-axis coarsening only as far
+ * as the bucket table requires.  (The first version used a Morton code with 8 bits per axis: the moment the grid
+ * passed 256 cells on one axis -- 2048^2: iteration 9, the radius shrinks every iteration -- every bucket became a
+ * 2x2x2 block of cells in arrival order, a wave of K4 then touched ~21 distinct cells instead of ~13, and K4 jumped
+ * from 3.9 to 5.4 ms.  Halving ONE axis at a time keeps a bucket at 1, 2, 4 ... cells, and the full table is used
+ * before anything is coarsened: 257 x 251 x 257 still fits 2^24.) */
+struct QueryBuckets { uint32_t nx, ny; int sx, sy, sz; };
+__device__ __forceinline__ QueryBuckets query_buckets(const IterParams &P, const GridHeader *hdr)
+{   /* wave-uniform */
+    const V3 ext = P.invCellSize * (ld3(hdr->bboxMax) - ld3(hdr->bboxMin));
+    const uint32_t cx = (uint32_t)fmaxf(ext.x, 0.f) + 1u, cy = (uint32_t)fmaxf(ext.y, 0.f) + 1u, cz = (uint32_t)fmaxf(ext.z, 0.f) + 1u;
+    QueryBuckets b; b.sx = b.sy = b.sz = 0;
+    for (;;) {
+        const unsigned long long nx = ((cx - 1u) >> b.sx) + 1u, ny = ((cy - 1u) >> b.sy) + 1u, nz = ((cz - 1u) >> b.sz) + 1u;
+        if (nx * ny * nz <= (unsigned long long)VCM_QSORT_BUCKETS) { b.nx = (uint32_t)nx; b.ny = (uint32_t)ny; break; }
+        if (nx >= ny && nx >= nz) b.sx++; else if (ny >= nz) b.sy++; else b.sz++;
+    }
+    return b;
 }
 
 __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
@@ -263,15 +274,11 @@ __device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHea
     const V3 distMax = bmax - queryPos;
     if (distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f || distMin.z < 0.f || distMax.z < 0.f)
         return -1;   /* outside the photon bbox: HashGrid::Process returns at once (:116-122) */
-    /* coarsen until the grid extent fits 8 bits per axis (wave-uniform) */
-    const V3 ext = P.invCellSize * (bmax - bmin);
-    const uint32_t maxc = (uint32_t)fmaxf(fmaxf(ext.x, ext.y), fmaxf(ext.z, 0.f));
-    int shift = 0;
-    while ((maxc >> shift) >= (1u << VCM_QSORT_BITS)) shift++;
+    const QueryBuckets b = query_buckets(P, hdr);
     const V3 cellPt = P.invCellSize * distMin;
-    const uint32_t cx = (uint32_t)floorf(cellPt.x) >> shift, cy = (uint32_t)floorf(cellPt.y) >> shift,
-                   cz = (uint32_t)floorf(cellPt.z) >> shift;
-    return (int)(morton_part(cx) | (morton_part(cy) << 1) | (morton_part(cz) << 2));
+    const uint32_t cx = (uint32_t)floorf(cellPt.x) >> b.sx, cy = (uint32_t)floorf(cellPt.y) >> b.sy,
+                   cz = (uint32_t)floorf(cellPt.z) >> b.sz;
+    return (int)((cz * b.ny + cy) * b.nx + cx);
 }
 
 /* holes and out-of-bbox vertices are not sorted at all (key -1): they would all
