@@ -245,3 +245,44 @@ def test_path_tracer_converges_to_the_vcm_image():
         r.close()
     a, b = imgs[5].mean(axis=(0, 1)), imgs[4].mean(axis=(0, 1))
     assert np.all(np.abs(a - b) < 0.03 * b), (a, b)
+
+
+@pytest.mark.parametrize("sid,algo,res", [(1, 4, 128), (3, 2, 96), (0, 4, 64)])
+def test_late_iterations_equal_oracle(sid, algo, res):
+    """aIteration only drives the radius (vertexcm.hxx:295-296): late iterations have small radii, i.e. more grid cells
+    per axis than the query-sort bucket table has entries per axis -- the coarsened-bucket path of K4a -- and, at
+    iteration 300, a radius near the 1e-7 clamp of :298 is still far; the renderer-local counter wraps the 64-entry
+    statistics ring."""
+    sc = cornell_scene(sid, res, res)
+    o = Oracle(sc, algo, threads=8)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r.mMaxPathLength = 10
+    for it in (9, 40, 300, 5000):
+        o.run_iteration(it, 0, 10)
+        r.RunIteration(it)
+        so, sg = o.stats(), r.stats()
+        for k in ("lightVertices", "mergeQueries", "mergeCandidates", "mergeAccepted", "connections"):
+            assert so[k] == sg[k], (it, k, so[k], sg[k])
+        assert abs(sg["radius"] - so["radius"]) == 0
+    assert np.array_equal(r.framebuffer_sum().view(np.uint32), o.framebuffer().view(np.uint32))
+    r.close()
+
+
+def test_statistics_ring_keeps_the_last_iterations():
+    sc = cornell_scene(1, 64, 64)
+    r = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    r.mMaxPathLength = 10
+    per_iter = []
+    for it in range(70):            # more than the 64 slots of the ring
+        r.RunIteration(it)
+        if it >= 60:
+            per_iter.append(r.stats())
+    hist = [r.backend.stats_at(ago) for ago in range(10)]   # read after the batch: ago 0 = iteration 69
+    for ago, h in enumerate(hist):
+        ref = per_iter[9 - ago]
+        for k in ("lightVertices", "mergeCandidates", "mergeAccepted", "connections", "radius"):
+            assert h[k] == ref[k], (ago, k)
+        assert h["msTotal"] > 0 and h["msMergeKernel"] > 0
+    with pytest.raises(RuntimeError):
+        r.backend.stats_at(64)
+    r.close()
