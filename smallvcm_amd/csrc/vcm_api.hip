@@ -158,7 +158,7 @@ static Arena *arena_get(int device, bool shared)
 static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
-    DFREE(s.store.v); DFREE(s.store.count);
+    DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
     DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
@@ -186,7 +186,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
-    if (dalloc(&s.store.v, slots * VCM_LV_FIELDS) || dalloc(&s.store.count, cl)) return -1;
+    if (dalloc(&s.store.v, slots * VCM_LV_FIELDS) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;

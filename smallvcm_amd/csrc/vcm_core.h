@@ -63,6 +63,8 @@ struct LightStore {
                  k=3 localDirFix.xyz | dVM
                  k=4 WorldDirFix().xyz | ContinuationProb()                  */
     unsigned char *count;   /* stored vertices per local path (mPathEnds, :395) */
+    uint32_t *lenMask;      /* per local path: bit L set <=> a vertex with pathLength L is stored (stored vertices have
+                               increasing pathLength, so vertex j is the j-th set bit); valid while maxPathLength <= 31 */
 };
 VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return s.v[slot * VCM_LV_FIELDS + (size_t)k]; }
 
@@ -852,12 +854,14 @@ struct LightPath {
     PathRng rng;
     int lp;          /* local path index */
     int nStored;
+    uint32_t lenMask;   /* see LightStore::lenMask */
 };
 
 VCM_HD void light_path_begin(const vcm_scene_desc &sc, const IterParams &P, LightPath &lp, int localPath)
 {
     lp.lp = localPath;
     lp.nStored = 0;
+    lp.lenMask = 0u;
     rng_init(lp.rng, P.seed, P.localIter, (uint32_t)(P.p0 + localPath), 0u);
     generate_light_sample(sc, P, lp.rng, lp.st);
 }
@@ -894,6 +898,7 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
         lv(store, slot, 3) = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
         lv(store, slot, 4) = mk4(wdir.x, wdir.y, wdir.z, bsdf.contProb);
         lp.nStored++;
+        lp.lenMask |= (st.pathLength < 32u) ? (1u << st.pathLength) : 0u;
         if (P.useVC || P.useVM) ls.stored++;   /* the reference stores nothing in light-trace mode (:364) */
     }
     if (MODE == 0 && !bsdf.isDelta && (P.useVC || P.lightTraceOnly)) {   /* :380-384 */
@@ -1403,14 +1408,19 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
                 hasDI = 1;
             }
             /* the light vertices this camera vertex connects to (:508-521) */
+            /* vertex j of the light path has the j-th smallest stored pathLength; the window of :512-521
+               (minLen <= lvLen + 1 + camLen <= maxLen) is a range of lengths, hence a range of j: pure bit
+               arithmetic on the path's length mask instead of one dependent 16-byte gather per light vertex */
             uint32_t jmask = 0u;
             if (P.useVC) {
-                const int n = store.count[cp.lp];
-                for (int j = 0; j < n; j++) {
-                    const uint32_t lvLen = f2u(lv(store, (size_t)j * (size_t)P.nLocal + (size_t)cp.lp, 0).w) & 0xffu;
-                    if (lvLen + 1 + st.pathLength < P.minLen) continue;
-                    if (lvLen + 1 + st.pathLength > P.maxLen) break;
-                    jmask |= 1u << j;
+                const uint32_t M = store.lenMask[cp.lp];
+                const int loLen = (int)P.minLen - 1 - (int)st.pathLength;    /* lvLen >= loLen */
+                const int hiLen = (int)P.maxLen - 1 - (int)st.pathLength;    /* lvLen <= hiLen */
+                if (hiLen >= 0) {
+                    const uint32_t below = (loLen <= 0) ? 0u : (loLen >= 32 ? 0xffffffffu : ((1u << loLen) - 1u));
+                    const uint32_t upto = (hiLen >= 31) ? 0xffffffffu : ((1u << (hiLen + 1)) - 1u);
+                    const int jlo = __builtin_popcount(M & below), jhi = __builtin_popcount(M & upto);
+                    if (jhi > jlo) jmask = ((jhi >= 32) ? 0xffffffffu : ((1u << jhi) - 1u)) & ~((1u << jlo) - 1u);
                 }
             }
             const int nvc = __builtin_popcount(jmask);

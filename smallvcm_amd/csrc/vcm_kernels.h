@@ -84,6 +84,7 @@ k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore s
             alive = light_path_step<MODE>(sc, P, path, store, fb, ls);
             if (!alive) {
                 store.count[path.lp] = (unsigned char)path.nStored;   /* mPathEnds :395 */
+                store.lenMask[path.lp] = path.lenMask;
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
         }

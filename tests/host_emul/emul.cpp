@@ -122,7 +122,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     e.v0.assign(slots * VCM_LV_FIELDS, mk4(0, 0, 0, 0));
     e.count.assign((size_t)e.nLocal, 0); e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
     lane_stats_zero(e.ls);
-    LightStore store; store.v = e.v0.data(); store.count = e.count.data();
+    std::vector<uint32_t> lenMask((size_t)e.nLocal, 0u);
+    LightStore store; store.v = e.v0.data(); store.count = e.count.data(); store.lenMask = lenMask.data();
 
     /* K1 */
     for (int lp = 0; lp < e.nLocal; lp++) {
@@ -130,6 +131,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
         light_path_begin(e.sd.sc, P, path, lp);
         while (light_path_step<0>(e.sd.sc, P, path, store, e.fb.data(), e.ls)) {}
         e.count[lp] = (unsigned char)path.nStored;
+        lenMask[lp] = path.lenMask;
         e.rngL[lp] = (unsigned char)path.rng.k;
     }
     /* K1b: records in reference order */
