@@ -1,6 +1,6 @@
 // vcm_core.h -- device functions of the VCM hot path (host+device so that the
 // unit tests can also drive them on the CPU; the shipped library only ever
-// runs them inside the HIP kernels of vcm_kernels.hip).
+// runs them inside the HIP kernels of vcm_kernels.h).
 //
 // One lane owns one sub-path.  Every function states which reference code it
 // replaces; expression order is the reference's (see vcm_math.h).
@@ -9,7 +9,7 @@
 //   BSDF         src/bsdf.hxx:95-566
 //   lights       src/lights.hxx:112-514
 //   samplers     src/utils.hxx:36-259
-//   integrator   src/vertexcm.hxx:284-1006
+//   integrator   src/vertexcm.hxx:284-1006; src/pathtracer.hxx:45-215; src/eyelight.hxx:46-77
 //   hash grid    src/hashgrid.hxx:110-201 (query side; build is in the kernels)
 #ifndef SMALLVCM_AMD_VCM_CORE_H
 #define SMALLVCM_AMD_VCM_CORE_H

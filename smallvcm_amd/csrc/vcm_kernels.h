@@ -1,17 +1,22 @@
 // vcm_kernels.h -- HIP kernels of one VCM iteration on gfx950 (MI355X).
 //
-//   K1  k_light_trace     light sub-paths, vertex store, camera splats
-//   K1b k_compact_records slot-major store -> contiguous merge records
+//   K1  k_light_trace     light sub-paths: trace, scattering, vertex store (80-byte slot records)
+//   K1b scan + k_compact_records   mPathEnds; dense vertex -> slot list (+ the 52-byte merge records
+//                         when they have to travel: sharded renderer, debug read-out)
+//   K1c k_connect_camera  every stored vertex to the camera: BSDF, MIS, one shadow ray -> (rgb, pixel)
+//   K1d pixel histogram / scan / k_splat_scatter / k_splat_apply
+//                         the light splats added per pixel in the reference's order
 //   K2  k_bbox / k_cell_count / scan / k_cell_scatter / k_cell_rank_gather
 //                         hash-grid build with vertices SORTED BY CELL
 //   K3  k_camera_trace    camera sub-paths: trace, emission, scattering; appends a
 //                         record per non-delta vertex + its DI / VC tasks
 //   K3b k_connect_di      direct illumination tasks (dense, one lane each)
 //   K3c k_connect_vc      vertex connection tasks (dense, one lane each)
-//   K4a k_query_count/scatter  counting sort of the vertices by base-cell bucket
+//   K4a k_query_count/scatter  counting sort of the camera vertices by the cell they lie in
 //   K4  k_merge_lane      range-merge, one lane per camera vertex
 //   K5  k_resolve         replays every path's additions in the reference's order,
 //                         Framebuffer::AddColor
+//   PathTracer / EyeLight: k_path_trace, k_eye_light (+ K5)
 //
 // Execution model: one lane per sub-path.  K1/K3 are persistent: each wave
 // owns a contiguous chunk of path indices and REFILLS lanes whose path ended
