@@ -110,7 +110,7 @@ struct vcm_ctx : Scratch {
     double stampKHz;
 
     bool importedRecords;
-    bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid;
+    bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera;
     bool strictOrder;
     IterParams P;
     bool inIteration;
@@ -516,7 +516,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -726,7 +726,14 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         return 0;
     }
     if (c->P.wavefront) {
-        /* K3: needs the light-vertex store, NOT the hash grid */
+        /* K3: needs the light-vertex store, NOT the hash grid.  If the grid exists already (single-rank order
+           light -> grid -> camera) every camera vertex takes its K4a bucket key and place when it is appended. */
+        c->countedInCamera = c->useVM && c->gridBuilt;
+        c->vs.sortHdr = c->countedInCamera ? c->dHdr : NULL;
+        c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
+        c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
+        c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
+        if (c->countedInCamera) HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)VCM_QSORT_BUCKETS + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
         if (mark(c, EV_CAMERA_K1)) return -1;
@@ -759,9 +766,11 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
             const int nb = VCM_QSORT_BUCKETS;
-            HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
-            hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
-                               (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount);
+            if (!c->countedInCamera) {
+                HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+                hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
+                                   (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount);
+            }
             if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
             hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
                                (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);

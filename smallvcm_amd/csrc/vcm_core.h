@@ -105,6 +105,10 @@ struct VertexStore {
     F4 *diOut;       /* per path slot: throughput * DirectIllumination()  (:491)   */
     F4 *vcOut;       /* per VC task:   throughput * lvThroughput * ConnectVertices() (:523) */
     F4 *mergeOut;    /* per path slot: throughput * vmNormalization * contrib (:534) */
+    /* K4a folded into K3 when the grid exists before the camera pass (single-rank order light -> grid -> camera):
+       the vertex takes its bucket key and its place in the bucket the moment it is appended; NULL otherwise */
+    const GridHeader *sortHdr;
+    int *sortKey, *sortArrival, *bucketCount;
 };
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
@@ -1251,6 +1255,46 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
     return contrib;
 }
 
+/* ---- K4a bucket keys (counting sort of the camera vertices by the cell they lie in) ---- */
+#ifndef VCM_QSORT_BITS
+#define VCM_QSORT_BITS 8
+#endif
+#define VCM_QSORT_BUCKETS (1 << (3 * VCM_QSORT_BITS))   /* entries of the bucket table */
+/* Bucket index of a cell: row-major over the cells the photon bbox spans, with per-axis coarsening only as far
+ * as the bucket table requires.  (The first version used a Morton code with 8 bits per axis: the moment the grid
+ * passed 256 cells on one axis -- 2048^2: iteration 9, the radius shrinks every iteration -- every bucket became a
+ * 2x2x2 block of cells in arrival order, a wave of K4 then touched ~21 distinct cells instead of ~13, and K4 jumped
+ * from 3.9 to 5.4 ms.  Halving ONE axis at a time keeps a bucket at 1, 2, 4 ... cells, and the full table is used
+ * before anything is coarsened: 257 x 251 x 257 still fits 2^24.) */
+struct QueryBuckets { uint32_t nx, ny; int sx, sy, sz; };
+VCM_HD QueryBuckets query_buckets(const IterParams &P, const GridHeader *hdr)
+{   /* wave-uniform */
+    const V3 ext = P.invCellSize * (ld3(hdr->bboxMax) - ld3(hdr->bboxMin));
+    const uint32_t cx = (uint32_t)fmaxf(ext.x, 0.f) + 1u, cy = (uint32_t)fmaxf(ext.y, 0.f) + 1u, cz = (uint32_t)fmaxf(ext.z, 0.f) + 1u;
+    QueryBuckets b; b.sx = b.sy = b.sz = 0;
+    for (;;) {
+        const unsigned long long nx = ((cx - 1u) >> b.sx) + 1u, ny = ((cy - 1u) >> b.sy) + 1u, nz = ((cz - 1u) >> b.sz) + 1u;
+        if (nx * ny * nz <= (unsigned long long)VCM_QSORT_BUCKETS) { b.nx = (uint32_t)nx; b.ny = (uint32_t)ny; break; }
+        if (nx >= ny && nx >= nz) b.sx++; else if (ny >= nz) b.sy++; else b.sz++;
+    }
+    return b;
+}
+
+VCM_HD int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
+{
+    const V3 bmin = ld3(hdr->bboxMin), bmax = ld3(hdr->bboxMax);
+    const V3 distMin = queryPos - bmin;
+    const V3 distMax = bmax - queryPos;
+    if (distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f || distMin.z < 0.f || distMax.z < 0.f)
+        return -1;   /* outside the photon bbox: HashGrid::Process returns at once (:116-122) */
+    const QueryBuckets b = query_buckets(P, hdr);
+    const V3 cellPt = P.invCellSize * distMin;
+    const uint32_t cx = (uint32_t)floorf(cellPt.x) >> b.sx, cy = (uint32_t)floorf(cellPt.y) >> b.sy,
+                   cz = (uint32_t)floorf(cellPt.z) >> b.sz;
+    return (int)((cz * b.ny + cy) * b.nx + cx);
+}
+
+
 struct CameraPath {
     SubPathState st;
     PathRng rng;
@@ -1426,7 +1470,10 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
             const int nvc = __builtin_popcount(jmask);
             const int vi = wave_queue_alloc(wqs.v, &vs.count[0], VCM_QBLOCK_VERTEX, 1,
                 [&](int first, int cnt, int rank, int na) {
-                    for (int i = rank; i < cnt; i += na) vs.q0[first + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu)); });
+                    for (int i = rank; i < cnt; i += na) {
+                        vs.q0[first + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+                        if (vs.sortKey) vs.sortKey[first + i] = -1;
+                    } });
             const int di = wave_queue_alloc(wqs.di, &vs.count[1], VCM_QBLOCK_DI, hasDI,
                 [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.diTask[first + i] = -1; });
             const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], VCM_QBLOCK_VC, nvc,
@@ -1438,6 +1485,14 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
             vs.q4[vi] = mk4(st.dVC, u2f(diK), 0.f, 0.f);
             I4 m; m.x = hasDI ? di : -1; m.y = vc0; m.z = nvc; m.w = 0;
             vs.meta[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = m;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (vs.sortKey && P.useVM) {   /* K4a's histogram pass, here (see VertexStore) */
+                const int k = query_sort_key(P, vs.sortHdr, hitPoint);
+                vs.sortKey[vi] = k;
+                if (k >= 0) vs.sortArrival[vi] = atomicAdd(&vs.bucketCount[k], 1);
+                else vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
+            }
+#endif
             if (hasDI) vs.diTask[di] = vi;
             int t = vc0;
             while (jmask) {

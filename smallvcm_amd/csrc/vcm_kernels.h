@@ -141,7 +141,10 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     }
     if (MODE == 1) {   /* mark the unused tails of this wave's last blocks as holes */
         const int vb = wqs.v.p[0], vl = wqs.v.p[1], db = wqs.di.p[0], dl = wqs.di.p[1], cb = wqs.vc.p[0], cl = wqs.vc.p[1];
-        for (int i = (int)lane; i < vl; i += VCM_WAVE) vs.q0[vb + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+        for (int i = (int)lane; i < vl; i += VCM_WAVE) {
+            vs.q0[vb + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+            if (vs.sortKey) vs.sortKey[vb + i] = -1;
+        }
         for (int i = (int)lane; i < dl; i += VCM_WAVE) vs.diTask[db + i] = -1;
         for (int i = (int)lane; i < cl; i += VCM_WAVE) vs.vcTask[2 * (cb + i)] = -1;
     }
@@ -247,45 +250,6 @@ k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
  * unrelated and K4 re-fetched ~10x the photon data from HBM.  The order inside
  * a key is arbitrary (atomics) and does not matter: every vertex has its own
  * output slot. */
-#ifndef VCM_QSORT_BITS
-#define VCM_QSORT_BITS 8
-#endif
-//                       /* per axis */
-#define VCM_QSORT_BUCKETS (1 << (3 * VCM_QSORT_BITS))
-
-/* Bucket index of a cell: row-major over the cells the photon bbox spans, with per-axis coarsening only as far
- * as the bucket table requires.  (The first version used a Morton code with 8 bits per axis: the moment the grid
- * passed 256 cells on one axis -- 2048^2: iteration 9, the radius shrinks every iteration -- every bucket became a
- * 2x2x2 block of cells in arrival order, a wave of K4 then touched ~21 distinct cells instead of ~13, and K4 jumped
- * from 3.9 to 5.4 ms.  Halving ONE axis at a time keeps a bucket at 1, 2, 4 ... cells, and the full table is used
- * before anything is coarsened: 257 x 251 x 257 still fits 2^24.) */
-struct QueryBuckets { uint32_t nx, ny; int sx, sy, sz; };
-__device__ __forceinline__ QueryBuckets query_buckets(const IterParams &P, const GridHeader *hdr)
-{   /* wave-uniform */
-    const V3 ext = P.invCellSize * (ld3(hdr->bboxMax) - ld3(hdr->bboxMin));
-    const uint32_t cx = (uint32_t)fmaxf(ext.x, 0.f) + 1u, cy = (uint32_t)fmaxf(ext.y, 0.f) + 1u, cz = (uint32_t)fmaxf(ext.z, 0.f) + 1u;
-    QueryBuckets b; b.sx = b.sy = b.sz = 0;
-    for (;;) {
-        const unsigned long long nx = ((cx - 1u) >> b.sx) + 1u, ny = ((cy - 1u) >> b.sy) + 1u, nz = ((cz - 1u) >> b.sz) + 1u;
-        if (nx * ny * nz <= (unsigned long long)VCM_QSORT_BUCKETS) { b.nx = (uint32_t)nx; b.ny = (uint32_t)ny; break; }
-        if (nx >= ny && nx >= nz) b.sx++; else if (ny >= nz) b.sy++; else b.sz++;
-    }
-    return b;
-}
-
-__device__ __forceinline__ int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
-{
-    const V3 bmin = ld3(hdr->bboxMin), bmax = ld3(hdr->bboxMax);
-    const V3 distMin = queryPos - bmin;
-    const V3 distMax = bmax - queryPos;
-    if (distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f || distMin.z < 0.f || distMax.z < 0.f)
-        return -1;   /* outside the photon bbox: HashGrid::Process returns at once (:116-122) */
-    const QueryBuckets b = query_buckets(P, hdr);
-    const V3 cellPt = P.invCellSize * distMin;
-    const uint32_t cx = (uint32_t)floorf(cellPt.x) >> b.sx, cy = (uint32_t)floorf(cellPt.y) >> b.sy,
-                   cz = (uint32_t)floorf(cellPt.z) >> b.sz;
-    return (int)((cz * b.ny + cy) * b.nx + cx);
-}
 
 /* holes and out-of-bbox vertices are not sorted at all (key -1): they would all
  * land in one bucket, i.e. on one atomic word */

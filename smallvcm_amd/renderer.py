@@ -129,6 +129,8 @@ class HipBackend:
         self.world = world
         self.device = device
         self._tstream = None
+        strict = os.environ.get("SMALLVCM_AMD_STRICT_ORDER", "")[:1] == "1"
+        self.camera_before_grid = world > 1 and not strict
 
     def stream_context(self):
         """Run this context's kernels and the caller's torch ops (collectives,
@@ -154,7 +156,7 @@ class HipBackend:
     def set_strict_order(self, on):
         """True: DI / VC / merge inside the camera path as the reference does (slower, same bits)."""
         _check(self.L, self.L.vcm_set_strict_order(self.ctx, 1 if on else 0), "vcm_set_strict_order")
-        self.camera_before_grid = not on
+        self.camera_before_grid = (not on) and self.world > 1
 
     def set_stream(self, stream_handle):
         _check(self.L, self.L.vcm_set_stream(self.ctx, stream_handle), "vcm_set_stream")
@@ -174,8 +176,10 @@ class HipBackend:
     def merge(self):
         _check(self.L, self.L.vcm_merge(self.ctx), "vcm_merge")
 
-    #: the camera trace needs only the local light vertices (not the grid) unless strict mode is on
-    camera_before_grid = True
+    #: The camera trace needs only the local light vertices, not the grid (unless strict mode is on): a sharded
+    #: renderer runs it while the other ranks' vertices are in flight.  A single-rank renderer builds the grid first:
+    #: the camera pass then also takes over the histogram of the query sort.  Set per instance in __init__.
+    camera_before_grid = False
 
     def end(self):
         _check(self.L, self.L.vcm_end_iteration(self.ctx), "vcm_end_iteration")
