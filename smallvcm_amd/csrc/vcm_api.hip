@@ -110,7 +110,7 @@ struct vcm_ctx : Scratch {
     double stampKHz;
 
     bool importedRecords;
-    bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera;
+    bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI;
     bool strictOrder;
     IterParams P;
     bool inIteration;
@@ -516,7 +516,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -738,8 +738,13 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
+            /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
+               VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
+            c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
+            if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, VCM_QSORT_BUCKETS, c->dQueryStart, NULL, 1)) return -1;
             hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
-                               c->dStats);
+                               c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
+                               c->scatteredInDI ? c->dSortedVertex : (int *)NULL);
             hipLaunchKernelGGL(k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->store, c->dStats);
         }
@@ -771,9 +776,11 @@ static int vcm_merge_impl(vcm_ctx *c)
                 hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
                                    (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount);
             }
-            if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
-            hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
-                               (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
+            if (!c->scatteredInDI) {
+                if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
+                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
+                                   (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
+            }
             if (mark(c, EV_SORT_K1)) return -1;
             /* K4 */
             static int mergeChunk = 0;

@@ -209,7 +209,8 @@ k_eye_light(const vcm_scene_desc *__restrict__ scp, IterParams P, F4 *camOut, un
  * lane and at 23 % lane utilisation (profiles/r01b_pmc_*). */
 #define VCM_TASK_BLOCK 256
 __global__ void __launch_bounds__(VCM_TASK_BLOCK)
-k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats)
+k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats,
+             const int *__restrict__ bucketStart, int *sortedVertex)
 {
     const vcm_scene_desc &sc = *scp;
     const int n = vs.count[1];
@@ -220,6 +221,10 @@ k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
         size_t ps;
         const V3 v = eval_di_task(sc, P, vs, vi, ls, ps);
         vs.diOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+        if (sortedVertex) {   /* K4a's scatter pass, here: this kernel visits every camera vertex once */
+            const int k = vs.sortKey[vi];
+            if (k >= 0) sortedVertex[bucketStart[k] + vs.sortArrival[vi]] = vi;
+        }
     }
     flush_stats(ls, gstats);
 }
