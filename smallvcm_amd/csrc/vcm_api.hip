@@ -49,6 +49,7 @@ struct Scratch {
     int *dPathStart;                  /* nLocal+1 */
     int *dLocalTotal;                 /* 1 */
     int *dTileSums;                   /* scan scratch */
+    int *dTileSumsSide;               /* scan scratch of the side stream (grid build) */
     float *dRecordsLocal;             /* S*nLocal records */
     int *dSlotOfVertex;               /* S*nLocal: dense vertex index -> slot in the light store */
     F4 *dSplat;                       /* S*nLocal: splat of each light vertex (rgb | pixel) */
@@ -95,6 +96,9 @@ struct vcm_ctx : Scratch {
 
     hipStream_t stream;
     bool ownStream;
+    hipStream_t side;                 /* the grid build runs here, next to the camera pass on `stream` */
+    hipEvent_t evFork, evBbox, evGrid; /* main -> side, side -> main (bbox known), side -> main (grid complete) */
+    bool gridInFlight;
     bool deviceReady;
     Arena *arena; bool holdsArena;
 
@@ -159,7 +163,7 @@ static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
     DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
-    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums);
+    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums); DFREE(s.dTileSumsSide);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
     DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
@@ -190,7 +194,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
-    if (dalloc(&s.dTileSums, maxScan / VCM_SCAN_TILE + 2)) return -1;
+    if (dalloc(&s.dTileSums, maxScan / VCM_SCAN_TILE + 2) || dalloc(&s.dTileSumsSide, maxScan / VCM_SCAN_TILE + 2)) return -1;
     if (dalloc(&s.dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dSlotOfVertex, slots) || dalloc(&s.dSplat, slots)) return -1;
     if (sh && dalloc(&s.dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
@@ -249,6 +253,8 @@ static int abort_iteration(vcm_ctx *c, int rc)
 {
     if (rc != 0 && g_hipFailed && c && c->holdsArena) {
         (void)hipStreamSynchronize(c->stream);
+        if (c->deviceReady) (void)hipStreamSynchronize(c->side);
+        c->gridInFlight = false;
         c->inIteration = false;
         arena_release(c, false);
     }
@@ -270,6 +276,10 @@ static int ensure_device(vcm_ctx *c)
     if (!c->deviceReady) {
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evBbox, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
         {
             SceneDev *sd = new SceneDev();
             scene_dev_build(c->scene, *sd);
@@ -307,25 +317,30 @@ static int ensure_device(vcm_ctx *c)
  * made kernel times come out 10-20 % longer than in the batch. */
 static __global__ void k_stamp(unsigned long long *t) { *t = wall_clock64(); }
 static __global__ void k_note_grid_vertices(const GridHeader *hdr, unsigned long long *out) { *out = (unsigned long long)hdr->nRecords; }
-static int mark(vcm_ctx *c, int ev)
+static int mark_on(vcm_ctx *c, int ev, hipStream_t stream)
 {
-    HIPCHK(hipEventRecord(c->ev[ev], c->stream));
-    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, c->stream, c->dStamps + (size_t)(c->iterations % VCM_STAMP_RING) * EV_COUNT + ev);
+    HIPCHK(hipEventRecord(c->ev[ev], stream));
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, stream, c->dStamps + (size_t)(c->iterations % VCM_STAMP_RING) * EV_COUNT + ev);
     HIPCHK(hipGetLastError());
     return 0;
 }
+static int mark(vcm_ctx *c, int ev) { return mark_on(c, ev, c->stream); }
 
 /* exclusive scan of n ints/bytes on the context's stream */
 template <typename T>
-static int launch_scan(vcm_ctx *c, const T *in, int n, int *out, int *totalOut, int writeTotalAtN)
+static int launch_scan_on(hipStream_t stream, int *tileSums, const T *in, int n, int *out, int *totalOut, int writeTotalAtN)
 {
     const int nTiles = (n + VCM_SCAN_TILE - 1) / VCM_SCAN_TILE;
-    hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, c->stream, in, n, c->dTileSums);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(VCM_SCAN_BLOCK), 0, c->stream, c->dTileSums, nTiles, totalOut);
-    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, c->stream, in, n, c->dTileSums, out,
-                       writeTotalAtN);
+    hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(VCM_SCAN_BLOCK), 0, stream, tileSums, nTiles, totalOut);
+    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums, out, writeTotalAtN);
     HIPCHK(hipGetLastError());
     return 0;
+}
+template <typename T>
+static int launch_scan(vcm_ctx *c, const T *in, int n, int *out, int *totalOut, int writeTotalAtN)
+{
+    return launch_scan_on<T>(c->stream, c->dTileSums, in, n, out, totalOut, writeTotalAtN);
 }
 
 static void trace_launch_shape(int nLocal, int *blocks, int *chunk)
@@ -446,6 +461,9 @@ void vcm_destroy(vcm_ctx *c)
     if (c->deviceReady) {
         DFREE(c->dScene); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
+        (void)hipStreamSynchronize(c->side);
+        (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
+        (void)hipStreamDestroy(c->side);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -516,7 +534,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -660,38 +678,62 @@ static int vcm_import_light_records_impl(vcm_ctx *c, const void *devPtr, const l
     return 0;
 }
 
+/* the main stream continues only after the side stream's grid build */
+static int join_grid(vcm_ctx *c)
+{
+    if (!c->gridInFlight) return 0;
+    HIPCHK(hipStreamWaitEvent(c->stream, c->evGrid, 0));
+    c->gridInFlight = false;
+    return 0;
+}
+
 static int vcm_build_grid_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:403-408 -> HashGrid::Build hashgrid.hxx:41-107 */
     if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
     if (use_device(c)) return -1;
     if (flush_light_splats(c)) return -1;
-    if (mark(c, EV_GRID_K0)) return -1;
     c->gridBuilt = true;
     if (c->useVM) {
+        /* The grid build is atomic- and gather-bound, the camera pass that follows in the single-rank order
+           (K3, K3b, K3c) is VALU-bound and does not read the grid: the build runs on a side stream next to it.
+           Main waits for the bounding box only (K3 derives the query-sort keys from it); vcm_merge waits for the
+           rest.  Strict mode merges inside K3 and waits at once. */
+        hipStream_t q = c->side;
+        HIPCHK(hipEventRecord(c->evFork, c->stream));
+        HIPCHK(hipStreamWaitEvent(q, c->evFork, 0));
+        if (mark_on(c, EV_GRID_K0, q)) return -1;
         VertexSource recs;
         recs.records = c->importedRecords ? c->dRecordsAll : (c->recordsValid ? c->dRecordsLocal : NULL);
         recs.store = c->store;
         recs.slotOfVertex = c->dSlotOfVertex;
         const int nCells = c->P.nCells;
         const dim3 g(2048), b(256);
-        HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr);
-        hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, c->stream, recs, c->dHdr);
-        hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr);
-        hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
+        HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), q));
+        hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr);
+        hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
+        hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr);
+        HIPCHK(hipEventRecord(c->evBbox, q));
+        hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
                            c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount);
         HIPCHK(hipGetLastError());
-        if (launch_scan<int>(c, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
-        hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
+        if (launch_scan_on<int>(q, c->dTileSumsSide, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
+        hipLaunchKernelGGL(k_cell_scatter, g, b, 0, q, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
                            (const int *)c->dSortedIndex, (const int *)c->dCellStart,
                            recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
-        hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, c->stream, (const GridHeader *)c->dHdr, recs,
+        hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, q, (const GridHeader *)c->dHdr, recs,
                            (const int *)c->dCellStart, (const I4 *)c->dUnsorted, c->dGx,
                            c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
-        hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, c->stream, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT);
+        hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT);
         HIPCHK(hipGetLastError());
+        if (mark_on(c, EV_GRID, q)) return -1;
+        HIPCHK(hipEventRecord(c->evGrid, q));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->evBbox, 0));
+        c->gridInFlight = true;
+        if (!c->P.wavefront && join_grid(c)) return -1;
+    } else {
+        if (mark(c, EV_GRID_K0)) return -1;
+        if (mark(c, EV_GRID)) return -1;
     }
-    if (mark(c, EV_GRID)) return -1;
     return 0;
 }
 
@@ -769,6 +811,7 @@ static int vcm_merge_impl(vcm_ctx *c)
         if (mark(c, EV_MERGE_K0)) return -1;
         if (c->P.wavefront && c->useVM) {
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
+            if (join_grid(c)) return -1;
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
             const int nb = VCM_QSORT_BUCKETS;
             if (!c->countedInCamera) {
@@ -821,6 +864,7 @@ int vcm_end_iteration(vcm_ctx *c)
 {
     if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
     if (!c->merged) return fail("vcm_end_iteration", "vcm_merge has not run");
+    if (join_grid(c)) return -1;   /* (a merge-free algorithm never waited) */
     c->iterations++;   /* :547 */
     c->inIteration = false;
     c->evValid = true;
