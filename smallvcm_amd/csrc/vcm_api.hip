@@ -811,7 +811,6 @@ static int vcm_merge_impl(vcm_ctx *c)
         if (mark(c, EV_MERGE_K0)) return -1;
         if (c->P.wavefront && c->useVM) {
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
-            if (join_grid(c)) return -1;
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
             const int nb = VCM_QSORT_BUCKETS;
             if (!c->countedInCamera) {
@@ -825,7 +824,9 @@ static int vcm_merge_impl(vcm_ctx *c)
                                    (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
             }
             if (mark(c, EV_SORT_K1)) return -1;
-            /* K4 */
+            /* K4: needs the grid; the query sort above only needed its bounding box, so in the sharded order
+               (camera pass before the grid build) it ran next to the build */
+            if (join_grid(c)) return -1;
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
             hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
