@@ -204,6 +204,12 @@ int vcm_end_iteration(vcm_ctx *ctx); /* :547 */
  * `count` is read back from the device (synchronises the stream). */
 int vcm_light_records(vcm_ctx *ctx, void **devPtr, long long *count);
 
+/* Sharded hosts: the bounding box (and number) of this rank's light vertices after vcm_trace_light -- empty:
+ * min = +1e36, max = -1e36 (hashgrid.hxx:47-48) -- and, the other way, the box of ALL ranks' vertices (min / max of
+ * the per-rank boxes), to be set before vcm_trace_camera / vcm_build_grid.  Exchanging 7 numbers per rank instead
+ * of the count alone lets the camera pass prepare the query sort while the vertices are still in flight. */
+int vcm_local_light_bbox(vcm_ctx *ctx, float *min3, float *max3, long long *count);
+int vcm_set_grid_bbox(vcm_ctx *ctx, const float *min3, const float *max3);
 /* Copy the local merge records (count from vcm_light_records) / the
  * framebuffer into caller-owned DEVICE memory (e.g. a torch tensor that is
  * then handed to an RCCL collective).  Asynchronous on the context's stream. */

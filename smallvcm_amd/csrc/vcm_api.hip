@@ -114,7 +114,7 @@ struct vcm_ctx : Scratch {
     double stampKHz;
 
     bool importedRecords;
-    bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI;
+    bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI, bboxPreset;
     bool strictOrder;
     IterParams P;
     bool inIteration;
@@ -316,6 +316,11 @@ static int ensure_device(vcm_ctx *c)
  * figures afterwards -- reading back between iterations lets the GPU idle and return at a lower clock, which
  * made kernel times come out 10-20 % longer than in the batch. */
 static __global__ void k_stamp(unsigned long long *t) { *t = wall_clock64(); }
+static __global__ void k_set_bbox(GridHeader *hdr, float x0, float y0, float z0, float x1, float y1, float z1)
+{
+    hdr->bboxMin[0] = x0; hdr->bboxMin[1] = y0; hdr->bboxMin[2] = z0;
+    hdr->bboxMax[0] = x1; hdr->bboxMax[1] = y1; hdr->bboxMax[2] = z1;
+}
 static __global__ void k_note_grid_vertices(const GridHeader *hdr, unsigned long long *out) { *out = (unsigned long long)hdr->nRecords; }
 static int mark_on(vcm_ctx *c, int ev, hipStream_t stream)
 {
@@ -534,7 +539,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
     HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->bboxPreset = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -636,6 +641,41 @@ int vcm_light_records(vcm_ctx *c, void **devPtr, long long *count)
     return 0;
 }
 
+/* The bounding box of this rank's light vertices and their number, after vcm_trace_light: what a sharded host
+ * exchanges (7 numbers per rank) instead of only the count, so that every rank knows the box of ALL vertices
+ * before they have arrived (HashGrid::Build takes it over the whole array, hashgrid.hxx:50-61; min / max over
+ * ranks of the per-rank min / max is the same box, bit for bit).  Empty: min = +1e36, max = -1e36 (:47-48). */
+int vcm_local_light_bbox(vcm_ctx *c, float *min3, float *max3, long long *count)
+{
+    if (!c || !c->inIteration || !min3 || !max3) return fail("vcm_local_light_bbox", "call it between vcm_trace_light and vcm_build_grid");
+    if (use_device(c)) return -1;
+    VertexSource src; src.records = NULL; src.store = c->store; src.slotOfVertex = c->dSlotOfVertex;
+    hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr);
+    hipLaunchKernelGGL(k_bbox, dim3(512), dim3(256), 0, c->stream, src, c->dHdr);
+    hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr);
+    HIPCHK(hipGetLastError());
+    GridHeader h;
+    HIPCHK(hipMemcpyAsync(&h, c->dHdr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) { min3[i] = h.bboxMin[i]; max3[i] = h.bboxMax[i]; }
+    if (count) *count = h.nLocalRecords;
+    return 0;
+}
+
+/* The box of all ranks' vertices, computed by the host from vcm_local_light_bbox of every rank.  With it the
+ * camera pass can take over the query-sort histogram (it needs the box, not the grid) although the grid is built
+ * only after the exchange, and vcm_build_grid skips its own reduction. */
+int vcm_set_grid_bbox(vcm_ctx *c, const float *min3, const float *max3)
+{
+    if (!c || !c->inIteration || !min3 || !max3) return fail("vcm_set_grid_bbox", "no iteration in progress");
+    if (c->gridBuilt) return fail("vcm_set_grid_bbox", "the grid is built already");
+    if (use_device(c)) return -1;
+    hipLaunchKernelGGL(k_set_bbox, dim3(1), dim3(1), 0, c->stream, c->dHdr, min3[0], min3[1], min3[2], max3[0], max3[1], max3[2]);
+    HIPCHK(hipGetLastError());
+    c->bboxPreset = true;
+    return 0;
+}
+
 int vcm_export_light_records(vcm_ctx *c, void *dstDev, long long count)
 {
     if (!dstDev) return fail("vcm_export_light_records", "bad argument");
@@ -709,9 +749,11 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         const int nCells = c->P.nCells;
         const dim3 g(2048), b(256);
         HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), q));
-        hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr);
-        hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
-        hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr);
+        if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
+            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr);
+            hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
+            hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr);
+        }
         HIPCHK(hipEventRecord(c->evBbox, q));
         hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
                            c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount);
@@ -770,7 +812,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     if (c->P.wavefront) {
         /* K3: needs the light-vertex store, NOT the hash grid.  If the grid exists already (single-rank order
            light -> grid -> camera) every camera vertex takes its K4a bucket key and place when it is appended. */
-        c->countedInCamera = c->useVM && c->gridBuilt;
+        c->countedInCamera = c->useVM && (c->gridBuilt || c->bboxPreset);
         c->vs.sortHdr = c->countedInCamera ? c->dHdr : NULL;
         c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;

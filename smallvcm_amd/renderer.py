@@ -71,6 +71,8 @@ def load_library(require_gpu=True):
         L.vcm_framebuffer_device.argtypes = [vp, C.POINTER(vp)]
         L.vcm_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.vcm_get_stats_at.argtypes = [vp, C.c_int, C.POINTER(Stats)]
+        L.vcm_local_light_bbox.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), llp]
+        L.vcm_set_grid_bbox.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vcm_get_rng_counts.argtypes = [vp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
         L.vcm_local_path_range.argtypes = [vp, ip, ip]
         L.vcm_scene_cornell.argtypes = [C.c_int, C.c_int, C.c_uint, C.POINTER(SceneDesc)]
@@ -195,6 +197,16 @@ class HipBackend:
         ptr, n = C.c_void_p(), C.c_longlong()
         _check(self.L, self.L.vcm_light_records(self.ctx, C.byref(ptr), C.byref(n)), "vcm_light_records")
         return n.value
+
+    def local_bbox(self):
+        """(min3, max3, count) of this rank's light vertices (after trace_light); one stream synchronisation"""
+        mn, mx, n = (C.c_float * 3)(), (C.c_float * 3)(), C.c_longlong()
+        _check(self.L, self.L.vcm_local_light_bbox(self.ctx, mn, mx, C.byref(n)), "vcm_local_light_bbox")
+        return [float(x) for x in mn], [float(x) for x in mx], n.value
+
+    def set_grid_bbox(self, mn, mx):
+        """the box of all ranks' light vertices, before trace_camera / build_grid"""
+        _check(self.L, self.L.vcm_set_grid_bbox(self.ctx, (C.c_float * 3)(*mn), (C.c_float * 3)(*mx)), "vcm_set_grid_bbox")
 
     def export_records(self, dst_tensor, count):
         """copy `count` local records into a torch device tensor"""
@@ -352,14 +364,27 @@ class ShardedVertexCM:
         b.trace_light()
         work = counts = stride = gathered = None
         if self.world > 1:
-            n_local = b.local_record_count()
-            # 1) counts (tiny all-gather)
+            # 1) counts -- and, if the backend can use it, the bounding box of the local vertices: 7 numbers per rank
+            #    in one tiny all-gather.  min / max over the ranks' boxes is the box HashGrid::Build takes over the
+            #    whole array (hashgrid.hxx:50-61); knowing it now lets the camera pass below prepare the query sort.
             dev = b.new_tensor(1).device
-            cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
-            cnts = torch.empty(self.world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(cnts, cnt, group=self.group)
-            counts = [int(x) for x in cnts.tolist()]
+            boxed = hasattr(b, "local_bbox")
+            if boxed:
+                mn, mx, n_local = b.local_bbox()
+            else:
+                mn, mx, n_local = [0.0] * 3, [0.0] * 3, b.local_record_count()
+            mine = torch.tensor([float(n_local)] + mn + mx, dtype=torch.float64, device=dev)   # fp32 values, exact
+            every = torch.empty(7 * self.world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            rows = every.cpu().reshape(self.world, 7).numpy()
+            counts = [int(x) for x in rows[:, 0]]
             stride = max(max(counts), 1)
+            if boxed:
+                full = rows[rows[:, 0] > 0]
+                if len(full):
+                    b.set_grid_bbox([float(x) for x in full[:, 1:4].min(axis=0)], [float(x) for x in full[:, 4:7].max(axis=0)])
+                else:
+                    b.set_grid_bbox([1e36] * 3, [-1e36] * 3)
             # 2) records, padded to the largest shard; asynchronous: the camera
             #    trace below does not need the other ranks' vertices
             need = stride * VCM_MERGE_RECORD_FLOATS

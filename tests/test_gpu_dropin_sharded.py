@@ -164,7 +164,8 @@ def test_sharded_contexts_equal_single_context(world, sid, algo, res, iters):
             r.mMaxPathLength, r.mMinPathLength = 10, 0
             for it in range(iters):
                 r.RunIteration(it)
-            results[rank] = (r.framebuffer_sum(), b.stats())
+            grid = b.grid() if algo in (1, 2, 4) else None
+            results[rank] = (r.framebuffer_sum(), b.stats(), grid)
             b.close()
         except Exception as e:   # noqa: BLE001
             errors.append(repr(e))
@@ -184,13 +185,19 @@ def test_sharded_contexts_equal_single_context(world, sid, algo, res, iters):
     for it in range(iters):
         one.RunIteration(it)
     ref, st1 = one.framebuffer_sum(), one.stats()
+    grid1 = one.backend.grid() if algo in (1, 2, 4) else None
     one.close()
-    for fb, st in results:
+    for _, _, grid in results:
+        if grid is not None:   # the box exchanged as 7 numbers per rank and the grid built over the gathered records
+            assert np.array_equal(grid[2], grid1[2]), "bounding box"
+            assert np.array_equal(grid[0], grid1[0]) and np.array_equal(grid[1], grid1[1]), "cell ranges / in-cell order"
+    for fb, st, _ in results:
         assert np.allclose(fb, ref, rtol=2e-6, atol=2e-7)
         assert st["gridVertices"] == st1["gridVertices"]          # every rank built the full grid
-    assert sum(st["lightVertices"] for _, st in results) == st1["lightVertices"]
-    assert sum(st["mergeAccepted"] for _, st in results) == st1["mergeAccepted"]
-    assert sum(st["connections"] for _, st in results) == st1["connections"]
+    assert sum(st["lightVertices"] for _, st, _ in results) == st1["lightVertices"]
+    assert sum(st["mergeAccepted"] for _, st, _ in results) == st1["mergeAccepted"]
+    assert sum(st["mergeCandidates"] for _, st, _ in results) == st1["mergeCandidates"]
+    assert sum(st["connections"] for _, st, _ in results) == st1["connections"]
 
 
 # ---- many renderers on one device: the shared iteration-scratch arena -------------------------------------------
