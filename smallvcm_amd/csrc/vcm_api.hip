@@ -1049,6 +1049,8 @@ int vcm_debug_read_grid(vcm_ctx *c, int *cellStart, int *sortedIndex, float *bbo
 {
     if (scratch_readable(c, "vcm_debug_read_grid")) return -1;
     if (use_device(c)) return -1;
+    /* the context's stream may be a caller's non-blocking stream (torch): a plain hipMemcpy would not wait for it */
+    HIPCHK(hipStreamSynchronize(c->stream));
     GridHeader hdr;
     HIPCHK(hipMemcpy(&hdr, c->dHdr, sizeof(hdr), hipMemcpyDeviceToHost));
     if (nRecords) *nRecords = hdr.nRecords;
