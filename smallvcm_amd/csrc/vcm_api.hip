@@ -531,6 +531,20 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     P.wavefront = (!c->strictOrder && !c->lightTraceOnly && !c->renderer && maxLen <= 31) ? 1 : 0;
     P.renderer = c->renderer;
     P.iteration = iteration;
+    /* Queue blocks of K3: the unused tail of every wave's last block is holes the task kernels step over (half a
+       block per wave and queue on average), while small blocks mean more atomics on one hot counter word.
+       Measured (VC block 2048 / 1024 / 512 / 256): 703 / 708 / 689 / 584 Mpaths/s at 2048^2, 252 / 283 / 291 / 281
+       at 512^2. */
+    const bool big = c->nLocal >= (1 << 20);
+    P.qblockVertex = big ? 512 : 256; P.qblockDI = big ? 512 : 256; P.qblockVC = big ? 1024 : 512;
+    /* Query-sort bucket table: its scan and memset cost 0.3 ms per iteration at the full 2^24 entries whatever the
+       resolution (the cell count follows the radius, not the pixel count), 14 % of a 512^2 iteration; with few
+       queries per cell anyway a bucket may as well span a few cells there. */
+    {
+        long long nb = 16LL * c->nLocal;
+        if (nb < (1 << 18)) nb = 1 << 18;
+        P.nBuckets = nb < VCM_QSORT_BUCKETS ? (int)nb : VCM_QSORT_BUCKETS;
+    }
 
     if (mark(c, EV_START)) return -1;
     c->dStats = c->dStatsRing + (size_t)(c->iterations % VCM_STAMP_RING) * VCM_STAT_SLOTS;
@@ -817,7 +831,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
-        if (c->countedInCamera) HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)VCM_QSORT_BUCKETS + 1) * sizeof(int), c->stream));
+        if (c->countedInCamera) HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)c->P.nBuckets + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
         if (mark(c, EV_CAMERA_K1)) return -1;
@@ -825,7 +839,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
-            if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, VCM_QSORT_BUCKETS, c->dQueryStart, NULL, 1)) return -1;
+            if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
             hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
                                c->scatteredInDI ? c->dSortedVertex : (int *)NULL);
@@ -854,7 +868,7 @@ static int vcm_merge_impl(vcm_ctx *c)
         if (c->P.wavefront && c->useVM) {
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
-            const int nb = VCM_QSORT_BUCKETS;
+            const int nb = c->P.nBuckets;
             if (!c->countedInCamera) {
                 HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
                 hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,

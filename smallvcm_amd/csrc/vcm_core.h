@@ -37,6 +37,8 @@ struct IterParams {
     int   wavefront;               /* 1: DI / VC / merge deferred to task kernels (default) */
     int   renderer;                /* 0: VertexCM family; 1: PathTracer (pathtracer.hxx); 2: EyeLight (eyelight.hxx) */
     int   iteration;               /* aIteration as passed to RunIteration (EyeLight reads it, eyelight.hxx:61) */
+    int   qblockVertex, qblockDI, qblockVC;   /* slots a wave of K3 reserves per atomic (wave_queue_alloc) */
+    int   nBuckets;                /* entries of the query-sort bucket table in use (<= VCM_QSORT_BUCKETS) */
 };
 
 /* device-resident hash-grid header: bbox is reduced on the device */
@@ -1259,7 +1261,7 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
 #ifndef VCM_QSORT_BITS
 #define VCM_QSORT_BITS 8
 #endif
-#define VCM_QSORT_BUCKETS (1 << (3 * VCM_QSORT_BITS))   /* entries of the bucket table */
+#define VCM_QSORT_BUCKETS (1 << (3 * VCM_QSORT_BITS))   /* entries of the bucket table: upper bound, IterParams::nBuckets is in use */
 /* Bucket index of a cell: row-major over the cells the photon bbox spans, with per-axis coarsening only as far
  * as the bucket table requires.  (The first version used a Morton code with 8 bits per axis: the moment the grid
  * passed 256 cells on one axis -- 2048^2: iteration 9, the radius shrinks every iteration -- every bucket became a
@@ -1274,7 +1276,7 @@ VCM_HD QueryBuckets query_buckets(const IterParams &P, const GridHeader *hdr)
     QueryBuckets b; b.sx = b.sy = b.sz = 0;
     for (;;) {
         const unsigned long long nx = ((cx - 1u) >> b.sx) + 1u, ny = ((cy - 1u) >> b.sy) + 1u, nz = ((cz - 1u) >> b.sz) + 1u;
-        if (nx * ny * nz <= (unsigned long long)VCM_QSORT_BUCKETS) { b.nx = (uint32_t)nx; b.ny = (uint32_t)ny; break; }
+        if (nx * ny * nz <= (unsigned long long)P.nBuckets) { b.nx = (uint32_t)nx; b.ny = (uint32_t)ny; break; }
         if (nx >= ny && nx >= nz) b.sx++; else if (ny >= nz) b.sy++; else b.sz++;
     }
     return b;
@@ -1311,7 +1313,7 @@ struct CameraPath {
  * atomic per block) and hands slots to its lanes with ballot + prefix
  * popcount; the unused tail of a block is filled with hole markers that the
  * consumers skip.  On the host build (one lane) it degenerates to a counter. */
-#define VCM_QBLOCK_VERTEX 512
+#define VCM_QBLOCK_VERTEX 512   /* upper bounds (buffer sizing); the sizes in use are in IterParams */
 #define VCM_QBLOCK_DI     512
 #define VCM_QBLOCK_VC     2048
 /* allocator state of ONE wave: {next free slot, slots left in the block}.  It
@@ -1468,15 +1470,15 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
                 }
             }
             const int nvc = __builtin_popcount(jmask);
-            const int vi = wave_queue_alloc(wqs.v, &vs.count[0], VCM_QBLOCK_VERTEX, 1,
+            const int vi = wave_queue_alloc(wqs.v, &vs.count[0], P.qblockVertex, 1,
                 [&](int first, int cnt, int rank, int na) {
                     for (int i = rank; i < cnt; i += na) {
                         vs.q0[first + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
                         if (vs.sortKey) vs.sortKey[first + i] = -1;
                     } });
-            const int di = wave_queue_alloc(wqs.di, &vs.count[1], VCM_QBLOCK_DI, hasDI,
+            const int di = wave_queue_alloc(wqs.di, &vs.count[1], P.qblockDI, hasDI,
                 [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.diTask[first + i] = -1; });
-            const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], VCM_QBLOCK_VC, nvc,
+            const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], P.qblockVC, nvc,
                 [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.vcTask[2 * (first + i)] = -1; });
             vs.q0[vi] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
             vs.q1[vi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));

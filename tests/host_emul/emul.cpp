@@ -90,6 +90,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     P.nCells = e.N;
 
     P.renderer = e.renderer; P.iteration = iteration;
+    P.qblockVertex = P.qblockDI = 512; P.qblockVC = 2048; P.nBuckets = VCM_QSORT_BUCKETS;
     if (e.renderer) {   /* PathTracer / EyeLight: pixel loop, then AddColor in pixel order */
         e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
         e.records.clear();
