@@ -286,3 +286,29 @@ def test_statistics_ring_keeps_the_last_iterations():
     with pytest.raises(RuntimeError):
         r.backend.stats_at(64)
     r.close()
+
+
+def test_soak_many_iterations_stay_exact():
+    """40 consecutive iterations (side-stream grid build, statistics ring, shrinking radius, two renderers
+    interleaved on the shared arena): the accumulated framebuffer must still equal the oracle's bit for bit."""
+    import os
+    sc = cornell_scene(1, 320, 240)
+    o = Oracle(sc, 4, threads=os.cpu_count() or 1)
+    r = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    other = VertexCM(cornell_scene(3, 200, 200), 2, 0.003, 0.75, 99)   # a second renderer borrowing the same arena
+    r.mMaxPathLength = other.mMaxPathLength = 10
+    for it in range(40):
+        o.run_iteration(it, 0, 10)
+        r.RunIteration(it)
+        if it % 3 == 0:
+            other.RunIteration(it)
+    assert np.array_equal(r.framebuffer_sum().view(np.uint32), o.framebuffer().view(np.uint32))
+    so, sg = o.stats(), r.stats()
+    for k in ("lightVertices", "mergeCandidates", "mergeAccepted", "connections", "lightSplats"):
+        assert so[k] == sg[k], k
+    o2 = Oracle(cornell_scene(3, 200, 200), 2, seed=99, threads=os.cpu_count() or 1)
+    for it in range(0, 40, 3):
+        o2.run_iteration(it, 0, 10)
+    assert np.array_equal(other.framebuffer_sum().view(np.uint32), o2.framebuffer().view(np.uint32))
+    r.close()
+    other.close()
