@@ -223,6 +223,16 @@ int vcm_import_light_records(vcm_ctx *ctx, const void *devPtr,
                              const long long *counts, int nSeg,
                              long long strideRecords);
 
+/* The image in the reference's two 8-bit output encodings, converted on the device (a quarter / a third of
+ * the bytes of the fp32 framebuffer cross PCIe).  The framebuffer (running sum) is scaled by `scale` first --
+ * 1 / iterations gives what GetFramebuffer returns (renderer.hxx:49-55).
+ *   VCM_IMAGE_BGR8  Framebuffer::SaveBMP's pixel data (framebuffer.hxx:194-214): rows bottom-up, B,G,R bytes,
+ *                   byte(min(255, max(0, pow(c, 1/gamma) * 255))); resX*resY*3 bytes.  pow is the deterministic
+ *                   powf of this library, so a byte can differ by one level from a glibc build of the reference.
+ *   VCM_IMAGE_RGBE  Framebuffer::SaveHDR's pixel data (:229-247): rows top-down, R,G,B,E bytes; resX*resY*4
+ *                   bytes, bit-identical to the reference's (frexp and IEEE double arithmetic only). */
+enum { VCM_IMAGE_BGR8 = 0, VCM_IMAGE_RGBE = 1 };
+int vcm_read_image(vcm_ctx *ctx, int format, float scale, float gamma, unsigned char *outHost);
 /* Framebuffer = running SUM over iterations of this context (the reference's
  * mFramebuffer, src/renderer.hxx:68); W*H*3 floats, row-major, RGB. */
 int vcm_read_framebuffer(vcm_ctx *ctx, float *rgbHost);

@@ -316,6 +316,32 @@ static int ensure_device(vcm_ctx *c)
  * figures afterwards -- reading back between iterations lets the GPU idle and return at a lower clock, which
  * made kernel times come out 10-20 % longer than in the batch. */
 static __global__ void k_stamp(unsigned long long *t) { *t = wall_clock64(); }
+/* Framebuffer::SaveBMP / SaveHDR pixel encodings (framebuffer.hxx:194-214, :229-247), one lane per pixel */
+static __global__ void k_encode_image(const float *fb, int resX, int resY, int format, float scale, float invGamma, unsigned char *out)
+{
+    const int n = resX * resY;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        if (format == VCM_IMAGE_BGR8) {
+            const int x = p % resX, y = p / resX;
+            const float *c = fb + (size_t)(x + (resY - y - 1) * resX) * 3;   /* bottom-up (:200) */
+            const float r = c[0] * scale, g = c[1] * scale, b = c[2] * scale;
+            const float v[3] = { dm_powf(b, invGamma) * 255.f, dm_powf(g, invGamma) * 255.f, dm_powf(r, invGamma) * 255.f };
+            for (int k = 0; k < 3; k++) out[(size_t)p * 3 + k] = (unsigned char)fminf(255.f, fmaxf(0.f, v[k]));
+        } else {
+            const float *c = fb + (size_t)p * 3;
+            const float r = c[0] * scale, g = c[1] * scale, b = c[2] * scale;
+            unsigned char e4[4] = { 0, 0, 0, 0 };
+            float v = fmaxf(r, fmaxf(g, b));
+            if (v >= 1e-32f) {
+                int e;
+                v = (float)(frexp((double)v, &e) * 256.f / v);   /* :241, evaluated in double like the reference */
+                e4[0] = (unsigned char)(r * v); e4[1] = (unsigned char)(g * v); e4[2] = (unsigned char)(b * v);
+                e4[3] = (unsigned char)(e + 128);
+            }
+            for (int k = 0; k < 4; k++) out[(size_t)p * 4 + k] = e4[k];
+        }
+    }
+}
 static __global__ void k_set_bbox(GridHeader *hdr, float x0, float y0, float z0, float x1, float y1, float z1)
 {
     hdr->bboxMin[0] = x0; hdr->bboxMin[1] = y0; hdr->bboxMin[2] = z0;
@@ -958,6 +984,25 @@ int vcm_read_framebuffer(vcm_ctx *c, float *rgbHost)
     if (use_device(c)) return -1;
     HIPCHK(hipMemcpyAsync(rgbHost, c->dFb, (size_t)c->N * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vcm_read_image(vcm_ctx *c, int format, float scale, float gamma, unsigned char *outHost)
+{
+    if (!c || !outHost) return fail("vcm_read_image", "NULL argument");
+    if (format != VCM_IMAGE_BGR8 && format != VCM_IMAGE_RGBE) return fail("vcm_read_image", "unknown format");
+    if (!(gamma > 0.f)) return fail("vcm_read_image", "gamma must be positive");
+    if (ensure_device(c)) return -1;
+    const size_t bytes = (size_t)c->N * (format == VCM_IMAGE_BGR8 ? 3 : 4);
+    unsigned char *d = NULL;
+    if (dalloc(&d, bytes)) return -1;
+    hipLaunchKernelGGL(k_encode_image, dim3(1024), dim3(256), 0, c->stream, (const float *)c->dFb, c->resX, c->resY, format,
+                       scale, 1.f / gamma, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(outHost, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_hipFailed = true; return fail("vcm_read_image", hipGetErrorString(e)); }
     return 0;
 }
 

@@ -15,13 +15,19 @@
 // (src/config.hxx:246-395; scenes = g_SceneConfigs[0..3], :146-151).
 // --renderers R reproduces render() (src/smallvcm.cxx:52-151) with R "threads":
 // renderer g has seed S+g and runs the iterations OpenMP's static schedule gives
-// thread g; the image is the mean of the used renderers' means.  -o writes the
-// averaged framebuffer as PFM exactly like Framebuffer::SavePFM
-// (src/framebuffer.hxx:137-146: "PF", "W H", "-1", rows top to bottom).
+// thread g; the image is the mean of the used renderers' means.  -o picks the
+// format by extension like the reference (src/smallvcm.cxx:300-309): .bmp
+// (gamma 2.2, Framebuffer::SaveBMP src/framebuffer.hxx:170-214), .hdr (SaveHDR
+// :219-251), anything else raw fp32 PFM (SavePFM :137-146: "PF", "W H", "-1",
+// rows top to bottom).  With one renderer the 8-bit formats are encoded on the
+// device (vcm_read_image); with several, from the averaged framebuffer here.
 #include <chrono>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -127,15 +133,57 @@ int main(int argc, char **argv)
     vcm_stats st;
     memset(&st, 0, sizeof(st));
     vcm_get_stats(r[0], &st);
-    for (int g = 0; g < renderers; g++) vcm_destroy(r[g]);
 
-    if (!out.empty()) {   // Framebuffer::SavePFM, framebuffer.hxx:137-146
+    if (!out.empty()) {
+        const std::string ext = out.size() >= 4 ? out.substr(out.size() - 4) : "";
+        const bool bmp = ext == ".bmp", hdr = ext == ".hdr";
+        std::vector<unsigned char> px;
+        if (bmp || hdr) {
+            px.resize((size_t)resX * resY * (bmp ? 3 : 4));
+            if (renderers == 1) {   // encoded on the device
+                if (vcm_read_image(r[0], bmp ? VCM_IMAGE_BGR8 : VCM_IMAGE_RGBE, 1.f / vcm_iterations(r[0]), 2.2f, px.data()))
+                    return die("vcm_read_image");
+            } else if (bmp) {       // Framebuffer::SaveBMP, framebuffer.hxx:194-214
+                const float invGamma = 1.f / 2.2f;
+                for (int y = 0; y < resY; y++) for (int x = 0; x < resX; x++) {
+                    const float *c = &fb[((size_t)x + (size_t)(resY - y - 1) * resX) * 3];
+                    unsigned char *o = &px[((size_t)y * resX + x) * 3];
+                    for (int k = 0; k < 3; k++)
+                        o[k] = (unsigned char)std::min(255.f, std::max(0.f, std::pow(c[2 - k], invGamma) * 255.f));
+                }
+            } else {                // Framebuffer::SaveHDR, framebuffer.hxx:229-247
+                for (size_t p = 0; p < (size_t)resX * resY; p++) {
+                    const float *c = &fb[p * 3];
+                    unsigned char *o = &px[p * 4];
+                    o[0] = o[1] = o[2] = o[3] = 0;
+                    float v = std::max(c[0], std::max(c[1], c[2]));
+                    if (v >= 1e-32f) {
+                        int e;
+                        v = float(frexp(v, &e) * 256.f / v);
+                        o[0] = (unsigned char)(c[0] * v); o[1] = (unsigned char)(c[1] * v); o[2] = (unsigned char)(c[2] * v);
+                        o[3] = (unsigned char)(e + 128);
+                    }
+                }
+            }
+        }
         FILE *f = fopen(out.c_str(), "wb");
         if (!f) { fprintf(stderr, "vcm_render: cannot write %s\n", out.c_str()); return 2; }
-        fprintf(f, "PF\n%d %d\n-1\n", resX, resY);
-        fwrite(fb.data(), sizeof(float), n3, f);
+        if (bmp) {   // BmpHeader, framebuffer.hxx:150-168, :175-191
+            const uint32_t img = (uint32_t)resX * resY * 3;
+            uint32_t h[13] = { 54u + img, 0u, 54u, 40u, (uint32_t)resX, (uint32_t)resY, 1u | (24u << 16), 0u, img, 2953u, 2953u, 0u, 0u };
+            fwrite("BM", 1, 2, f);
+            fwrite(h, 4, 13, f);
+            fwrite(px.data(), 1, px.size(), f);
+        } else if (hdr) {
+            fprintf(f, "#?RADIANCE\n# SmallVCM\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", resY, resX);
+            fwrite(px.data(), 1, px.size(), f);
+        } else {     // Framebuffer::SavePFM, framebuffer.hxx:137-146
+            fprintf(f, "PF\n%d %d\n-1\n", resX, resY);
+            fwrite(fb.data(), sizeof(float), n3, f);
+        }
         fclose(f);
     }
+    for (int g = 0; g < renderers; g++) vcm_destroy(r[g]);
     double mean[3] = { 0, 0, 0 };
     for (size_t i = 0; i < n3; i++) mean[i % 3] += fb[i];
     const double paths = (algorithm == VCM_ALGO_PATH_TRACE || algorithm == VCM_ALGO_EYE_LIGHT ? 1.0 : 2.0) * resX * resY * iterations;

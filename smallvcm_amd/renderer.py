@@ -71,6 +71,7 @@ def load_library(require_gpu=True):
         L.vcm_framebuffer_device.argtypes = [vp, C.POINTER(vp)]
         L.vcm_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.vcm_get_stats_at.argtypes = [vp, C.c_int, C.POINTER(Stats)]
+        L.vcm_read_image.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_ubyte)]
         L.vcm_local_light_bbox.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), llp]
         L.vcm_set_grid_bbox.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vcm_get_rng_counts.argtypes = [vp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
@@ -239,6 +240,14 @@ class HipBackend:
         s = Stats()
         _check(self.L, self.L.vcm_get_stats(self.ctx, C.byref(s)), "vcm_get_stats")
         return s.asdict()
+
+    def read_image(self, fmt, scale, gamma=2.2):
+        """the framebuffer * scale in the reference's BMP (fmt 0: BGR8, rows bottom-up) or HDR (fmt 1: RGBE) pixel
+        encoding, converted on the device (Framebuffer::SaveBMP / SaveHDR, framebuffer.hxx:170-251)"""
+        out = np.zeros((self.resy, self.resx, 3 if fmt == 0 else 4), np.uint8)
+        _check(self.L, self.L.vcm_read_image(self.ctx, fmt, scale, gamma, out.ctypes.data_as(C.POINTER(C.c_ubyte))),
+               "vcm_read_image")
+        return out
 
     def stats_at(self, ago):
         """counters and phase times of the iteration `ago` iterations before the last completed one (<= 63)"""

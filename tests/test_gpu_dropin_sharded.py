@@ -379,3 +379,39 @@ def test_cpp_host_equals_python_host(tmp_path, name, algo, renderers, iters):
 def test_cpp_host_rejects_bad_arguments():
     r = subprocess.run([HOST, "-a", "nope"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2
+
+
+@pytest.mark.skipif(not (os.path.exists(HOST) and os.path.exists(DROPIN)), reason="needs vcm_render and the drop-in binary")
+def test_cpp_host_writes_the_reference_file_formats(tmp_path):
+    """vcm_render -o x.hdr / x.bmp (pixels encoded on the device, vcm_read_image) against the files the reference's
+    own writers produce from the same render (unchanged smallvcm.cxx over the drop-in)."""
+    ref_hdr, ref_bmp = str(tmp_path / "ref.hdr"), str(tmp_path / "ref.bmp")
+    mine_hdr, mine_bmp = str(tmp_path / "mine.hdr"), str(tmp_path / "mine.bmp")
+    for out in (ref_hdr, ref_bmp):
+        r = subprocess.run([DROPIN, "-s", "1", "-a", "vcm", "-i", "1", "-o", out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+    for out in (mine_hdr, mine_bmp):
+        r = subprocess.run([HOST, "-s", "1", "-a", "vcm", "-i", "1", "-o", out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+    assert open(ref_hdr, "rb").read() == open(mine_hdr, "rb").read()          # header and RGBE pixels, byte for byte
+    a, b = open(ref_bmp, "rb").read(), open(mine_bmp, "rb").read()
+    assert a[:54] == b[:54] and len(a) == len(b) == 54 + 512 * 512 * 3
+    d = np.abs(np.frombuffer(a[54:], np.uint8).astype(np.int32) - np.frombuffer(b[54:], np.uint8).astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01   # glibc pow vs the library's deterministic pow: at most one level
+
+
+def test_read_image_encodings():
+    sc = cornell_scene(1, 96, 64)
+    v = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    v.mMaxPathLength = 10
+    for it in range(3):
+        v.RunIteration(it)
+    fb = v.GetFramebuffer()
+    rgbe = v.backend.read_image(1, 1.0 / 3.0)
+    assert np.array_equal(rgbe, _rgbe(v.framebuffer_sum() * np.float32(1.0 / 3.0)))
+    bgr = v.backend.read_image(0, 1.0 / 3.0, 2.2)
+    ref = np.clip(np.power((v.framebuffer_sum() * np.float32(1.0 / 3.0)).astype(np.float64), 1 / 2.2) * 255.0, 0, 255)
+    ref = ref[::-1, :, ::-1]                      # bottom-up, BGR
+    assert np.abs(bgr.astype(np.float64) - np.floor(ref)).max() <= 1
+    assert np.allclose(fb, v.framebuffer_sum() / 3)
+    v.close()
