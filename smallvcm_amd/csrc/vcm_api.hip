@@ -685,7 +685,7 @@ int vcm_light_records(vcm_ctx *c, void **devPtr, long long *count)
  * exchanges (7 numbers per rank) instead of only the count, so that every rank knows the box of ALL vertices
  * before they have arrived (HashGrid::Build takes it over the whole array, hashgrid.hxx:50-61; min / max over
  * ranks of the per-rank min / max is the same box, bit for bit).  Empty: min = +1e36, max = -1e36 (:47-48). */
-int vcm_local_light_bbox(vcm_ctx *c, float *min3, float *max3, long long *count)
+static int vcm_local_light_bbox_impl(vcm_ctx *c, float *min3, float *max3, long long *count)
 {
     if (!c || !c->inIteration || !min3 || !max3) return fail("vcm_local_light_bbox", "call it between vcm_trace_light and vcm_build_grid");
     if (use_device(c)) return -1;
@@ -705,7 +705,7 @@ int vcm_local_light_bbox(vcm_ctx *c, float *min3, float *max3, long long *count)
 /* The box of all ranks' vertices, computed by the host from vcm_local_light_bbox of every rank.  With it the
  * camera pass can take over the query-sort histogram (it needs the box, not the grid) although the grid is built
  * only after the exchange, and vcm_build_grid skips its own reduction. */
-int vcm_set_grid_bbox(vcm_ctx *c, const float *min3, const float *max3)
+static int vcm_set_grid_bbox_impl(vcm_ctx *c, const float *min3, const float *max3)
 {
     if (!c || !c->inIteration || !min3 || !max3) return fail("vcm_set_grid_bbox", "no iteration in progress");
     if (c->gridBuilt) return fail("vcm_set_grid_bbox", "the grid is built already");
@@ -937,6 +937,16 @@ int vcm_import_light_records(vcm_ctx *c, const void *devPtr, const long long *co
 {
     g_hipFailed = false;
     return abort_iteration(c, vcm_import_light_records_impl(c, devPtr, counts, nSeg, strideRecords));
+}
+int vcm_local_light_bbox(vcm_ctx *c, float *min3, float *max3, long long *count)
+{
+    g_hipFailed = false;
+    return abort_iteration(c, vcm_local_light_bbox_impl(c, min3, max3, count));
+}
+int vcm_set_grid_bbox(vcm_ctx *c, const float *min3, const float *max3)
+{
+    g_hipFailed = false;
+    return abort_iteration(c, vcm_set_grid_bbox_impl(c, min3, max3));
 }
 int vcm_trace_light(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_trace_light_impl(c)); }
 int vcm_build_grid(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_build_grid_impl(c)); }
