@@ -181,6 +181,9 @@ int vcm_set_strict_order(vcm_ctx *ctx, int on);
  * work of this context; NULL = the context's own stream. */
 int vcm_set_stream(vcm_ctx *ctx, void *hipStream);
 
+/* Optional: allocate up front everything the first iteration with this maxPathLength would allocate lazily
+ * (the context's buffers and the device's scratch arena), e.g. before a timed region. */
+int vcm_reserve(vcm_ctx *ctx, unsigned maxPathLength);
 /* Replaces VertexCM::RunIteration(aIteration) (src/vertexcm.hxx:284-548) for a
  * single-GPU renderer.  minLen/maxLen are AbstractRenderer::mMinPathLength /
  * mMaxPathLength, which the driver assigns after construction

@@ -948,6 +948,20 @@ int vcm_set_grid_bbox(vcm_ctx *c, const float *min3, const float *max3)
     g_hipFailed = false;
     return abort_iteration(c, vcm_set_grid_bbox_impl(c, min3, max3));
 }
+/* allocate now what the first iteration would allocate (context buffers, the device's scratch arena) */
+int vcm_reserve(vcm_ctx *c, unsigned maxLen)
+{
+    if (!c) return fail("vcm_reserve", "ctx is NULL");
+    if (c->inIteration) return fail("vcm_reserve", "iteration in progress");
+    if (maxLen > 255) return fail("vcm_reserve", "maxPathLength > 255 unsupported");
+    g_hipFailed = false;
+    if (ensure_device(c)) return -1;
+    const int S = c->renderer ? 1 : ((maxLen >= 2) ? (int)maxLen - 1 : 1);
+    const int L = c->renderer ? 1 : ((maxLen >= 1) ? (int)maxLen : 1);
+    const int rc = arena_acquire(c, S, L);
+    if (c->holdsArena) arena_release(c, false);
+    return rc;
+}
 int vcm_trace_light(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_trace_light_impl(c)); }
 int vcm_build_grid(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_build_grid_impl(c)); }
 int vcm_trace_camera(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_trace_camera_impl(c)); }

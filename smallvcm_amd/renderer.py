@@ -71,6 +71,7 @@ def load_library(require_gpu=True):
         L.vcm_framebuffer_device.argtypes = [vp, C.POINTER(vp)]
         L.vcm_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.vcm_get_stats_at.argtypes = [vp, C.c_int, C.POINTER(Stats)]
+        L.vcm_reserve.argtypes = [vp, C.c_uint]
         L.vcm_read_image.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_ubyte)]
         L.vcm_local_light_bbox.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), llp]
         L.vcm_set_grid_bbox.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -163,6 +164,10 @@ class HipBackend:
 
     def set_stream(self, stream_handle):
         _check(self.L, self.L.vcm_set_stream(self.ctx, stream_handle), "vcm_set_stream")
+
+    def reserve(self, max_len):
+        """allocate now what the first iteration would allocate"""
+        _check(self.L, self.L.vcm_reserve(self.ctx, max_len), "vcm_reserve")
 
     def begin(self, it, min_len, max_len):
         _check(self.L, self.L.vcm_begin_iteration(self.ctx, it, min_len, max_len), "vcm_begin_iteration")
