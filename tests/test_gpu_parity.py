@@ -161,9 +161,10 @@ def test_full_size_properties_2048():
     r.close()
 
 
-@pytest.mark.parametrize("sid,algo,res,stride", [(1, 4, 2048, 32), (1, 2, 2048, 64), (3, 4, 1024, 16)],
-                         ids=["s1-vcm-2048", "s1-bpm-2048", "s3-vcm-1024"])
-def test_full_size_rows_equal_oracle(sid, algo, res, stride):
+@pytest.mark.parametrize("sid,algo,res,stride,iteration", [(1, 4, 2048, 32, 0), (1, 2, 2048, 64, 0), (3, 4, 1024, 16, 0),
+                                                           (1, 4, 2048, 64, 25)],
+                         ids=["s1-vcm-2048", "s1-bpm-2048", "s3-vcm-1024", "s1-vcm-2048-iteration25"])
+def test_full_size_rows_equal_oracle(sid, algo, res, stride, iteration):
     """BASELINE.json's GPU configs at their FULL size against the oracle, bit for bit, on a sample of pixel rows:
     the oracle (all host cores) runs the complete light pass + grid build and the camera paths of two adjacent
     rows out of every `stride`; the second row of each pair then holds every contribution it gets in the
@@ -172,13 +173,13 @@ def test_full_size_rows_equal_oracle(sid, algo, res, stride):
     sc = cornell_scene(sid, res, res)
     r = VertexCM(sc, algo, 0.003, 0.75, 1234)
     r.mMaxPathLength, r.mMinPathLength = 10, 0
-    r.RunIteration(0)
+    r.RunIteration(iteration)   # the index only sets the radius: 25 -> more than 256 grid cells per axis at this size
     fb = r.framebuffer_sum()
     st = r.stats()
     lc, _ = r.backend.rng_counts()
     r.close()
     o = oracle_lib.Oracle(sc, algo, threads=os.cpu_count() or 1)
-    o.begin(0, 0, 10)
+    o.begin(iteration, 0, 10)
     o.trace_light()
     o.build_grid()
     o.trace_camera(row_stride=stride, row_width=2)
