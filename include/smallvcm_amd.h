@@ -176,6 +176,10 @@ void vcm_destroy(vcm_ctx *ctx);
  * the reference does (about 2x slower; light splats are fp32 atomics there).
  * The environment variable SMALLVCM_AMD_STRICT_ORDER=1 sets the default. */
 int vcm_set_strict_order(vcm_ctx *ctx, int on);
+/* 1 if an iteration with this maxPathLength will run in wavefront mode, 0 if it falls back to / was set to the
+ * strict order (vcm_set_strict_order, or maxPathLength > 31: the per-path vertex masks are 32 bits).  A sharded
+ * host asks this to know whether vcm_trace_camera may run before vcm_build_grid. */
+int vcm_is_wavefront(vcm_ctx *ctx, unsigned maxPathLength);
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all
  * work of this context; NULL = the context's own stream. */
@@ -195,6 +199,8 @@ int vcm_run_iteration(vcm_ctx *ctx, int iteration, unsigned minLen, unsigned max
  * of the light-vertex records between trace_light and build_grid; in the
  * default (wavefront) mode vcm_trace_camera does not need the grid, so it may
  * run BEFORE vcm_build_grid, overlapping the all-gather. */
+/* A phase call that fails ENDS the iteration (HIP error or wrong call order alike): the iteration scratch goes
+ * back to the device's arena and the next call must be vcm_begin_iteration. */
 int vcm_begin_iteration(vcm_ctx *ctx, int iteration, unsigned minLen, unsigned maxLen); /* :288-316 */
 int vcm_trace_light(vcm_ctx *ctx);   /* :321-396, then compaction into merge records */
 int vcm_build_grid(vcm_ctx *ctx);    /* :403-408 -> hashgrid.hxx:41-107 */

@@ -12,6 +12,7 @@
 #include <string>
 #include <new>
 #include <mutex>
+#include <condition_variable>
 #include <atomic>
 
 #include "vcm_kernels.h"
@@ -31,6 +32,7 @@ static int fail(const char *what, const char *detail)
         if (e_ != hipSuccess) { g_hipFailed = true; return fail(#expr, hipGetErrorString(e_)); } \
     } while (0)
 
+#define VCM_MAX_TRACE_WAVES (256 * 32)   /* upper bound of the persistent waves of K1 / K3 */
 #define VCM_STAMP_RING 64   /* iterations of phase timestamps and counters kept on the device */
 #define VCM_STAT_SLOTS (STAT_COUNT + 1)   /* + the number of vertices in the grid */
 enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID_K0, EV_GRID, EV_CAMERA_K0, EV_CAMERA_K1, EV_CONNECT_K1,
@@ -70,16 +72,22 @@ struct Scratch {
 
 struct vcm_ctx;
 struct Arena {
-    std::mutex mtx;                   /* held by the context between begin and end */
+    /* `m` guards the fields below and is only ever held INSIDE an API call.  The arena itself is lent with the
+       `busy` token (condition variable), not by holding a mutex from vcm_begin_iteration to vcm_end_iteration:
+       the two calls may come from different host threads, and vcm_create / vcm_destroy of other contexts must
+       not block behind an open iteration. */
+    std::mutex m;
+    std::condition_variable cv;
+    bool busy;                        /* lent to a context (between begin and end) */
+    unsigned long long ownerThread;   /* host thread that borrowed it, 0 = none */
     int device;
     Scratch s;
     size_t capLocal, capN; int capS, capL; bool capSharded;
     bool allocated;
     hipEvent_t lastUse; bool eventReady, lastValid;
-    vcm_ctx *lastUser;
+    vcm_ctx *lastUser;                /* whose iteration the buffers still hold (NULL: nobody's) */
     int users;                        /* live contexts on this device */
     bool shared;                      /* registry arena (false: private to one sharded context) */
-    std::atomic<unsigned long long> ownerThread;   /* host thread holding mtx, 0 = none */
 };
 static std::atomic<unsigned long long> g_threadCounter{0};
 static thread_local unsigned long long g_threadId = 0;
@@ -145,7 +153,7 @@ static Arena *arena_new(int device, bool shared)
     memset((void *)&a->s, 0, sizeof(Scratch));
     a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
     a->allocated = false; a->eventReady = a->lastValid = false; a->lastUser = NULL; a->users = 0;
-    a->shared = shared; a->ownerThread = 0;
+    a->shared = shared; a->ownerThread = 0; a->busy = false;
     return a;
 }
 /* single-rank contexts share the device's arena; a sharded context (one process per GPU, its
@@ -175,7 +183,7 @@ static void arena_free_buffers(Arena *a)
     a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
 }
 
-/* called with a->mtx held; grows the arena to what this context needs */
+/* called by the context that holds the busy token; grows the arena to what this context needs */
 static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sharded)
 {
     if (!a->eventReady) { HIPCHK(hipEventCreateWithFlags(&a->lastUse, hipEventDisableTiming)); a->eventReady = true; }
@@ -187,6 +195,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const bool sh = sharded || a->capSharded;
     arena_free_buffers(a);
     a->lastValid = false;
+    a->lastUser = NULL;   /* the previous borrower's Scratch copy points at freed memory now */
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
@@ -207,10 +216,14 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l connects to
        light vertices of length <= L-1-l, so <= (L-1)(L-2)/2 VC tasks per path; + one partly used
        block per wave (holes) */
-    const size_t maxWaves = (size_t)256 * 32;
-    const size_t vslots = (size_t)(cL > 0 ? cL : 1) * cl + maxWaves * VCM_QBLOCK_VERTEX;
+    /* Holes: when a wave's block cannot serve a request it abandons what is left of it, which is less than the
+       request itself (wave_queue_alloc): <= 64 of every >= 256 slots for the vertex / DI queues (one item per
+       lane), up to as many slots as items for the VC queue (<= 29 items per lane). */
+    const size_t maxWaves = (size_t)VCM_MAX_TRACE_WAVES;
+    const size_t vitems = (size_t)(cL > 0 ? cL : 1) * cl;
+    const size_t vslots = vitems + vitems / 3 + maxWaves * VCM_QBLOCK_VERTEX;
     const size_t vcPerPath = (cL >= 3) ? (size_t)(cL - 1) * (size_t)(cL - 2) / 2 : 1;
-    const size_t vcslots = vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
+    const size_t vcslots = 2 * vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
     if (dalloc(&s.vs.q0, vslots) || dalloc(&s.vs.q1, vslots) || dalloc(&s.vs.q2, vslots) ||
         dalloc(&s.vs.q3, vslots) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
         dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.diOut, vslots) ||
@@ -228,35 +241,53 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
 static int arena_acquire(vcm_ctx *c, int S, int L)
 {
     Arena *a = c->arena;
-    if (a->ownerThread.load() == this_thread_id())
-        return fail("vcm_begin_iteration", "this thread is already inside an iteration of another context on this "
-                                           "device: single-rank contexts share the iteration scratch, end that iteration first");
-    a->mtx.lock();
-    a->ownerThread = this_thread_id();
+    bool wait;
+    {
+        std::unique_lock<std::mutex> lk(a->m);
+        if (a->busy && a->ownerThread == this_thread_id())
+            return fail("vcm_begin_iteration", "this thread is already inside an iteration of another context on this "
+                                               "device: single-rank contexts share the iteration scratch, end that iteration first");
+        a->cv.wait(lk, [a] { return !a->busy; });
+        a->busy = true;
+        a->ownerThread = this_thread_id();
+        wait = a->lastValid && a->lastUser != c;
+        if (a->lastUser != c) a->lastUser = NULL;   /* from here on the buffers are this context's */
+    }
     c->holdsArena = true;
     if (arena_ensure(a, (size_t)c->nLocal, (size_t)c->N, S, L, c->world > 1)) return -1;
     *static_cast<Scratch *>(c) = a->s;
-    if (a->lastValid && a->lastUser != c) HIPCHK(hipStreamWaitEvent(c->stream, a->lastUse, 0));
+    if (wait && a->lastValid) HIPCHK(hipStreamWaitEvent(c->stream, a->lastUse, 0));
     return 0;
 }
 static void arena_release(vcm_ctx *c, bool recordEvent)
 {
     if (!c->holdsArena) return;
     Arena *a = c->arena;
-    if (recordEvent && a->eventReady && hipEventRecord(a->lastUse, c->stream) == hipSuccess) { a->lastValid = true; a->lastUser = c; }
+    const bool recorded = recordEvent && a->eventReady && hipEventRecord(a->lastUse, c->stream) == hipSuccess;
     c->holdsArena = false;
-    a->ownerThread = 0;
-    a->mtx.unlock();
+    {
+        std::lock_guard<std::mutex> g(a->m);
+        if (recorded) { a->lastValid = true; a->lastUser = c; }
+        a->busy = false;
+        a->ownerThread = 0;
+    }
+    a->cv.notify_one();
 }
-/* error inside an iteration: give the arena back so that other contexts do not dead-lock */
+/* A failed phase call ENDS the iteration -- a HIP error as well as a call-order error: its work is abandoned,
+ * the arena goes back (other contexts must not dead-lock behind it) and the next call has to be
+ * vcm_begin_iteration.  What the iteration had already added to the framebuffer stays there. */
 static int abort_iteration(vcm_ctx *c, int rc)
 {
-    if (rc != 0 && g_hipFailed && c && c->holdsArena) {
+    if (rc != 0 && c && c->inIteration && c->holdsArena) {
+        const std::string keep = g_err;   /* the message of the failure, not of the clean-up */
         (void)hipStreamSynchronize(c->stream);
         if (c->deviceReady) (void)hipStreamSynchronize(c->side);
         c->gridInFlight = false;
         c->inIteration = false;
         arena_release(c, false);
+        g_err = keep;
+    } else if (rc != 0 && c && c->holdsArena && !c->inIteration) {
+        arena_release(c, false);   /* vcm_begin_iteration failed after borrowing */
     }
     return rc;
 }
@@ -265,8 +296,11 @@ static int abort_iteration(vcm_ctx *c, int rc)
 static int scratch_readable(vcm_ctx *c, const char *what)
 {
     if (!c || !c->deviceReady || (!c->inIteration && c->iterations == 0)) return fail(what, "no iteration has run");
-    if (!c->holdsArena && c->arena->lastUser != c)
-        return fail(what, "the iteration scratch has since been used by another context of this device");
+    if (!c->holdsArena) {
+        std::lock_guard<std::mutex> g(c->arena->m);
+        if (c->arena->lastUser != c)
+            return fail(what, "the iteration scratch has since been used by another context of this device");
+    }
     return 0;
 }
 
@@ -381,7 +415,8 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk)
     int waves = (nLocal + VCM_WAVE - 1) / VCM_WAVE;
     static const char *tw = getenv("SMALLVCM_AMD_TRACE_WAVES");
     /* 4096 = 16 waves per CU: measured best (fewer, longer-lived waves leave fewer partly used queue blocks) */
-    const int maxWaves = (tw && atoi(tw) > 0) ? atoi(tw) : 256 * 16;
+    int maxWaves = (tw && atoi(tw) > 0) ? atoi(tw) : 256 * 16;
+    if (maxWaves > VCM_MAX_TRACE_WAVES) maxWaves = VCM_MAX_TRACE_WAVES;   /* the queue buffers hold one spare block per wave */
     if (waves > maxWaves) waves = maxWaves;
     if (waves < 1) waves = 1;
     const int wavesPerBlock = VCM_TRACE_BLOCK / VCM_WAVE;
@@ -453,7 +488,7 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     c->ownStream = true;
     c->arena = arena_get(device, worldSize == 1);
     if (!c->arena) { delete c; fail("vcm_create", "device index out of range"); return NULL; }
-    { std::lock_guard<std::mutex> g(c->arena->mtx); c->arena->users++; }
+    { std::lock_guard<std::mutex> g(c->arena->m); c->arena->users++; }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
     return c;
@@ -476,9 +511,9 @@ void vcm_destroy(vcm_ctx *c)
     arena_release(c, false);
     if (c->arena) {
         Arena *a = c->arena;
-        std::lock_guard<std::mutex> g(a->mtx);
+        std::unique_lock<std::mutex> lk(a->m);
         if (a->lastUser == c) { a->lastUser = NULL; }   /* the event stays valid: its work was synchronised above */
-        if (--a->users == 0 && a->allocated) {
+        if (--a->users == 0 && a->allocated) {          /* no context left, so nobody holds or wants the token */
             (void)hipSetDevice(a->device);
             (void)hipDeviceSynchronize();
             arena_free_buffers(a);
@@ -531,7 +566,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     const int S = c->renderer ? 1 : ((maxLen >= 2) ? (int)maxLen - 1 : 1);
     const int L = c->renderer ? 1 : ((maxLen >= 1) ? (int)maxLen : 1);
     if (ensure_device(c)) return -1;
-    if (arena_acquire(c, S, L)) { g_hipFailed = true; return abort_iteration(c, -1); }
+    if (arena_acquire(c, S, L)) return -1;   /* the wrapper gives the arena back if it was borrowed */
 
     IterParams &P = c->P;
     memset(&P, 0, sizeof(P));
@@ -554,7 +589,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     P.cellSize = radius * 2.f;                                                /* hashgrid.hxx:47 */
     P.invCellSize = 1.f / P.cellSize;                                         /* :48 */
     P.nCells = c->N;                                                          /* vertexcm.hxx:406 */
-    P.wavefront = (!c->strictOrder && !c->lightTraceOnly && !c->renderer && maxLen <= 31) ? 1 : 0;
+    P.wavefront = vcm_is_wavefront(c, maxLen);
     P.renderer = c->renderer;
     P.iteration = iteration;
     /* Queue blocks of K3: the unused tail of every wave's last block is holes the task kernels step over (half a
@@ -911,8 +946,19 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (join_grid(c)) return -1;
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
-            hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
-                               c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk);
+            /* default: cell lists staged through LDS by the workgroup (k_merge_staged); SMALLVCM_AMD_MERGE=lane
+               selects the per-lane gathers of round 1 (same bits, kept for A/B measurements) */
+            static int mergeStaged = -1;
+            if (mergeStaged < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE"); mergeStaged = (e && !strcmp(e, "lane")) ? 0 : 1; }
+            if (mergeStaged) {
+                int ch = mergeChunk * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK;
+                if (ch < 1) ch = 1;
+                hipLaunchKernelGGL(k_merge_staged, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
+                                   c->stream, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
+                                   (const int *)(c->dQueryStart + nb), c->dStats, ch);
+            } else
+                hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk);
         } else {
             if (mark(c, EV_SORT_K1)) return -1;
         }
@@ -931,7 +977,15 @@ static int vcm_merge_impl(vcm_ctx *c)
 int vcm_begin_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)
 {
     g_hipFailed = false;
+    if (c && c->inIteration) return fail("vcm_begin_iteration", "previous iteration not ended");   /* it stays open */
     return abort_iteration(c, vcm_begin_iteration_impl(c, iteration, minLen, maxLen));
+}
+/* 1 if an iteration with this maxPathLength runs in wavefront mode (camera pass independent of the grid),
+ * 0 if everything is evaluated inside the paths (strict order requested, or maxPathLength > 31) */
+int vcm_is_wavefront(vcm_ctx *c, unsigned maxLen)
+{
+    if (!c) return 0;
+    return (!c->strictOrder && !c->lightTraceOnly && !c->renderer && maxLen <= 31) ? 1 : 0;
 }
 int vcm_import_light_records(vcm_ctx *c, const void *devPtr, const long long *counts, int nSeg, long long strideRecords)
 {

@@ -1329,10 +1329,13 @@ VCM_HD uint32_t lanes_below_mask_popc(unsigned long long m)
     (void)m; return 0u;
 #endif
 }
-/* n in [0,15] items for this lane (only active lanes call): returns the lane's
- * first slot; refills the wave's block from *counter when it runs out.
- * holeFill(first, count, rank, nActive) must mark slots [first, first+count) as
- * holes; it is called by the nActive active lanes, rank = 0..nActive-1. */
+/* n in [0,31] items for this lane (only active lanes call; n <= maxPathLength - 2 <= 29 in wavefront mode,
+ * vcm_begin_iteration): returns the lane's first slot; refills the wave's block from *counter when it runs
+ * out -- with as many blocks as the wave's request needs (64 lanes x 29 items exceed one block), taken with
+ * ONE atomic so that they are contiguous.  holeFill(first, count, rank, nActive) must mark slots
+ * [first, first+count) as holes; it is called by the nActive active lanes, rank = 0..nActive-1.
+ * Space: a refill abandons fewer slots than the request it could not serve, so holes <= items; the buffers are
+ * sized for 2 x the worst-case item count + one block per wave (arena_ensure). */
 template <typename HoleFill>
 VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, int n, HoleFill holeFill)
 {
@@ -1341,7 +1344,7 @@ VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, in
     const int rank = (int)lanes_below_mask_popc(act);
     int prefix = 0, total = 0;
 #pragma unroll
-    for (int bit = 0; bit < 4; bit++) {
+    for (int bit = 0; bit < 5; bit++) {
         const unsigned long long m = __ballot((n >> bit) & 1);
         prefix += (int)lanes_below_mask_popc(m) << bit;
         total += __popcll(m) << bit;
@@ -1349,10 +1352,11 @@ VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, in
     int base = wq.p[0], left = wq.p[1];   /* same values in every active lane */
     if (total > left) {   /* wave-uniform */
         holeFill(base, left, rank, (int)__popcll(act));
+        const int take = ((total + blockSize - 1) / blockSize) * blockSize;
         int nb = 0;
-        if (rank == 0) nb = atomicAdd(counter, blockSize);
+        if (rank == 0) nb = atomicAdd(counter, take);
         base = __shfl(nb, __ffsll((long long)act) - 1, 64);
-        left = blockSize;
+        left = take;
     }
     if (rank == 0) { wq.p[0] = base + total; wq.p[1] = left - total; }
     return base + prefix;

@@ -331,6 +331,249 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
     flush_stats(ls, gstats);
 }
 
+/* ---------------- K4 (default): range-merge with the cell lists staged through LDS ---------------- */
+/* HashGrid::Process walks 8 hashed cells per query (hashgrid.hxx:142-167).  k_merge_lane reads the candidates of
+ * those cells with per-lane global loads: three 16-byte loads per lane and step, each touching as many cache lines
+ * as the wave has distinct cells (~13) -- the L1/TA path, not HBM and not the VALU, bounds its scan half (2.1 of
+ * 4.1 ms at 2048^2; its measured HBM traffic is still 30x the photon set because every XCD streams the positions
+ * again and again).  Here a WORKGROUP handles a batch of VCM_STAGE_BLOCK consecutive queries of the cell-sorted
+ * order -- neighbours in space, so their 8-cell neighbourhoods overlap almost completely -- in four steps:
+ *   A  every lane hashes its 8 cells, fetches their ranges (cellStart) and enters them into a small open-addressed
+ *      table in LDS (key = hashed cell); the lane that creates an entry (the CAS winner) reserves the space for the
+ *      cell's run in the staging area; duplicates -- the same cell wanted by hundreds of lanes -- cost one CAS;
+ *   B  the distinct runs are copied global -> LDS cooperatively: contiguous, coalesced reads of gx / gy / gz,
+ *      once per workgroup instead of once per query (16 lanes per run, 4 runs per wave at a time);
+ *   C  every lane scans ITS 8 cells in the reference's order out of LDS (ds_read_b128: lanes of the same cell
+ *      broadcast), tests 4 candidates per step with packed fp32, queues accepted photon indices per lane and
+ *      drains the queue through the BSDF evaluation exactly as k_merge_lane does -- same operations, same order,
+ *      same bits;
+ *   D  barrier, table reset, next batch.
+ * A run that does not fit (staging area or table full: caustic hot spots, or late iterations where the cells are
+ * tiny and every query has its own neighbourhood) is simply read from global memory by the lanes that need it,
+ * so the staging is a cache, never a limit.  Only positions are staged (12 of the 52 bytes): the distance test
+ * is 1.27 G candidates per iteration, the 40 bytes of an ACCEPTED photon (0.2 G) stay per-lane gathers. */
+#ifndef VCM_STAGE_BLOCK
+#define VCM_STAGE_BLOCK 512
+#endif
+#define VCM_STAGE_HT (VCM_STAGE_BLOCK)                 /* table slots, power of two */
+#define VCM_STAGE_CAP (5 * VCM_STAGE_BLOCK)            /* staged photons per workgroup */
+#define VCM_STAGE_NOSLOT 1023u
+#if defined(__HIP_DEVICE_COMPILE__)
+struct StageLds {
+    float sx[VCM_STAGE_CAP], sy[VCM_STAGE_CAP], sz[VCM_STAGE_CAP];   /* 16-byte aligned runs (every run starts at a multiple of 4) */
+    int key[VCM_STAGE_HT];                   /* hashed cell, -1 = free */
+    int lo[VCM_STAGE_HT], len[VCM_STAGE_HT], off[VCM_STAGE_HT];   /* run in the grid arrays; where it is staged (-1: not) */
+    unsigned short list[VCM_STAGE_HT];       /* slots in use, dense: the copy phase walks this */
+    int count, used;
+};
+
+/* 16-byte aligned LDS read through an explicitly LOCAL pointer (ds_read_b128).  Written through the generic
+ * reference alone, the compiler merges "staged ? LDS : global" into one flat_load of a selected generic pointer,
+ * which sends every candidate read through the vector-memory path again -- the thing this kernel exists to avoid. */
+typedef float vcm_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ vcm_f4 lds_read4(const float *p)
+{
+    return *(const __attribute__((address_space(3))) vcm_f4 *)p;
+}
+
+/* step A for one cell: returns the table slot that holds `cell`, VCM_STAGE_NOSLOT if the table is full */
+__device__ __forceinline__ uint32_t stage_insert(StageLds &L, int cell, int lo, int hi)
+{
+    uint32_t slot = ((uint32_t)cell * 2654435761u) >> (32 - __builtin_ctz(VCM_STAGE_HT));
+#pragma unroll 1
+    for (int probe = 0; probe < 8; probe++) {
+        const int prev = atomicCAS(&L.key[slot], -1, cell);
+        if (prev == -1) {   /* this lane creates the entry */
+            const int len = hi - lo, padded = (len + 3) & ~3;
+            int off = -1;
+            if (len > 0) {
+                const int o = atomicAdd(&L.used, padded);
+                if (o + padded <= VCM_STAGE_CAP) off = o;
+            }
+            L.lo[slot] = lo; L.len[slot] = len; L.off[slot] = off;
+            L.list[atomicAdd(&L.count, 1)] = (unsigned short)slot;
+            return slot;
+        }
+        if (prev == cell) return slot;
+        slot = (slot + 1u) & (uint32_t)(VCM_STAGE_HT - 1);
+    }
+    return VCM_STAGE_NOSLOT;
+}
+
+/* HashGrid::Process + RangeQuery::Process for one camera vertex, candidates out of LDS where staged.
+ * Mirrors merge_query (vcm_core.h) statement by statement; `slots` = the 8 table slots of step A, 10 bits each. */
+__device__ __forceinline__ V3 merge_query_staged(const vcm_scene_desc &sc, const IterParams &P, const GridStore &g,
+                                                 const Bsdf &cameraBsdf, const SubPathState &st, V3 queryPos, bool inside,
+                                                 int px, int py, int pz, int pxo, int pyo, int pzo,
+                                                 uint32_t s0, uint32_t s1, uint32_t s2, const StageLds &L, LaneStats &ls,
+                                                 const MergeScratch &ms)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    V3 contrib = sp3(0.f);
+    MergeEval ev;
+    merge_eval_setup(ev, sc, P, cameraBsdf, st);
+    const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
+    int qn = 0;
+    for (int j = 0; j < 8; j++) {
+        int lo = 0, len = 0, off = -1;
+        if (inside) {
+            const uint32_t w = (j < 3) ? s0 : ((j < 6) ? s1 : s2);
+            const uint32_t slot = (w >> (10 * (j % 3))) & 1023u;
+            if (slot != VCM_STAGE_NOSLOT) {
+                lo = L.lo[slot]; len = L.len[slot]; off = L.off[slot];
+            } else {   /* table full: the lane fetches the range itself */
+                const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
+                lo = g.cellStart[cell];
+                len = g.cellStart[cell + 1] - lo;
+            }
+        }
+        ls.mergeCandidates += (uint32_t)len;   /* one distance test per entry (:162-165) */
+        const bool staged = off >= 0;
+        /* software-pipelined like merge_query: the candidates of step s+1 are in flight while step s is tested.
+           Staged runs are read 16-byte aligned (LDS offset and step are multiples of 4; the read past a run's end
+           stays inside its padding or falls back to its first quad); global runs as in merge_query. */
+        f4u X, Y, Z;
+        if (staged) { X = lds_read4(L.sx + off); Y = lds_read4(L.sy + off); Z = lds_read4(L.sz + off); }
+        else { X = *(const f4u *)(g.gx + lo); Y = *(const f4u *)(g.gy + lo); Z = *(const f4u *)(g.gz + lo); }
+        int i = 0;
+        while (wave_any(i < len)) {
+            const int ni = i + VCM_MERGE_UNROLL;
+            f4u Xn, Yn, Zn;
+            if (staged) {
+                const int a = off + ((ni < len) ? ni : 0);
+                Xn = lds_read4(L.sx + a); Yn = lds_read4(L.sy + a); Zn = lds_read4(L.sz + a);
+            } else {
+                const int a = lo + ((ni < len) ? ni : len);
+                Xn = *(const f4u *)(g.gx + a); Yn = *(const f4u *)(g.gy + a); Zn = *(const f4u *)(g.gz + a);
+            }
+            float distSqr[VCM_MERGE_UNROLL];
+            {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */
+                const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
+                const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
+                const f2 da = dxa * dxa + dya * dya + dza * dza;
+                const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
+                distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
+            }
+            X = Xn; Y = Yn; Z = Zn;
+#pragma unroll
+            for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
+                const bool acc = (i + u < len) & (distSqr[u] <= P.radiusSqr);   /* :165 */
+                ms.q[qn * ms.stride] = (uint32_t)(lo + i + u);
+                qn += acc ? 1 : 0;
+            }
+            i = (ni < len) ? ni : len;
+            if (wave_any(qn > VCM_MERGE_Q - VCM_MERGE_UNROLL)) {
+                ls.mergeAccepted += (uint32_t)qn;
+                merge_drain(P, g, ev, ms, qn, contrib);
+                qn = 0;
+            }
+        }
+    }
+    ls.mergeAccepted += (uint32_t)qn;
+    merge_drain(P, g, ev, ms, qn, contrib);
+    return contrib;
+}
+#endif
+
+__global__ void __launch_bounds__(VCM_STAGE_BLOCK)
+k_merge_staged(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
+               const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const vcm_scene_desc &sc = *scp;
+    const int nQ = *nSorted;
+    __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_STAGE_BLOCK];
+    __shared__ __attribute__((aligned(16))) StageLds L;
+    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_STAGE_BLOCK;
+    LaneStats ls; lane_stats_zero(ls);
+    const int tid = (int)threadIdx.x;
+    const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
+    /* batches are dealt to the XCDs in chunks, as in k_merge_lane: a region's photons stay in one L2 */
+    const int nBatches = (nQ + VCM_STAGE_BLOCK - 1) / VCM_STAGE_BLOCK;
+    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
+    for (int t = wgOfXcd;; t += wgPerXcd) {
+        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
+        if ((t / chunk) * 8 * chunk >= nBatches) break;   /* block-uniform */
+        if (b >= nBatches) continue;
+        /* ---- reset the table (the previous batch's readers are past the barrier at the end of the loop body) */
+        for (int i = tid; i < VCM_STAGE_HT; i += VCM_STAGE_BLOCK) L.key[i] = -1;
+        if (tid == 0) { L.count = 0; L.used = 0; }
+        __syncthreads();
+        /* ---- A: this lane's query, its 8 cells, their ranges -> table */
+        const int q = b * VCM_STAGE_BLOCK + tid;
+        const bool active = q < nQ;
+        int vi = 0;
+        V3 pos = sp3(0.f);
+        bool inside = false;
+        int px = 0, py = 0, pz = 0, pxo = 0, pyo = 0, pzo = 0;
+        uint32_t s0 = 0u, s1 = 0u, s2 = 0u;
+        if (active) {
+            vi = sortedVertex[q];
+            const F4 a = vs.q0[vi];
+            pos = mk3(a.x, a.y, a.z);
+            const V3 distMin = pos - bmin, distMax = bmax - pos;
+            inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
+                       distMin.z < 0.f || distMax.z < 0.f);   /* hashgrid.hxx:116-122 */
+            const V3 cellPt = P.invCellSize * distMin;          /* :124-138 */
+            const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+            px = int(coordF.x); py = int(coordF.y); pz = int(coordF.z);
+            const V3 fractCoord = cellPt - coordF;
+            pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+            pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+            pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+            if (inside) {
+                int cell[8], lo[8], hi[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {   /* :142-155, all 16 range words in flight together */
+                    cell[j] = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
+                    lo[j] = g.cellStart[cell[j]];
+                    hi[j] = g.cellStart[cell[j] + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t slot = stage_insert(L, cell[j], lo[j], hi[j]);
+                    if (j < 3) s0 |= slot << (10 * j);
+                    else if (j < 6) s1 |= slot << (10 * (j - 3));
+                    else s2 |= slot << (10 * (j - 6));
+                }
+            }
+        }
+        __syncthreads();
+        /* ---- B: copy the distinct runs, 16 lanes per run */
+        {
+            const int n = L.count;
+            const int sub = tid >> 4, lane16 = tid & 15;
+            for (int e = sub; e < n; e += VCM_STAGE_BLOCK / 16) {
+                const int slot = L.list[e];
+                const int off = L.off[slot];
+                if (off < 0) continue;
+                const int lo = L.lo[slot], len = L.len[slot];
+                for (int i = lane16; i < len; i += 16) {
+                    L.sx[off + i] = g.gx[lo + i];
+                    L.sy[off + i] = g.gy[lo + i];
+                    L.sz[off + i] = g.gz[lo + i];
+                }
+            }
+        }
+        __syncthreads();
+        /* ---- C: scan + evaluate (eval_merge_task with the staged scan) */
+        if (active) {
+            const F4 a = vs.q0[vi], bq = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+            const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
+            Bsdf bsdf;
+            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), (int)((f2u(bq.w) >> 8) & 0xffu), sc);
+            SubPathState st;
+            st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
+            const V3 contrib = merge_query_staged(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
+            const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+        }
+        __syncthreads();
+    }
+    flush_stats(ls, gstats);
+#endif
+}
+
 /* ---------------- K5: Framebuffer::AddColor of camera colours ----------- */
 /* vertexcm.hxx:544 adds colour p to the pixel of its jittered sample, in path
  * order.  Pixel q can receive from paths q-resX-1, q-resX, q-1, q (ascending

@@ -58,6 +58,7 @@ def load_library(require_gpu=True):
         L.vcm_destroy.restype = None
         L.vcm_set_stream.argtypes = [vp, vp]
         L.vcm_set_strict_order.argtypes = [vp, C.c_int]
+        L.vcm_is_wavefront.argtypes = [vp, C.c_uint]
         L.vcm_run_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
         L.vcm_begin_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
         for n in ("vcm_trace_light", "vcm_build_grid", "vcm_trace_camera", "vcm_merge", "vcm_end_iteration", "vcm_synchronize",
@@ -133,8 +134,7 @@ class HipBackend:
         self.world = world
         self.device = device
         self._tstream = None
-        strict = os.environ.get("SMALLVCM_AMD_STRICT_ORDER", "")[:1] == "1"
-        self.camera_before_grid = world > 1 and not strict
+        self._max_len = 2
 
     def stream_context(self):
         """Run this context's kernels and the caller's torch ops (collectives,
@@ -160,7 +160,6 @@ class HipBackend:
     def set_strict_order(self, on):
         """True: DI / VC / merge inside the camera path as the reference does (slower, same bits)."""
         _check(self.L, self.L.vcm_set_strict_order(self.ctx, 1 if on else 0), "vcm_set_strict_order")
-        self.camera_before_grid = (not on) and self.world > 1
 
     def set_stream(self, stream_handle):
         _check(self.L, self.L.vcm_set_stream(self.ctx, stream_handle), "vcm_set_stream")
@@ -170,6 +169,7 @@ class HipBackend:
         _check(self.L, self.L.vcm_reserve(self.ctx, max_len), "vcm_reserve")
 
     def begin(self, it, min_len, max_len):
+        self._max_len = int(max_len)
         _check(self.L, self.L.vcm_begin_iteration(self.ctx, it, min_len, max_len), "vcm_begin_iteration")
 
     def trace_light(self):
@@ -184,10 +184,13 @@ class HipBackend:
     def merge(self):
         _check(self.L, self.L.vcm_merge(self.ctx), "vcm_merge")
 
-    #: The camera trace needs only the local light vertices, not the grid (unless strict mode is on): a sharded
-    #: renderer runs it while the other ranks' vertices are in flight.  A single-rank renderer builds the grid first:
-    #: the camera pass then also takes over the histogram of the query sort.  Set per instance in __init__.
-    camera_before_grid = False
+    @property
+    def camera_before_grid(self):
+        """The camera trace needs only the local light vertices, not the grid -- in wavefront mode, which the LIBRARY
+        decides per iteration (strict order requested, or maxPathLength > 31: vcm_is_wavefront): a sharded renderer
+        then runs it while the other ranks' vertices are in flight.  A single-rank renderer builds the grid first:
+        the camera pass then also takes over the histogram of the query sort."""
+        return self.world > 1 and bool(self.L.vcm_is_wavefront(self.ctx, self._max_len))
 
     def end(self):
         _check(self.L, self.L.vcm_end_iteration(self.ctx), "vcm_end_iteration")

@@ -161,39 +161,104 @@ def test_full_size_properties_2048():
     r.close()
 
 
-@pytest.mark.parametrize("sid,algo,res,stride,iteration", [(1, 4, 2048, 32, 0), (1, 2, 2048, 64, 0), (3, 4, 1024, 16, 0),
-                                                           (1, 4, 2048, 64, 25)],
-                         ids=["s1-vcm-2048", "s1-bpm-2048", "s3-vcm-1024", "s1-vcm-2048-iteration25"])
-def test_full_size_rows_equal_oracle(sid, algo, res, stride, iteration):
-    """BASELINE.json's GPU configs at their FULL size against the oracle, bit for bit, on a sample of pixel rows:
-    the oracle (all host cores) runs the complete light pass + grid build and the camera paths of two adjacent
-    rows out of every `stride`; the second row of each pair then holds every contribution it gets in the
-    reference (light splats from anywhere, camera colours of rows y-1 and y)."""
+FULL_FRAME = [(1, 4, 512, 0, True), (3, 4, 1024, 0, True), (1, 2, 2048, 0, False), (1, 4, 2048, 0, True), (1, 4, 2048, 25, False)]
+
+
+@pytest.mark.parametrize("sid,algo,res,iteration,replay", FULL_FRAME,
+                         ids=["C1-s1-vcm-512", "C2-s3-vcm-1024", "C3-s1-bpm-2048", "C4-s1-vcm-2048", "C4-s1-vcm-2048-iteration25"])
+def test_baseline_configs_full_frame(sid, algo, res, iteration, replay):
+    """Every GPU config of BASELINE.json at its FULL size, the WHOLE frame, bit for bit:
+      * against the oracle (all host cores: light pass, grid build, every camera path) -- framebuffer, random-number
+        tape of both passes and all workload counters;
+      * `replay`: the GPU's tape replayed into the UNMODIFIED reference (oracle/_ref, serial like the reference:
+        about 2 s at 512^2, a minute or so at 2048^2) -- framebuffer, and the reference must consume exactly the
+        taped number of floats.
+    Iteration 25 only sets the radius (vertexcm.hxx:295-296): more than 256 grid cells per axis at 2048^2, i.e. the
+    coarsened query buckets."""
     import os
     sc = cornell_scene(sid, res, res)
     r = VertexCM(sc, algo, 0.003, 0.75, 1234)
     r.mMaxPathLength, r.mMinPathLength = 10, 0
-    r.RunIteration(iteration)   # the index only sets the radius: 25 -> more than 256 grid cells per axis at this size
+    r.RunIteration(iteration)
     fb = r.framebuffer_sum()
     st = r.stats()
-    lc, _ = r.backend.rng_counts()
+    lc, cc = r.backend.rng_counts()
     r.close()
     o = oracle_lib.Oracle(sc, algo, threads=os.cpu_count() or 1)
-    o.begin(iteration, 0, 10)
-    o.trace_light()
-    o.build_grid()
-    o.trace_camera(row_stride=stride, row_width=2)
-    o.end()
+    o.run_iteration(iteration, 0, 10)
     ref = o.framebuffer()
     ost = o.stats()
-    rows = np.arange(1, res, stride)
-    assert len(rows) >= 8
-    assert np.array_equal(fb[rows].view(np.uint32), ref[rows].view(np.uint32))
-    assert fb[rows].max() > 0
-    for k in ("lightVertices", "lightRays", "lightSplats"):   # the light pass ran in full on both sides
-        assert st[k] == ost[k], k
-    olc, _ = o.counts()
-    assert np.array_equal(lc, olc)
+    olc, occ = o.counts()
+    del o
+    assert np.array_equal(lc, olc) and np.array_equal(cc, occ), "random-number tape"
+    for k in ("lightVertices", "lightRays", "cameraRays", "shadowRays", "mergeQueries", "mergeCandidates", "mergeAccepted",
+              "connections", "lightSplats"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    assert np.array_equal(fb.view(np.uint32), ref.view(np.uint32))
+    assert fb.max() > 0
+    if replay and oracle_lib.have_ref():
+        rfb, consumed, bad = oracle_lib.ref_run_tape(SCENE_CONFIGS[sid], res, res, algo, lc, cc, first_iteration=iteration)
+        assert bad == 0 and consumed == int(lc.sum(dtype=np.int64)) + int(cc.sum(dtype=np.int64))
+        assert np.array_equal(fb.view(np.uint32), rfb.view(np.uint32))
+
+
+# Box masks outside g_SceneConfigs (scene.hxx:112-126): vcm_scene_cornell accepts them, so they are rendered too
+OTHER_MASKS = [(1 | 32, 4, 160, 2, 0, 10), (1 | 64 | 128, 4, 128, 1, 0, 10), (1 | 2 | 4 | 8 | 256 | 128, 4, 128, 2, 0, 10),
+               (1 | 2 | 4 | 8 | 256 | 128, 2, 96, 1, 0, 10), (16 | 32 | 1 | 256, 3, 96, 1, 0, 10), (8 | 64, 5, 96, 1, 0, 10)]
+
+
+@pytest.mark.parametrize("mask,algo,res,nit,mn,mx", OTHER_MASKS,
+                         ids=["large-glass-sphere-diffuse-floor", "kDefault", "all-light-types-vcm", "all-light-types-bpm",
+                              "both-large-spheres-bpt", "background-only-pt"])
+def test_other_box_masks_equal_oracle_and_reference(mask, algo, res, nit, mn, mx):
+    sc = cornell_scene(mask, res, res, is_mask=True)
+    o = Oracle(sc, algo, threads=8)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r.mMinPathLength, r.mMaxPathLength = mn, mx
+    lcs, ccs = [], []
+    for it in range(nit):
+        o.run_iteration(it, mn, mx)
+        r.RunIteration(it)
+        lc, cc = r.backend.rng_counts()
+        olc, occ = o.counts()
+        assert np.array_equal(lc, olc) and np.array_equal(cc, occ)
+        lcs.append(lc)
+        ccs.append(cc)
+        so, sg = o.stats(), r.stats()
+        for k in ("lightVertices", "lightRays", "cameraRays", "shadowRays", "mergeQueries", "mergeCandidates",
+                  "mergeAccepted", "connections", "lightSplats"):
+            assert so[k] == sg[k], (k, so[k], sg[k])
+    fb = r.framebuffer_sum()
+    r.close()
+    assert np.array_equal(fb.view(np.uint32), o.framebuffer().view(np.uint32))
+    assert fb.max() > 0
+    if oracle_lib.have_ref():
+        rfb, consumed, bad = oracle_lib.ref_run_tape(mask, res, res, algo, np.concatenate(lcs), np.concatenate(ccs),
+                                                     n_iter=nit, min_len=mn, max_len=mx)
+        assert bad == 0
+        assert np.array_equal(fb.view(np.uint32), rfb.view(np.uint32))
+
+
+@pytest.mark.parametrize("mx,res", [(18, 96), (24, 128), (31, 64), (40, 48)])
+def test_long_paths(mx, res):
+    """maxPathLength 18..31 in wavefront mode: a camera vertex connects to up to maxPathLength - 2 light vertices, more
+    than 15 per lane and more than one queue block per wave (wave_queue_alloc); 40 runs in the path (per-path masks are
+    32 bits).  Glass sphere on a diffuse floor under the ceiling light: long specular chains."""
+    sc = cornell_scene(1 | 32, res, res, is_mask=True)
+    o = Oracle(sc, 4, threads=8)
+    r = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    r.mMinPathLength, r.mMaxPathLength = 0, mx
+    assert r.backend.L.vcm_is_wavefront(r.backend.ctx, mx) == (1 if mx <= 31 else 0)
+    for it in range(2):
+        o.run_iteration(it, 0, mx)
+        r.RunIteration(it)
+        so, sg = o.stats(), r.stats()
+        for k in ("lightVertices", "connections", "shadowRays", "mergeAccepted"):
+            assert so[k] == sg[k], (k, so[k], sg[k])
+    lc, _ = r.backend.rng_counts()
+    assert int(lc.max()) > 5 + 4 * 15, "no light path long enough to exercise the case"
+    assert np.array_equal(r.framebuffer_sum().view(np.uint32), o.framebuffer().view(np.uint32))
+    r.close()
 
 
 # ---- the reference's two other renderers on the GPU (SURVEY section 8(f) "next" #2) ----------------------------------

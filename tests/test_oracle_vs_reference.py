@@ -70,6 +70,32 @@ def test_oracle_matches_live_reference(sid, algo, res, nit, mn, mx, threads):
     assert np.array_equal(fb, o.framebuffer())
 
 
+# Box masks OUTSIDE g_SceneConfigs (scene.hxx:112-126): large glass sphere on a diffuse floor; kDefault; every light
+# type at once (2 area + sun + point + background); both large spheres requested (the loader keeps the mirror one);
+# and long paths (maxPathLength 24: more than 15 stored vertices per light path occur).
+MASK_CASES = [(1 | 32, 4, 80, 2, 0, 10), (1 | 64 | 128, 4, 64, 1, 0, 10), (1 | 2 | 4 | 8 | 256 | 128, 4, 64, 2, 0, 10),
+              (1 | 2 | 4 | 8 | 256 | 128, 2, 48, 1, 0, 10), (16 | 32 | 1 | 256, 3, 64, 1, 0, 10), (1 | 32, 4, 48, 1, 0, 24),
+              (8 | 64, 5, 64, 1, 0, 10)]
+
+
+@needs_ref
+@pytest.mark.parametrize("mask,algo,res,nit,mn,mx", MASK_CASES)
+def test_oracle_matches_live_reference_on_other_box_masks(mask, algo, res, nit, mn, mx):
+    sc = ref_scene(mask, res, res)
+    o = Oracle(sc, algo, threads=4)
+    lcs, ccs = [], []
+    for it in range(nit):
+        o.run_iteration(it, mn, mx)
+        a, b = o.counts()
+        lcs.append(a)
+        ccs.append(b)
+    fb, consumed, bad = ref_run_tape(mask, res, res, algo, np.concatenate(lcs), np.concatenate(ccs), n_iter=nit,
+                                     min_len=mn, max_len=mx)
+    assert bad == 0
+    assert np.array_equal(fb, o.framebuffer())
+    assert fb.max() > 0
+
+
 @needs_ref
 def test_libm_interposition_is_active():
     before = oracle_lib.ref_tape().ref_detmath_calls()
