@@ -232,10 +232,13 @@ int ref_run_tape(unsigned boxMask, int resX, int resY, int vcmAlgo,
 /* render() of src/smallvcm.cxx:52-151, iteration-based branch (:96-109),
  * with resolution / threads / seed as parameters and wall-clock timing.
  * fbOut = averaged framebuffer exactly as render() leaves it (:116-142). */
-int ref_render_stock(unsigned boxMask, int resX, int resY, int configAlgo /* Config::Algorithm or -1 */,
-                     int vcmAlgo, int iterations, int numThreads, int baseSeed,
-                     unsigned minLen, unsigned maxLen, float radiusFactor, float radiusAlpha,
-                     float *fbOut, double *wallSeconds)
+/* iterIndex (optional): the value handed to RunIteration for loop index i -- it only sets the merge radius
+ * (vertexcm.hxx:295-296), so a benchmark can make the reference render the SAME radius window the GPU is timed on
+ * while keeping render()'s one-renderer-per-thread loop; NULL = the loop index itself, as in render(). */
+int ref_render_stock_iters(unsigned boxMask, int resX, int resY, int configAlgo /* Config::Algorithm or -1 */,
+                           int vcmAlgo, int iterations, const int *iterIndex, int numThreads, int baseSeed,
+                           unsigned minLen, unsigned maxLen, float radiusFactor, float radiusAlpha,
+                           float *fbOut, double *wallSeconds)
 {
     Scene *scene = make_scene(boxMask, resX, resY);
     Config config;
@@ -266,7 +269,7 @@ int ref_render_stock(unsigned boxMask, int resX, int resY, int configAlgo /* Con
 #pragma omp parallel for
     for (iter = 0; iter < config.mIterations; iter++) {
         const int threadId = omp_get_thread_num();
-        renderers[threadId]->RunIteration(iter);
+        renderers[threadId]->RunIteration(iterIndex ? iterIndex[iter] : iter);
     }
     const auto t1 = std::chrono::steady_clock::now();
     int usedRenderers = 0;
@@ -282,6 +285,14 @@ int ref_render_stock(unsigned boxMask, int resX, int resY, int configAlgo /* Con
     if (wallSeconds) *wallSeconds = std::chrono::duration<double>(t1 - t0).count();
     delete scene;
     return usedRenderers;
+}
+
+int ref_render_stock(unsigned boxMask, int resX, int resY, int configAlgo, int vcmAlgo, int iterations, int numThreads,
+                     int baseSeed, unsigned minLen, unsigned maxLen, float radiusFactor, float radiusAlpha,
+                     float *fbOut, double *wallSeconds)
+{
+    return ref_render_stock_iters(boxMask, resX, resY, configAlgo, vcmAlgo, iterations, NULL, numThreads, baseSeed, minLen,
+                                  maxLen, radiusFactor, radiusAlpha, fbOut, wallSeconds);
 }
 #endif
 

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates the profiles of a round ON THE GPU BOX (run through gpurun from the repo root):
-#   bash profiles/collect.sh r01d
+#   bash profiles/collect.sh r02a            (BENCH_ARGS="--res 512" etc. selects another configuration)
 # writes gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards.
 set -u
 TAG=${1:-rXX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-CMD="python bench.py --no-cpu-baseline"
+CMD="python bench.py --no-cpu-baseline --no-configs --no-traffic ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- $CMD > gpurun_out/${TAG}_bench.log 2>&1
 # counters in their own runs, never combined with trace domains other than --kernel-trace
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_fetch -- $CMD > /dev/null 2>&1

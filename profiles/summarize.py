@@ -55,7 +55,10 @@ for k in sorted(fetch, key=lambda k: -dur.get(k, 0)):
         continue
     kernels[k] = {"avg_us": round(dur[k], 1), "fetch_bytes_x2": int(2 * 1024 * fetch[k].get("FETCH_SIZE", 0)),
                   "write_bytes": int(1024 * write.get(k, {}).get("WRITE_SIZE", 0))}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py scene 1 vcm 2048^2, mean over dispatches "
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402  (the sources the counters were collected on: run this BEFORE editing kernels)
+json.dump({"kernel_src_sha16": kernel_source_hash(),
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py scene 1 vcm 2048^2, mean over dispatches "
                    "after the first two; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md section HBM; WRITE_SIZE (KB) uncalibrated; "
                    "avg_us is the duration under counter collection (serialised dispatches)",
            "kernels": kernels}, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)

@@ -178,6 +178,8 @@ def ref_stock():
         L.ref_flatten_scene.argtypes = [C.c_uint, C.c_int, C.c_int, C.POINTER(SceneDesc)]
         L.ref_render_stock.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_uint, C.c_uint, C.c_float, C.c_float, _fp, C.POINTER(C.c_double)]
+        L.ref_render_stock_iters.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                             C.c_int, C.c_uint, C.c_uint, C.c_float, C.c_float, _fp, C.POINTER(C.c_double)]
         _ref_stock = L
     return _ref_stock
 
@@ -205,10 +207,15 @@ def ref_run_tape(mask, resx, resy, algo, light_counts, cam_counts, radius_factor
 
 
 def ref_render_stock(mask, resx, resy, algo, iterations=1, threads=1, seed=1234, min_len=0, max_len=10,
-                     radius_factor=0.003, radius_alpha=0.75, config_algo=-1):
-    """Unmodified reference (mt19937 + glibc), render() semantics. Returns (fb averaged, wall seconds)."""
+                     radius_factor=0.003, radius_alpha=0.75, config_algo=-1, iteration_index=None):
+    """Unmodified reference (mt19937 + glibc), render() semantics. Returns (fb averaged, wall seconds).
+    iteration_index: optional list, the aIteration passed for loop index i (sets the radius only)."""
     fb = np.zeros((resy, resx, 3), np.float32)
     wall = C.c_double()
-    ref_stock().ref_render_stock(mask, resx, resy, config_algo, algo, iterations, threads, seed, min_len, max_len,
-                                 radius_factor, radius_alpha, _fptr(fb), C.byref(wall))
+    idx = None
+    if iteration_index is not None:
+        assert len(iteration_index) == iterations
+        idx = (C.c_int * iterations)(*[int(i) for i in iteration_index])
+    ref_stock().ref_render_stock_iters(mask, resx, resy, config_algo, algo, iterations, idx, threads, seed, min_len, max_len,
+                                       radius_factor, radius_alpha, _fptr(fb), C.byref(wall))
     return fb, wall.value
