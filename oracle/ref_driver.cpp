@@ -134,6 +134,7 @@ public:
 #undef protected
 
 #include "../smallvcm_amd/dropin/flatten_scene.hxx"
+#include "../include/smallvcm_amd_debug.h"
 
 static Scene *make_scene(unsigned boxMask, int resX, int resY)
 {   /* as ParseCommandline does: src/config.hxx:366-370 */
@@ -151,6 +152,43 @@ static Config::Algorithm algo_from_vcm(int vcmAlgo)
     case VCM_ALGO_BPM: return Config::kBidirectionalPhotonMapping;
     case VCM_ALGO_BPT: return Config::kBidirectionalPathTracing;
     default: return Config::kVertexConnectionMerging;
+    }
+}
+
+/* Function-level known answers (T0): the records of include/smallvcm_amd_debug.h
+ * (VCM_KAT_*) answered by the reference's OWN classes, one call per record.  Compared bit for bit with the
+ * product's device functions on the host (tests/host_emul) and on the device (vcm_debug_kat). */
+template <bool FixIsLight>
+static void kat_bsdf(const Scene &scene, int op, const float *in, float *out)
+{
+    Ray ray(Vec3f(0), Vec3f(in[0], in[1], in[2]), 0);
+    Isect isect(1e36f);
+    isect.normal = Vec3f(in[3], in[4], in[5]);
+    isect.matID = (int)in[6];
+    isect.lightID = -1;
+    BSDF<FixIsLight> bsdf(ray, isect, scene);
+    if (!bsdf.IsValid()) return;
+    out[0] = 1.f;
+    if (op == VCM_KAT_BSDF_EVAL) {
+        out[1] = bsdf.IsDelta() ? 1.f : 0.f; out[2] = bsdf.ContinuationProb();
+        const Vec3f gen(in[7], in[8], in[9]);
+        float cosGen = 0.f, dirPdf = 0.f, revPdf = 0.f;
+        const Vec3f f = bsdf.Evaluate(scene, gen, cosGen, &dirPdf, &revPdf);
+        out[3] = f.x; out[4] = f.y; out[5] = f.z;
+        if (!f.IsZero()) out[6] = cosGen;
+        out[7] = dirPdf; out[8] = revPdf;
+        out[9] = bsdf.Pdf(scene, gen, false);
+        out[10] = bsdf.Pdf(scene, gen, true);
+        const Vec3f w = bsdf.WorldDirFix();
+        out[11] = w.x; out[12] = w.y; out[13] = w.z; out[14] = bsdf.CosThetaFix();
+    } else {
+        Vec3f gen(0);
+        float pdfW = 0.f, cosGen = 0.f;
+        uint ev = 0;
+        const Vec3f f = bsdf.Sample(scene, Vec3f(in[7], in[8], in[9]), gen, pdfW, cosGen, &ev);
+        if (f.IsZero()) return;
+        out[1] = f.x; out[2] = f.y; out[3] = f.z; out[4] = gen.x; out[5] = gen.y; out[6] = gen.z;
+        out[7] = pdfW; out[8] = cosGen; out[9] = (float)ev;
     }
 }
 
@@ -175,6 +213,72 @@ void ref_world_to_raster(unsigned boxMask, int resX, int resY, int n, const floa
         out[2*i] = r.x; out[2*i+1] = r.y;
     }
     delete scene;
+}
+
+int ref_kat(unsigned boxMask, int resX, int resY, int op, int n, const float *inAll, float *outAll)
+{
+    Scene *scene = make_scene(boxMask, resX, resY);
+    for (int i = 0; i < n; i++) {
+        const float *in = inAll + (size_t)i * VCM_KAT_FLOATS;
+        float *out = outAll + (size_t)i * VCM_KAT_FLOATS;
+        for (int k = 0; k < VCM_KAT_FLOATS; k++) out[k] = 0.f;
+        switch (op) {
+        case VCM_KAT_INTERSECT: {
+            Ray ray(Vec3f(in[0], in[1], in[2]), Vec3f(in[3], in[4], in[5]), in[6]);
+            Isect is(1e36f);
+            if (scene->Intersect(ray, is)) {
+                out[0] = 1.f; out[1] = is.dist; out[2] = (float)is.matID; out[3] = (float)is.lightID;
+                out[4] = is.normal.x; out[5] = is.normal.y; out[6] = is.normal.z;
+            }
+        } break;
+        case VCM_KAT_OCCLUDED:
+            out[0] = scene->Occluded(Vec3f(in[0], in[1], in[2]), Vec3f(in[3], in[4], in[5]), in[6]) ? 1.f : 0.f;
+            break;
+        case VCM_KAT_BSDF_EVAL:
+            kat_bsdf<false>(*scene, op, in, out);
+            break;
+        case VCM_KAT_BSDF_SAMPLE:
+            if (in[10] != 0.f) kat_bsdf<true>(*scene, op, in, out); else kat_bsdf<false>(*scene, op, in, out);
+            break;
+        case VCM_KAT_LIGHT_EMIT: {
+            const AbstractLight *l = scene->GetLightPtr((int)in[0]);
+            Vec3f pos(0), dir(0);
+            float emissionPdfW = 0.f, directPdfA = 0.f, cosLight = 0.f;
+            const Vec3f e = l->Emit(scene->mSceneSphere, Vec2f(in[1], in[2]), Vec2f(in[3], in[4]), pos, dir, emissionPdfW,
+                                    &directPdfA, &cosLight);
+            out[0] = e.x; out[1] = e.y; out[2] = e.z; out[3] = pos.x; out[4] = pos.y; out[5] = pos.z;
+            out[6] = dir.x; out[7] = dir.y; out[8] = dir.z; out[9] = emissionPdfW; out[10] = directPdfA; out[11] = cosLight;
+            out[12] = l->IsFinite() ? 1.f : 0.f; out[13] = l->IsDelta() ? 1.f : 0.f;
+        } break;
+        case VCM_KAT_LIGHT_ILLUMINATE: {
+            const AbstractLight *l = scene->GetLightPtr((int)in[0]);
+            Vec3f dir(0);
+            float dist = 0.f, directPdfW = 0.f, emissionPdfW = 0.f, cosAtLight = 0.f;
+            const Vec3f r = l->Illuminate(scene->mSceneSphere, Vec3f(in[1], in[2], in[3]), Vec2f(in[4], in[5]), dir, dist,
+                                          directPdfW, &emissionPdfW, &cosAtLight);
+            out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = dir.x; out[4] = dir.y; out[5] = dir.z; out[6] = dist;
+            if (!r.IsZero()) { out[7] = directPdfW; out[8] = emissionPdfW; out[9] = cosAtLight; }
+        } break;
+        case VCM_KAT_LIGHT_RADIANCE: {
+            const AbstractLight *l = scene->GetLightPtr((int)in[0]);
+            float directPdfA = 0.f, emissionPdfW = 0.f;
+            const Vec3f r = l->GetRadiance(scene->mSceneSphere, Vec3f(in[1], in[2], in[3]), Vec3f(in[4], in[5], in[6]),
+                                           &directPdfA, &emissionPdfW);
+            out[0] = r.x; out[1] = r.y; out[2] = r.z;
+            if (!r.IsZero()) { out[3] = directPdfA; out[4] = emissionPdfW; }
+        } break;
+        case VCM_KAT_CAMERA: {
+            const Ray ray = scene->mCamera.GenerateRay(Vec2f(in[0], in[1]));
+            out[0] = ray.dir.x; out[1] = ray.dir.y; out[2] = ray.dir.z;
+            const Vec2f ip = scene->mCamera.WorldToRaster(Vec3f(in[2], in[3], in[4]));
+            out[3] = ip.x; out[4] = ip.y;
+            out[5] = scene->mCamera.CheckRaster(ip) ? 1.f : 0.f;
+        } break;
+        default: delete scene; return -1;
+        }
+    }
+    delete scene;
+    return 0;
 }
 
 #ifdef REF_TAPE

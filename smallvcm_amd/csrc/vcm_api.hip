@@ -16,6 +16,7 @@
 #include <atomic>
 
 #include "vcm_kernels.h"
+#include "vcm_kat.h"
 
 using namespace vcm;
 
@@ -1230,6 +1231,15 @@ __global__ void k_numeric_spec(int op, int n, const float *a, const float *b, fl
     }
     out[i] = r;
 }
+__global__ void k_kat(const vcm_scene_desc *__restrict__ scp, int op, int n, const float *in, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a[VCM_KAT_FLOATS], r[VCM_KAT_FLOATS];
+    for (int k = 0; k < VCM_KAT_FLOATS; k++) a[k] = in[(size_t)i * VCM_KAT_FLOATS + k];
+    kat_eval(*scp, op, a, r);
+    for (int k = 0; k < VCM_KAT_FLOATS; k++) out[(size_t)i * VCM_KAT_FLOATS + k] = r[k];
+}
 __global__ void k_philox_spec(uint32_t seed, uint32_t iter, uint32_t kind, int nPaths, int nFloats, float *out)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1253,6 +1263,24 @@ int vcm_debug_numeric_spec(int op, int n, const float *a, const float *b, float 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return 0;
+}
+
+int vcm_debug_kat(vcm_ctx *c, int op, int n, const float *in, float *out)
+{
+    if (!c || !in || !out || n < 0 || op < 0 || op >= VCM_KAT_OPS) return fail("vcm_debug_kat", "bad argument");
+    if (ensure_device(c)) return -1;
+    if (n == 0) return 0;
+    float *din = NULL, *dout = NULL;
+    const size_t bytes = (size_t)n * VCM_KAT_FLOATS * sizeof(float);
+    HIPCHK(hipMalloc((void **)&din, bytes));
+    HIPCHK(hipMalloc((void **)&dout, bytes));
+    HIPCHK(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat, dim3((n + 63) / 64), dim3(64), 0, 0, (const vcm_scene_desc *)c->dScene, op, n, (const float *)din, dout);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    if (e != hipSuccess) return fail("vcm_debug_kat", hipGetErrorString(e));
     return 0;
 }
 

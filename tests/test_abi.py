@@ -3,6 +3,7 @@ include/smallvcm_amd.h declares; PODs have the sizes the ctypes mirror assumes."
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -12,10 +13,15 @@ from smallvcm_amd.renderer import LIB_PATH, load_library
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "smallvcm_amd.h")).read()
+def _declared_symbols(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(vcm_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(vcm_[a-z_0-9]+)\s*\(", src)))
+
+
+def _exported_symbols():
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and l.split()[2].startswith("vcm_"))
 
 
 def test_library_is_built():
@@ -23,11 +29,21 @@ def test_library_is_built():
 
 
 def test_exports_every_declared_symbol():
+    """include/smallvcm_amd.h is the drop-in boundary, include/smallvcm_amd_debug.h the test entry points"""
     L = load_library(require_gpu=False)
-    names = _declared_symbols()
+    names = _declared_symbols("smallvcm_amd.h")
     assert len(names) >= 25
-    missing = [n for n in names if not hasattr(L, n)]
+    missing = [n for n in names + _declared_symbols("smallvcm_amd_debug.h") if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_every_exported_symbol_is_declared():
+    """no entry point outside the two headers: what a host can call is what the headers document"""
+    declared = set(_declared_symbols("smallvcm_amd.h")) | set(_declared_symbols("smallvcm_amd_debug.h"))
+    undeclared = [n for n in _exported_symbols() if n not in declared]
+    assert not undeclared, undeclared
+    # the boundary header itself carries no debug / test entry points
+    assert not [n for n in _declared_symbols("smallvcm_amd.h") if n.startswith(("vcm_debug_", "vcm_host_", "vcm_sizeof_"))]
 
 
 def test_pod_sizes_match_ctypes_mirror():
