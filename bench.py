@@ -52,7 +52,10 @@ KERNEL_KEYS = {"k_light_trace": ["vcm::k_light_trace<1>"], "k_camera_trace": ["v
                "k_merge": ["vcm::k_merge_staged", "vcm::k_merge_lane"]}
 KERNEL_SOURCES = ["vcm_api.hip", "vcm_kernels.h", "vcm_core.h", "vcm_math.h", "detmath.h", "philox.h", "Makefile"]
 # BASELINE.json configs that fit one GPU, besides the headline (C4 at one GPU)
-OTHER_CONFIGS = [("C1", 1, "vcm", 512), ("C2", 3, "vcm", 1024), ("C3", 1, "bpm", 2048)]
+# (name, scene, algorithm, resolution, renderers in flight): "x4" = four renderers (seeds 1234..1237, the reference's
+# iteration-parallel threads, smallvcm.cxx:61-108) taking turns on the one GPU, their iterations overlapping
+OTHER_CONFIGS = [("C1", 1, "vcm", 512, 1), ("C1x4", 1, "vcm", 512, 4), ("C2", 3, "vcm", 1024, 1), ("C2x2", 3, "vcm", 1024, 2),
+                 ("C3", 1, "bpm", 2048, 1), ("C4x2", 1, "vcm", 2048, 2)]
 
 
 def kernel_source_hash():
@@ -350,17 +353,22 @@ def main():
                 roof["traffic_over_algorithmic"] = round(traffic / max(roof["algorithmic_bytes_per_launch"], 1), 4)
         if world == 1 and headline and not args.no_configs:
             cfgs = []
-            for name, scene, algo_name, r in OTHER_CONFIGS:
+            for name, scene, algo_name, r, nfl in OTHER_CONFIGS:
                 try:
-                    f2 = make_farm(scene, algo_name, r, 1, None)
+                    f2 = make_farm(scene, algo_name, r, 1, nfl)
                     e2, s2 = timed_run(f2, args.steps, args.warmup, sync)
                     nl = f2.backend.count
                     f2.close()
                     _, roof2 = roofline_block(s2, nl, r * r)
-                    cfgs.append({"name": name, "workload": workload_name(scene, algo_name, r, 1, args.warmup,
-                                                                         args.warmup + args.steps - 1),
-                                 "value": round(2.0 * r * r * args.steps / e2 / 1e6, 3), "unit": "Mpaths/s",
+                    if nfl > 1:
+                        roof2["scope"] = "first of the %d renderers; its kernels share the GPU with the others', so per-kernel " \
+                                         "times are longer than alone" % nfl
+                    cfgs.append({"name": name, "workload": workload_name(scene, algo_name, r, nfl, args.warmup * nfl,
+                                                                         (args.warmup + args.steps) * nfl - 1),
+                                 "renderers_in_flight": nfl,
+                                 "value": round(2.0 * r * r * args.steps * nfl / e2 / 1e6, 3), "unit": "Mpaths/s",
                                  "ms_per_step": round(e2 / args.steps * 1e3, 3), "steps": args.steps, "warmup": args.warmup,
+                                 "paths_per_step": 2 * r * r * nfl,
                                  "roofline": roof2,
                                  "counters": {k: int(s2[k]) for k in ("lightVertices", "mergeQueries", "mergeCandidates",
                                                                       "mergeAccepted", "connections", "lightSplats")}})

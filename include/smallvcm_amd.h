@@ -185,6 +185,13 @@ int vcm_is_wavefront(vcm_ctx *ctx, unsigned maxPathLength);
  * work of this context; NULL = the context's own stream. */
 int vcm_set_stream(vcm_ctx *ctx, void *hipStream);
 
+/* Iteration scratch (light-vertex store, hash grid, camera-vertex queues: 1.5 GB at 512^2, 24 GB at 2048^2) is not
+ * owned by a renderer: single-rank renderers of a device borrow it per iteration from a pool of arenas, so the
+ * reference's one-renderer-per-host-core driver (smallvcm.cxx:66) fits in HBM and iterations of different renderers
+ * overlap on the GPU.  maxArenas 1..8, 0 = as many as fit a quarter of the device memory (default; environment
+ * SMALLVCM_AMD_ARENAS). */
+int vcm_set_arena_limit(int device, int maxArenas);
+
 /* Optional: allocate up front everything the first iteration with this maxPathLength would allocate lazily
  * (the context's buffers and the device's scratch arena), e.g. before a timed region. */
 int vcm_reserve(vcm_ctx *ctx, unsigned maxPathLength);

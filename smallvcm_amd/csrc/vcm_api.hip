@@ -40,13 +40,14 @@ enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID_K0, EV_GRID, EV
        EV_MERGE_K0, EV_SORT_K1, EV_MERGE_K1, EV_CAMERA, EV_COUNT };
 
 /* Iteration scratch: everything that is dead once an iteration has been
- * resolved into the framebuffer.  It lives in a per-device ARENA shared by all
- * contexts of the process: the reference's render() creates one renderer per
- * host core and runs them concurrently (smallvcm.cxx:66, :82-108) -- 256
- * private copies (1.2 GB each at 512^2, 18 GB at 2048^2) do not fit in HBM.  A
- * context borrows the arena from vcm_begin_iteration to vcm_end_iteration
- * (host mutex); consecutive borrowers are ordered on the GPU by an event, the
- * host never waits for the device. */
+ * resolved into the framebuffer.  It lives in ARENAS that all single-rank contexts of a device share: the
+ * reference's render() creates one renderer per host core and runs them concurrently (smallvcm.cxx:66, :82-108)
+ * -- 256 private copies (1.5 GB each at 512^2, 24 GB at 2048^2) do not fit in HBM.  A context borrows an arena
+ * from vcm_begin_iteration to vcm_end_iteration; consecutive borrowers of one arena are ordered on the GPU by an
+ * event, the host never waits for the device.  A device keeps a small POOL of arenas (as many as fit a quarter of
+ * its memory, at most 8; vcm_set_arena_limit): iterations of different renderers then overlap on the GPU -- one
+ * renderer's tails and latency-bound helper kernels run next to another's wide kernels, which is what fills the
+ * chip at 512^2, where a single iteration is too small to do it. */
 struct Scratch {
     LightStore store;                 /* S*nLocal slots (+ count[nLocal]) */
     int *dPathStart;                  /* nLocal+1 */
@@ -72,23 +73,36 @@ struct Scratch {
 };
 
 struct vcm_ctx;
+struct ArenaPool;
 struct Arena {
-    /* `m` guards the fields below and is only ever held INSIDE an API call.  The arena itself is lent with the
-       `busy` token (condition variable), not by holding a mutex from vcm_begin_iteration to vcm_end_iteration:
-       the two calls may come from different host threads, and vcm_create / vcm_destroy of other contexts must
-       not block behind an open iteration. */
-    std::mutex m;
-    std::condition_variable cv;
+    /* *mtx guards the fields below (the pool's mutex, or the arena's own for the private arena of a sharded
+       context) and is only ever held INSIDE an API call.  The arena itself is lent with the `busy` token, not by
+       holding a mutex from vcm_begin_iteration to vcm_end_iteration: the two calls may come from different host
+       threads, and vcm_create / vcm_destroy of other contexts must not block behind an open iteration. */
+    std::mutex *mtx;
+    std::condition_variable *cv;
+    std::mutex ownMtx;
+    std::condition_variable ownCv;
+    ArenaPool *pool;                  /* NULL: private to one sharded context */
     bool busy;                        /* lent to a context (between begin and end) */
     unsigned long long ownerThread;   /* host thread that borrowed it, 0 = none */
     int device;
     Scratch s;
     size_t capLocal, capN; int capS, capL; bool capSharded;
+    size_t bytes;                     /* device memory held */
     bool allocated;
     hipEvent_t lastUse; bool eventReady, lastValid;
     vcm_ctx *lastUser;                /* whose iteration the buffers still hold (NULL: nobody's) */
-    int users;                        /* live contexts on this device */
-    bool shared;                      /* registry arena (false: private to one sharded context) */
+};
+#define VCM_MAX_ARENAS 8
+struct ArenaPool {
+    std::mutex m;
+    std::condition_variable cv;
+    int device;
+    int users;                        /* live single-rank contexts on this device */
+    int limit;                        /* arenas this pool may hold (<= VCM_MAX_ARENAS); 0 = by memory budget */
+    int count;
+    Arena *arenas[VCM_MAX_ARENAS];
 };
 static std::atomic<unsigned long long> g_threadCounter{0};
 static thread_local unsigned long long g_threadId = 0;
@@ -109,7 +123,8 @@ struct vcm_ctx : Scratch {
     hipEvent_t evFork, evBbox, evGrid; /* main -> side, side -> main (bbox known), side -> main (grid complete) */
     bool gridInFlight;
     bool deviceReady;
-    Arena *arena; bool holdsArena;
+    ArenaPool *pool;                  /* the device's shared arenas (NULL: sharded context with a private one) */
+    Arena *arena; bool holdsArena;    /* the arena of the current / last iteration */
 
     /* per context: survives the iteration */
     vcm_scene_desc *dScene;           /* first member of a device-resident SceneDev */
@@ -134,38 +149,46 @@ struct vcm_ctx : Scratch {
 
 static int use_device(vcm_ctx *c) { HIPCHK(hipSetDevice(c->device)); return 0; }
 
+static thread_local size_t g_allocBytes;   /* bytes dalloc handed out on this thread (arena_ensure reads the difference) */
 template <typename T> static int dalloc(T **p, size_t n)
 {
     void *v = NULL;
     HIPCHK(hipMalloc(&v, (n ? n : 1) * sizeof(T)));
+    g_allocBytes += (n ? n : 1) * sizeof(T);
     *p = (T *)v;
     return 0;
 }
 #define DFREE(p) do { if (p) { (void)hipFree(p); p = NULL; } } while (0)
 
-/* ---- arena -------------------------------------------------------------- */
+/* ---- arenas ------------------------------------------------------------- */
 static std::mutex g_arenaRegistryMutex;
-static Arena *g_arenas[64];
+static ArenaPool *g_pools[64];
 
-static Arena *arena_new(int device, bool shared)
+static Arena *arena_new(int device, ArenaPool *pool)
 {
     Arena *a = new Arena();
     a->device = device;
     memset((void *)&a->s, 0, sizeof(Scratch));
-    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
-    a->allocated = false; a->eventReady = a->lastValid = false; a->lastUser = NULL; a->users = 0;
-    a->shared = shared; a->ownerThread = 0; a->busy = false;
+    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false; a->bytes = 0;
+    a->allocated = false; a->eventReady = a->lastValid = false; a->lastUser = NULL;
+    a->pool = pool; a->ownerThread = 0; a->busy = false;
+    a->mtx = pool ? &pool->m : &a->ownMtx;
+    a->cv = pool ? &pool->cv : &a->ownCv;
     return a;
 }
-/* single-rank contexts share the device's arena; a sharded context (one process per GPU, its
-   iteration spans host-side collectives) gets a private one */
-static Arena *arena_get(int device, bool shared)
+static ArenaPool *pool_get(int device)
 {
     if (device < 0 || device >= 64) return NULL;
-    if (!shared) return arena_new(device, false);
     std::lock_guard<std::mutex> g(g_arenaRegistryMutex);
-    if (!g_arenas[device]) g_arenas[device] = arena_new(device, true);
-    return g_arenas[device];
+    if (!g_pools[device]) {
+        ArenaPool *p = new ArenaPool();
+        p->device = device; p->users = 0; p->count = 0;
+        memset(p->arenas, 0, sizeof(p->arenas));
+        const char *e = getenv("SMALLVCM_AMD_ARENAS");
+        p->limit = (e && atoi(e) > 0) ? (atoi(e) < VCM_MAX_ARENAS ? atoi(e) : VCM_MAX_ARENAS) : 0;
+        g_pools[device] = p;
+    }
+    return g_pools[device];
 }
 
 static void arena_free_buffers(Arena *a)
@@ -197,6 +220,8 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     arena_free_buffers(a);
     a->lastValid = false;
     a->lastUser = NULL;   /* the previous borrower's Scratch copy points at freed memory now */
+    a->bytes = 0;
+    const size_t bytesBefore = g_allocBytes;
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
@@ -235,24 +260,71 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
         dalloc(&s.dQueryArrival, vslots)) return -1;
     a->capLocal = cl; a->capN = cn; a->capS = cs; a->capL = cL; a->capSharded = sh;
     a->allocated = true;
+    a->bytes = g_allocBytes - bytesBefore;
     return 0;
 }
 
-/* borrow the device's arena for one iteration */
+/* may the pool grow by one more arena?  Budget: a quarter of the device's memory, the existing arenas as the
+   estimate of the next one's size (a pool with an explicit limit just counts) */
+static bool pool_may_grow(ArenaPool *p)
+{
+    if (p->count >= VCM_MAX_ARENAS) return false;
+    if (p->limit > 0) return p->count < p->limit;
+    if (p->count == 0) return true;
+    size_t held = 0, largest = 0;
+    for (int i = 0; i < p->count; i++) { held += p->arenas[i]->bytes; if (p->arenas[i]->bytes > largest) largest = p->arenas[i]->bytes; }
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return false;
+    return held + largest <= totalB / 4 && largest + (totalB / 16) <= freeB;
+}
+
+/* borrow an arena for one iteration */
 static int arena_acquire(vcm_ctx *c, int S, int L)
 {
-    Arena *a = c->arena;
+    Arena *a = NULL;
     bool wait;
-    {
-        std::unique_lock<std::mutex> lk(a->m);
-        if (a->busy && a->ownerThread == this_thread_id())
-            return fail("vcm_begin_iteration", "this thread is already inside an iteration of another context on this "
-                                               "device: single-rank contexts share the iteration scratch, end that iteration first");
-        a->cv.wait(lk, [a] { return !a->busy; });
+    if (c->pool) {
+        ArenaPool *p = c->pool;
+        std::unique_lock<std::mutex> lk(p->m);
+        for (;;) {
+            Arena *mine = NULL, *idle = NULL, *lru = NULL;
+            bool allMineBusy = p->count > 0;
+            for (int i = 0; i < p->count; i++) {
+                Arena *x = p->arenas[i];
+                if (x->busy) { if (x->ownerThread != this_thread_id()) allMineBusy = false; continue; }
+                allMineBusy = false;
+                if (x->lastUser == c) mine = x;
+                else if (!x->lastValid || hipEventQuery(x->lastUse) == hipSuccess) idle = x;
+                else lru = x;
+            }
+            (void)hipGetLastError();   /* hipEventQuery reports hipErrorNotReady through the sticky error too */
+            a = mine ? mine : idle;
+            if (!a && pool_may_grow(p)) { a = arena_new(p->device, p); p->arenas[p->count++] = a; }
+            if (!a) a = lru;
+            if (a) break;
+            if (allMineBusy)
+                return fail("vcm_begin_iteration", "this thread is already inside an iteration on every arena of this device: "
+                                                   "single-rank contexts share the iteration scratch, end an iteration first "
+                                                   "(or raise vcm_set_arena_limit)");
+            p->cv.wait(lk);
+        }
         a->busy = true;
         a->ownerThread = this_thread_id();
         wait = a->lastValid && a->lastUser != c;
         if (a->lastUser != c) a->lastUser = NULL;   /* from here on the buffers are this context's */
+        /* the arena this context used before (if another one) no longer holds anything it may read */
+        if (c->arena && c->arena != a && c->arena->lastUser == c) c->arena->lastUser = NULL;
+        c->arena = a;
+    } else {
+        a = c->arena;
+        std::unique_lock<std::mutex> lk(*a->mtx);
+        if (a->busy && a->ownerThread == this_thread_id())
+            return fail("vcm_begin_iteration", "this thread is already inside an iteration of this sharded context");
+        a->cv->wait(lk, [a] { return !a->busy; });
+        a->busy = true;
+        a->ownerThread = this_thread_id();
+        wait = a->lastValid && a->lastUser != c;
+        if (a->lastUser != c) a->lastUser = NULL;
     }
     c->holdsArena = true;
     if (arena_ensure(a, (size_t)c->nLocal, (size_t)c->N, S, L, c->world > 1)) return -1;
@@ -267,12 +339,12 @@ static void arena_release(vcm_ctx *c, bool recordEvent)
     const bool recorded = recordEvent && a->eventReady && hipEventRecord(a->lastUse, c->stream) == hipSuccess;
     c->holdsArena = false;
     {
-        std::lock_guard<std::mutex> g(a->m);
+        std::lock_guard<std::mutex> g(*a->mtx);
         if (recorded) { a->lastValid = true; a->lastUser = c; }
         a->busy = false;
         a->ownerThread = 0;
     }
-    a->cv.notify_one();
+    a->cv->notify_all();
 }
 /* A failed phase call ENDS the iteration -- a HIP error as well as a call-order error: its work is abandoned,
  * the arena goes back (other contexts must not dead-lock behind it) and the next call has to be
@@ -298,7 +370,8 @@ static int scratch_readable(vcm_ctx *c, const char *what)
 {
     if (!c || !c->deviceReady || (!c->inIteration && c->iterations == 0)) return fail(what, "no iteration has run");
     if (!c->holdsArena) {
-        std::lock_guard<std::mutex> g(c->arena->m);
+        if (!c->arena) return fail(what, "no iteration has run");
+        std::lock_guard<std::mutex> g(*c->arena->mtx);
         if (c->arena->lastUser != c)
             return fail(what, "the iteration scratch has since been used by another context of this device");
     }
@@ -487,9 +560,14 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     c->p0 = (int)((long long)c->N * rank / worldSize);
     c->nLocal = (int)((long long)c->N * (rank + 1) / worldSize) - c->p0;
     c->ownStream = true;
-    c->arena = arena_get(device, worldSize == 1);
-    if (!c->arena) { delete c; fail("vcm_create", "device index out of range"); return NULL; }
-    { std::lock_guard<std::mutex> g(c->arena->m); c->arena->users++; }
+    if (worldSize == 1) {   /* single-rank contexts share the device's arenas */
+        c->pool = pool_get(device);
+        if (!c->pool) { delete c; fail("vcm_create", "device index out of range"); return NULL; }
+        std::lock_guard<std::mutex> g(c->pool->m);
+        c->pool->users++;
+    } else {                /* a sharded context's iteration spans host-side collectives: private arena */
+        c->arena = arena_new(device, NULL);
+    }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
     return c;
@@ -510,21 +588,30 @@ void vcm_destroy(vcm_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     }
     arena_release(c, false);
-    if (c->arena) {
-        Arena *a = c->arena;
-        std::unique_lock<std::mutex> lk(a->m);
-        if (a->lastUser == c) { a->lastUser = NULL; }   /* the event stays valid: its work was synchronised above */
-        if (--a->users == 0 && a->allocated) {          /* no context left, so nobody holds or wants the token */
-            (void)hipSetDevice(a->device);
+    if (c->pool) {
+        ArenaPool *p = c->pool;
+        std::unique_lock<std::mutex> lk(p->m);
+        for (int i = 0; i < p->count; i++)
+            if (p->arenas[i]->lastUser == c) p->arenas[i]->lastUser = NULL;   /* the events stay valid: synchronised above */
+        if (--p->users == 0) {   /* no context left, so nobody holds or wants an arena: give the memory back */
+            (void)hipSetDevice(p->device);
             (void)hipDeviceSynchronize();
-            arena_free_buffers(a);
-            a->lastValid = false;
+            for (int i = 0; i < p->count; i++) {
+                Arena *a = p->arenas[i];
+                if (a->allocated) arena_free_buffers(a);
+                if (a->eventReady) (void)hipEventDestroy(a->lastUse);
+                delete a;
+                p->arenas[i] = NULL;
+            }
+            p->count = 0;
         }
+    } else if (c->arena) {
+        Arena *a = c->arena;
+        if (a->allocated) { (void)hipSetDevice(a->device); (void)hipDeviceSynchronize(); arena_free_buffers(a); }
+        if (a->eventReady) (void)hipEventDestroy(a->lastUse);
+        delete a;
     }
-    if (c->arena && !c->arena->shared) {
-        if (c->arena->eventReady) (void)hipEventDestroy(c->arena->lastUse);
-        delete c->arena;
-    }
+    c->arena = NULL;
     if (c->deviceReady) {
         DFREE(c->dScene); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
@@ -555,6 +642,19 @@ int vcm_set_stream(vcm_ctx *c, void *hipStream)
     if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
     else if (c->deviceReady) { HIPCHK(hipStreamCreate(&c->stream)); c->ownStream = true; }
     else { c->stream = NULL; c->ownStream = true; }
+    return 0;
+}
+
+/* How many iteration-scratch arenas the single-rank contexts of `device` may share (1..8; 0 = as many as fit a
+ * quarter of the device memory, the default; environment SMALLVCM_AMD_ARENAS).  1 serialises the iterations of
+ * different renderers on the GPU. */
+int vcm_set_arena_limit(int device, int maxArenas)
+{
+    if (maxArenas < 0 || maxArenas > VCM_MAX_ARENAS) return fail("vcm_set_arena_limit", "limit must be 0..8");
+    ArenaPool *p = pool_get(device);
+    if (!p) return fail("vcm_set_arena_limit", "device index out of range");
+    std::lock_guard<std::mutex> g(p->m);
+    p->limit = maxArenas;   /* arenas beyond a lowered limit stay until the last context of the device is destroyed */
     return 0;
 }
 

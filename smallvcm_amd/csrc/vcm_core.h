@@ -142,7 +142,17 @@ VCM_HD void fb_atomic_add(float *addr, float v)
 /* ------------------------------------------------------------------ */
 /* Ray / Isect: ray.hxx:34-65                                           */
 struct Ray { V3 org, dir; float tmin; };
-struct Isect { float dist; int matID; int lightID; V3 normal; };
+struct Isect { float dist; int matID; int lightID; V3 normal; int prim; /* index in vcm_scene_desc::prims of the hit */ };
+
+/* wave-level "any lane" (one lane on the host build) */
+VCM_HD bool wave_any(bool x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(x);
+#else
+    return x;
+#endif
+}
 
 /* ---- two-wide fp32 (packed v_pk_mul_f32 / v_pk_add_f32 on gfx950: IEEE per half,
  *      twice the scalar fp32 rate; never fused, the build has -ffp-contract=off) */
@@ -176,19 +186,32 @@ VCM_HD f2 f2_dot(f2 ax, f2 ay, f2 az, f2 bx, f2 by, f2 bz)
 struct alignas(8) TriPair {
     float p0x[2], p0y[2], p0z[2], p1x[2], p1y[2], p1z[2], p2x[2], p2y[2], p2z[2], nx[2], ny[2], nz[2];
     int matID[2];
+    int prim[2];  /* index of each triangle in vcm_scene_desc::prims */
     int valid1;   /* 0: the pair holds only one triangle */
     int pad;
 };
 struct PrimOp { int kind; int index; };   /* kind 0: TriPair pairs[index]; kind 1: sphere sc.prims[index] */
+/* Shading tables.  BSDF::Setup (bsdf.hxx:95-117) builds a frame from the surface normal and the component
+ * probabilities from the material; for a TRIANGLE the normal is a constant of the primitive, and for a material
+ * without a refractive index (ior < 0: FresnelDielectric returns 1, utils.hxx:47-48) the probabilities do not
+ * depend on the direction either.  Both are evaluated once per scene by the very functions the per-hit code
+ * runs (scene_dev_build), so looking them up gives the same bits as recomputing them: ~200 instructions (two
+ * normalisations, seven divisions) per BSDF that is rebuilt from a stored vertex -- every connection, direct
+ * illumination, camera connection and merge query does that. */
+struct PrimShade { float mX[3], mY[3], mZ[3]; int isTriangle; int pad[2]; };
+struct MatShade { float diffProb, phongProb, reflProb, refrProb, contProb, reflectCoeff; int constant; int pad; };
 struct SceneDev {
     vcm_scene_desc sc;   /* must stay the first member (scene_dev()) */
     int nOps, pad0;
     PrimOp ops[VCM_MAX_PRIMS];
     TriPair pairs[VCM_MAX_PRIMS];
+    PrimShade primShade[VCM_MAX_PRIMS];
+    MatShade matShade[VCM_MAX_MATERIALS];
 };
 /* every vcm_scene_desc the device functions see is the first member of a SceneDev */
 VCM_HD const SceneDev &scene_dev(const vcm_scene_desc &sc) { return *reinterpret_cast<const SceneDev *>(&sc); }
 
+inline void scene_dev_build_tables(SceneDev &sd);   /* below, after the BSDF functions it calls */
 inline void scene_dev_build(const vcm_scene_desc &sc, SceneDev &sd)
 {
     __builtin_memset(&sd, 0, sizeof(sd));
@@ -207,10 +230,12 @@ inline void scene_dev_build(const vcm_scene_desc &sc, SceneDev &sd)
             tp.p2x[h] = t.p2[0]; tp.p2y[h] = t.p2[1]; tp.p2z[h] = t.p2[2];
             tp.nx[h] = t.n[0]; tp.ny[h] = t.n[1]; tp.nz[h] = t.n[2];
             tp.matID[h] = t.matID;
+            tp.prim[h] = (h == 1 && two) ? i + 1 : i;
         }
         tp.valid1 = two ? 1 : 0;
         i += two ? 2 : 1;
     }
+    scene_dev_build_tables(sd);
 }
 
 /* ---- utils.hxx ---------------------------------------------------- */
@@ -309,7 +334,7 @@ VCM_HD float pdf_a_to_w(float pdfA, float dist, float cosThere)
 }
 
 /* ---- geometry.hxx ------------------------------------------------- */
-VCM_HD bool sph_intersect(const vcm_prim &s, const Ray &ray, Isect &res)
+VCM_HD bool sph_intersect(const vcm_prim &s, int primIndex, const Ray &ray, Isect &res)
 {   /* Sphere::Intersect :198-237.  The discriminant is evaluated in float and
        only then widened (:211); sqrt, q, t0, t1 are double (:216-220). */
     const V3 center = ld3(s.p0);
@@ -332,46 +357,103 @@ VCM_HD bool sph_intersect(const vcm_prim &s, const Ray &ray, Isect &res)
     else return false;
     res.dist = resT;
     res.matID = s.matID;
+    res.prim = primIndex;
     res.normal = normalize(to + sp3(resT) * ray.dir);
     return true;
 }
-/* Triangle::Intersect (:125-156) for the two triangles of a pair: the edge
- * functions and the plane distance of both are evaluated with packed
- * operations, then the two closest-hit updates are applied in list order
- * (exactly what two consecutive calls of Triangle::Intersect do). */
-VCM_HD bool tri_pair_intersect(const TriPair &t, const Ray &ray, Isect &res)
+/* Triangle::Intersect (:125-156) for the two triangles of a pair, in two parts: the plane part (ao = p0 - org,
+ * num = Dot(normal, ao), den = Dot(normal, dir): the operands of `distance = num / den`, :144-147) and the edge
+ * functions (:133-142), both with packed operations -- IEEE per half, the reference's expression trees. */
+struct TriPairPlane { f2 ox, oy, oz, dx, dy, dz, aox, aoy, aoz, nx, ny, nz, num, den; };
+VCM_HD void tri_pair_plane(const TriPair &t, V3 org, V3 dir, TriPairPlane &p)
 {
-    const f2 ox = f2_sp(ray.org.x), oy = f2_sp(ray.org.y), oz = f2_sp(ray.org.z);
-    const f2 dx = f2_sp(ray.dir.x), dy = f2_sp(ray.dir.y), dz = f2_sp(ray.dir.z);
-    const f2 aox = f2_ld(t.p0x) - ox, aoy = f2_ld(t.p0y) - oy, aoz = f2_ld(t.p0z) - oz;
-    const f2 box = f2_ld(t.p1x) - ox, boy = f2_ld(t.p1y) - oy, boz = f2_ld(t.p1z) - oz;
-    const f2 cox = f2_ld(t.p2x) - ox, coy = f2_ld(t.p2y) - oy, coz = f2_ld(t.p2z) - oz;
+    p.ox = f2_sp(org.x); p.oy = f2_sp(org.y); p.oz = f2_sp(org.z);
+    p.dx = f2_sp(dir.x); p.dy = f2_sp(dir.y); p.dz = f2_sp(dir.z);
+    p.aox = f2_ld(t.p0x) - p.ox; p.aoy = f2_ld(t.p0y) - p.oy; p.aoz = f2_ld(t.p0z) - p.oz;
+    p.nx = f2_ld(t.nx); p.ny = f2_ld(t.ny); p.nz = f2_ld(t.nz);
+    p.num = f2_dot(p.nx, p.ny, p.nz, p.aox, p.aoy, p.aoz);
+    p.den = f2_dot(p.nx, p.ny, p.nz, p.dx, p.dy, p.dz);
+}
+VCM_HD void tri_pair_inside(const TriPair &t, const TriPairPlane &p, bool inside[2])
+{
+    const f2 box = f2_ld(t.p1x) - p.ox, boy = f2_ld(t.p1y) - p.oy, boz = f2_ld(t.p1z) - p.oz;
+    const f2 cox = f2_ld(t.p2x) - p.ox, coy = f2_ld(t.p2y) - p.oy, coz = f2_ld(t.p2z) - p.oz;
+    const f2 aox = p.aox, aoy = p.aoy, aoz = p.aoz;
     /* v0 = Cross(co, bo), v1 = Cross(bo, ao), v2 = Cross(ao, co)  (math.hxx:154-162) */
     const f2 v0x = coy * boz - coz * boy, v0y = coz * box - cox * boz, v0z = cox * boy - coy * box;
     const f2 v1x = boy * aoz - boz * aoy, v1y = boz * aox - box * aoz, v1z = box * aoy - boy * aox;
     const f2 v2x = aoy * coz - aoz * coy, v2y = aoz * cox - aox * coz, v2z = aox * coy - aoy * cox;
-    const f2 v0d = f2_dot(v0x, v0y, v0z, dx, dy, dz);
-    const f2 v1d = f2_dot(v1x, v1y, v1z, dx, dy, dz);
-    const f2 v2d = f2_dot(v2x, v2y, v2z, dx, dy, dz);
-    const f2 nx = f2_ld(t.nx), ny = f2_ld(t.ny), nz = f2_ld(t.nz);
-    const f2 num = f2_dot(nx, ny, nz, aox, aoy, aoz);
-    const f2 den = f2_dot(nx, ny, nz, dx, dy, dz);
-    bool anyHit = false;
+    const f2 v0d = f2_dot(v0x, v0y, v0z, p.dx, p.dy, p.dz);
+    const f2 v1d = f2_dot(v1x, v1y, v1z, p.dx, p.dy, p.dz);
+    const f2 v2d = f2_dot(v2x, v2y, v2z, p.dx, p.dy, p.dz);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int h = 0; h < 2; h++) {
         const float a = f2_get(v0d, h), b = f2_get(v1d, h), c = f2_get(v2d, h);
-        const bool inside = ((a < 0.f) && (b < 0.f) && (c < 0.f)) || ((a >= 0.f) && (b >= 0.f) && (c >= 0.f));
-        const float distance = f2_get(num, h) / f2_get(den, h);
-        if ((h == 0 || t.valid1) && inside && (distance > ray.tmin) && (distance < res.dist)) {
-            res.normal = mk3(f2_get(nx, h), f2_get(ny, h), f2_get(nz, h));
+        inside[h] = ((a < 0.f) && (b < 0.f) && (c < 0.f)) || ((a >= 0.f) && (b >= 0.f) && (c >= 0.f));
+    }
+}
+/* the two closest-hit updates are applied in list order (exactly what two consecutive calls of
+ * Triangle::Intersect do) */
+VCM_HD bool tri_pair_intersect(const TriPair &t, const Ray &ray, Isect &res)
+{
+    TriPairPlane p;
+    tri_pair_plane(t, ray.org, ray.dir, p);
+    bool inside[2];
+    tri_pair_inside(t, p, inside);
+    bool anyHit = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int h = 0; h < 2; h++) {
+        const float distance = f2_get(p.num, h) / f2_get(p.den, h);
+        if ((h == 0 || t.valid1) && inside[h] && (distance > ray.tmin) && (distance < res.dist)) {
+            res.normal = mk3(f2_get(p.nx, h), f2_get(p.ny, h), f2_get(p.nz, h));
             res.matID = t.matID[h];
+            res.prim = t.prim[h];
             res.dist = distance;
             anyHit = true;
         }
     }
     return anyHit;
+}
+/* Any-hit form for Scene::Occluded (GeometryList::IntersectP returns at the first primitive that reports a hit,
+ * geometry.hxx:80-91, so every primitive is tested against the SAME interval (0, tmax)).  Before the edge
+ * functions (3/4 of the work) the plane part decides, EXACTLY, whether a triangle can report a hit at all:
+ * `distance = num / den` (fp32 division, correctly rounded) is positive only if num and den have the same sign,
+ * and it is < tmax only if |num| < tmax * |den| -- rounding is monotonic, so |num| >= tmax * |den| in exact
+ * arithmetic implies fl(num / den) >= tmax; the test below allows for the rounding of its own two
+ * multiplications (1.000001f > (1 - 2^-24)^-2).  The condition is a superset of the hits, never an
+ * approximation of them: a triangle that passes it takes the full test.  A shadow segment between two surface
+ * points of the Cornell box passes it for none of the walls (they lie behind its start or beyond its end), and
+ * the wave skips the edge functions when no lane needs them. */
+VCM_HD bool tri_pair_occluded(const TriPair &t, V3 org, V3 dir, float tmax)
+{
+    TriPairPlane p;
+    tri_pair_plane(t, org, dir, p);
+    bool can[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int h = 0; h < 2; h++) {
+        const float a = f2_get(p.num, h), b = f2_get(p.den, h);
+        const bool sameSign = ((f2u(a) ^ f2u(b)) & 0x80000000u) == 0u;
+        const bool beyond = fabsf(a) >= 1.000001f * (tmax * fabsf(b));   /* false for NaN: the full test decides */
+        can[h] = sameSign && !beyond && (h == 0 || t.valid1);
+    }
+    if (!wave_any(can[0] || can[1])) return false;
+    bool inside[2];
+    tri_pair_inside(t, p, inside);
+    bool hit = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int h = 0; h < 2; h++) {
+        const float distance = f2_get(p.num, h) / f2_get(p.den, h);
+        if ((h == 0 || t.valid1) && inside[h] && (distance > 0.f) && (distance < tmax)) hit = true;
+    }
+    return hit;
 }
 /* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78):
  * brute force over <= 22 primitives in list order; the op index is wave-uniform,
@@ -383,7 +465,7 @@ VCM_HD bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res
     for (int i = 0; i < sd.nOps; i++) {
         const PrimOp op = sd.ops[i];
         const bool hit = (op.kind == 0) ? tri_pair_intersect(sd.pairs[op.index], ray, res)
-                                        : sph_intersect(sc.prims[op.index], ray, res);
+                                        : sph_intersect(sc.prims[op.index], op.index, ray, res);
         if (hit) any = hit;
     }
     if (any) res.lightID = sc.mat2light[res.matID];
@@ -397,15 +479,18 @@ VCM_HD bool scene_occluded(const vcm_scene_desc &sc, V3 point, V3 dir, float tma
     ray.org = point + dir * VCM_EPS_RAY;
     ray.dir = dir;
     ray.tmin = 0;
-    Isect isect;
-    isect.dist = tmax - 2 * VCM_EPS_RAY;
-    isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    const float tmaxp = tmax - 2 * VCM_EPS_RAY;
     bool occluded = false;
     for (int i = 0; i < sd.nOps; i++) {
         const PrimOp op = sd.ops[i];
         if (!occluded) {
-            const bool hit = (op.kind == 0) ? tri_pair_intersect(sd.pairs[op.index], ray, isect)
-                                            : sph_intersect(sc.prims[op.index], ray, isect);
+            bool hit;
+            if (op.kind == 0) hit = tri_pair_occluded(sd.pairs[op.index], ray.org, ray.dir, tmaxp);
+            else {
+                Isect isect;
+                isect.dist = tmaxp; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
+                hit = sph_intersect(sc.prims[op.index], op.index, ray, isect);
+            }
             if (hit) occluded = true;
         }
     }
@@ -445,26 +530,78 @@ VCM_HD void bsdf_component_probabilities(Bsdf &b, const vcm_material &m)
         b.contProb = smin(1.f, smax(0.f, b.contProb));
     }
 }
-/* Setup :95-117.  rayDir = the incoming ray direction, normal = isect.normal */
-VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, const vcm_scene_desc &sc)
+/* frame and component probabilities of a hit: from the scene's tables where they are constants of the primitive /
+ * the material (SceneDev), by Frame::SetFromZ / GetComponentProbabilities otherwise -- the same bits either way.
+ * prim < 0: no primitive known. */
+VCM_HD void bsdf_frame(Bsdf &b, V3 normal, int prim, const vcm_scene_desc &sc)
+{
+    const SceneDev &sd = scene_dev(sc);
+    if (prim >= 0 && sd.primShade[prim].isTriangle) {
+        const PrimShade &ps = sd.primShade[prim];
+        b.frame.mX = ld3(ps.mX); b.frame.mY = ld3(ps.mY); b.frame.mZ = ld3(ps.mZ);
+    } else {
+        frame_from_z(b.frame, normal);
+    }
+}
+VCM_HD void bsdf_probabilities(Bsdf &b, int matID, const vcm_scene_desc &sc)
+{
+    const SceneDev &sd = scene_dev(sc);
+    const MatShade &ms = sd.matShade[matID];
+    if (ms.constant) {
+        b.diffProb = ms.diffProb; b.phongProb = ms.phongProb; b.reflProb = ms.reflProb; b.refrProb = ms.refrProb;
+        b.contProb = ms.contProb; b.reflectCoeff = ms.reflectCoeff;
+    } else {
+        bsdf_component_probabilities(b, sc.materials[matID]);
+    }
+}
+/* Setup :95-117.  rayDir = the incoming ray direction, normal = isect.normal, prim = isect.prim */
+VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, int prim, const vcm_scene_desc &sc)
 {
     b.matID = -1;
-    frame_from_z(b.frame, normal);
+    bsdf_frame(b, normal, prim, sc);
     b.localDirFix = to_local(b.frame, -rayDir);
     if (fabsf(b.localDirFix.z) < VCM_EPS_COSINE) return;
-    bsdf_component_probabilities(b, sc.materials[matID]);
+    bsdf_probabilities(b, matID, sc);
     b.isDelta = (b.diffProb == 0.f) && (b.phongProb == 0.f);
     b.matID = matID;
 }
-/* Rebuild the BSDF of a STORED light vertex from (isect.normal, mLocalDirFix,
- * matID): the same operations Setup ran, hence the same bits. */
-VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, int matID, const vcm_scene_desc &sc)
+/* What a stored vertex keeps of its surface, in the upper 24 bits of the word that holds its path length:
+ * matID (8 bits) and prim + 1 (16 bits, 0 = unknown). */
+VCM_HD uint32_t shade_code(int matID, int prim) { return (uint32_t)matID | ((uint32_t)(prim + 1) << 8); }
+/* Rebuild the BSDF of a STORED vertex from (isect.normal, mLocalDirFix, shade code): the same operations Setup
+ * ran -- or the same table entries -- hence the same bits. */
+VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, uint32_t code, const vcm_scene_desc &sc)
 {
-    frame_from_z(b.frame, normal);
+    const int matID = (int)(code & 0xffu), prim = (int)(code >> 8) - 1;
+    bsdf_frame(b, normal, prim, sc);
     b.localDirFix = localDirFix;
-    bsdf_component_probabilities(b, sc.materials[matID]);
+    bsdf_probabilities(b, matID, sc);
     b.isDelta = false;
     b.matID = matID;
+}
+inline void scene_dev_build_tables(SceneDev &sd)
+{
+    const vcm_scene_desc &sc = sd.sc;
+    for (int i = 0; i < sc.nPrims && i < VCM_MAX_PRIMS; i++) {
+        PrimShade &ps = sd.primShade[i];
+        ps.isTriangle = sc.prims[i].type == VCM_PRIM_TRIANGLE ? 1 : 0;
+        if (!ps.isTriangle) continue;
+        Frame f;
+        frame_from_z(f, ld3(sc.prims[i].n));   /* Triangle::Intersect reports mNormal itself (geometry.hxx:150) */
+        ps.mX[0] = f.mX.x; ps.mX[1] = f.mX.y; ps.mX[2] = f.mX.z;
+        ps.mY[0] = f.mY.x; ps.mY[1] = f.mY.y; ps.mY[2] = f.mY.z;
+        ps.mZ[0] = f.mZ.x; ps.mZ[1] = f.mZ.y; ps.mZ[2] = f.mZ.z;
+    }
+    for (int i = 0; i < sc.nMaterials && i < VCM_MAX_MATERIALS; i++) {
+        MatShade &ms = sd.matShade[i];
+        ms.constant = sc.materials[i].ior < 0.f ? 1 : 0;   /* FresnelDielectric == 1 whatever the direction */
+        if (!ms.constant) continue;
+        Bsdf b;
+        b.localDirFix = mk3(0.f, 0.f, 1.f);   /* only its z enters, and only through the Fresnel term */
+        bsdf_component_probabilities(b, sc.materials[i]);
+        ms.diffProb = b.diffProb; ms.phongProb = b.phongProb; ms.reflProb = b.reflProb; ms.refrProb = b.refrProb;
+        ms.contProb = b.contProb; ms.reflectCoeff = b.reflectCoeff;
+    }
 }
 VCM_HD V3 bsdf_eval_diffuse(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf)
 {   /* EvaluateDiffuse :393-412 */
@@ -881,13 +1018,13 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
 {
     SubPathState &st = lp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
-    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
     ls.lightRays++;
     if (!scene_intersect(sc, ray, isect)) return false;
     const V3 hitPoint = ray.org + ray.dir * isect.dist;
     isect.dist += VCM_EPS_RAY;
     Bsdf bsdf;
-    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, sc);
+    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, isect.prim, sc);
     if (bsdf.matID < 0) return false;
     {   /* :351-360 */
         if (st.pathLength > 1 || st.isFiniteLight == 1) st.dVCM *= mis(sqr(isect.dist));
@@ -898,7 +1035,7 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
     if (!bsdf.isDelta && (P.useVC || P.useVM || (MODE == 1 && P.lightTraceOnly))) {   /* :364-377 */
         const size_t slot = (size_t)lp.nStored * (size_t)P.nLocal + (size_t)lp.lp;
         const V3 wdir = to_world(bsdf.frame, bsdf.localDirFix);   /* WorldDirFix bsdf.hxx:264 */
-        lv(store, slot, 0) = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
+        lv(store, slot, 0) = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f(st.pathLength | (shade_code(bsdf.matID, isect.prim) << 8)));
         lv(store, slot, 1) = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVCM);
         lv(store, slot, 2) = mk4(isect.normal.x, isect.normal.y, isect.normal.z, st.dVC);
         lv(store, slot, 3) = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
@@ -928,7 +1065,7 @@ VCM_HD void connect_stored_vertex_to_camera(const vcm_scene_desc &sc, const Iter
     st.throughput = mk3(b.x, b.y, b.z);
     st.dVCM = b.w; st.dVC = c.w; st.dVM = d.w;
     Bsdf bsdf;
-    bsdf_restore(bsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
+    bsdf_restore(bsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), f2u(a.w) >> 8, sc);
     connect_to_camera(sc, P, st, mk3(a.x, a.y, a.z), bsdf, fb, ls, splatOut);
 }
 
@@ -1032,16 +1169,6 @@ VCM_HD int grid_cell_of_point(V3 p, V3 bboxMin, float invCellSize, int nCells)
     const float fy = floorf(invCellSize * distMin.y);
     const float fz = floorf(invCellSize * distMin.z);
     return grid_cell_hash(int(fx), int(fy), int(fz), nCells);
-}
-
-/* wave-level "any lane" (one lane on the host build) */
-VCM_HD bool wave_any(bool x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __any(x);
-#else
-    return x;
-#endif
 }
 
 /* Per-lane queue of accepted photon indices, in LDS on the device:
@@ -1418,7 +1545,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
 {
     SubPathState &st = cp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
-    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
     ls.cameraRays++;
     if (!scene_intersect(sc, ray, isect)) {   /* :434-447 */
         if (sc.backgroundLight >= 0) {
@@ -1430,7 +1557,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
     const V3 hitPoint = ray.org + ray.dir * isect.dist;
     isect.dist += VCM_EPS_RAY;
     Bsdf bsdf;
-    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, sc);
+    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, isect.prim, sc);
     if (bsdf.matID < 0) return false;
     {   /* :459-464 */
         st.dVCM *= mis(sqr(isect.dist));
@@ -1485,7 +1612,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
             const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], P.qblockVC, nvc,
                 [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.vcTask[2 * (first + i)] = -1; });
             vs.q0[vi] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
-            vs.q1[vi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | ((uint32_t)bsdf.matID << 8)));
+            vs.q1[vi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | (shade_code(bsdf.matID, isect.prim) << 8)));
             vs.q2[vi] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
             vs.q3[vi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
             vs.q4[vi] = mk4(st.dVC, u2f(diK), 0.f, 0.f);
@@ -1535,7 +1662,7 @@ VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, Came
                 const F4 c = lv(store, slot, 2);
                 const F4 d = lv(store, slot, 3);
                 Bsdf lvBsdf;
-                bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
+                bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), f2u(a.w) >> 8, sc);
                 cp.color = cp.color + st.throughput * mk3(b.x, b.y, b.z) *
                            connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, bsdf, hitPoint, st, ls);
             }
@@ -1565,7 +1692,7 @@ VCM_HD void load_cam_vertex(const vcm_scene_desc &sc, const VertexStore &vs, int
     const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi], e = vs.q4[vi];
     v.hit = mk3(a.x, a.y, a.z);
     v.lp = f2u(a.w);
-    bsdf_restore(v.bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (int)((f2u(b.w) >> 8) & 0xffu), sc);
+    bsdf_restore(v.bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(b.w) >> 8, sc);
     v.throughput = mk3(d.x, d.y, d.z);
     v.st.pathLength = f2u(b.w) & 0xffu;
     v.st.dVCM = c.w; v.st.dVM = d.w; v.st.dVC = e.x;
@@ -1594,7 +1721,7 @@ VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const Vert
     const size_t slot = (size_t)j * (size_t)P.nLocal + (size_t)v.lp;
     const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), c = lv(store, slot, 2), d = lv(store, slot, 3);
     Bsdf lvBsdf;
-    bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), (int)((f2u(a.w) >> 8) & 0xffu), sc);
+    bsdf_restore(lvBsdf, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), f2u(a.w) >> 8, sc);
     return v.throughput * mk3(b.x, b.y, b.z) *
            connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, v.bsdf, v.hit, v.st, ls);
 }
@@ -1605,7 +1732,7 @@ VCM_HD V3 eval_merge_task(const vcm_scene_desc &sc, const IterParams &P, const V
     const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
     pathSlot = path_slot(P, f2u(b.w) & 0xffu, f2u(a.w));
     Bsdf bsdf;
-    bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (int)((f2u(b.w) >> 8) & 0xffu), sc);
+    bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(b.w) >> 8, sc);
     SubPathState st;
     st.pathLength = f2u(b.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
     const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms);
@@ -1684,7 +1811,7 @@ VCM_HD bool pt_path_step(const vcm_scene_desc &sc, const IterParams &P, PtPath &
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;   /* :48-49 */
     Ray ray; ray.org = pp.org; ray.dir = pp.dir; ray.tmin = 0;
-    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
     ls.cameraRays++;
     if (!scene_intersect(sc, ray, isect)) {   /* :73-97 */
         if (pp.pathLength < P.minLen) return false;
@@ -1700,7 +1827,7 @@ VCM_HD bool pt_path_step(const vcm_scene_desc &sc, const IterParams &P, PtPath &
     const V3 hitPoint = ray.org + ray.dir * isect.dist;   /* :99-100 */
     isect.dist += VCM_EPS_RAY;
     Bsdf bsdf;
-    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, sc);
+    bsdf_setup(bsdf, ray.dir, isect.normal, isect.matID, isect.prim, sc);
     if (bsdf.matID < 0) return false;
     if (isect.lightID >= 0) {   /* :107-129 */
         if (pp.pathLength < P.minLen) return false;
@@ -1791,7 +1918,7 @@ VCM_HD bool eyelight_path(const vcm_scene_desc &sc, const IterParams &P, int loc
     ray.org = ld3(cam.position);
     ray.dir = normalize(worldRaster - ray.org);
     ray.tmin = 0;
-    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f);
+    Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
     ls.cameraRays++;
     if (!scene_intersect(sc, ray, isect)) return false;
     const float dotLN = dot(isect.normal, -ray.dir);   /* :70-75 */

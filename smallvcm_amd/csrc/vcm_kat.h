@@ -28,7 +28,7 @@ VCM_HD void kat_eval(const vcm_scene_desc &sc, int op, const float *in, float *o
         break;
     case VCM_KAT_BSDF_EVAL: {   /* BSDF::Setup / Evaluate / Pdf / accessors, bsdf.hxx:95-180, :260-264 */
         Bsdf b;
-        bsdf_setup(b, ld3(in), ld3(in + 3), (int)in[6], sc);
+        bsdf_setup(b, ld3(in), ld3(in + 3), (int)in[6], (int)in[11] - 1, sc);   /* in[11]: prim + 1, 0 = unknown (no table) */
         if (b.matID < 0) break;
         out[0] = 1.f; out[1] = b.isDelta ? 1.f : 0.f; out[2] = b.contProb;
         float cosGen = 0.f, dirPdf = 0.f, revPdf = 0.f;
@@ -43,7 +43,7 @@ VCM_HD void kat_eval(const vcm_scene_desc &sc, int op, const float *in, float *o
     } break;
     case VCM_KAT_BSDF_SAMPLE: {   /* BSDF<FixIsLight>::Sample bsdf.hxx:191-257 */
         Bsdf b;
-        bsdf_setup(b, ld3(in), ld3(in + 3), (int)in[6], sc);
+        bsdf_setup(b, ld3(in), ld3(in + 3), (int)in[6], (int)in[11] - 1, sc);   /* in[11]: prim + 1, 0 = unknown (no table) */
         if (b.matID < 0) break;
         out[0] = 1.f;
         V3 gen = sp3(0.f);

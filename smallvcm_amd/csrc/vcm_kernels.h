@@ -561,7 +561,7 @@ k_merge_staged(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g
             const F4 a = vs.q0[vi], bq = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
             const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
             Bsdf bsdf;
-            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), (int)((f2u(bq.w) >> 8) & 0xffu), sc);
+            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
             SubPathState st;
             st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
             const V3 contrib = merge_query_staged(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);

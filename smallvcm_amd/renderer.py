@@ -59,6 +59,7 @@ def load_library(require_gpu=True):
         L.vcm_set_stream.argtypes = [vp, vp]
         L.vcm_set_strict_order.argtypes = [vp, C.c_int]
         L.vcm_is_wavefront.argtypes = [vp, C.c_uint]
+        L.vcm_set_arena_limit.argtypes = [C.c_int, C.c_int]
         L.vcm_run_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
         L.vcm_begin_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
         for n in ("vcm_trace_light", "vcm_build_grid", "vcm_trace_camera", "vcm_merge", "vcm_end_iteration", "vcm_synchronize",

@@ -256,8 +256,20 @@ def test_concurrent_contexts_share_scratch_and_stay_exact():
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_interleaving_two_iterations_on_one_thread_is_refused_not_deadlocked():
+def test_interleaving_two_iterations_on_one_thread():
+    """The iteration scratch is borrowed from a per-device pool of arenas.  With ONE arena a thread that opens a second
+    iteration before ending the first is refused (it would wait for itself); with two, both iterations are open at
+    once, overlap on the GPU, and each renderer's scratch stays readable afterwards."""
+    from smallvcm_amd.renderer import load_library
+    L = load_library()
     sc = cornell_scene(0, 32, 32)
+    alone = []
+    for seed in (1, 2):
+        x = HipBackend(sc, 4, 0.003, 0.75, seed)
+        x.run_iteration(0, 0, 10)
+        alone.append((x.framebuffer_sum(), x.records()))
+        x.close()
+    assert L.vcm_set_arena_limit(0, 1) == 0
     a = HipBackend(sc, 4, 0.003, 0.75, 1)
     b = HipBackend(sc, 4, 0.003, 0.75, 2)
     a.begin(0, 0, 10)
@@ -271,6 +283,17 @@ def test_interleaving_two_iterations_on_one_thread_is_refused_not_deadlocked():
         a.records()
     assert b.records().shape[0] > 0
     a.close(); b.close()
+    assert L.vcm_set_arena_limit(0, 2) == 0
+    a = HipBackend(sc, 4, 0.003, 0.75, 1)
+    b = HipBackend(sc, 4, 0.003, 0.75, 2)
+    a.begin(0, 0, 10); b.begin(0, 0, 10)
+    a.trace_light(); b.trace_light(); a.build_grid(); b.build_grid(); b.trace_camera(); a.trace_camera()
+    a.merge(); b.merge(); b.end(); a.end()
+    for x, (fb, recs) in zip((a, b), alone):
+        assert np.array_equal(x.framebuffer_sum().view(np.uint32), fb.view(np.uint32))
+        assert np.array_equal(x.records().view(np.uint32), recs.view(np.uint32))
+    a.close(); b.close()
+    assert L.vcm_set_arena_limit(0, 0) == 0
 
 
 @pytest.mark.parametrize("world,shards,inflight,algo,res,iters", [(4, 2, 1, 4, 96, 5), (3, 1, 1, 4, 64, 4), (2, 2, 2, 4, 96, 5),

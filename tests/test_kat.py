@@ -53,6 +53,13 @@ def make_inputs(op, scene, n, seed):
         k = n // 4   # axis-aligned normals as the box has them, incl. the |z.x| > 0.99 frame switch (frame.hxx:56)
         a[:k, 3:6] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, k)] * rng.choice(np.float32([-1, 1]), (k, 1))
         a[:, 6] = rng.integers(0, nmat, n)
+        # half of the records name a triangle of the scene (normal, material and index of that primitive): the product
+        # then takes frame and component probabilities from its per-scene tables instead of computing them
+        tris = [i for i in range(scene.nPrims) if scene.prims[i].type == 0]
+        pick = rng.choice(tris, n // 2)
+        a[n // 2:n // 2 + len(pick), 3:6] = np.float32([list(scene.prims[i].n) for i in pick])
+        a[n // 2:n // 2 + len(pick), 6] = [scene.prims[i].matID for i in pick]
+        a[n // 2:n // 2 + len(pick), 11] = pick + 1
         if op == "bsdf_eval":
             a[:, 7:10] = _unit(rng, n)
             m = n // 4   # directions near the mirror direction: the Phong lobe (exponent 90) is non-zero there
