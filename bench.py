@@ -329,7 +329,7 @@ def main():
                        "parallelism": "%d renderer(s) (iteration-parallel, smallvcm.cxx:61-108), each on %d path-index shard(s) "
                                       "(RCCL all-gather of light vertices), %d renderer(s) in flight per GPU group"
                                       % (replicas, shards, farm.inflight),
-                       "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "staged")},
+                       "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "lane")},
             "roofline": roof,
             "counters": {k: int(st[k]) for k in ("lightVertices", "gridVertices", "mergeQueries", "mergeCandidates",
                                                  "mergeAccepted", "connections", "lightSplats", "lightRays", "cameraRays",

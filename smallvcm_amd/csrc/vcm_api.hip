@@ -458,6 +458,9 @@ static __global__ void k_set_bbox(GridHeader *hdr, float x0, float y0, float z0,
 static __global__ void k_note_grid_vertices(const GridHeader *hdr, unsigned long long *out) { *out = (unsigned long long)hdr->nRecords; }
 static int mark_on(vcm_ctx *c, int ev, hipStream_t stream)
 {
+    static int off = -1;   /* SMALLVCM_AMD_NO_STAMPS=1: no phase marks at all (vcm_get_stats then reports counters only) */
+    if (off < 0) { const char *e = getenv("SMALLVCM_AMD_NO_STAMPS"); off = (e && e[0] == '1') ? 1 : 0; }
+    if (off) return 0;
     HIPCHK(hipEventRecord(c->ev[ev], stream));
     hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, stream, c->dStamps + (size_t)(c->iterations % VCM_STAMP_RING) * EV_COUNT + ev);
     HIPCHK(hipGetLastError());
@@ -1047,10 +1050,12 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (join_grid(c)) return -1;
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
-            /* default: cell lists staged through LDS by the workgroup (k_merge_staged); SMALLVCM_AMD_MERGE=lane
-               selects the per-lane gathers of round 1 (same bits, kept for A/B measurements) */
+            /* Two kernels, same bits.  k_merge_lane (default): per-lane gathers of the candidates.  k_merge_staged
+               (SMALLVCM_AMD_MERGE=staged): the workgroup stages the cell lists of its queries through LDS -- 27 % less
+               HBM traffic (13.7 -> 9.9 GB per launch) but 4 % slower (profiles/r02c_ab_summary.txt): the kernel is bound
+               by VALU issue, not by the candidate loads, and the staging adds instructions and barriers. */
             static int mergeStaged = -1;
-            if (mergeStaged < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE"); mergeStaged = (e && !strcmp(e, "lane")) ? 0 : 1; }
+            if (mergeStaged < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE"); mergeStaged = (e && !strcmp(e, "staged")) ? 1 : 0; }
             if (mergeStaged) {
                 int ch = mergeChunk * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK;
                 if (ch < 1) ch = 1;

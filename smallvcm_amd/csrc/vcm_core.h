@@ -442,7 +442,9 @@ VCM_HD bool tri_pair_occluded(const TriPair &t, V3 org, V3 dir, float tmax)
         const bool beyond = fabsf(a) >= 1.000001f * (tmax * fabsf(b));   /* false for NaN: the full test decides */
         can[h] = sameSign && !beyond && (h == 0 || t.valid1);
     }
+#if !defined(VCM_NO_OCCLUSION_PRETEST)   /* measurement switch: evaluate every triangle in full */
     if (!wave_any(can[0] || can[1])) return false;
+#endif
     bool inside[2];
     tri_pair_inside(t, p, inside);
     bool hit = false;
@@ -536,6 +538,11 @@ VCM_HD void bsdf_component_probabilities(Bsdf &b, const vcm_material &m)
 VCM_HD void bsdf_frame(Bsdf &b, V3 normal, int prim, const vcm_scene_desc &sc)
 {
     const SceneDev &sd = scene_dev(sc);
+    /* VCM_SHADE_TABLES off (default): measured 5.6 % SLOWER at 2048^2 (profiles/r02c_ab_summary.txt) -- the per-lane
+       table gathers sit in dependent chains at the head of every task; kept behind the switch for a rework */
+#if !defined(VCM_SHADE_TABLES)
+    prim = -1;
+#endif
     if (prim >= 0 && sd.primShade[prim].isTriangle) {
         const PrimShade &ps = sd.primShade[prim];
         b.frame.mX = ld3(ps.mX); b.frame.mY = ld3(ps.mY); b.frame.mZ = ld3(ps.mZ);
@@ -547,7 +554,11 @@ VCM_HD void bsdf_probabilities(Bsdf &b, int matID, const vcm_scene_desc &sc)
 {
     const SceneDev &sd = scene_dev(sc);
     const MatShade &ms = sd.matShade[matID];
+#if !defined(VCM_SHADE_TABLES)
+    if (false) {
+#else
     if (ms.constant) {
+#endif
         b.diffProb = ms.diffProb; b.phongProb = ms.phongProb; b.reflProb = ms.reflProb; b.refrProb = ms.refrProb;
         b.contProb = ms.contProb; b.reflectCoeff = ms.reflectCoeff;
     } else {
@@ -1175,10 +1186,10 @@ VCM_HD int grid_cell_of_point(V3 p, V3 bboxMin, float invCellSize, int nCells)
  * entry k of this lane is q[k * stride], k = 0..VCM_MERGE_Q (one spare row: the
  * scan writes every candidate at the tail and only advances it on acceptance). */
 #ifndef VCM_MERGE_Q
-#define VCM_MERGE_Q 16
+#define VCM_MERGE_Q 32   /* 16 -> 32: the wave drains when ONE lane is nearly full; deeper queues even out the lanes (-2.8 % K4) */
 #endif
 #define VCM_MERGE_UNROLL 4
-struct MergeScratch { uint32_t *q; int stride; };
+struct MergeScratch { uint32_t *q; int stride; int cap; /* entries per lane (+1 spare row) */ };
 
 /* Everything of RangeQuery::Process (vertexcm.hxx:130-169) and of the camera
  * BSDF::Evaluate (bsdf.hxx:128-153, :393-446) that does not depend on the
@@ -1272,7 +1283,7 @@ VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval
     if (!wave_any(0 < qn)) return;
     MergePhoton cur, nxt;
     merge_photon_load(g, ms, 0, qn, cur);
-    for (int k = 0; k < VCM_MERGE_Q; k++) {
+    for (int k = 0; k < ms.cap; k++) {
         const bool more = wave_any(k + 1 < qn);
         if (more) merge_photon_load(g, ms, k + 1, qn, nxt);
         if (k < qn)
@@ -1372,7 +1383,7 @@ VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridS
                 qn += acc ? 1 : 0;
             }
             lo = nextLo;
-            if (wave_any(qn > VCM_MERGE_Q - VCM_MERGE_UNROLL)) {
+            if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
                 ls.mergeAccepted += (uint32_t)qn;
                 merge_drain(P, g, ev, ms, qn, contrib);
                 qn = 0;

@@ -113,7 +113,7 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
     const int end = min(P.nLocal, next + chunk);
     LaneStats ls; lane_stats_zero(ls);
     __shared__ uint32_t accQ[MODE == 1 ? 1 : (VCM_MERGE_Q + 1) * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
-    MergeScratch ms; ms.q = accQ + (MODE == 1 ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK;
+    MergeScratch ms; ms.q = accQ + (MODE == 1 ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK; ms.cap = VCM_MERGE_Q;
     __shared__ int wqState[(VCM_TRACE_BLOCK / VCM_WAVE) * 6];   /* per wave: 3 queues x {next, left} */
     int *myState = wqState + (threadIdx.x / VCM_WAVE) * 6;
     if (lane < 6) myState[lane] = 0;
@@ -305,7 +305,7 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
     const vcm_scene_desc &sc = *scp;
     const int nQ = *nSorted;
     __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_MERGE_BLOCK];
-    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK;
+    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK; ms.cap = VCM_MERGE_Q;
     LaneStats ls; lane_stats_zero(ls);
     /* XCD-aware dealing of the sorted queries.  A batch = 256 consecutive queries of the Morton order, a chunk =
        `chunk` consecutive batches = one compact region of the scene.  Workgroup i runs on XCD i mod 8 (round-robin
@@ -355,6 +355,7 @@ k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, 
 #ifndef VCM_STAGE_BLOCK
 #define VCM_STAGE_BLOCK 512
 #endif
+#define VCM_STAGE_Q 16   /* accepted-index queue per lane: the staging area needs the LDS a deeper queue would take */
 #define VCM_STAGE_HT (VCM_STAGE_BLOCK)                 /* table slots, power of two */
 #define VCM_STAGE_CAP (5 * VCM_STAGE_BLOCK)            /* staged photons per workgroup */
 #define VCM_STAGE_NOSLOT 1023u
@@ -462,7 +463,7 @@ __device__ __forceinline__ V3 merge_query_staged(const vcm_scene_desc &sc, const
                 qn += acc ? 1 : 0;
             }
             i = (ni < len) ? ni : len;
-            if (wave_any(qn > VCM_MERGE_Q - VCM_MERGE_UNROLL)) {
+            if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
                 ls.mergeAccepted += (uint32_t)qn;
                 merge_drain(P, g, ev, ms, qn, contrib);
                 qn = 0;
@@ -482,9 +483,9 @@ k_merge_staged(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g
 #if defined(__HIP_DEVICE_COMPILE__)
     const vcm_scene_desc &sc = *scp;
     const int nQ = *nSorted;
-    __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_STAGE_BLOCK];
+    __shared__ uint32_t accQ[(VCM_STAGE_Q + 1) * VCM_STAGE_BLOCK];
     __shared__ __attribute__((aligned(16))) StageLds L;
-    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_STAGE_BLOCK;
+    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_STAGE_BLOCK; ms.cap = VCM_STAGE_Q;
     LaneStats ls; lane_stats_zero(ls);
     const int tid = (int)threadIdx.x;
     const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);

@@ -185,7 +185,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
         for (int lp = 0; lp < e.nLocal; lp++) {
             CameraPath path;
             uint32_t q[VCM_MERGE_Q + 1];
-            MergeScratch ms; ms.q = q; ms.stride = 1;
+            MergeScratch ms; ms.q = q; ms.stride = 1; ms.cap = VCM_MERGE_Q;
             camera_path_begin(e.sd.sc, P, path, lp);
             VertexStore vs; memset(&vs, 0, sizeof(vs));
             int wqState[6] = {0, 0, 0, 0, 0, 0};
