@@ -8,16 +8,18 @@
  * results differ in the last bit for a fraction of inputs, and one flipped
  * Russian-roulette / lobe / hit decision per few million paths already breaks
  * the RMSE < 1e-4 bar (SURVEY.md section 7 "Hard parts").  So both sides compute
- * these three functions with the SAME sequence of IEEE-754 binary64
- * add/mul/div/floor operations (no FMA contraction), which is bit-reproducible
- * on x86-64 and gfx950.  oracle/_ref links the unmodified reference against
- * these definitions (symbol interposition of sinf/cosf/sincosf/powf).
+ * these three functions with the SAME sequence of IEEE-754 operations (no FMA
+ * contraction), which is bit-reproducible on x86-64 and gfx950.  oracle/_ref links
+ * the unmodified reference against these definitions (symbol interposition of
+ * sinf/cosf/sincosf/powf).
  *
- * Accuracy (tests/test_rng_detmath.py): <= 1 ulp(float) versus glibc on the
- * domains used: sin/cos |x| <= 1e4, pow x >= 0, y > 0.
- *
- * The same functions are restated for the device in
- * smallvcm_amd/csrc/detmath.h; tests compare the two bit-for-bit.
+ * Definition (round 2; smallvcm_amd/csrc/detmath.h states it for the device, tests compare the two
+ * bit for bit):
+ *   sinf, cosf   binary32: r = x - n pi/2 by a four-term Cody-Waite reduction, minimax polynomials of degree
+ *                7 / 8 on [-pi/4, pi/4]; <= 1.6 ulp for |x| <= 8.
+ *   powf(x, y)   |y| = n + f: x^n by binary exponentiation in binary64, x^f in binary32 as exp2(f log2 x);
+ *                <= 1.9 ulp for 0 < y < 1, integer exponents correctly rounded; x <= 0 -> 0, y == 0 -> 1.
+ * (tests/test_rng_detmath.py measures both bounds.)
  */
 #ifndef ORACLE_DETMATH_REF_H
 #define ORACLE_DETMATH_REF_H
@@ -25,141 +27,101 @@
 #include <string.h>
 #include <math.h>
 
-static inline double dmr_from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
-static inline uint64_t dmr_to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+static inline float dmr_from_bits32(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static inline uint32_t dmr_to_bits32(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
-/* r = x - n*pi/2 (two-term Cody-Waite), n = round(x*2/pi); |r| <= pi/4 */
-static inline double dmr_reduce(double x, int *n)
+/* *s = sin x, *c = cos x */
+static inline void dmr_sincosf(float x, float *s, float *c)
 {
-    const double q  = x * 0.63661977236758138;
-    const double nf = floor(q + 0.5);
-    *n = (int)nf;
-    return (x - nf * 1.5707963267948966) - nf * 6.123233995736766e-17;
-}
-
-static inline double dmr_sin_poly(double r)
-{
-    const double r2 = r * r;
-    double p = -1.0 / 1307674368000.0;
-    p = p * r2 + 1.0 / 6227020800.0;
-    p = p * r2 + -1.0 / 39916800.0;
-    p = p * r2 + 1.0 / 362880.0;
-    p = p * r2 + -1.0 / 5040.0;
-    p = p * r2 + 1.0 / 120.0;
-    p = p * r2 + -1.0 / 6.0;
-    return r + r * (r2 * p);
-}
-
-static inline double dmr_cos_poly(double r)
-{
-    const double r2 = r * r;
-    double p = 1.0 / 20922789888000.0;
-    p = p * r2 + -1.0 / 87178291200.0;
-    p = p * r2 + 1.0 / 479001600.0;
-    p = p * r2 + -1.0 / 3628800.0;
-    p = p * r2 + 1.0 / 40320.0;
-    p = p * r2 + -1.0 / 720.0;
-    p = p * r2 + 1.0 / 24.0;
-    p = p * r2 + -0.5;
-    return 1.0 + r2 * p;
-}
-
-static inline float dmr_sinf(float xf)
-{
-    int n;
-    const double r = dmr_reduce((double)xf, &n);
-    double v;
+    const float q  = x * 0.636619747f;      /* 2/pi */
+    const float nf = floorf(q + 0.5f);
+    const int   n  = (int)nf;
+    /* pi/2 = 1.5703125 + 4.83751297e-4 + 7.54979013e-8 - 1.71512451e-15; the first two products are exact */
+    float r = x - nf * 1.5703125f;
+    r = r - nf * 4.83751297e-4f;
+    r = r - nf * 7.54953362e-8f;
+    r = r - nf * 2.56334407e-12f;
+    const float z = r * r;
+    float ps = -1.95094646e-4f;
+    ps = ps * z + 8.33211839e-3f;
+    ps = ps * z + -1.66666538e-1f;
+    const float sinr = r + r * (z * ps);
+    float pc = 2.44285529e-5f;
+    pc = pc * z + -1.38872792e-3f;
+    pc = pc * z + 4.16666456e-2f;
+    const float cosr = (1.0f - 0.5f * z) + (z * z) * pc;
     switch (n & 3) {
-    case 0:  v =  dmr_sin_poly(r); break;
-    case 1:  v =  dmr_cos_poly(r); break;
-    case 2:  v = -dmr_sin_poly(r); break;
-    default: v = -dmr_cos_poly(r); break;
+    case 0:  *s =  sinr; *c =  cosr; break;
+    case 1:  *s =  cosr; *c = -sinr; break;
+    case 2:  *s = -sinr; *c = -cosr; break;
+    default: *s = -cosr; *c =  sinr; break;
     }
-    return (float)v;
 }
+static inline float dmr_sinf(float x) { float s, c; dmr_sincosf(x, &s, &c); return s; }
+static inline float dmr_cosf(float x) { float s, c; dmr_sincosf(x, &s, &c); return c; }
 
-static inline float dmr_cosf(float xf)
+/* x^f, x > 0, 0 < f < 1, binary32 */
+static inline float dmr_pow_frac(float x, float f)
 {
-    int n;
-    const double r = dmr_reduce((double)xf, &n);
-    double v;
-    switch (n & 3) {
-    case 0:  v =  dmr_cos_poly(r); break;
-    case 1:  v = -dmr_sin_poly(r); break;
-    case 2:  v = -dmr_cos_poly(r); break;
-    default: v =  dmr_sin_poly(r); break;
-    }
-    return (float)v;
+    uint32_t bits = dmr_to_bits32(x);
+    int e = -127;
+    if (bits < 0x00800000u) { bits = dmr_to_bits32(x * 16777216.f); e = -127 - 24; }
+    e += (int)(bits >> 23);
+    float m = dmr_from_bits32((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }
+    /* ln(m) = 2 s (1 + z (L0 + L1 z + L2 z^2 + L3 z^3)), s = (m-1)/(m+1), z = s^2 */
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    float p = 1.17941231e-1f;
+    p = p * z + 1.42684832e-1f;
+    p = p * z + 2.00001702e-1f;
+    p = p * z + 3.33333313e-1f;
+    const float s2 = s + s;
+    const float lg = (s2 + s2 * (z * p)) * 1.44269502f;
+    /* t = f * (e + lg) with f * e exact: f = fh + fl, 12 bits each */
+    const float ef = (float)e;
+    const float fh = dmr_from_bits32(dmr_to_bits32(f) & 0xfffff000u), fl = f - fh;
+    const float a = fh * ef;
+    const float b = fl * ef + f * lg;
+    const float kf = floorf((a + b) + 0.5f);
+    const float w = (a - kf) + b;
+    float q = 1.54673908e-4f;
+    q = q * w + 1.34004594e-3f;
+    q = q * w + 9.61803552e-3f;
+    q = q * w + 5.55032715e-2f;
+    q = q * w + 2.40226507e-1f;
+    q = q * w + 6.93147182e-1f;
+    const float r = 1.0f + w * q;
+    const int k = (int)kf, k1 = k >> 1, k2 = k - k1;
+    return (r * dmr_from_bits32((uint32_t)(k1 + 127) << 23)) * dmr_from_bits32((uint32_t)(k2 + 127) << 23);
 }
 
-/* x^y for x >= 0, y > 0 (the only uses on the hot path: Phong lobe,
- * bsdf.hxx:317, :445, utils.hxx:91, :111; radius schedule vertexcm.hxx:296).
- * x <= 0 -> 0, y == 0 -> 1. */
+/* x^y (the uses on the hot path: Phong lobe bsdf.hxx:317, :445, utils.hxx:91, :111; radius schedule
+ * vertexcm.hxx:296).  x <= 0 -> 0, y == 0 -> 1. */
 static inline float dmr_powf(float xf, float yf)
 {
     if (yf == 0.0f) return 1.0f;
     if (!(xf > 0.0f)) return 0.0f;
     if (xf == 1.0f) return 1.0f;
-
-    const double x = (double)xf;
-    /* small positive integer exponent (the Phong exponent, 90 in the built-in
-       scenes): binary exponentiation in binary64, least-significant bit first */
-    if (yf >= 1.0f && yf <= 256.0f && yf == floorf(yf)) {
-        unsigned n = (unsigned)yf;
-        double b = x, r = 1.0;
+    const float ya = fabsf(yf);
+    const float nf = floorf(ya);
+    const float f = ya - nf;
+    double p = 1.0;
+    if (nf >= 1.0f) {   /* integer part: binary exponentiation in binary64, least-significant bit first */
+        unsigned n = (nf < 4294967040.f) ? (unsigned)nf : 4294967040u;
+        double b = (double)xf;
         for (;;) {
-            if (n & 1u) r = r * b;
+            if (n & 1u) p = p * b;
             n >>= 1;
             if (n == 0u) break;
             b = b * b;
         }
-        return (float)r;
+        if (f != 0.0f) p = p * (double)dmr_pow_frac(xf, f);
+    } else {
+        p = (double)dmr_pow_frac(xf, f);
     }
-    const uint64_t bits = dmr_to_bits(x);
-    int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    double m = dmr_from_bits((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
-    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
-
-    /* ln(m) = 2 s (1 + s^2/3 + s^4/5 + ...), s = (m-1)/(m+1), |s| <= 0.1716 */
-    const double s  = (m - 1.0) / (m + 1.0);
-    const double s2 = s * s;
-    double p = 1.0 / 21.0;
-    p = p * s2 + 1.0 / 19.0;
-    p = p * s2 + 1.0 / 17.0;
-    p = p * s2 + 1.0 / 15.0;
-    p = p * s2 + 1.0 / 13.0;
-    p = p * s2 + 1.0 / 11.0;
-    p = p * s2 + 1.0 / 9.0;
-    p = p * s2 + 1.0 / 7.0;
-    p = p * s2 + 1.0 / 5.0;
-    p = p * s2 + 1.0 / 3.0;
-    p = p * s2 + 1.0;
-    const double lnm   = 2.0 * s * p;
-    const double log2x = (double)e + lnm * 1.4426950408889634;
-
-    const double t = (double)yf * log2x;
-    if (t >= 128.0)  return INFINITY;
-    if (t < -160.0)  return 0.0f;
-
-    const double kf = floor(t + 0.5);
-    const int    k  = (int)kf;
-    const double z  = (t - kf) * 0.6931471805599453;   /* |z| <= 0.3466 */
-    double q = 1.0 / 6227020800.0;
-    q = q * z + 1.0 / 479001600.0;
-    q = q * z + 1.0 / 39916800.0;
-    q = q * z + 1.0 / 3628800.0;
-    q = q * z + 1.0 / 362880.0;
-    q = q * z + 1.0 / 40320.0;
-    q = q * z + 1.0 / 5040.0;
-    q = q * z + 1.0 / 720.0;
-    q = q * z + 1.0 / 120.0;
-    q = q * z + 1.0 / 24.0;
-    q = q * z + 1.0 / 6.0;
-    q = q * z + 0.5;
-    q = q * z + 1.0;
-    q = q * z + 1.0;
-    const double scale = dmr_from_bits((uint64_t)(k + 1023) << 52);   /* 2^k, k in [-160,128] */
-    return (float)(q * scale);
+    if (yf < 0.0f) p = 1.0 / p;
+    return (float)p;
 }
 
 #endif

@@ -7,145 +7,127 @@
 // of arguments), and a single flipped Russian-roulette / lobe / hit decision
 // per few million paths already exceeds the per-pixel RMSE budget.  These
 // three functions are therefore DEFINED as a fixed sequence of IEEE-754
-// binary64 add / mul / div / floor operations (no FMA), which every conforming
-// machine evaluates identically.  Results are correctly rounded to binary32
-// for all but ~1e-9 of arguments (tests/test_rng_detmath.py).
-// Domains: sin/cos |x| < ~1e4; pow x >= 0, y > 0 (x <= 0 -> 0, y == 0 -> 1).
-// The CPU checker (oracle/detmath_ref.h) states the same definition.
+// operations (no FMA: the library is built with -ffp-contract=off), which every
+// conforming machine evaluates identically; the CPU checker (oracle/detmath_ref.h)
+// states the same definition and the unmodified reference is linked against it
+// in the parity tests.
+//
+// Definition, round 2 (round 1 evaluated everything in binary64 with Taylor series to double accuracy: correctly
+// rounded, and ~330 instructions per general powf, ~150 per sincosf, at every bounce of every path):
+//   sinf/cosf  binary32 throughout: four-term Cody-Waite reduction by pi/2 (the first three products are exact),
+//              degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4].   <= 1.6 ulp for |x| <= 8 (the path
+//              passes 2 pi u, u in (0,1), and the concentric-disc angle in (-pi/4, 7 pi/4)).
+//   powf(x,y)  y = n + f, n = floor(y):  x^n by binary exponentiation in binary64 (one rounding at the end: the
+//              Phong lobe, x^90, is correctly rounded as before), x^f in binary32 as exp2(f log2 x): log2 via the
+//              atanh series in s = (m-1)/(m+1), the product f*e of the exponent part carried exactly (f split
+//              12 + 12 bits), exp2 by a degree-6 minimax polynomial.   <= 1.9 ulp for 0 < y < 1 over the whole
+//              binary32 range of x (tests/test_rng_detmath.py); x <= 0 -> 0, y == 0 -> 1, y < 0 -> 1 / x^|y|.
+// ~45 instructions per sincosf, ~60 per fractional powf.
 #ifndef SMALLVCM_AMD_DETMATH_H
 #define SMALLVCM_AMD_DETMATH_H
 #include "vcm_math.h"
 
 namespace vcm {
 
-VCM_HD double bits2d(uint64_t b) { double d; __builtin_memcpy(&d, &b, 8); return d; }
-VCM_HD uint64_t d2bits(double d) { uint64_t b; __builtin_memcpy(&b, &d, 8); return b; }
-
-/* r = x - n*pi/2 (two-term Cody-Waite), n = round(x*2/pi) */
-VCM_HD double dm_reduce(double x, int &n)
-{
-    const double q  = x * 0.63661977236758138;
-    const double nf = floor(q + 0.5);
-    n = (int)nf;
-    return (x - nf * 1.5707963267948966) - nf * 6.123233995736766e-17;
-}
-
-VCM_HD double dm_sin_poly(double r)
-{
-    const double r2 = r * r;
-    double p = -1.0 / 1307674368000.0;
-    p = p * r2 + 1.0 / 6227020800.0;
-    p = p * r2 + -1.0 / 39916800.0;
-    p = p * r2 + 1.0 / 362880.0;
-    p = p * r2 + -1.0 / 5040.0;
-    p = p * r2 + 1.0 / 120.0;
-    p = p * r2 + -1.0 / 6.0;
-    return r + r * (r2 * p);
-}
-
-VCM_HD double dm_cos_poly(double r)
-{
-    const double r2 = r * r;
-    double p = 1.0 / 20922789888000.0;
-    p = p * r2 + -1.0 / 87178291200.0;
-    p = p * r2 + 1.0 / 479001600.0;
-    p = p * r2 + -1.0 / 3628800.0;
-    p = p * r2 + 1.0 / 40320.0;
-    p = p * r2 + -1.0 / 720.0;
-    p = p * r2 + 1.0 / 24.0;
-    p = p * r2 + -0.5;
-    return 1.0 + r2 * p;
-}
-
 /* sin and cos of the same argument share the reduction (every call site
    needs both: utils.hxx:97-101, :156-158, :180-183, :219-222) */
-VCM_HD void dm_sincosf(float xf, float &s, float &c)
+VCM_HD void dm_sincosf(float x, float &s, float &c)
 {
-    int n;
-    const double r = dm_reduce((double)xf, n);
-    const double sp = dm_sin_poly(r);
-    const double cp = dm_cos_poly(r);
-    double sv, cv;
-    switch (n & 3) {
-    case 0:  sv =  sp; cv =  cp; break;
-    case 1:  sv =  cp; cv = -sp; break;
-    case 2:  sv = -sp; cv = -cp; break;
-    default: sv = -cp; cv =  sp; break;
-    }
-    s = (float)sv;
-    c = (float)cv;
+    /* r = x - n pi/2, n = round(x 2/pi); pi/2 = P1 + P2 + P3 + P4, n P1, n P2 and n P3 exact for |n| < 2^12 */
+    const float q  = x * 0.636619747f;                 /* 0x3f22f983 */
+    const float nf = floorf(q + 0.5f);
+    const int   n  = (int)nf;
+    float r = x - nf * 1.5703125f;                      /* 0x3fc90000 */
+    r = r - nf * 4.83751297e-4f;                        /* 0x39fda000 */
+    r = r - nf * 7.54953362e-8f;                        /* 0x33a22000 */
+    r = r - nf * 2.56334407e-12f;                      /* 0x2c34611a: keeps sin / cos near their zeros to an ulp */
+    const float z = r * r;
+    float ps = -1.95094646e-4f;                         /* 0xb94c9252 */
+    ps = ps * z + 8.33211839e-3f;                       /* 0x3c088370 */
+    ps = ps * z + -1.66666538e-1f;                      /* 0xbe2aaaa2 */
+    const float sp = r + r * (z * ps);
+    float pc = 2.44285529e-5f;                          /* 0x37ccebeb */
+    pc = pc * z + -1.38872792e-3f;                      /* 0xbab605fa */
+    pc = pc * z + 4.16666456e-2f;                       /* 0x3d2aaaa5 */
+    const float cp = (1.0f - 0.5f * z) + (z * z) * pc;
+    const int k = n & 3;
+    const float sv = (k & 1) ? cp : sp;
+    const float cv = (k & 1) ? sp : cp;
+    s = (k & 2) ? -sv : sv;                             /* k: 0 sp, 1 cp, 2 -sp, 3 -cp */
+    c = ((k + 1) & 2) ? -cv : cv;                       /* k: 0 cp, 1 -sp, 2 -cp, 3 sp */
 }
 VCM_HD float dm_sinf(float x) { float s, c; dm_sincosf(x, s, c); return s; }
 VCM_HD float dm_cosf(float x) { float s, c; dm_sincosf(x, s, c); return c; }
+
+/* x^n, n >= 1 an integer-valued float: binary exponentiation in binary64, least-significant bit first */
+VCM_HD double dm_pow_int(float xf, float nf)
+{
+    unsigned n = (nf < 4294967040.f) ? (unsigned)nf : 4294967040u;
+    double b = (double)xf, r = 1.0;
+    for (;;) {
+        if (n & 1u) r = r * b;
+        n >>= 1;
+        if (n == 0u) break;
+        b = b * b;
+    }
+    return r;
+}
+
+/* x^f for x > 0 (finite), 0 < f < 1, binary32 throughout */
+VCM_HD float dm_pow_frac(float x, float f)
+{
+    uint32_t bits = f2u(x);
+    int e = -127;
+    if (bits < 0x00800000u) { bits = f2u(x * 16777216.f); e = -127 - 24; }   /* subnormal x: scaled by 2^24 */
+    e += (int)(bits >> 23);
+    float m = u2f((bits & 0x007fffffu) | 0x3f800000u);                        /* [1, 2) */
+    if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }                         /* [sqrt(1/2), sqrt 2) */
+    /* ln m = 2 s + 2 s z (L0 + L1 z + L2 z^2 + L3 z^3), s = (m-1)/(m+1), z = s^2, |s| <= 0.1716 */
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    float p = 1.17941231e-1f;                           /* 0x3df18b2c */
+    p = p * z + 1.42684832e-1f;                         /* 0x3e121bf9 */
+    p = p * z + 2.00001702e-1f;                         /* 0x3e4ccd3f */
+    p = p * z + 3.33333313e-1f;                         /* 0x3eaaaaaa */
+    const float s2 = s + s;
+    const float lg = (s2 + s2 * (z * p)) * 1.44269502f; /* log2 m; 0x3fb8aa3b */
+    /* t = f (e + lg): f e is the large part and is carried exactly (f = fh + fl, 12 bits each; |e| < 2^8) */
+    const float ef = (float)e;
+    const float fh = u2f(f2u(f) & 0xfffff000u), fl = f - fh;
+    const float a = fh * ef;
+    const float b = fl * ef + f * lg;
+    const float kf = floorf((a + b) + 0.5f);
+    const float w = (a - kf) + b;                       /* [-0.5, 0.5] */
+    float q = 1.54673908e-4f;                           /* 0x39222ff6 */
+    q = q * w + 1.34004594e-3f;                         /* 0x3aafa47b */
+    q = q * w + 9.61803552e-3f;                         /* 0x3c1d94f7 */
+    q = q * w + 5.55032715e-2f;                         /* 0x3d635766 */
+    q = q * w + 2.40226507e-1f;                         /* 0x3e75fdf0 */
+    q = q * w + 6.93147182e-1f;                         /* 0x3f317218 */
+    const float r = 1.0f + w * q;                       /* 2^w */
+    /* times 2^k in two steps (k in [-150, 128]: either factor is a normal number) */
+    const int k = (int)kf, k1 = k >> 1, k2 = k - k1;
+    return (r * u2f((uint32_t)(k1 + 127) << 23)) * u2f((uint32_t)(k2 + 127) << 23);
+}
 
 VCM_HD float dm_powf(float xf, float yf)
 {
     if (yf == 0.0f) return 1.0f;
     if (!(xf > 0.0f)) return 0.0f;
     if (xf == 1.0f) return 1.0f;
-
-    const double x = (double)xf;
-    /* small positive integer exponent (the Phong exponent, 90 in the built-in
-       scenes): binary exponentiation in binary64, least-significant bit first */
-    if (yf >= 1.0f && yf <= 256.0f && yf == floorf(yf)) {
-        unsigned n = (unsigned)yf;
-        double b = x, r = 1.0;
-        for (;;) {
-            if (n & 1u) r = r * b;
-            n >>= 1;
-            if (n == 0u) break;
-            b = b * b;
-        }
-        return (float)r;
-    }
-    const uint64_t bits = d2bits(x);
-    int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    double m = bits2d((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
-    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
-
-    const double s  = (m - 1.0) / (m + 1.0);
-    const double s2 = s * s;
-    double p = 1.0 / 21.0;
-    p = p * s2 + 1.0 / 19.0;
-    p = p * s2 + 1.0 / 17.0;
-    p = p * s2 + 1.0 / 15.0;
-    p = p * s2 + 1.0 / 13.0;
-    p = p * s2 + 1.0 / 11.0;
-    p = p * s2 + 1.0 / 9.0;
-    p = p * s2 + 1.0 / 7.0;
-    p = p * s2 + 1.0 / 5.0;
-    p = p * s2 + 1.0 / 3.0;
-    p = p * s2 + 1.0;
-    const double lnm   = 2.0 * s * p;
-    const double log2x = (double)e + lnm * 1.4426950408889634;
-
-    const double t = (double)yf * log2x;
-    if (t >= 128.0)  return INFINITY;
-    if (t < -160.0)  return 0.0f;
-
-    const double kf = floor(t + 0.5);
-    const int    k  = (int)kf;
-    const double z  = (t - kf) * 0.6931471805599453;
-    double q = 1.0 / 6227020800.0;
-    q = q * z + 1.0 / 479001600.0;
-    q = q * z + 1.0 / 39916800.0;
-    q = q * z + 1.0 / 3628800.0;
-    q = q * z + 1.0 / 362880.0;
-    q = q * z + 1.0 / 40320.0;
-    q = q * z + 1.0 / 5040.0;
-    q = q * z + 1.0 / 720.0;
-    q = q * z + 1.0 / 120.0;
-    q = q * z + 1.0 / 24.0;
-    q = q * z + 1.0 / 6.0;
-    q = q * z + 0.5;
-    q = q * z + 1.0;
-    q = q * z + 1.0;
-    const double scale = bits2d((uint64_t)(k + 1023) << 52);
-    return (float)(q * scale);
+    const float ya = fabsf(yf);
+    const float nf = floorf(ya);
+    const float f = ya - nf;                            /* exact */
+    /* ONE call site of each part (the function is inlined wherever a Phong lobe is evaluated); a factor 1.0 and a
+       binary32 value widened to binary64 and back are exact */
+    double p = (nf >= 1.0f) ? dm_pow_int(xf, nf) : 1.0;
+    if (f != 0.0f) p = p * (double)dm_pow_frac(xf, f);
+    if (yf < 0.0f) p = 1.0 / p;                         /* not on the path (the exponents there are positive) */
+    return (float)p;
 }
 
 /* dm_powf for call sites where the exponent is a material constant (the Phong
- * exponent): if every active lane of the wave holds the same small integer
+ * exponent): if every active lane of the wave holds the same integer
  * exponent, the binary exponentiation is driven by SCALAR control flow -- only
  * the ~log2(n)+popcount(n) binary64 multiplies remain as vector work, instead
  * of a per-lane loop with selects.  Same multiplication sequence as dm_powf,
@@ -154,7 +136,7 @@ VCM_HD float dm_powf_wave(float xf, float yf)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yf)));
-    if (y0 >= 1.0f && y0 <= 256.0f && y0 == floorf(y0) && __all(yf == y0)) {   /* wave-uniform */
+    if (y0 >= 1.0f && y0 <= 65536.0f && y0 == floorf(y0) && __all(yf == y0)) {   /* wave-uniform */
         unsigned n = (unsigned)y0;
         double b = (double)xf, r = 1.0;
         for (;;) {
