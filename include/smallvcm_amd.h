@@ -159,6 +159,11 @@ const char *vcm_last_error(void);
  * src/renderer.hxx:58, src/smallvcm.cxx:66). */
 vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm,
                     float radiusFactor, float radiusAlpha, int seed);
+/* On a multi-GPU node consecutive vcm_create calls go round-robin over the visible devices (the reference's
+ * render() builds one renderer per host core, smallvcm.cxx:61-72: dealt out like this, every GPU renders whole
+ * iterations of its share of the renderers and the driver's own framebuffer average is the only reduce).
+ * Environment SMALLVCM_AMD_DEVICES: "all" (default), "current" (the calling thread's current HIP device) or a list
+ * such as "0,2,5".  vcm_create_sharded takes the device explicitly. */
 
 /* Same, for one rank of a sharded renderer: rank r of worldSize traces light
  * paths and pixels [r*N/W, (r+1)*N/W) on HIP device `device`. */
@@ -231,6 +236,9 @@ int vcm_set_grid_bbox(vcm_ctx *ctx, const float *min3, const float *max3);
  * then handed to an RCCL collective).  Asynchronous on the context's stream. */
 int vcm_export_light_records(vcm_ctx *ctx, void *dstDev, long long count);
 int vcm_export_framebuffer(vcm_ctx *ctx, void *dstDev);
+/* the same multiplied by `scale` (1 / iterations gives GetFramebuffer, renderer.hxx:49-55): what a multi-GPU host
+ * hands to the framebuffer all-reduce */
+int vcm_export_framebuffer_scaled(vcm_ctx *ctx, void *dstDev, float scale);
 
 /* Install the all-gathered records: nSeg segments (one per rank, rank order),
  * segment s holds counts[s] records starting at devPtr + s*strideRecords

@@ -12,6 +12,7 @@
 #include <string>
 #include <new>
 #include <mutex>
+#include <vector>
 #include <condition_variable>
 #include <atomic>
 
@@ -144,6 +145,7 @@ struct vcm_ctx : Scratch {
     bool inIteration;
     hipEvent_t ev[EV_COUNT];
     bool evValid;
+    unsigned long long *pend[2][4]; int nPend[2];   /* stamp slots waiting for the next kernel on [0] main, [1] side stream */
     vcm_stats lastStats;
 };
 
@@ -423,7 +425,6 @@ static int ensure_device(vcm_ctx *c)
  * VCM_STAMP_RING iterations, so a host can run a batch of iterations back to back and ask for per-iteration
  * figures afterwards -- reading back between iterations lets the GPU idle and return at a lower clock, which
  * made kernel times come out 10-20 % longer than in the batch. */
-static __global__ void k_stamp(unsigned long long *t) { *t = wall_clock64(); }
 /* Framebuffer::SaveBMP / SaveHDR pixel encodings (framebuffer.hxx:194-214, :229-247), one lane per pixel */
 static __global__ void k_encode_image(const float *fb, int resX, int resY, int format, float scale, float invGamma, unsigned char *out)
 {
@@ -455,25 +456,50 @@ static __global__ void k_set_bbox(GridHeader *hdr, float x0, float y0, float z0,
     hdr->bboxMin[0] = x0; hdr->bboxMin[1] = y0; hdr->bboxMin[2] = z0;
     hdr->bboxMax[0] = x1; hdr->bboxMax[1] = y1; hdr->bboxMax[2] = z1;
 }
-static __global__ void k_note_grid_vertices(const GridHeader *hdr, unsigned long long *out) { *out = (unsigned long long)hdr->nRecords; }
+static __global__ void k_note_grid_vertices(const GridHeader *hdr, unsigned long long *out, StampArgs st) { stamp_entry(st); *out = (unsigned long long)hdr->nRecords; }
+static __global__ void k_stamp_many(StampArgs st) { stamp_entry(st); }
+static StampArgs take_stamps(vcm_ctx *c, hipStream_t stream)
+{
+    const int w = (stream == c->side) ? 1 : 0;
+    StampArgs st;
+    for (int k = 0; k < 4; k++) st.p[k] = (k < c->nPend[w]) ? c->pend[w][k] : NULL;
+    c->nPend[w] = 0;
+    return st;
+}
+/* stamps still pending when a phase has no further kernel: one tiny launch writes them */
+static int flush_stamps(vcm_ctx *c, hipStream_t stream)
+{
+    const int w = (stream == c->side) ? 1 : 0;
+    if (c->nPend[w] == 0) return 0;
+    hipLaunchKernelGGL(k_stamp_many, dim3(1), dim3(1), 0, stream, take_stamps(c, stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+/* mark a phase boundary on `stream`: the NEXT kernel launched there writes the device clock into the mark's slot when
+ * it starts (take_stamps / stamp_entry) -- the boundary costs no launch of its own.  SMALLVCM_AMD_NO_STAMPS=1: no
+ * marks at all (vcm_get_stats then reports counters only); SMALLVCM_AMD_TIMING=events additionally records a HIP
+ * event per mark (the two agree; the events only remember the last iteration). */
 static int mark_on(vcm_ctx *c, int ev, hipStream_t stream)
 {
-    static int off = -1;   /* SMALLVCM_AMD_NO_STAMPS=1: no phase marks at all (vcm_get_stats then reports counters only) */
+    static int off = -1, events = -1;
     if (off < 0) { const char *e = getenv("SMALLVCM_AMD_NO_STAMPS"); off = (e && e[0] == '1') ? 1 : 0; }
+    if (events < 0) { const char *e = getenv("SMALLVCM_AMD_TIMING"); events = (e && !strcmp(e, "events")) ? 1 : 0; }
     if (off) return 0;
-    HIPCHK(hipEventRecord(c->ev[ev], stream));
-    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, stream, c->dStamps + (size_t)(c->iterations % VCM_STAMP_RING) * EV_COUNT + ev);
-    HIPCHK(hipGetLastError());
+    if (events) HIPCHK(hipEventRecord(c->ev[ev], stream));
+    const int w = (stream == c->side) ? 1 : 0;
+    if (c->nPend[w] == 4 && flush_stamps(c, stream)) return -1;
+    c->pend[w][c->nPend[w]++] = c->dStamps + (size_t)(c->iterations % VCM_STAMP_RING) * EV_COUNT + ev;
     return 0;
 }
 static int mark(vcm_ctx *c, int ev) { return mark_on(c, ev, c->stream); }
 
 /* exclusive scan of n ints/bytes on the context's stream */
 template <typename T>
-static int launch_scan_on(hipStream_t stream, int *tileSums, const T *in, int n, int *out, int *totalOut, int writeTotalAtN)
+static int launch_scan_on(hipStream_t stream, int *tileSums, const T *in, int n, int *out, int *totalOut, int writeTotalAtN,
+                          StampArgs st)
 {
     const int nTiles = (n + VCM_SCAN_TILE - 1) / VCM_SCAN_TILE;
-    hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums);
+    hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums, st);
     hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(VCM_SCAN_BLOCK), 0, stream, tileSums, nTiles, totalOut);
     hipLaunchKernelGGL((k_scan_apply<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums, out, writeTotalAtN);
     HIPCHK(hipGetLastError());
@@ -482,7 +508,7 @@ static int launch_scan_on(hipStream_t stream, int *tileSums, const T *in, int n,
 template <typename T>
 static int launch_scan(vcm_ctx *c, const T *in, int n, int *out, int *totalOut, int writeTotalAtN)
 {
-    return launch_scan_on<T>(c->stream, c->dTileSums, in, n, out, totalOut, writeTotalAtN);
+    return launch_scan_on<T>(c->stream, c->dTileSums, in, n, out, totalOut, writeTotalAtN, take_stamps(c, c->stream));
 }
 
 static void trace_launch_shape(int nLocal, int *blocks, int *chunk)
@@ -576,11 +602,41 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     return c;
 }
 
+/* Which device the next vcm_create goes to.  The reference's driver builds one renderer per host core and runs
+ * them concurrently (smallvcm.cxx:61-72, :99-108): on a multi-GPU node they are dealt round-robin over the visible
+ * devices -- every GPU renders whole iterations of its renderers (replicas, no per-iteration exchange) and the
+ * driver's own framebuffer average (smallvcm.cxx:116-142) is the reduce.  SMALLVCM_AMD_DEVICES = "all" (default),
+ * "current" (the calling thread's hipGetDevice, the behaviour of round 1) or a list "0,2,5". */
+static int next_device(void)
+{
+    static std::mutex m;
+    static std::vector<int> devs;
+    static unsigned long long counter = 0;
+    static bool current = false, init = false;
+    std::lock_guard<std::mutex> g(m);
+    const int n = vcm_device_count();
+    if (!init) {
+        init = true;
+        const char *e = getenv("SMALLVCM_AMD_DEVICES");
+        if (e && !strcmp(e, "current")) current = true;
+        else if (e && strcmp(e, "all") && *e) {
+            for (const char *p = e; *p;) {
+                char *end = NULL;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                if (d >= 0 && d < n) devs.push_back((int)d);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+        if (!current && devs.empty()) for (int d = 0; d < n; d++) devs.push_back(d);
+    }
+    if (current || devs.empty()) { int dev = 0; if (n > 0) (void)hipGetDevice(&dev); return dev; }
+    return devs[(size_t)(counter++ % devs.size())];
+}
+
 vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha, int seed)
 {
-    int dev = 0;
-    if (vcm_device_count() > 0) (void)hipGetDevice(&dev);
-    return vcm_create_sharded(scene, algorithm, radiusFactor, radiusAlpha, seed, dev, 0, 1);
+    return vcm_create_sharded(scene, algorithm, radiusFactor, radiusAlpha, seed, next_device(), 0, 1);
 }
 
 void vcm_destroy(vcm_ctx *c)
@@ -711,6 +767,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
         P.nBuckets = nb < VCM_QSORT_BUCKETS ? (int)nb : VCM_QSORT_BUCKETS;
     }
 
+    c->nPend[0] = c->nPend[1] = 0;
     if (mark(c, EV_START)) return -1;
     c->dStats = c->dStatsRing + (size_t)(c->iterations % VCM_STAMP_RING) * VCM_STAT_SLOTS;
     c->radiusRing[c->iterations % VCM_STAMP_RING] = radius;
@@ -758,9 +815,9 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         if (mark(c, EV_LIGHT_K0)) return -1;
         if (mark(c, EV_LIGHT_K1)) return -1;
         HIPCHK(hipMemsetAsync(c->dLocalTotal, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
+        if (mark(c, EV_LIGHT)) return -1;   /* written by the phase's last kernel as it starts */
+        hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
-        if (mark(c, EV_LIGHT)) return -1;
         return 0;
     }
     int blocks, chunk;
@@ -769,10 +826,10 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     const bool wf = !c->strictOrder;
     if (wf)
         hipLaunchKernelGGL(k_light_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                           c->dFb, c->dRngLight, c->dStats, chunk);
+                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream));
     else
         hipLaunchKernelGGL(k_light_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                           c->dFb, c->dRngLight, c->dStats, chunk);
+                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream));
     HIPCHK(hipGetLastError());
     if (mark(c, EV_LIGHT_K1)) return -1;
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
@@ -790,9 +847,9 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         c->splatsPending = true;
         if (c->world == 1 && flush_light_splats(c)) return -1;
     }
-    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0);
+    if (mark(c, EV_LIGHT)) return -1;   /* written by the phase's last (one-lane) kernel as it starts */
+    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0, take_stamps(c, c->stream));
     HIPCHK(hipGetLastError());
-    if (mark(c, EV_LIGHT)) return -1;
     return 0;
 }
 
@@ -829,7 +886,7 @@ static int vcm_local_light_bbox_impl(vcm_ctx *c, float *min3, float *max3, long 
     if (!c || !c->inIteration || !min3 || !max3) return fail("vcm_local_light_bbox", "call it between vcm_trace_light and vcm_build_grid");
     if (use_device(c)) return -1;
     VertexSource src; src.records = NULL; src.store = c->store; src.slotOfVertex = c->dSlotOfVertex;
-    hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr);
+    hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr, take_stamps(c, c->stream));
     hipLaunchKernelGGL(k_bbox, dim3(512), dim3(256), 0, c->stream, src, c->dHdr);
     hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr);
     HIPCHK(hipGetLastError());
@@ -867,6 +924,20 @@ int vcm_export_light_records(vcm_ctx *c, void *dstDev, long long count)
     return 0;
 }
 
+static __global__ void k_scale_copy(const float *src, float *dst, size_t n, float scale)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
+}
+/* dst = framebuffer * scale (renderer.hxx:53-54 with scale = 1 / mIterations), device to device, asynchronous */
+int vcm_export_framebuffer_scaled(vcm_ctx *c, void *dstDev, float scale)
+{
+    if (!c || !dstDev) return fail("vcm_export_framebuffer_scaled", "bad argument");
+    if (ensure_device(c)) return -1;
+    hipLaunchKernelGGL(k_scale_copy, dim3(1024), dim3(256), 0, c->stream, (const float *)c->dFb, (float *)dstDev, (size_t)c->N * 3, scale);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int vcm_export_framebuffer(vcm_ctx *c, void *dstDev)
 {
     if (!c || !dstDev) return fail("vcm_export_framebuffer", "bad argument");
@@ -891,7 +962,7 @@ static int vcm_import_light_records_impl(vcm_ctx *c, const void *devPtr, const l
                                   (size_t)counts[s] * recBytes, hipMemcpyDeviceToDevice, c->stream));
         total += counts[s];
     }
-    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 0, (int)total);
+    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 0, (int)total, take_stamps(c, c->stream));
     HIPCHK(hipGetLastError());
     c->importedRecords = true;
     return 0;
@@ -929,24 +1000,24 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         const dim3 g(2048), b(256);
         HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), q));
         if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
-            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr);
+            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr, take_stamps(c, q));
             hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
             hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr);
         }
         HIPCHK(hipEventRecord(c->evBbox, q));
         hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
-                           c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount);
+                           c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount, take_stamps(c, q));
         HIPCHK(hipGetLastError());
-        if (launch_scan_on<int>(q, c->dTileSumsSide, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
+        if (launch_scan_on<int>(q, c->dTileSumsSide, c->dCellCount, nCells, c->dCellStart, NULL, 1, take_stamps(c, q))) return -1;
         hipLaunchKernelGGL(k_cell_scatter, g, b, 0, q, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
                            (const int *)c->dSortedIndex, (const int *)c->dCellStart,
                            recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
         hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, q, (const GridHeader *)c->dHdr, recs,
                            (const int *)c->dCellStart, (const I4 *)c->dUnsorted, c->dGx,
                            c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
-        hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT);
-        HIPCHK(hipGetLastError());
         if (mark_on(c, EV_GRID, q)) return -1;
+        hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT, take_stamps(c, q));
+        HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->evGrid, q));
         HIPCHK(hipStreamWaitEvent(c->stream, c->evBbox, 0));
         c->gridInFlight = true;
@@ -979,10 +1050,10 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     if (c->renderer) {   /* PathTracer / EyeLight: colour + jittered pixel per path; K5 adds them in path order */
         if (c->renderer == 1)
             hipLaunchKernelGGL(k_path_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->dCamOut,
-                               c->dRngCam, c->dStats, chunk);
+                               c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         else
             hipLaunchKernelGGL(k_eye_light, dim3(2048), dim3(256), 0, c->stream, c->dScene, c->P, c->dCamOut, c->dRngCam,
-                               c->dStats);
+                               c->dStats, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (mark(c, EV_CONNECT_K1)) return -1;
@@ -998,7 +1069,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
         if (c->countedInCamera) HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)c->P.nBuckets + 1) * sizeof(int), c->stream));
         hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
-                           c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+                           c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
             /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
@@ -1007,7 +1078,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
             hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
-                               c->scatteredInDI ? c->dSortedVertex : (int *)NULL);
+                               c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
             hipLaunchKernelGGL(k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->store, c->dStats);
         }
@@ -1015,11 +1086,12 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     } else {
         if (c->useVM && !c->gridBuilt) return fail("vcm_trace_camera", "strict mode merges inside the camera pass: call vcm_build_grid first");
         hipLaunchKernelGGL(k_camera_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
-                           c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk);
+                           c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (mark(c, EV_CONNECT_K1)) return -1;
     }
     HIPCHK(hipGetLastError());
+    if (c->world > 1 && flush_stamps(c, c->stream)) return -1;   /* the exchange may sit between this phase and the merge */
     return 0;
 }
 
@@ -1037,7 +1109,7 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (!c->countedInCamera) {
                 HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
                 hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
-                                   (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount);
+                                   (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount, take_stamps(c, c->stream));
             }
             if (!c->scatteredInDI) {
                 if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
@@ -1046,7 +1118,9 @@ static int vcm_merge_impl(vcm_ctx *c)
             }
             if (mark(c, EV_SORT_K1)) return -1;
             /* K4: needs the grid; the query sort above only needed its bounding box, so in the sharded order
-               (camera pass before the grid build) it ran next to the build */
+               (camera pass before the grid build) it ran next to the build.  If the stream has to wait for the side
+               stream, the pending marks are written first (they must not absorb the wait). */
+            if (c->gridInFlight && hipEventQuery(c->evGrid) != hipSuccess) { (void)hipGetLastError(); if (flush_stamps(c, c->stream)) return -1; }
             if (join_grid(c)) return -1;
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
@@ -1061,20 +1135,21 @@ static int vcm_merge_impl(vcm_ctx *c)
                 if (ch < 1) ch = 1;
                 hipLaunchKernelGGL(k_merge_staged, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
                                    c->stream, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
-                                   (const int *)(c->dQueryStart + nb), c->dStats, ch);
+                                   (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
             } else
                 hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
-                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk);
+                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
         } else {
             if (mark(c, EV_SORT_K1)) return -1;
         }
         if (mark(c, EV_MERGE_K1)) return -1;
         /* K5 */
         hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
-                           (const uint32_t *)c->dCamMask, c->vs, c->dFb);
+                           (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
     }
     if (mark(c, EV_CAMERA)) return -1;
+    if (flush_stamps(c, c->stream)) return -1;   /* nothing of this iteration follows: the end mark gets its own (one-lane) launch */
     c->merged = true;
     return 0;
 }
@@ -1132,6 +1207,7 @@ int vcm_end_iteration(vcm_ctx *c)
     if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
     if (!c->merged) return fail("vcm_end_iteration", "vcm_merge has not run");
     if (join_grid(c)) return -1;   /* (a merge-free algorithm never waited) */
+    if (flush_stamps(c, c->stream) || (c->deviceReady && flush_stamps(c, c->side))) return -1;
     c->iterations++;   /* :547 */
     c->inIteration = false;
     c->evValid = true;

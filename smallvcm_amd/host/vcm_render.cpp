@@ -10,6 +10,13 @@
 //              [--res W H] [--seed S] [--minlen A] [--maxlen B]
 //              [--renderers R] [--radius-factor F] [--radius-alpha A]
 //              [--device D] [--strict] [--warmup W] [-o out.pfm] [--json]
+//              [--gpus N [--shards S] [--inflight K] [--devices 0,1,..] [--collectives rccl|threads]]
+//
+// --gpus N: the multi-GPU host (vcm_farm.hpp): N ranks = N host threads, one per GPU, cut into N / S groups; a
+// renderer lives on a group (S path-index shards, RCCL all-gather of the light vertices every iteration), K
+// renderers take turns on a group, one RCCL all-reduce of the framebuffers at read-out.  --shards 1 = one renderer per
+// GPU (the reference's own iteration-parallel scheme).  --collectives threads replaces RCCL by an in-process
+// stand-in so that several ranks can share one GPU (tests; RCCL refuses two ranks on one device).
 //
 // -s / -a / -i keep the meaning they have in the reference's CLI
 // (src/config.hxx:246-395; scenes = g_SceneConfigs[0..3], :146-151).
@@ -32,6 +39,7 @@
 #include <vector>
 
 #include "smallvcm_amd.h"
+#include "vcm_farm.hpp"
 
 static int die(const char *what)
 {
@@ -56,6 +64,8 @@ int main(int argc, char **argv)
     int sceneID = 0, algorithm = VCM_ALGO_VCM, iterations = 1, resX = 512, resY = 512, seed = 1234;   // config.hxx:233-240
     unsigned minLen = 0, maxLen = 10;
     int renderers = 1, device = 0, warmup = 0, strict = 0, json = 0;
+    int gpus = 0, shards = 0, inflight = 0, rccl = 1;
+    std::vector<int> devices;
     float radiusFactor = 0.003f, radiusAlpha = 0.75f;
     std::string out, algoName = "vcm";
     for (int i = 1; i < argc; i++) {
@@ -74,6 +84,11 @@ int main(int argc, char **argv)
         else if (a == "--radius-alpha") { need(1); radiusAlpha = (float)atof(argv[++i]); }
         else if (a == "--device") { need(1); device = atoi(argv[++i]); }
         else if (a == "--warmup") { need(1); warmup = atoi(argv[++i]); }
+        else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
+        else if (a == "--shards") { need(1); shards = atoi(argv[++i]); }
+        else if (a == "--inflight") { need(1); inflight = atoi(argv[++i]); }
+        else if (a == "--collectives") { need(1); rccl = std::string(argv[++i]) == "threads" ? 0 : 1; }
+        else if (a == "--devices") { need(1); for (const char *p = argv[++i]; *p;) { char *e; devices.push_back((int)strtol(p, &e, 10)); p = (*e == ',') ? e + 1 : e; if (e == p && *p) break; } }
         else if (a == "--strict") strict = 1;
         else if (a == "--json") json = 1;
         else { fprintf(stderr, "vcm_render: unknown option %s (see the header of vcm_render.cpp)\n", a.c_str()); return 2; }
@@ -86,8 +101,31 @@ int main(int argc, char **argv)
     vcm_scene_desc scene;
     if (vcm_scene_cornell(resX, resY, vcm_scene_config_mask(sceneID), &scene)) return die("vcm_scene_cornell");
 
+    const size_t n3 = (size_t)resX * resY * 3;
+    std::vector<float> fb(n3, 0.f), tmp(n3);
+    double wall = 0;
+    vcm_stats st;
+    memset(&st, 0, sizeof(st));
+    std::vector<vcm_ctx *> r;
+    if (gpus > 0) {   // multi-GPU host: ranks x shards x in-flight renderers (vcm_farm.hpp)
+        FarmConfig fc;
+        fc.scene = scene; fc.algorithm = algorithm; fc.radiusFactor = radiusFactor; fc.radiusAlpha = radiusAlpha;
+        fc.baseSeed = seed; fc.minLen = minLen; fc.maxLen = maxLen; fc.iterations = iterations; fc.ranks = gpus;
+        fc.shards = shards > 0 ? shards : ((gpus % 2 == 0) ? 2 : gpus);
+        fc.inflight = inflight > 0 ? inflight : (fc.shards > 1 ? 2 : 1);
+        fc.rccl = rccl != 0; fc.warmup = warmup;
+        const int visible = vcm_device_count();
+        if (visible <= 0) { fprintf(stderr, "vcm_render: no HIP device available (this program has no CPU path)\n"); return 2; }
+        for (int k = 0; k < gpus; k++) fc.devices.push_back(k < (int)devices.size() ? devices[(size_t)k] : (fc.rccl ? k : k % visible));
+        for (int d : fc.devices) if (d < 0 || d >= visible) { fprintf(stderr, "vcm_render: device %d not visible (%d device(s))\n", d, visible); return 2; }
+        const FarmResult fr = farm_render(fc);
+        if (!fr.error.empty()) { fprintf(stderr, "vcm_render: %s\n", fr.error.c_str()); return 2; }
+        fb = fr.image;
+        wall = fr.wallSeconds;
+        renderers = fr.renderers;
+    } else {
     // render(): one renderer per "thread", seed base + i (smallvcm.cxx:61-72)
-    std::vector<vcm_ctx *> r((size_t)renderers, (vcm_ctx *)NULL);
+    r.assign((size_t)renderers, (vcm_ctx *)NULL);
     for (int g = 0; g < renderers; g++) {
         r[g] = vcm_create_sharded(&scene, algorithm, radiusFactor, radiusAlpha, seed + g, device, 0, 1);
         if (!r[g]) return die("vcm_create");
@@ -112,11 +150,9 @@ int main(int argc, char **argv)
             if (vcm_run_iteration(r[g], it, minLen, maxLen)) return die("vcm_run_iteration");
     }
     for (int g = 0; g < renderers; g++) if (vcm_synchronize(r[g])) return die("vcm_synchronize");
-    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     // accumulate the used renderers: mean of (running sum / own iterations), smallvcm.cxx:116-142
-    const size_t n3 = (size_t)resX * resY * 3;
-    std::vector<float> fb(n3, 0.f), tmp(n3);
     int used = 0;
     for (int g = 0; g < renderers; g++) {
         const int its = vcm_iterations(r[g]);
@@ -129,10 +165,8 @@ int main(int argc, char **argv)
     }
     const float su = 1.f / used;                      // Framebuffer::Scale, smallvcm.cxx:142
     for (size_t i = 0; i < n3; i++) fb[i] = fb[i] * su;
-
-    vcm_stats st;
-    memset(&st, 0, sizeof(st));
     vcm_get_stats(r[0], &st);
+    }
 
     if (!out.empty()) {
         const std::string ext = out.size() >= 4 ? out.substr(out.size() - 4) : "";
@@ -140,7 +174,7 @@ int main(int argc, char **argv)
         std::vector<unsigned char> px;
         if (bmp || hdr) {
             px.resize((size_t)resX * resY * (bmp ? 3 : 4));
-            if (renderers == 1) {   // encoded on the device
+            if (renderers == 1 && !r.empty()) {   // encoded on the device
                 if (vcm_read_image(r[0], bmp ? VCM_IMAGE_BGR8 : VCM_IMAGE_RGBE, 1.f / vcm_iterations(r[0]), 2.2f, px.data()))
                     return die("vcm_read_image");
             } else if (bmp) {       // Framebuffer::SaveBMP, framebuffer.hxx:194-214
@@ -183,14 +217,14 @@ int main(int argc, char **argv)
         }
         fclose(f);
     }
-    for (int g = 0; g < renderers; g++) vcm_destroy(r[g]);
+    for (size_t g = 0; g < r.size(); g++) vcm_destroy(r[g]);
     double mean[3] = { 0, 0, 0 };
     for (size_t i = 0; i < n3; i++) mean[i % 3] += fb[i];
     const double paths = (algorithm == VCM_ALGO_PATH_TRACE || algorithm == VCM_ALGO_EYE_LIGHT ? 1.0 : 2.0) * resX * resY * iterations;
     if (json)
         printf("{\"scene\": %d, \"algorithm\": \"%s\", \"res\": [%d, %d], \"iterations\": %d, \"renderers\": %d, \"seed\": %d, "
-               "\"wall_s\": %.6f, \"Mpaths_s\": %.3f, \"image_mean\": [%.6f, %.6f, %.6f], \"last_iteration_ms\": %.3f}\n",
-               sceneID, algoName.c_str(), resX, resY, iterations, renderers, seed, wall, paths / wall / 1e6,
+               "\"gpus\": %d, \"wall_s\": %.6f, \"Mpaths_s\": %.3f, \"image_mean\": [%.6f, %.6f, %.6f], \"last_iteration_ms\": %.3f}\n",
+               sceneID, algoName.c_str(), resX, resY, iterations, renderers, seed, gpus > 0 ? gpus : 1, wall, paths / wall / 1e6,
                mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal);
     else
         printf("scene %d, %s, %dx%d, %d iteration(s) on %d renderer(s): %.3f s wall clock, %.2f Mpaths/s\n", sceneID,

@@ -438,3 +438,78 @@ def test_read_image_encodings():
     assert np.abs(bgr.astype(np.float64) - np.floor(ref)).max() <= 1
     assert np.allclose(fb, v.framebuffer_sum() / 3)
     v.close()
+
+
+def _read_bmp_mean(path):
+    """mean of a 24-bit BMP as Framebuffer::SaveBMP writes it (framebuffer.hxx:170-216): 54-byte header, BGR rows"""
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"BM"
+    w = int.from_bytes(raw[18:22], "little", signed=True)
+    h = int.from_bytes(raw[22:26], "little", signed=True)
+    off = int.from_bytes(raw[10:14], "little")
+    px = np.frombuffer(raw, np.uint8, count=w * abs(h) * 3, offset=off).reshape(abs(h), w, 3)
+    return w, abs(h), px.astype(np.float64).mean(axis=(0, 1))[::-1]   # -> RGB
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs a SmallVCM checkout)")
+def test_reference_driver_full_report_over_dropin(tmp_path):
+    """`smallvcm --report -t 1` (FullReport, smallvcm.cxx:156-263; html_writer.hxx) of the UNCHANGED driver over the
+    drop-in: every scene x algorithm combination renders on the GPU (7 algorithms x 4 scenes, one renderer per host
+    core each), index.html and the 28 images are written, and the images of one scene agree: the unbiased / consistent
+    estimators (pt, bpt, bpm, vcm) have the same mean up to Monte-Carlo error and 8-bit gamma quantisation."""
+    r = subprocess.run([DROPIN, "--report", "-t", "1"], cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Whole run took" in r.stdout
+    html = open(os.path.join(str(tmp_path), "index.html")).read()
+    bmps = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith(".bmp"))
+    assert len(bmps) == 28, bmps
+    for f in bmps:
+        assert f in html
+    by_scene = {}
+    for f in bmps:
+        w, h, mean = _read_bmp_mean(os.path.join(str(tmp_path), f))
+        assert (w, h) == (512, 512) and mean.max() > 1.0, f
+        # DefaultFilename (config.hxx:153-218): <scene acronym>_<algorithm acronym>.bmp
+        scene, algo = f[:-4].rsplit("_", 1)
+        by_scene.setdefault(scene, {})[algo] = mean
+    assert len(by_scene) == 4 and all(len(v) == 7 for v in by_scene.values()), {k: sorted(v) for k, v in by_scene.items()}
+    for scene, imgs in by_scene.items():
+        ref = imgs["vcm"]
+        for algo in ("pt", "bpt", "bpm"):
+            assert np.all(np.abs(imgs[algo] - ref) < 0.08 * ref + 2.0), (scene, algo, imgs[algo], ref)
+
+
+# ---- the C++ multi-GPU host (smallvcm_amd/host/vcm_farm.cpp): ranks = host threads, RCCL between them -----------------
+def _farm(tmp_path, tag, *extra, iters=5, res=(96, 80), algo="vcm", scene=1):
+    import json
+    out = str(tmp_path / ("farm_%s.pfm" % tag))
+    r = subprocess.run([HOST, "-s", str(scene), "-a", algo, "-i", str(iters), "--res", str(res[0]), str(res[1]), "-o", out, "--json",
+                        *extra], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return _read_pfm(out), json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="vcm_render not built")
+def test_cpp_farm_with_rccl_on_one_rank_is_bit_exact(tmp_path):
+    """--gpus 1: the real RCCL calls (ncclCommInitAll, the framebuffer path) with one rank = one renderer; its image is
+    the single renderer's, bit for bit."""
+    ref, _ = _farm(tmp_path, "ref", "--renderers", "1")
+    one, info = _farm(tmp_path, "rccl1", "--gpus", "1", "--shards", "1")
+    assert info["gpus"] == 1 and info["renderers"] == 1
+    assert np.array_equal(ref.view(np.uint32), one.view(np.uint32))
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="vcm_render not built")
+@pytest.mark.parametrize("ranks,shards,inflight,algo,iters", [(2, 2, 1, "vcm", 4), (4, 2, 2, "vcm", 9), (3, 3, 1, "bpm", 3), (4, 1, 1, "vcm", 6),
+                                                              (2, 2, 2, "bpt", 5)])
+def test_cpp_farm_thread_ranks_equal_single_gpu_renderers(tmp_path, ranks, shards, inflight, algo, iters):
+    """Several ranks on the one GPU (in-process stand-in for RCCL, same rank logic: 7-number exchange, all-gather of the
+    merge records on the second stream, import, grid, merge, framebuffer reduce): the image equals the mean of the
+    renderers run alone (seeds base + g, static-schedule iteration blocks) up to the order of the final sum."""
+    img, info = _farm(tmp_path, "t", "--gpus", str(ranks), "--shards", str(shards), "--inflight", str(inflight), "--collectives",
+                      "threads", iters=iters, algo=algo)
+    renderers = (ranks // shards) * inflight
+    assert info["renderers"] == renderers
+    ref, _ = _farm(tmp_path, "r", "--renderers", str(renderers), iters=iters, algo=algo)
+    assert np.allclose(img, ref, rtol=3e-6, atol=2e-7)
+    assert img.max() > 0
