@@ -309,7 +309,23 @@ def main():
         return
     fb = farm.framebuffer()   # includes the framebuffer reduce over ranks (mean image, smallvcm.cxx:116-142)
     n_local = farm.backend.count
+    inflight_used = farm.inflight
     farm.close()
+    # N > 1: the pure north_star decomposition next to the default one, same steps: ONE renderer whose paths are sharded
+    # over all N GPUs (all-gather of the light vertices over the whole node every iteration, nothing to hide it behind)
+    strong = None
+    if world > 1 and not args.child and (shards != world or inflight_used != 1):
+        f3 = make_farm(args.scene, args.algo, res, world, 1)
+        e3, s3 = timed_run(f3, args.steps, args.warmup, sync)
+        t = torch.tensor([e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e3 = float(t.item())
+        f3.close()
+        strong = {"value": round(2.0 * n_paths * args.steps / e3 / 1e6, 3), "unit": "Mpaths/s", "scaling": "strong",
+                  "ms_per_step": round(e3 / args.steps * 1e3, 3), "paths_per_step": 2 * n_paths,
+                  "parallelism": "1 renderer on %d path-index shards (RCCL all-gather of the light vertices every iteration, "
+                                 "framebuffer all-reduce at read-out), 1 renderer in flight" % world,
+                  "iteration_ms_rank0": round(s3["msTotal"], 3)}
 
     if rank == 0:
         value = 2.0 * n_paths * args.steps * replicas / elapsed / 1e6
@@ -328,7 +344,7 @@ def main():
                        "paths_per_step": 2 * n_paths * replicas,
                        "parallelism": "%d renderer(s) (iteration-parallel, smallvcm.cxx:61-108), each on %d path-index shard(s) "
                                       "(RCCL all-gather of light vertices), %d renderer(s) in flight per GPU group"
-                                      % (replicas, shards, farm.inflight),
+                                      % (replicas, shards, inflight_used),
                        "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "lane")},
             "roofline": roof,
             "counters": {k: int(st[k]) for k in ("lightVertices", "gridVertices", "mergeQueries", "mergeCandidates",
@@ -336,6 +352,8 @@ def main():
                                                  "shadowRays")},
             "image_mean": [round(float(x), 5) for x in fb.mean(axis=(0, 1))],
         }
+        if strong is not None:
+            out["strong_decomposition"] = strong
         if world == 1:
             traffic, src = (None, "disabled (--no-traffic)") if args.no_traffic else live_traffic(dom, args)
             if traffic is None:
