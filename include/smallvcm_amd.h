@@ -107,6 +107,28 @@ typedef struct vcm_scene_desc {
     vcm_camera   camera;
 } vcm_scene_desc;
 
+/* Scene description, version 2: the same members with POINTER + count for primitives, materials and lights, for
+ * scenes beyond the reference's built-in Cornell boxes (which is all its CLI can load: config.hxx:146-151; "no
+ * acceleration structure", README:208-209; Scene::Intersect is a loop over every primitive, scene.hxx:53-70).  A
+ * scene with more than VCM_MAX_PRIMS primitives is traced through a BVH built at vcm_create2; the results are those of
+ * the reference's list walk (closest hit, ties to the lower list index: geometry.hxx:65-78).  The arrays are copied:
+ * they may be freed after the call.  mat2light has nMaterials entries (Scene::mMaterial2Light: an emissive triangle
+ * needs a material of its own, as in scene.hxx:333-361); at most 2^24 materials. */
+typedef struct vcm_scene_desc2 {
+    int                 nPrims;
+    const vcm_prim     *prims;
+    int                 nMaterials;
+    const vcm_material *materials;
+    const int          *mat2light;
+    int                 nLights;
+    const vcm_light    *lights;
+    int                 backgroundLight;
+    float               sceneCenter[3];
+    float               sceneRadius;
+    float               invSceneRadiusSqr;
+    vcm_camera          camera;
+} vcm_scene_desc2;
+
 /* VertexCM::AlgorithmType (src/vertexcm.hxx:182-204) -- same values */
 enum {
     VCM_ALGO_LIGHT_TRACE = 0,
@@ -170,6 +192,13 @@ vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm,
 vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm,
                             float radiusFactor, float radiusAlpha, int seed,
                             int device, int rank, int worldSize);
+
+/* The same for a version-2 scene description. */
+vcm_ctx *vcm_create2(const vcm_scene_desc2 *scene, int algorithm,
+                     float radiusFactor, float radiusAlpha, int seed);
+vcm_ctx *vcm_create_sharded2(const vcm_scene_desc2 *scene, int algorithm,
+                             float radiusFactor, float radiusAlpha, int seed,
+                             int device, int rank, int worldSize);
 
 void vcm_destroy(vcm_ctx *ctx);
 
@@ -286,6 +315,31 @@ int vcm_local_path_range(vcm_ctx *ctx, int *first, int *count);
 int vcm_scene_cornell(int resX, int resY, unsigned boxMask, vcm_scene_desc *out);
 /* g_SceneConfigs[sceneID] (src/config.hxx:146-151) */
 unsigned vcm_scene_config_mask(int sceneID);
+
+/* Building a version-2 scene: one call per object, each computing the derived members the way the reference's
+ * constructor does (same operations, same bits), so that a scene assembled here equals what the reference would hold
+ * for the same input:
+ *   vcm_make_triangle          Triangle::Triangle        geometry.hxx:111-123  (mNormal)
+ *   vcm_make_sphere            Sphere::Sphere            geometry.hxx:184-192
+ *   vcm_make_area_light        AreaLight::AreaLight      lights.hxx:116-127    (edges, frame, 1 / area)
+ *   vcm_make_directional_light DirectionalLight          lights.hxx:239-243    (frame)
+ *   vcm_make_point_light       PointLight                lights.hxx:324-328
+ *   vcm_make_background_light  BackgroundLight           lights.hxx:404-408    (the reference's sky colour)
+ *   vcm_make_material          Material::Reset           materials.hxx:44-51   (black, exponent 1, no refraction)
+ *   vcm_make_camera            Camera::Setup             camera.hxx:37-76
+ *   vcm_make_scene_sphere      Scene::BuildSceneSphere   scene.hxx:387-398
+ * An emissive triangle is a primitive with a material of its own whose mat2light entry names the area light over the
+ * same three points (scene.hxx:333-361). */
+void vcm_make_triangle(const float *p0, const float *p1, const float *p2, int matID, vcm_prim *out);
+void vcm_make_sphere(const float *center, float radius, int matID, vcm_prim *out);
+void vcm_make_area_light(const float *p0, const float *p1, const float *p2, const float *intensity, vcm_light *out);
+void vcm_make_directional_light(const float *direction, const float *intensity, vcm_light *out);
+void vcm_make_point_light(const float *position, const float *intensity, vcm_light *out);
+void vcm_make_background_light(float scale, vcm_light *out);
+void vcm_make_material(vcm_material *out);
+int  vcm_make_camera(const float *position, const float *forward, const float *up, float horizontalFovDeg, int resX, int resY,
+                     vcm_camera *out);
+void vcm_make_scene_sphere(const vcm_prim *prims, int nPrims, float *center3, float *radius, float *invRadiusSqr);
 
 #ifdef __cplusplus
 }

@@ -281,8 +281,216 @@ int ref_kat(unsigned boxMask, int resX, int resY, int op, int n, const float *in
     return 0;
 }
 
+/* ---- version-2 scenes (include/smallvcm_amd.h vcm_scene_desc2): the reference has no loader for anything but its
+ *      Cornell boxes, so the harness builds a reference `Scene` from the arrays WITH THE REFERENCE'S OWN CONSTRUCTORS
+ *      (Triangle, Sphere, AreaLight, DirectionalLight, PointLight, BackgroundLight, Camera::Setup is not re-run: the
+ *      camera members are public) and checks that every derived member the description carries -- triangle normals,
+ *      light frames, 1 / area -- is what the constructor produced.  Returns NULL (and sets *why) otherwise. */
+static bool same3(const Vec3f &a, const float *b) { return a.x == b[0] && a.y == b[1] && a.z == b[2]; }
+static Scene *make_scene2(const vcm_scene_desc2 *d, int *why)
+{
+    *why = 0;
+    Scene *scene = new Scene;
+    GeometryList *list = new GeometryList;
+    scene->mGeometry = list;
+    for (int i = 0; i < d->nMaterials; i++) {
+        const vcm_material &m = d->materials[i];
+        Material mat;
+        mat.Reset();
+        mat.mDiffuseReflectance = Vec3f(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
+        mat.mPhongReflectance = Vec3f(m.phong[0], m.phong[1], m.phong[2]);
+        mat.mPhongExponent = m.phongExp;
+        mat.mMirrorReflectance = Vec3f(m.mirror[0], m.mirror[1], m.mirror[2]);
+        mat.mIOR = m.ior;
+        scene->mMaterials.push_back(mat);
+        if (d->mat2light[i] >= 0) scene->mMaterial2Light.insert(std::make_pair(i, d->mat2light[i]));
+    }
+    for (int i = 0; i < d->nPrims; i++) {
+        const vcm_prim &p = d->prims[i];
+        if (p.type == VCM_PRIM_TRIANGLE) {
+            Triangle *t = new Triangle(Vec3f(p.p0[0], p.p0[1], p.p0[2]), Vec3f(p.p1[0], p.p1[1], p.p1[2]), Vec3f(p.p2[0], p.p2[1], p.p2[2]), p.matID);
+            if (!same3(t->mNormal, p.n)) *why = 1;
+            list->mGeometry.push_back(t);
+        } else {
+            list->mGeometry.push_back(new Sphere(Vec3f(p.p0[0], p.p0[1], p.p0[2]), p.p1[0], p.matID));
+        }
+    }
+    for (int i = 0; i < d->nLights; i++) {
+        const vcm_light &l = d->lights[i];
+        const Vec3f inten(l.intensity[0], l.intensity[1], l.intensity[2]);
+        if (l.type == VCM_LIGHT_AREA) {
+            const Vec3f p0(l.p0[0], l.p0[1], l.p0[2]);
+            AreaLight *a = new AreaLight(p0, p0 + Vec3f(l.e1[0], l.e1[1], l.e1[2]), p0 + Vec3f(l.e2[0], l.e2[1], l.e2[2]));
+            /* p0 + e - p0 need not give e back bit for bit: the description's edges are the truth, the frame and the
+               area must be what the constructor derives from THEM */
+            a->e1 = Vec3f(l.e1[0], l.e1[1], l.e1[2]); a->e2 = Vec3f(l.e2[0], l.e2[1], l.e2[2]);
+            const Vec3f normal = Cross(a->e1, a->e2);
+            a->mInvArea = 2.f / normal.Length();
+            a->mFrame.SetFromZ(normal);
+            if (a->mInvArea != l.invArea || !same3(a->mFrame.mX, l.frameX) || !same3(a->mFrame.mY, l.frameY) || !same3(a->mFrame.mZ, l.frameZ)) *why = 2;
+            a->mIntensity = inten;
+            scene->mLights.push_back(a);
+        } else if (l.type == VCM_LIGHT_DIRECTIONAL) {
+            DirectionalLight *dl = new DirectionalLight(Vec3f(l.frameZ[0], l.frameZ[1], l.frameZ[2]));
+            dl->mFrame.mX = Vec3f(l.frameX[0], l.frameX[1], l.frameX[2]); dl->mFrame.mY = Vec3f(l.frameY[0], l.frameY[1], l.frameY[2]);
+            dl->mFrame.mZ = Vec3f(l.frameZ[0], l.frameZ[1], l.frameZ[2]);
+            dl->mIntensity = inten;
+            scene->mLights.push_back(dl);
+        } else if (l.type == VCM_LIGHT_POINT) {
+            PointLight *pl = new PointLight(Vec3f(l.p0[0], l.p0[1], l.p0[2]));
+            pl->mIntensity = inten;
+            scene->mLights.push_back(pl);
+        } else {
+            BackgroundLight *bl = new BackgroundLight;
+            bl->mBackgroundColor = inten; bl->mScale = l.scale;
+            scene->mLights.push_back(bl);
+            if (i == d->backgroundLight) scene->mBackground = bl;
+        }
+    }
+    scene->mSceneSphere.mSceneCenter = Vec3f(d->sceneCenter[0], d->sceneCenter[1], d->sceneCenter[2]);
+    scene->mSceneSphere.mSceneRadius = d->sceneRadius;
+    scene->mSceneSphere.mInvSceneRadiusSqr = d->invSceneRadiusSqr;
+    {   /* the reference's own BuildSceneSphere must agree */
+        Scene probe; probe.mGeometry = list;
+        probe.BuildSceneSphere();
+        if (!same3(probe.mSceneSphere.mSceneCenter, d->sceneCenter) || probe.mSceneSphere.mSceneRadius != d->sceneRadius ||
+            probe.mSceneSphere.mInvSceneRadiusSqr != d->invSceneRadiusSqr) *why = 3;
+        probe.mGeometry = NULL;
+    }
+    Camera &c = scene->mCamera;
+    c.mPosition = Vec3f(d->camera.position[0], d->camera.position[1], d->camera.position[2]);
+    c.mForward = Vec3f(d->camera.forward[0], d->camera.forward[1], d->camera.forward[2]);
+    c.mResolution = Vec2f(d->camera.resolution[0], d->camera.resolution[1]);
+    memcpy(&c.mRasterToWorld, d->camera.rasterToWorld, 16 * sizeof(float));
+    memcpy(&c.mWorldToRaster, d->camera.worldToRaster, 16 * sizeof(float));
+    c.mImagePlaneDist = d->camera.imagePlaneDist;
+    if (*why) { delete scene; return NULL; }
+    return scene;
+}
+
+/* the reference's constructors, one object each (tests compare the product's vcm_make_* with these bit for bit) */
+void ref_make_triangle(const float *p0, const float *p1, const float *p2, int matID, vcm_prim *out)
+{
+    Triangle t(Vec3f(p0[0], p0[1], p0[2]), Vec3f(p1[0], p1[1], p1[2]), Vec3f(p2[0], p2[1], p2[2]), matID);
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_PRIM_TRIANGLE; out->matID = t.matID;
+    for (int k = 0; k < 3; k++) { out->p0[k] = t.p[0].Get(k); out->p1[k] = t.p[1].Get(k); out->p2[k] = t.p[2].Get(k); out->n[k] = t.mNormal.Get(k); }
+}
+void ref_make_area_light(const float *p0, const float *p1, const float *p2, const float *intensity, vcm_light *out)
+{
+    AreaLight a(Vec3f(p0[0], p0[1], p0[2]), Vec3f(p1[0], p1[1], p1[2]), Vec3f(p2[0], p2[1], p2[2]));
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_LIGHT_AREA;
+    for (int k = 0; k < 3; k++) {
+        out->p0[k] = a.p0.Get(k); out->e1[k] = a.e1.Get(k); out->e2[k] = a.e2.Get(k);
+        out->frameX[k] = a.mFrame.mX.Get(k); out->frameY[k] = a.mFrame.mY.Get(k); out->frameZ[k] = a.mFrame.mZ.Get(k);
+        out->intensity[k] = intensity[k];
+    }
+    out->invArea = a.mInvArea;
+}
+void ref_make_directional_light(const float *dir, const float *intensity, vcm_light *out)
+{
+    DirectionalLight d(Vec3f(dir[0], dir[1], dir[2]));
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_LIGHT_DIRECTIONAL;
+    for (int k = 0; k < 3; k++) {
+        out->frameX[k] = d.mFrame.mX.Get(k); out->frameY[k] = d.mFrame.mY.Get(k); out->frameZ[k] = d.mFrame.mZ.Get(k);
+        out->intensity[k] = intensity[k];
+    }
+}
+int ref_make_camera(const float *pos, const float *fwd, const float *up, float fov, int resX, int resY, vcm_camera *out)
+{
+    Camera c;
+    c.Setup(Vec3f(pos[0], pos[1], pos[2]), Vec3f(fwd[0], fwd[1], fwd[2]), Vec3f(up[0], up[1], up[2]), Vec2f(float(resX), float(resY)), fov);
+    memset(out, 0, sizeof(*out));
+    for (int k = 0; k < 3; k++) { out->position[k] = c.mPosition.Get(k); out->forward[k] = c.mForward.Get(k); }
+    out->resolution[0] = c.mResolution.x; out->resolution[1] = c.mResolution.y;
+    memcpy(out->rasterToWorld, &c.mRasterToWorld, 16 * sizeof(float));
+    memcpy(out->worldToRaster, &c.mWorldToRaster, 16 * sizeof(float));
+    out->imagePlaneDist = c.mImagePlaneDist;
+    return 0;
+}
+/* 0 = the description is what the reference's constructors build from the same input; 1 triangle normal, 2 area light,
+   3 scene sphere differ */
+int ref_check_scene2(const vcm_scene_desc2 *d)
+{
+    int why = 0;
+    Scene *s = make_scene2(d, &why);
+    delete s;
+    return why;
+}
+/* function-level known answers over a version-2 scene (the same records as ref_kat; Scene::Intersect = the brute-force
+   walk over every primitive) */
+int ref_kat2(const vcm_scene_desc2 *d, int op, int n, const float *inAll, float *outAll)
+{
+    int why = 0;
+    Scene *scene = make_scene2(d, &why);
+    if (!scene) return -100 - why;
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; i++) {
+        const float *in = inAll + (size_t)i * VCM_KAT_FLOATS;
+        float *out = outAll + (size_t)i * VCM_KAT_FLOATS;
+        for (int k = 0; k < VCM_KAT_FLOATS; k++) out[k] = 0.f;
+        if (op == VCM_KAT_INTERSECT) {
+            Ray ray(Vec3f(in[0], in[1], in[2]), Vec3f(in[3], in[4], in[5]), in[6]);
+            Isect is(1e36f);
+            if (scene->Intersect(ray, is)) {
+                out[0] = 1.f; out[1] = is.dist; out[2] = (float)is.matID; out[3] = (float)is.lightID;
+                out[4] = is.normal.x; out[5] = is.normal.y; out[6] = is.normal.z;
+            }
+        } else if (op == VCM_KAT_OCCLUDED) {
+            out[0] = scene->Occluded(Vec3f(in[0], in[1], in[2]), Vec3f(in[3], in[4], in[5]), in[6]) ? 1.f : 0.f;
+        } else rc = -1;
+    }
+    delete scene;
+    return rc;
+}
+
 #ifdef REF_TAPE
 long long ref_detmath_calls(void) { return g_detmath_calls; }
+
+/* ref_run_tape for a version-2 scene */
+int ref_run_tape2(const vcm_scene_desc2 *d, int vcmAlgo, float radiusFactor, float radiusAlpha, int seed,
+                  int firstIteration, int nIter, unsigned minLen, unsigned maxLen,
+                  const unsigned char *lightCounts, const unsigned char *camCounts, float *fbSumOut, long long *consumedOut)
+{
+    int why = 0;
+    Scene *scene = make_scene2(d, &why);
+    if (!scene) return -100 - why;
+    const int N = int(d->camera.resolution[0]) * int(d->camera.resolution[1]);
+    AbstractRenderer *r;
+    bool lightTraceOnly = false;
+    if (vcmAlgo == 5) r = new PathTracer(*scene, seed);
+    else if (vcmAlgo == 6) r = new EyeLight(*scene, seed);
+    else {
+        VertexCM *v = new VertexCM(*scene, (VertexCM::AlgorithmType)vcmAlgo, radiusFactor, radiusAlpha, seed);
+        lightTraceOnly = v->mLightTraceOnly;
+        r = v;
+    }
+    r->mMaxPathLength = maxLen;
+    r->mMinPathLength = minLen;
+    int bad = 0;
+    long long total = 0;
+    for (int i = 0; i < nIter; i++) {
+        memset(&g_tape, 0, sizeof(g_tape));
+        g_tape.counts[0] = lightCounts + (size_t)i * N;
+        g_tape.counts[1] = camCounts + (size_t)i * N;
+        g_tape.N = N;
+        g_tape.key[0] = (uint32_t)seed;
+        g_tape.key[1] = (uint32_t)i;
+        long long expect = 0;
+        for (int p = 0; p < N; p++) expect += g_tape.counts[0][p];
+        if (!lightTraceOnly) for (int p = 0; p < N; p++) expect += g_tape.counts[1][p];
+        r->RunIteration(firstIteration + i);
+        if (g_tape.overrun || g_tape.consumed != expect) bad = 1;
+        total += g_tape.consumed;
+    }
+    memcpy(fbSumOut, &r->mFramebuffer.mColor[0], (size_t)N * 3 * sizeof(float));
+    if (consumedOut) *consumedOut = total;
+    delete r;
+    delete scene;
+    return bad;
+}
 
 /* Runs nIter iterations (global iteration index = firstIteration + i, RNG
  * local iteration = i) of the reference's VertexCM on one renderer.

@@ -42,6 +42,21 @@
 
 namespace {
 
+/* The scene as the oracle reads it: the members of vcm_scene_desc by the same names, the arrays owned here, so that
+ * the built-in boxes (vcm_scene_desc) and arbitrary scenes (vcm_scene_desc2: any number of primitives / materials /
+ * lights) go through the same restatement -- always the reference's brute-force walk over every primitive in list
+ * order (scene.hxx:53-85); the oracle has no acceleration structure, like the reference. */
+struct OScene {
+    int nPrims, nMaterials, nLights, backgroundLight;
+    std::vector<vcm_prim> prims;
+    std::vector<vcm_material> materials;
+    std::vector<int> mat2light;
+    std::vector<vcm_light> lights;
+    float sceneCenter[3], sceneRadius, invSceneRadiusSqr;
+    vcm_camera camera;
+};
+
+
 /* ---- constants: src/math.hxx:30-31, src/utils.hxx:32-33, src/bsdf.hxx:59 */
 #define O_PI_F     3.14159265358979f
 #define O_INV_PI_F (1.f / O_PI_F)
@@ -264,7 +279,7 @@ struct SubPathState {   /* src/vertexcm.hxx:64-76 */
 struct Splat { int pixel; V3 c; };
 
 struct Oracle {
-    vcm_scene_desc sc;
+    OScene sc;
     bool useVM, useVC, lightTraceOnly, ppm;
     int renderer;               /* 0 VertexCM, 1 PathTracer (pathtracer.hxx), 2 EyeLight (eyelight.hxx) */
     int iteration;              /* aIteration of the current RunIteration */
@@ -299,7 +314,7 @@ struct Oracle {
 };
 
 /* ---- scene: src/scene.hxx:53-102 */
-static bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res)
+static bool scene_intersect(const OScene &sc, const Ray &ray, Isect &res)
 {   /* :53-70 + GeometryList::Intersect geometry.hxx:65-78 */
     bool any = false;
     for (int i = 0; i < sc.nPrims; i++) {
@@ -309,7 +324,7 @@ static bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res
     if (any) res.lightID = sc.mat2light[res.matID];
     return any;
 }
-static bool scene_occluded(const vcm_scene_desc &sc, V3 point, V3 dir, float tmax)
+static bool scene_occluded(const OScene &sc, V3 point, V3 dir, float tmax)
 {   /* :72-85 + GeometryList::IntersectP geometry.hxx:80-91 */
     Ray ray;
     ray.org = point + dir * O_EPS_RAY;
@@ -344,7 +359,7 @@ static void bsdf_component_probabilities(Bsdf &b, const vcm_material &m)
         b.contProb = omin(1.f, omax(0.f, b.contProb));
     }
 }
-static void bsdf_setup(Bsdf &b, const Ray &ray, const Isect &isect, const vcm_scene_desc &sc)
+static void bsdf_setup(Bsdf &b, const Ray &ray, const Isect &isect, const OScene &sc)
 {   /* bsdf.hxx:95-117 */
     b.matID = -1;
     b.isectNormal = isect.normal;
@@ -396,7 +411,7 @@ static void bsdf_pdf_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *
         if (revPdf) *revPdf += pdfW;
     }
 }
-static V3 bsdf_evaluate(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, float &cosThetaGen,
+static V3 bsdf_evaluate(const Bsdf &b, const OScene &sc, V3 worldDirGen, float &cosThetaGen,
                         float *dirPdf, float *revPdf)
 {   /* bsdf.hxx:128-153 */
     V3 result = sp(0);
@@ -410,7 +425,7 @@ static V3 bsdf_evaluate(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen,
     result = result + bsdf_eval_phong(b, m, gen, dirPdf, revPdf);
     return result;
 }
-static float bsdf_pdf(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, bool evalRev)
+static float bsdf_pdf(const Bsdf &b, const OScene &sc, V3 worldDirGen, bool evalRev)
 {   /* bsdf.hxx:161-180 */
     const V3 gen = to_local(b.frame, worldDirGen);
     if (gen.z * b.localDirFix.z < 0) return 0;
@@ -420,7 +435,7 @@ static float bsdf_pdf(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, b
     bsdf_pdf_phong(b, m, gen, &directPdfW, &reversePdfW);
     return evalRev ? reversePdfW : directPdfW;
 }
-static V3 bsdf_sample(const Bsdf &b, const vcm_scene_desc &sc, bool fixIsLight, V3 rnd,
+static V3 bsdf_sample(const Bsdf &b, const OScene &sc, bool fixIsLight, V3 rnd,
                       V3 &worldDirGen, float &pdfW, float &cosThetaGen, unsigned &sampledEvent)
 {   /* bsdf.hxx:191-257 */
     if (rnd.z < b.diffProb) sampledEvent = kDiffuse;
@@ -498,7 +513,7 @@ static inline bool light_is_finite(const vcm_light &l) { return l.type == VCM_LI
 static inline bool light_is_delta(const vcm_light &l) { return l.type == VCM_LIGHT_DIRECTIONAL || l.type == VCM_LIGHT_POINT; }
 static inline Frame light_frame(const vcm_light &l) { Frame f; f.mX = ld3(l.frameX); f.mY = ld3(l.frameY); f.mZ = ld3(l.frameZ); return f; }
 
-static V3 light_illuminate(const vcm_light &l, const vcm_scene_desc &sc, V3 recvPos, float rx, float ry,
+static V3 light_illuminate(const vcm_light &l, const OScene &sc, V3 recvPos, float rx, float ry,
                            V3 &dirToLight, float &distance, float &directPdfW,
                            float *emissionPdfW, float *cosAtLight)
 {
@@ -547,7 +562,7 @@ static V3 light_illuminate(const vcm_light &l, const vcm_scene_desc &sc, V3 recv
     }
 }
 
-static V3 light_emit(const vcm_light &l, const vcm_scene_desc &sc, float dx, float dy, float px, float py,
+static V3 light_emit(const vcm_light &l, const OScene &sc, float dx, float dy, float px, float py,
                      V3 &position, V3 &direction, float &emissionPdfW, float *directPdfA, float *cosThetaLight)
 {
     switch (l.type) {
@@ -597,7 +612,7 @@ static V3 light_emit(const vcm_light &l, const vcm_scene_desc &sc, float dx, flo
     }
 }
 
-static V3 light_get_radiance(const vcm_light &l, const vcm_scene_desc &sc, V3 rayDir, V3 /*hitPoint*/,
+static V3 light_get_radiance(const vcm_light &l, const OScene &sc, V3 rayDir, V3 /*hitPoint*/,
                              float *directPdfA, float *emissionPdfW)
 {
     switch (l.type) {
@@ -640,7 +655,7 @@ static V3 transform_point(const float *m, V3 v)
     }
     return mk(res[0], res[1], res[2]);
 }
-static inline const vcm_light &get_light(const vcm_scene_desc &sc, int idx)
+static inline const vcm_light &get_light(const OScene &sc, int idx)
 {   /* Scene::GetLightPtr scene.hxx:98-102 */
     idx = std::min<int>(idx, sc.nLights - 1);
     return sc.lights[idx];
@@ -651,7 +666,7 @@ static inline float mis(float pdf) { return pdf; }   /* vertexcm.hxx:553-557 */
 
 static void generate_light_sample(Oracle &o, PathRngRef &rng, SubPathState &st)
 {   /* vertexcm.hxx:816-858 */
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;
     const int lightID = int(path_rng_float_ref(&rng) * lightCount);
@@ -682,7 +697,7 @@ static void generate_light_sample(Oracle &o, PathRngRef &rng, SubPathState &st)
 static void connect_to_camera(Oracle &o, const SubPathState &st, V3 hitpoint, const Bsdf &bsdf,
                               std::vector<Splat> &splats, vcm_stats &stats)
 {   /* vertexcm.hxx:862-933 */
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     const vcm_camera &cam = sc.camera;
     V3 directionToCamera = ld3(cam.position) - hitpoint;
     if (dot(ld3(cam.forward), -directionToCamera) <= 0.f) return;
@@ -755,7 +770,7 @@ static bool sample_scattering(Oracle &o, PathRngRef &rng, const Bsdf &bsdf, V3 h
 static void trace_light_path(Oracle &o, int pathIdx, std::vector<LightVertex> &verts,
                              std::vector<Splat> &splats, unsigned char &rngCount, vcm_stats &stats)
 {
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     PathRngRef rng;
     path_rng_init_ref(&rng, (uint32_t)o.seed, (uint32_t)o.iterations, (uint32_t)pathIdx, 0u);
     SubPathState st;
@@ -931,7 +946,7 @@ static V3 get_light_radiance(const Oracle &o, const vcm_light &light, const SubP
 static V3 direct_illumination(Oracle &o, PathRngRef &rng, const SubPathState &st, V3 hitpoint, const Bsdf &bsdf,
                               vcm_stats &stats)
 {   /* :663-738 */
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;
     const int lightID = int(path_rng_float_ref(&rng) * lightCount);
@@ -962,7 +977,7 @@ static V3 direct_illumination(Oracle &o, PathRngRef &rng, const SubPathState &st
 static V3 connect_vertices(Oracle &o, const LightVertex &lv, const Bsdf &cameraBsdf, V3 cameraHitpoint,
                            const SubPathState &st, vcm_stats &stats)
 {   /* :743-809 */
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     stats.connections++;
     V3 direction = lv.hitpoint - cameraHitpoint;
     const float dist2 = lensqr(direction);
@@ -997,7 +1012,7 @@ static V3 connect_vertices(Oracle &o, const LightVertex &lv, const Bsdf &cameraB
 /* one camera sub-path: vertexcm.hxx:417-544 */
 static void trace_camera_path(Oracle &o, int pathIdx, unsigned char &rngCount, vcm_stats &stats)
 {
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     const vcm_camera &cam = sc.camera;
     PathRngRef rng;
     path_rng_init_ref(&rng, (uint32_t)o.seed, (uint32_t)o.iterations, (uint32_t)pathIdx, 1u);
@@ -1115,7 +1130,7 @@ static void store_path_colour(Oracle &o, int lp, float sx, float sy, V3 color, b
 
 static void trace_pt_path(Oracle &o, int pixID, unsigned char &rngCount, vcm_stats &stats)
 {
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     const vcm_camera &cam = sc.camera;
     PathRngRef rng;
     path_rng_init_ref(&rng, (uint32_t)o.seed, (uint32_t)o.iterations, (uint32_t)pixID, 1u);
@@ -1220,7 +1235,7 @@ static void trace_pt_path(Oracle &o, int pixID, unsigned char &rngCount, vcm_sta
 /* ================= EyeLight::RunIteration, src/eyelight.hxx:46-77 ================= */
 static void trace_eyelight_path(Oracle &o, int pixID, unsigned char &rngCount, vcm_stats &stats)
 {
-    const vcm_scene_desc &sc = o.sc;
+    const OScene &sc = o.sc;
     const vcm_camera &cam = sc.camera;
     PathRngRef rng;
     path_rng_init_ref(&rng, (uint32_t)o.seed, (uint32_t)o.iterations, (uint32_t)pixID, 1u);
@@ -1254,14 +1269,38 @@ static void add_stats(vcm_stats &a, const vcm_stats &b)
 
 } // namespace
 
+template <typename Desc> static void oscene_fill(OScene &s, const Desc &d)
+{
+    s.nPrims = d.nPrims; s.nMaterials = d.nMaterials; s.nLights = d.nLights; s.backgroundLight = d.backgroundLight;
+    s.prims.assign(d.prims, d.prims + d.nPrims);
+    s.materials.assign(d.materials, d.materials + d.nMaterials);
+    s.mat2light.assign(d.mat2light, d.mat2light + d.nMaterials);
+    s.lights.assign(d.lights, d.lights + d.nLights);
+    for (int k = 0; k < 3; k++) s.sceneCenter[k] = d.sceneCenter[k];
+    s.sceneRadius = d.sceneRadius; s.invSceneRadiusSqr = d.invSceneRadiusSqr;
+    s.camera = d.camera;
+}
 /* ======================= C API (ctypes) ================================ */
 extern "C" {
 
+static void *oracle_finish_create(Oracle *o, int algorithm, float radiusFactor, float radiusAlpha, int seed, int rank, int world);
 void *oracle_create(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha,
                     int seed, int rank, int world)
-{   /* VertexCM::VertexCM vertexcm.hxx:208-282 */
+{
     Oracle *o = new Oracle();
-    o->sc = *scene;
+    oscene_fill(o->sc, *scene);
+    return oracle_finish_create(o, algorithm, radiusFactor, radiusAlpha, seed, rank, world);
+}
+void *oracle_create2(const vcm_scene_desc2 *scene, int algorithm, float radiusFactor, float radiusAlpha,
+                     int seed, int rank, int world)
+{
+    Oracle *o = new Oracle();
+    oscene_fill(o->sc, *scene);
+    return oracle_finish_create(o, algorithm, radiusFactor, radiusAlpha, seed, rank, world);
+}
+static void *oracle_finish_create(Oracle *o, int algorithm, float radiusFactor, float radiusAlpha, int seed, int rank, int world)
+{   /* VertexCM::VertexCM vertexcm.hxx:208-282 */
+    const OScene *scene = &o->sc;
     o->useVM = o->useVC = o->lightTraceOnly = o->ppm = false;
     o->renderer = 0; o->iteration = 0;
     switch (algorithm) {

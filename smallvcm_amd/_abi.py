@@ -64,6 +64,17 @@ class SceneDesc(C.Structure):
         return cls.from_buffer_copy(b)
 
 
+class SceneDesc2(C.Structure):
+    """vcm_scene_desc2: pointer + count for primitives, materials and lights.  The arrays are owned by the Python
+    object that built it (SceneBuilder keeps them in `_keep`); the library copies them at vcm_create2."""
+    _fields_ = [("nPrims", C.c_int), ("prims", C.POINTER(Prim)),
+                ("nMaterials", C.c_int), ("materials", C.POINTER(Material)), ("mat2light", C.POINTER(C.c_int)),
+                ("nLights", C.c_int), ("lights", C.POINTER(Light)),
+                ("backgroundLight", C.c_int),
+                ("sceneCenter", f3), ("sceneRadius", C.c_float), ("invSceneRadiusSqr", C.c_float),
+                ("camera", Camera)]
+
+
 class Stats(C.Structure):
     _fields_ = [("lightVertices", C.c_longlong), ("gridVertices", C.c_longlong),
                 ("lightRays", C.c_longlong), ("cameraRays", C.c_longlong),

@@ -142,6 +142,53 @@ void add_area_light(vcm_scene_desc &d, V3 a0, V3 a1, V3 a2, float intensity, int
     put3(l.intensity, sp3(intensity));
     d.mat2light[matID] = idx;
 }
+void camera_setup(V3 aPosition, V3 aForward, V3 aUp, float rx, float ry, float fov, vcm_camera &cam)
+{   /* Camera::Setup camera.hxx:37-76 */
+    const V3 forward = normalize(aForward);
+    const V3 up = normalize(cross(aUp, -forward));
+    const V3 left = cross(-forward, up);
+    const V3 pos = mk3(dot(up, aPosition), dot(left, aPosition), dot(-forward, aPosition));
+    M4 worldToCamera = m4_identity();
+    const V3 nf = -forward;
+    at(worldToCamera, 0, 0) = up.x;   at(worldToCamera, 0, 1) = up.y;   at(worldToCamera, 0, 2) = up.z;   at(worldToCamera, 0, 3) = -pos.x;
+    at(worldToCamera, 1, 0) = left.x; at(worldToCamera, 1, 1) = left.y; at(worldToCamera, 1, 2) = left.z; at(worldToCamera, 1, 3) = -pos.y;
+    at(worldToCamera, 2, 0) = nf.x;   at(worldToCamera, 2, 1) = nf.y;   at(worldToCamera, 2, 2) = nf.z;   at(worldToCamera, 2, 3) = -pos.z;
+    const M4 perspective = m4_perspective(fov, 0.1f, 10000.f);
+    const M4 worldToNScreen = m4_mul(perspective, worldToCamera);
+    const M4 nscreenToWorld = m4_invert(worldToNScreen);
+    const M4 worldToRaster = m4_mul(m4_mul(m4_scale(mk3(rx * 0.5f, ry * 0.5f, 0)), m4_translate(mk3(1.f, 1.f, 0))),
+                                    worldToNScreen);
+    const M4 rasterToWorld = m4_mul(m4_mul(nscreenToWorld, m4_translate(mk3(-1.f, -1.f, 0))),
+                                    m4_scale(mk3(2.f / rx, 2.f / ry, 0)));
+    const float tanHalfAngle = tanf(fov * VCM_PI_F / 360.f);
+    put3(cam.position, aPosition);
+    put3(cam.forward, forward);
+    cam.resolution[0] = rx; cam.resolution[1] = ry;
+    memcpy(cam.rasterToWorld, rasterToWorld.m, sizeof(float) * 16);
+    memcpy(cam.worldToRaster, worldToRaster.m, sizeof(float) * 16);
+    cam.imagePlaneDist = rx / (2.f * tanHalfAngle);
+}
+void scene_sphere(const vcm_prim *prims, int nPrims, float *center3, float *radius, float *invRadiusSqr)
+{   /* BuildSceneSphere scene.hxx:387-398 (+ GrowBBox geometry.hxx:158-170, :239-259) */
+    BBox bb; bb.mn = sp3(1e36f); bb.mx = sp3(-1e36f);
+    for (int i = 0; i < nPrims; i++) {
+        const vcm_prim &p = prims[i];
+        if (p.type == VCM_PRIM_TRIANGLE) { grow(bb, ld3(p.p0)); grow(bb, ld3(p.p1)); grow(bb, ld3(p.p2)); }
+        else {
+            for (int k = 0; k < 8; k++) {
+                V3 h = sp3(p.p1[0]);
+                if (k & 1) h.x = -h.x;
+                if (k & 2) h.y = -h.y;
+                if (k & 4) h.z = -h.z;
+                grow(bb, ld3(p.p0) + h);
+            }
+        }
+    }
+    const float radius2 = lensqr(bb.mx - bb.mn);
+    put3(center3, (bb.mx + bb.mn) * 0.5f);
+    *radius = sqrtf(radius2) * 0.5f;
+    *invRadiusSqr = 1.f / sqr(*radius);
+}
 void reset_material(vcm_material &m)
 {   /* Material::Reset materials.hxx:44-51 */
     memset(&m, 0, sizeof(m));
@@ -186,36 +233,8 @@ extern "C" int vcm_scene_cornell(int resX, int resY, unsigned aBoxMask, vcm_scen
     if (light_point) light_box = false;   /* :152-153 */
 
     /* ---- Camera::Setup camera.hxx:37-76 with the arguments of scene.hxx:156-160 */
-    {
-        const V3 aPosition = mk3(-0.0439815f, -4.12529f, 0.222539f);
-        const V3 aForward = mk3(0.00688625f, 0.998505f, -0.0542161f);
-        const V3 aUp = mk3(3.73896e-4f, 0.0542148f, 0.998529f);
-        const float rx = float(resX), ry = float(resY);
-        const float fov = 45;
-        const V3 forward = normalize(aForward);
-        const V3 up = normalize(cross(aUp, -forward));
-        const V3 left = cross(-forward, up);
-        const V3 pos = mk3(dot(up, aPosition), dot(left, aPosition), dot(-forward, aPosition));
-        M4 worldToCamera = m4_identity();
-        const V3 nf = -forward;
-        at(worldToCamera, 0, 0) = up.x;   at(worldToCamera, 0, 1) = up.y;   at(worldToCamera, 0, 2) = up.z;   at(worldToCamera, 0, 3) = -pos.x;
-        at(worldToCamera, 1, 0) = left.x; at(worldToCamera, 1, 1) = left.y; at(worldToCamera, 1, 2) = left.z; at(worldToCamera, 1, 3) = -pos.y;
-        at(worldToCamera, 2, 0) = nf.x;   at(worldToCamera, 2, 1) = nf.y;   at(worldToCamera, 2, 2) = nf.z;   at(worldToCamera, 2, 3) = -pos.z;
-        const M4 perspective = m4_perspective(fov, 0.1f, 10000.f);
-        const M4 worldToNScreen = m4_mul(perspective, worldToCamera);
-        const M4 nscreenToWorld = m4_invert(worldToNScreen);
-        const M4 worldToRaster = m4_mul(m4_mul(m4_scale(mk3(rx * 0.5f, ry * 0.5f, 0)), m4_translate(mk3(1.f, 1.f, 0))),
-                                        worldToNScreen);
-        const M4 rasterToWorld = m4_mul(m4_mul(nscreenToWorld, m4_translate(mk3(-1.f, -1.f, 0))),
-                                        m4_scale(mk3(2.f / rx, 2.f / ry, 0)));
-        const float tanHalfAngle = tanf(fov * VCM_PI_F / 360.f);
-        put3(d.camera.position, aPosition);
-        put3(d.camera.forward, forward);
-        d.camera.resolution[0] = rx; d.camera.resolution[1] = ry;
-        memcpy(d.camera.rasterToWorld, rasterToWorld.m, sizeof(float) * 16);
-        memcpy(d.camera.worldToRaster, worldToRaster.m, sizeof(float) * 16);
-        d.camera.imagePlaneDist = rx / (2.f * tanHalfAngle);
-    }
+    camera_setup(mk3(-0.0439815f, -4.12529f, 0.222539f), mk3(0.00688625f, 0.998505f, -0.0542161f),
+                 mk3(3.73896e-4f, 0.0542148f, 0.998529f), float(resX), float(resY), 45, d.camera);
 
     /* ---- materials scene.hxx:162-209 */
     {
@@ -324,24 +343,75 @@ extern "C" int vcm_scene_cornell(int resX, int resY, unsigned aBoxMask, vcm_scen
         l.scale = 1.f;
     }
 
-    /* ---- BuildSceneSphere scene.hxx:387-398 (+ GrowBBox geometry.hxx:158-170, :239-259) */
-    BBox bb; bb.mn = sp3(1e36f); bb.mx = sp3(-1e36f);
-    for (int i = 0; i < d.nPrims; i++) {
-        const vcm_prim &p = d.prims[i];
-        if (p.type == VCM_PRIM_TRIANGLE) { grow(bb, ld3(p.p0)); grow(bb, ld3(p.p1)); grow(bb, ld3(p.p2)); }
-        else {
-            for (int k = 0; k < 8; k++) {
-                V3 h = sp3(p.p1[0]);
-                if (k & 1) h.x = -h.x;
-                if (k & 2) h.y = -h.y;
-                if (k & 4) h.z = -h.z;
-                grow(bb, ld3(p.p0) + h);
-            }
-        }
-    }
-    const float radius2 = lensqr(bb.mx - bb.mn);
-    put3(d.sceneCenter, (bb.mx + bb.mn) * 0.5f);
-    d.sceneRadius = sqrtf(radius2) * 0.5f;
-    d.invSceneRadiusSqr = 1.f / sqr(d.sceneRadius);
+    /* ---- BuildSceneSphere scene.hxx:387-398 */
+    scene_sphere(d.prims, d.nPrims, d.sceneCenter, &d.sceneRadius, &d.invSceneRadiusSqr);
     return 0;
+}
+
+/* ---- constructors for version-2 scenes: one call per object, each doing what the reference's constructor does (the
+ *      back end of a scene loader; include/smallvcm_amd.h).  Verified bit for bit against the reference's own classes
+ *      (tests/test_scene2.py through oracle/ref_driver.cpp). */
+extern "C" void vcm_make_triangle(const float *p0, const float *p1, const float *p2, int matID, vcm_prim *out)
+{   /* Triangle::Triangle geometry.hxx:111-123 */
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_PRIM_TRIANGLE; out->matID = matID;
+    put3(out->p0, ld3(p0)); put3(out->p1, ld3(p1)); put3(out->p2, ld3(p2));
+    put3(out->n, normalize(cross(ld3(p1) - ld3(p0), ld3(p2) - ld3(p0))));
+}
+extern "C" void vcm_make_sphere(const float *center, float radius, int matID, vcm_prim *out)
+{   /* Sphere::Sphere geometry.hxx:184-192 */
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_PRIM_SPHERE; out->matID = matID;
+    put3(out->p0, ld3(center)); out->p1[0] = radius;
+}
+extern "C" void vcm_make_area_light(const float *p0, const float *p1, const float *p2, const float *intensity, vcm_light *out)
+{   /* AreaLight::AreaLight lights.hxx:116-127 */
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_LIGHT_AREA;
+    const V3 e1 = ld3(p1) - ld3(p0), e2 = ld3(p2) - ld3(p0);
+    put3(out->p0, ld3(p0)); put3(out->e1, e1); put3(out->e2, e2);
+    const V3 normal = cross(e1, e2);
+    const float len = sqrtf(lensqr(normal));
+    out->invArea = 2.f / len;
+    Frame f; frame_from_z(f, normal);
+    put3(out->frameX, f.mX); put3(out->frameY, f.mY); put3(out->frameZ, f.mZ);
+    put3(out->intensity, ld3(intensity));
+}
+extern "C" void vcm_make_directional_light(const float *direction, const float *intensity, vcm_light *out)
+{   /* DirectionalLight::DirectionalLight lights.hxx:239-243 */
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_LIGHT_DIRECTIONAL;
+    Frame f; frame_from_z(f, ld3(direction));
+    put3(out->frameX, f.mX); put3(out->frameY, f.mY); put3(out->frameZ, f.mZ);
+    put3(out->intensity, ld3(intensity));
+}
+extern "C" void vcm_make_point_light(const float *position, const float *intensity, vcm_light *out)
+{   /* PointLight::PointLight lights.hxx:324-328 */
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_LIGHT_POINT;
+    put3(out->p0, ld3(position));
+    put3(out->intensity, ld3(intensity));
+}
+extern "C" void vcm_make_background_light(float scale, vcm_light *out)
+{   /* BackgroundLight::BackgroundLight lights.hxx:404-408 */
+    memset(out, 0, sizeof(*out));
+    out->type = VCM_LIGHT_BACKGROUND;
+    put3(out->intensity, mk3(135, 206, 250) / sp3(255.f));
+    out->scale = scale;
+}
+extern "C" void vcm_make_material(vcm_material *out)
+{   /* Material::Reset materials.hxx:44-51 */
+    reset_material(*out);
+}
+extern "C" int vcm_make_camera(const float *position, const float *forward, const float *up, float horizontalFovDeg, int resX,
+                               int resY, vcm_camera *out)
+{   /* Camera::Setup camera.hxx:37-76 */
+    if (!out || resX <= 0 || resY <= 0) return -1;
+    memset(out, 0, sizeof(*out));
+    camera_setup(ld3(position), ld3(forward), ld3(up), float(resX), float(resY), horizontalFovDeg, *out);
+    return 0;
+}
+extern "C" void vcm_make_scene_sphere(const vcm_prim *prims, int nPrims, float *center3, float *radius, float *invRadiusSqr)
+{   /* Scene::BuildSceneSphere scene.hxx:387-398 */
+    scene_sphere(prims, nPrims, center3, radius, invRadiusSqr);
 }

@@ -1,0 +1,247 @@
+// scene_host.h -- host side of the scene: copies a C-ABI scene description (vcm_scene_desc: the reference's built-in
+// boxes, fixed capacities; vcm_scene_desc2: any counts) into owned arrays and builds what the intersection code walks:
+//   * <= VCM_MAX_PRIMS primitives: GeometryList order, consecutive triangles packed in pairs (vcm_core.h TriPair) --
+//     the brute-force loop of Scene::Intersect (scene.hxx:53-70), which is what the reference does for every scene;
+//   * more (or SMALLVCM_AMD_FORCE_BVH=1): a binary BVH over the primitives' boxes, SAH-binned, at most 4 primitives per
+//     leaf, nodes in depth-first order with escape indices (stackless traversal, vcm_core.h bvh_intersect).  The
+//     reference has no acceleration structure (README:208-209); results are the same because the traversal only decides
+//     WHICH primitives are tested, never how (vcm_core.h explains the tie rule).
+// Host only (std::vector); vcm_api.hip uploads the arrays and hands the kernels a DScene of device pointers,
+// tests/host_emul walks the same structure on the CPU.
+#ifndef SMALLVCM_AMD_SCENE_HOST_H
+#define SMALLVCM_AMD_SCENE_HOST_H
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vcm_core.h"
+
+namespace vcm {
+
+struct SceneHost {
+    std::vector<vcm_prim> prims;
+    std::vector<vcm_material> materials;
+    std::vector<int> mat2light;
+    std::vector<vcm_light> lights;
+    int backgroundLight;
+    float sceneCenter[3], sceneRadius, invSceneRadiusSqr;
+    vcm_camera camera;
+    std::vector<PrimOp> ops;
+    std::vector<TriPair> pairs;
+    std::vector<BvhNode> nodes;
+    std::vector<int> leafPrims;
+
+    /* the view the device functions take; pointers into THIS object's arrays (host emulation) */
+    DScene view() const
+    {
+        DScene d;
+        fill_scalars(d);
+        d.prims = prims.data(); d.materials = materials.data(); d.mat2light = mat2light.data(); d.lights = lights.data();
+        d.ops = ops.data(); d.pairs = pairs.data(); d.nodes = nodes.data(); d.leafPrims = leafPrims.data();
+        return d;
+    }
+    void fill_scalars(DScene &d) const
+    {
+        d.nPrims = (int)prims.size(); d.nMaterials = (int)materials.size(); d.nLights = (int)lights.size();
+        d.backgroundLight = backgroundLight;
+        for (int k = 0; k < 3; k++) d.sceneCenter[k] = sceneCenter[k];
+        d.sceneRadius = sceneRadius; d.invSceneRadiusSqr = invSceneRadiusSqr;
+        d.camera = camera;
+        d.nOps = (int)ops.size(); d.nNodes = (int)nodes.size();
+    }
+};
+
+inline bool scene_host_check(const SceneHost &s, std::string &err)
+{
+    if (s.lights.empty()) { err = "scene has no light"; return false; }
+    if (s.materials.empty()) { err = "scene has no material"; return false; }
+    if (s.materials.size() >= (1u << 24)) { err = "more than 2^24 materials"; return false; }
+    for (const vcm_prim &p : s.prims)
+        if (p.matID < 0 || p.matID >= (int)s.materials.size()) { err = "primitive with a material index out of range"; return false; }
+    for (int l : s.mat2light)
+        if (l >= (int)s.lights.size()) { err = "mat2light entry out of range"; return false; }
+    if (s.backgroundLight >= (int)s.lights.size()) { err = "backgroundLight out of range"; return false; }
+    return true;
+}
+
+inline bool scene_host_from_desc(const vcm_scene_desc &sc, SceneHost &s, std::string &err)
+{
+    if (sc.nPrims < 0 || sc.nPrims > VCM_MAX_PRIMS || sc.nMaterials < 0 || sc.nMaterials > VCM_MAX_MATERIALS || sc.nLights < 1 ||
+        sc.nLights > VCM_MAX_LIGHTS) { err = "scene exceeds the fixed capacities of vcm_scene_desc (use vcm_scene_desc2)"; return false; }
+    s.prims.assign(sc.prims, sc.prims + sc.nPrims);
+    s.materials.assign(sc.materials, sc.materials + sc.nMaterials);
+    s.mat2light.assign(sc.mat2light, sc.mat2light + sc.nMaterials);
+    s.lights.assign(sc.lights, sc.lights + sc.nLights);
+    s.backgroundLight = sc.backgroundLight;
+    for (int k = 0; k < 3; k++) s.sceneCenter[k] = sc.sceneCenter[k];
+    s.sceneRadius = sc.sceneRadius; s.invSceneRadiusSqr = sc.invSceneRadiusSqr;
+    s.camera = sc.camera;
+    return scene_host_check(s, err);
+}
+
+inline bool scene_host_from_desc2(const vcm_scene_desc2 &sc, SceneHost &s, std::string &err)
+{
+    if (sc.nPrims < 0 || sc.nMaterials < 1 || sc.nLights < 1 || (sc.nPrims > 0 && !sc.prims) || !sc.materials || !sc.mat2light || !sc.lights) {
+        err = "vcm_scene_desc2: bad counts or NULL arrays"; return false;
+    }
+    s.prims.assign(sc.prims, sc.prims + sc.nPrims);
+    s.materials.assign(sc.materials, sc.materials + sc.nMaterials);
+    s.mat2light.assign(sc.mat2light, sc.mat2light + sc.nMaterials);
+    s.lights.assign(sc.lights, sc.lights + sc.nLights);
+    s.backgroundLight = sc.backgroundLight;
+    for (int k = 0; k < 3; k++) s.sceneCenter[k] = sc.sceneCenter[k];
+    s.sceneRadius = sc.sceneRadius; s.invSceneRadiusSqr = sc.invSceneRadiusSqr;
+    s.camera = sc.camera;
+    return scene_host_check(s, err);
+}
+
+/* ---- brute-force list: consecutive triangles in pairs, fields interleaved (vcm_core.h TriPair) ---- */
+inline void scene_host_build_pairs(SceneHost &s)
+{
+    s.ops.clear(); s.pairs.clear();
+    const int n = (int)s.prims.size();
+    for (int i = 0; i < n; ) {
+        PrimOp op;
+        if (s.prims[i].type != VCM_PRIM_TRIANGLE) { op.kind = 1; op.index = i; s.ops.push_back(op); i++; continue; }
+        op.kind = 0; op.index = (int)s.pairs.size();
+        s.ops.push_back(op);
+        TriPair tp;
+        std::memset(&tp, 0, sizeof(tp));
+        const bool two = (i + 1 < n) && s.prims[i + 1].type == VCM_PRIM_TRIANGLE;
+        for (int h = 0; h < 2; h++) {
+            const vcm_prim &t = s.prims[(h == 1 && two) ? i + 1 : i];
+            tp.p0x[h] = t.p0[0]; tp.p0y[h] = t.p0[1]; tp.p0z[h] = t.p0[2];
+            tp.p1x[h] = t.p1[0]; tp.p1y[h] = t.p1[1]; tp.p1z[h] = t.p1[2];
+            tp.p2x[h] = t.p2[0]; tp.p2y[h] = t.p2[1]; tp.p2z[h] = t.p2[2];
+            tp.nx[h] = t.n[0]; tp.ny[h] = t.n[1]; tp.nz[h] = t.n[2];
+            tp.matID[h] = t.matID;
+            tp.prim[h] = (h == 1 && two) ? i + 1 : i;
+        }
+        tp.valid1 = two ? 1 : 0;
+        s.pairs.push_back(tp);
+        i += two ? 2 : 1;
+    }
+}
+
+/* ---- BVH ---- */
+struct BvhBuildPrim { float lo[3], hi[3], c[3]; int index; };
+
+inline void bvh_prim_box(const vcm_prim &p, float lo[3], float hi[3])
+{
+    if (p.type == VCM_PRIM_TRIANGLE) {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(p.p0[k], std::min(p.p1[k], p.p2[k]));
+            hi[k] = std::max(p.p0[k], std::max(p.p1[k], p.p2[k]));
+        }
+    } else {   /* sphere: p0 = centre, p1[0] = radius */
+        for (int k = 0; k < 3; k++) { lo[k] = p.p0[k] - p.p1[0]; hi[k] = p.p0[k] + p.p1[0]; }
+    }
+}
+
+inline int bvh_build_node(SceneHost &s, std::vector<BvhBuildPrim> &bp, int first, int count, float pad)
+{
+    const int me = (int)s.nodes.size();
+    s.nodes.push_back(BvhNode());
+    float lo[3] = { 1e36f, 1e36f, 1e36f }, hi[3] = { -1e36f, -1e36f, -1e36f }, clo[3] = { 1e36f, 1e36f, 1e36f }, chi[3] = { -1e36f, -1e36f, -1e36f };
+    for (int i = first; i < first + count; i++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], bp[i].lo[k]); hi[k] = std::max(hi[k], bp[i].hi[k]);
+            clo[k] = std::min(clo[k], bp[i].c[k]); chi[k] = std::max(chi[k], bp[i].c[k]);
+        }
+    /* grown: the traversal's slab test and the primitives' own hit computations round (relative 1e-6); a box that is
+       larger by 1e-4 of the scene can only add visits */
+    for (int k = 0; k < 3; k++) { s.nodes[me].bmin[k] = lo[k] - pad; s.nodes[me].bmax[k] = hi[k] + pad; }
+    int axis = 0;
+    for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    const bool flat = !(chi[axis] - clo[axis] > 0.f);
+    if (count <= 4 || (flat && count <= 15)) {
+        s.nodes[me].leaf = ((int)s.leafPrims.size() << 4) | count;
+        for (int i = first; i < first + count; i++) s.leafPrims.push_back(bp[i].index);
+        s.nodes[me].escape = (int)s.nodes.size();
+        return me;
+    }
+    /* binned surface-area heuristic along the axis of the largest centroid extent; median split as the fallback */
+    int mid = first + count / 2;
+    if (!flat) {
+        const int B = 16;
+        float blo[B][3], bhi[B][3]; int bn[B];
+        for (int b = 0; b < B; b++) { bn[b] = 0; for (int k = 0; k < 3; k++) { blo[b][k] = 1e36f; bhi[b][k] = -1e36f; } }
+        const float scale = (float)B / (chi[axis] - clo[axis]);
+        auto bin_of = [&](const BvhBuildPrim &p) { int b = (int)((p.c[axis] - clo[axis]) * scale); return b < 0 ? 0 : (b >= B ? B - 1 : b); };
+        for (int i = first; i < first + count; i++) {
+            const int b = bin_of(bp[i]);
+            bn[b]++;
+            for (int k = 0; k < 3; k++) { blo[b][k] = std::min(blo[b][k], bp[i].lo[k]); bhi[b][k] = std::max(bhi[b][k], bp[i].hi[k]); }
+        }
+        auto area = [](const float *l, const float *h) { const float x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2]; return x * y + y * z + z * x; };
+        float best = 1e36f; int bestSplit = -1;
+        for (int sp = 1; sp < B; sp++) {
+            float l0[3] = { 1e36f, 1e36f, 1e36f }, h0[3] = { -1e36f, -1e36f, -1e36f }, l1[3] = { 1e36f, 1e36f, 1e36f }, h1[3] = { -1e36f, -1e36f, -1e36f };
+            int n0 = 0, n1 = 0;
+            for (int b = 0; b < B; b++) {
+                if (!bn[b]) continue;
+                float *l = b < sp ? l0 : l1, *h = b < sp ? h0 : h1;
+                (b < sp ? n0 : n1) += bn[b];
+                for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], blo[b][k]); h[k] = std::max(h[k], bhi[b][k]); }
+            }
+            if (!n0 || !n1) continue;
+            const float cost = area(l0, h0) * n0 + area(l1, h1) * n1;
+            if (cost < best) { best = cost; bestSplit = sp; }
+        }
+        if (bestSplit > 0) {
+            auto it = std::stable_partition(bp.begin() + first, bp.begin() + first + count, [&](const BvhBuildPrim &p) { return bin_of(p) < bestSplit; });
+            mid = (int)(it - bp.begin());
+        }
+    }
+    if (mid <= first || mid >= first + count) {   /* degenerate: all centroids in one bin */
+        std::stable_sort(bp.begin() + first, bp.begin() + first + count, [&](const BvhBuildPrim &a, const BvhBuildPrim &b) { return a.c[axis] < b.c[axis]; });
+        mid = first + count / 2;
+    }
+    s.nodes[me].leaf = -1;
+    bvh_build_node(s, bp, first, mid - first, pad);
+    bvh_build_node(s, bp, mid, first + count - mid, pad);
+    s.nodes[me].escape = (int)s.nodes.size();
+    return me;
+}
+
+inline void scene_host_build_bvh(SceneHost &s)
+{
+    s.nodes.clear(); s.leafPrims.clear();
+    const int n = (int)s.prims.size();
+    if (n == 0) return;
+    std::vector<BvhBuildPrim> bp((size_t)n);
+    float lo[3] = { 1e36f, 1e36f, 1e36f }, hi[3] = { -1e36f, -1e36f, -1e36f };
+    for (int i = 0; i < n; i++) {
+        bvh_prim_box(s.prims[i], bp[i].lo, bp[i].hi);
+        bp[i].index = i;
+        for (int k = 0; k < 3; k++) {
+            bp[i].c[k] = 0.5f * (bp[i].lo[k] + bp[i].hi[k]);
+            lo[k] = std::min(lo[k], bp[i].lo[k]); hi[k] = std::max(hi[k], bp[i].hi[k]);
+        }
+    }
+    float extent = 0.f;
+    for (int k = 0; k < 3; k++) extent = std::max(extent, std::max(hi[k] - lo[k], std::max(std::fabs(lo[k]), std::fabs(hi[k]))));
+    const float pad = 1e-4f * extent + 1e-30f;
+    s.nodes.reserve((size_t)n);
+    bvh_build_node(s, bp, 0, n, pad);
+}
+
+/* what the intersection code walks: the packed list for the reference's own scenes, the BVH beyond */
+inline void scene_host_build_accel(SceneHost &s, bool forceBvh)
+{
+    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.leafPrims.clear();
+    if ((int)s.prims.size() > VCM_MAX_PRIMS || (forceBvh && !s.prims.empty())) scene_host_build_bvh(s);
+    else scene_host_build_pairs(s);
+}
+inline bool scene_host_force_bvh()
+{
+    const char *e = getenv("SMALLVCM_AMD_FORCE_BVH");
+    return e && e[0] == '1';
+}
+
+} // namespace vcm
+#endif

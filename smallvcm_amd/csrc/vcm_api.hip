@@ -18,6 +18,7 @@
 
 #include "vcm_kernels.h"
 #include "vcm_kat.h"
+#include "scene_host.h"
 
 using namespace vcm;
 
@@ -110,7 +111,7 @@ static thread_local unsigned long long g_threadId = 0;
 static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_threadCounter; return g_threadId; }
 
 struct vcm_ctx : Scratch {
-    vcm_scene_desc scene;
+    SceneHost *scene;                 /* host copy of the scene + the structure the intersection code walks */
     bool useVM, useVC, lightTraceOnly, ppm;
     int renderer;                     /* 0 VertexCM family, 1 PathTracer, 2 EyeLight */
     float baseRadius, radiusAlpha;
@@ -128,7 +129,8 @@ struct vcm_ctx : Scratch {
     Arena *arena; bool holdsArena;    /* the arena of the current / last iteration */
 
     /* per context: survives the iteration */
-    vcm_scene_desc *dScene;           /* first member of a device-resident SceneDev */
+    DScene *dScene;                   /* the scene view in device memory (pointers into dSceneBlob) */
+    char *dSceneBlob;                 /* primitives, materials, lights, pairs / BVH: one allocation */
     float *dFb;                       /* N*3, running sum (mFramebuffer, renderer.hxx:68) */
     unsigned char *dRngLight, *dRngCam;   /* the random-number tape of the last iteration */
     GridHeader *dHdr;
@@ -390,15 +392,26 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evBbox, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
-        {
-            SceneDev *sd = new SceneDev();
-            scene_dev_build(c->scene, *sd);
-            SceneDev *dsd = NULL;
-            if (dalloc(&dsd, 1)) { delete sd; return -1; }
-            hipError_t e = hipMemcpy(dsd, sd, sizeof(SceneDev), hipMemcpyHostToDevice);
-            delete sd;
-            if (e != hipSuccess) return fail("hipMemcpy(scene)", hipGetErrorString(e));
-            c->dScene = &dsd->sc;
+        {   /* scene arrays in ONE device allocation, then the view of device pointers */
+            const SceneHost &h = *c->scene;
+            struct Part { const void *src; size_t bytes; size_t off; } parts[8] = {
+                { h.prims.data(), h.prims.size() * sizeof(vcm_prim), 0 }, { h.materials.data(), h.materials.size() * sizeof(vcm_material), 0 },
+                { h.mat2light.data(), h.mat2light.size() * sizeof(int), 0 }, { h.lights.data(), h.lights.size() * sizeof(vcm_light), 0 },
+                { h.ops.data(), h.ops.size() * sizeof(PrimOp), 0 }, { h.pairs.data(), h.pairs.size() * sizeof(TriPair), 0 },
+                { h.nodes.data(), h.nodes.size() * sizeof(BvhNode), 0 }, { h.leafPrims.data(), h.leafPrims.size() * sizeof(int), 0 } };
+            size_t total = 0;
+            for (Part &p : parts) { p.off = total; total += (p.bytes + 255) & ~(size_t)255; }
+            if (dalloc(&c->dSceneBlob, total + 256)) return -1;
+            for (const Part &p : parts)
+                if (p.bytes) HIPCHK(hipMemcpy(c->dSceneBlob + p.off, p.src, p.bytes, hipMemcpyHostToDevice));
+            DScene view;
+            h.fill_scalars(view);
+            view.prims = (const vcm_prim *)(c->dSceneBlob + parts[0].off); view.materials = (const vcm_material *)(c->dSceneBlob + parts[1].off);
+            view.mat2light = (const int *)(c->dSceneBlob + parts[2].off); view.lights = (const vcm_light *)(c->dSceneBlob + parts[3].off);
+            view.ops = (const PrimOp *)(c->dSceneBlob + parts[4].off); view.pairs = (const TriPair *)(c->dSceneBlob + parts[5].off);
+            view.nodes = (const BvhNode *)(c->dSceneBlob + parts[6].off); view.leafPrims = (const int *)(c->dSceneBlob + parts[7].off);
+            if (dalloc(&c->dScene, 1)) return -1;
+            HIPCHK(hipMemcpy(c->dScene, &view, sizeof(DScene), hipMemcpyHostToDevice));
         }
         if (dalloc(&c->dFb, (size_t)c->N * 3)) return -1;
         HIPCHK(hipMemset(c->dFb, 0, (size_t)c->N * 3 * sizeof(float)));
@@ -540,20 +553,19 @@ int vcm_device_count(void)
     return n;
 }
 
-vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha,
-                            int seed, int device, int rank, int worldSize)
+/* the part of vcm_create common to both scene descriptions; takes ownership of `h` */
+static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor, float radiusAlpha, int seed, int device,
+                                 int rank, int worldSize)
 {
-    if (!scene) { fail("vcm_create", "scene is NULL"); return NULL; }
-    if (worldSize < 1 || rank < 0 || rank >= worldSize) { fail("vcm_create", "bad rank/worldSize"); return NULL; }
-    if (scene->nPrims < 0 || scene->nPrims > VCM_MAX_PRIMS || scene->nMaterials > VCM_MAX_MATERIALS ||
-        scene->nLights < 1 || scene->nLights > VCM_MAX_LIGHTS) { fail("vcm_create", "scene exceeds fixed capacities"); return NULL; }
+    if (worldSize < 1 || rank < 0 || rank >= worldSize) { delete h; fail("vcm_create", "bad rank/worldSize"); return NULL; }
     int ndev = vcm_device_count();
-    if (ndev <= 0) { fail("vcm_create", "no HIP device available (this library has no CPU path)"); return NULL; }
-    if (device < 0 || device >= ndev) { fail("vcm_create", "device index out of range"); return NULL; }
+    if (ndev <= 0) { delete h; fail("vcm_create", "no HIP device available (this library has no CPU path)"); return NULL; }
+    if (device < 0 || device >= ndev) { delete h; fail("vcm_create", "device index out of range"); return NULL; }
     vcm_ctx *c = new (std::nothrow) vcm_ctx();
-    if (!c) { fail("vcm_create", "out of host memory"); return NULL; }
+    if (!c) { delete h; fail("vcm_create", "out of host memory"); return NULL; }
     memset((void *)c, 0, sizeof(*c));
-    c->scene = *scene;
+    c->scene = h;
+    scene_host_build_accel(*h, scene_host_force_bvh());
     /* VertexCM::VertexCM vertexcm.hxx:222-244 */
     switch (algorithm) {
     case VCM_ALGO_LIGHT_TRACE: c->lightTraceOnly = true; break;
@@ -563,11 +575,10 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     case VCM_ALGO_VCM: c->useVC = true; c->useVM = true; break;
     case VCM_ALGO_PATH_TRACE: c->renderer = 1; break;   /* PathTracer(scene, seed), config.hxx:120-121 */
     case VCM_ALGO_EYE_LIGHT: c->renderer = 2; break;    /* EyeLight(scene, seed), config.hxx:118-119 */
-    default: delete c; fail("vcm_create", "unknown algorithm"); return NULL;
+    default: delete h; delete c; fail("vcm_create", "unknown algorithm"); return NULL;
     }
     if (c->ppm) {   /* PPM -> BPM downgrade :246-278 */
-        for (int i = 0; i < scene->nMaterials; i++) {
-            const vcm_material &m = scene->materials[i];
+        for (const vcm_material &m : h->materials) {
             const bool hasNonSpecular = (vmax3(ld3(m.diffuse)) > 0) || (vmax3(ld3(m.phong)) > 0);
             const bool hasSpecular = (vmax3(ld3(m.mirror)) > 0) || (m.ior > 0);
             if (hasNonSpecular && hasSpecular) {
@@ -578,20 +589,20 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
             }
         }
     }
-    c->baseRadius = radiusFactor * scene->sceneRadius;   /* :280 */
+    c->baseRadius = radiusFactor * h->sceneRadius;   /* :280 */
     c->radiusAlpha = radiusAlpha;
     c->seed = seed;
     c->device = device; c->rank = rank; c->world = worldSize;
-    c->resX = (int)scene->camera.resolution[0];
-    c->resY = (int)scene->camera.resolution[1];
+    c->resX = (int)h->camera.resolution[0];
+    c->resY = (int)h->camera.resolution[1];
     c->N = c->resX * c->resY;
-    if (c->N <= 0) { delete c; fail("vcm_create", "empty resolution"); return NULL; }
+    if (c->N <= 0) { delete h; delete c; fail("vcm_create", "empty resolution"); return NULL; }
     c->p0 = (int)((long long)c->N * rank / worldSize);
     c->nLocal = (int)((long long)c->N * (rank + 1) / worldSize) - c->p0;
     c->ownStream = true;
     if (worldSize == 1) {   /* single-rank contexts share the device's arenas */
         c->pool = pool_get(device);
-        if (!c->pool) { delete c; fail("vcm_create", "device index out of range"); return NULL; }
+        if (!c->pool) { delete h; delete c; fail("vcm_create", "device index out of range"); return NULL; }
         std::lock_guard<std::mutex> g(c->pool->m);
         c->pool->users++;
     } else {                /* a sharded context's iteration spans host-side collectives: private arena */
@@ -600,6 +611,26 @@ vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float ra
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
     return c;
+}
+
+vcm_ctx *vcm_create_sharded(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha,
+                            int seed, int device, int rank, int worldSize)
+{
+    if (!scene) { fail("vcm_create", "scene is NULL"); return NULL; }
+    SceneHost *h = new (std::nothrow) SceneHost();
+    std::string err;
+    if (!h || !scene_host_from_desc(*scene, *h, err)) { delete h; fail("vcm_create", err.c_str()); return NULL; }
+    return create_from_host(h, algorithm, radiusFactor, radiusAlpha, seed, device, rank, worldSize);
+}
+
+vcm_ctx *vcm_create_sharded2(const vcm_scene_desc2 *scene, int algorithm, float radiusFactor, float radiusAlpha,
+                             int seed, int device, int rank, int worldSize)
+{
+    if (!scene) { fail("vcm_create2", "scene is NULL"); return NULL; }
+    SceneHost *h = new (std::nothrow) SceneHost();
+    std::string err;
+    if (!h || !scene_host_from_desc2(*scene, *h, err)) { delete h; fail("vcm_create2", err.c_str()); return NULL; }
+    return create_from_host(h, algorithm, radiusFactor, radiusAlpha, seed, device, rank, worldSize);
 }
 
 /* Which device the next vcm_create goes to.  The reference's driver builds one renderer per host core and runs
@@ -638,6 +669,10 @@ vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm, float radiusFact
 {
     return vcm_create_sharded(scene, algorithm, radiusFactor, radiusAlpha, seed, next_device(), 0, 1);
 }
+vcm_ctx *vcm_create2(const vcm_scene_desc2 *scene, int algorithm, float radiusFactor, float radiusAlpha, int seed)
+{
+    return vcm_create_sharded2(scene, algorithm, radiusFactor, radiusAlpha, seed, next_device(), 0, 1);
+}
 
 void vcm_destroy(vcm_ctx *c)
 {
@@ -671,8 +706,10 @@ void vcm_destroy(vcm_ctx *c)
         delete a;
     }
     c->arena = NULL;
+    delete c->scene;
+    c->scene = NULL;
     if (c->deviceReady) {
-        DFREE(c->dScene); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
+        DFREE(c->dScene); DFREE(c->dSceneBlob); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         (void)hipStreamSynchronize(c->side);
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
@@ -1412,7 +1449,7 @@ __global__ void k_numeric_spec(int op, int n, const float *a, const float *b, fl
     }
     out[i] = r;
 }
-__global__ void k_kat(const vcm_scene_desc *__restrict__ scp, int op, int n, const float *in, float *out)
+__global__ void k_kat(const DScene *__restrict__ scp, int op, int n, const float *in, float *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1457,7 +1494,7 @@ int vcm_debug_kat(vcm_ctx *c, int op, int n, const float *in, float *out)
     HIPCHK(hipMalloc((void **)&din, bytes));
     HIPCHK(hipMalloc((void **)&dout, bytes));
     HIPCHK(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat, dim3((n + 63) / 64), dim3(64), 0, 0, (const vcm_scene_desc *)c->dScene, op, n, (const float *)din, dout);
+    hipLaunchKernelGGL(k_kat, dim3((n + 63) / 64), dim3(64), 0, 0, (const DScene *)c->dScene, op, n, (const float *)din, dout);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(din); (void)hipFree(dout);

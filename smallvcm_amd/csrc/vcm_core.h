@@ -190,53 +190,38 @@ struct alignas(8) TriPair {
     int valid1;   /* 0: the pair holds only one triangle */
     int pad;
 };
-struct PrimOp { int kind; int index; };   /* kind 0: TriPair pairs[index]; kind 1: sphere sc.prims[index] */
-/* Shading tables.  BSDF::Setup (bsdf.hxx:95-117) builds a frame from the surface normal and the component
- * probabilities from the material; for a TRIANGLE the normal is a constant of the primitive, and for a material
- * without a refractive index (ior < 0: FresnelDielectric returns 1, utils.hxx:47-48) the probabilities do not
- * depend on the direction either.  Both are evaluated once per scene by the very functions the per-hit code
- * runs (scene_dev_build), so looking them up gives the same bits as recomputing them: ~200 instructions (two
- * normalisations, seven divisions) per BSDF that is rebuilt from a stored vertex -- every connection, direct
- * illumination, camera connection and merge query does that. */
-struct PrimShade { float mX[3], mY[3], mZ[3]; int isTriangle; int pad[2]; };
-struct MatShade { float diffProb, phongProb, reflProb, refrProb, contProb, reflectCoeff; int constant; int pad; };
-struct SceneDev {
-    vcm_scene_desc sc;   /* must stay the first member (scene_dev()) */
-    int nOps, pad0;
-    PrimOp ops[VCM_MAX_PRIMS];
-    TriPair pairs[VCM_MAX_PRIMS];
-    PrimShade primShade[VCM_MAX_PRIMS];
-    MatShade matShade[VCM_MAX_MATERIALS];
-};
-/* every vcm_scene_desc the device functions see is the first member of a SceneDev */
-VCM_HD const SceneDev &scene_dev(const vcm_scene_desc &sc) { return *reinterpret_cast<const SceneDev *>(&sc); }
+struct PrimOp { int kind; int index; };   /* kind 0: TriPair pairs[index]; kind 1: sphere prims[index] */
 
-inline void scene_dev_build_tables(SceneDev &sd);   /* below, after the BSDF functions it calls */
-inline void scene_dev_build(const vcm_scene_desc &sc, SceneDev &sd)
-{
-    __builtin_memset(&sd, 0, sizeof(sd));
-    sd.sc = sc;
-    int nPairs = 0;
-    for (int i = 0; i < sc.nPrims; ) {
-        PrimOp &op = sd.ops[sd.nOps++];
-        if (sc.prims[i].type != VCM_PRIM_TRIANGLE) { op.kind = 1; op.index = i; i++; continue; }
-        op.kind = 0; op.index = nPairs;
-        TriPair &tp = sd.pairs[nPairs++];
-        const bool two = (i + 1 < sc.nPrims) && sc.prims[i + 1].type == VCM_PRIM_TRIANGLE;
-        for (int h = 0; h < 2; h++) {
-            const vcm_prim &t = sc.prims[(h == 1 && two) ? i + 1 : i];
-            tp.p0x[h] = t.p0[0]; tp.p0y[h] = t.p0[1]; tp.p0z[h] = t.p0[2];
-            tp.p1x[h] = t.p1[0]; tp.p1y[h] = t.p1[1]; tp.p1z[h] = t.p1[2];
-            tp.p2x[h] = t.p2[0]; tp.p2y[h] = t.p2[1]; tp.p2z[h] = t.p2[2];
-            tp.nx[h] = t.n[0]; tp.ny[h] = t.n[1]; tp.nz[h] = t.n[2];
-            tp.matID[h] = t.matID;
-            tp.prim[h] = (h == 1 && two) ? i + 1 : i;
-        }
-        tp.valid1 = two ? 1 : 0;
-        i += two ? 2 : 1;
-    }
-    scene_dev_build_tables(sd);
-}
+/* One node of the bounding-volume hierarchy used for scenes with more primitives than the brute-force loop is
+ * meant for (the reference has no acceleration structure: README:208-209, Scene::Intersect scene.hxx:53-70).
+ * Nodes are stored in depth-first order and THREADED: a traversal needs no stack -- when the ray meets a node's box
+ * it moves on to the next node in memory (the first child, or for a leaf: after its primitives), otherwise it jumps
+ * to `escape`, the node after the subtree.  32 bytes, two 16-byte loads. */
+struct alignas(16) BvhNode {
+    float bmin[3]; int escape;        /* index of the node after this subtree (nNodes at the end) */
+    float bmax[3]; int leaf;          /* -1: inner node; else (first << 4) | count into leafPrims, count <= 15 */
+};
+
+/* The scene as the device functions see it.  Member names are those of vcm_scene_desc (the C-ABI struct the scene
+ * arrives in), but primitives, materials and lights are POINTERS: the same code serves the reference's built-in
+ * boxes (<= 32 primitives, brute force in list order over packed triangle pairs) and arbitrary scenes
+ * (vcm_scene_desc2: any counts, BVH).  Built by scene_host.h, uploaded once per context. */
+struct DScene {
+    int nPrims, nMaterials, nLights, backgroundLight;
+    const vcm_prim *prims;
+    const vcm_material *materials;
+    const int *mat2light;
+    const vcm_light *lights;
+    float sceneCenter[3], sceneRadius, invSceneRadiusSqr;
+    vcm_camera camera;
+    /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0) */
+    int nOps, nNodes;
+    const PrimOp *ops;
+    const TriPair *pairs;
+    /* BVH (nNodes > 0) */
+    const BvhNode *nodes;
+    const int *leafPrims;
+};
 
 /* ---- utils.hxx ---------------------------------------------------- */
 VCM_HD float luminance(V3 c)
@@ -457,16 +442,147 @@ VCM_HD bool tri_pair_occluded(const TriPair &t, V3 org, V3 dir, float tmax)
     }
     return hit;
 }
-/* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78):
- * brute force over <= 22 primitives in list order; the op index is wave-uniform,
- * so the primitive data comes in through scalar loads. */
-VCM_HD bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res)
+/* Triangle::Intersect (:125-156) for ONE triangle of the primitive array (BVH leaves; the brute-force loop uses the
+ * packed pairs): edge functions, then the plane distance.  `accept` decides what the closest-hit loop does with
+ * the distance (see bvh_intersect). */
+VCM_HD bool tri_inside(const vcm_prim &t, V3 org, V3 dir, float &distance)
 {
-    const SceneDev &sd = scene_dev(sc);
+    const V3 ao = ld3(t.p0) - org, bo = ld3(t.p1) - org, co = ld3(t.p2) - org;
+    const V3 v0 = cross(co, bo), v1 = cross(bo, ao), v2 = cross(ao, co);
+    const float v0d = dot(v0, dir), v1d = dot(v1, dir), v2d = dot(v2, dir);
+    const V3 n = ld3(t.n);
+    distance = dot(n, ao) / dot(n, dir);
+    return ((v0d < 0.f) && (v1d < 0.f) && (v2d < 0.f)) || ((v0d >= 0.f) && (v1d >= 0.f) && (v2d >= 0.f));
+}
+
+/* Does the ray meet the node's box within [0, tmax]?  The boxes are grown at build time by far more than the
+ * rounding of this test and of the primitives' own hit computations (scene_host.h), so the answer errs only towards
+ * "yes": the traversal visits a superset of the primitives that can report a hit. */
+VCM_HD bool bvh_box_hit(const BvhNode &nd, V3 org, V3 invDir, float tmax)
+{
+    const float ax = (nd.bmin[0] - org.x) * invDir.x, bx = (nd.bmax[0] - org.x) * invDir.x;
+    const float ay = (nd.bmin[1] - org.y) * invDir.y, by = (nd.bmax[1] - org.y) * invDir.y;
+    const float az = (nd.bmin[2] - org.z) * invDir.z, bz = (nd.bmax[2] - org.z) * invDir.z;
+    /* fminf / fmaxf return the other operand for a NaN (0 * inf on a slab plane): the slab then does not constrain */
+    const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+    const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return tnear <= tfar * 1.0000004f;
+}
+
+/* GeometryList::Intersect (geometry.hxx:65-78) literally: every primitive in list order, each keeping its hit only
+ * if strictly closer than what is held.  O(nPrims): the BVH traversal falls back to it for the rare ray whose
+ * outcome depends on the list order in a way a hierarchy cannot see (below). */
+VCM_HD bool list_intersect(const DScene &sc, const Ray &ray, Isect &res)
+{
     bool any = false;
-    for (int i = 0; i < sd.nOps; i++) {
-        const PrimOp op = sd.ops[i];
-        const bool hit = (op.kind == 0) ? tri_pair_intersect(sd.pairs[op.index], ray, res)
+    for (int pi = 0; pi < sc.nPrims; pi++) {
+        const vcm_prim &pr = sc.prims[pi];
+        if (pr.type == VCM_PRIM_TRIANGLE) {
+            float distance;
+            const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
+            if (inside && (distance > ray.tmin) && (distance < res.dist)) {
+                res.normal = ld3(pr.n); res.matID = pr.matID; res.prim = pi; res.dist = distance; any = true;
+            }
+        } else if (sph_intersect(pr, pi, ray, res)) any = true;
+    }
+    if (any) res.lightID = sc.mat2light[res.matID];
+    return any;
+}
+
+/* Scene::Intersect over a BVH.  The reference walks GeometryList in order and keeps a hit only if it is strictly
+ * closer (geometry.hxx:65-78, :150, :226-234), i.e. it returns the hit with the smallest distance, ties going to the
+ * lower list index.  A hierarchy visits the primitives in another order, so the comparison is made explicitly
+ * lexicographic on (distance, primitive index): same winner, bit for bit.
+ * One case depends on the list order beyond that: Sphere::Intersect compares its binary64 root with the binary32
+ * distance held so far and then holds the root rounded to binary32 (:216-234), so when a sphere and another
+ * primitive are hit within an ulp of each other the winner depends on which came first.  Such a ray (two surfaces
+ * within 1e-7 of each other along it: the contact point of a sphere resting on the floor) is re-done by the
+ * list walk. */
+VCM_HD bool near_tie(float a, float b) { const int d = (int)f2u(a) - (int)f2u(b); return d >= -2 && d <= 2; }
+VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
+{
+    const V3 invDir = mk3(1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z);
+    const Isect start = res;
+    bool any = false, ambiguous = false, bestIsSphere = false;
+    int node = 0;
+    while (node < sc.nNodes) {
+        const BvhNode nd = sc.nodes[node];
+        if (!bvh_box_hit(nd, ray.org, invDir, res.dist)) { node = nd.escape; continue; }
+        if (nd.leaf >= 0) {
+            const int first = nd.leaf >> 4, count = nd.leaf & 15;
+            for (int k = 0; k < count; k++) {
+                const int pi = sc.leafPrims[first + k];
+                const vcm_prim &pr = sc.prims[pi];
+                if (pr.type == VCM_PRIM_TRIANGLE) {
+                    float distance;
+                    const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
+                    if (inside && (distance > ray.tmin)) {
+                        if (any && bestIsSphere && near_tie(distance, res.dist)) ambiguous = true;
+                        if (distance < res.dist || (distance == res.dist && any && pi < res.prim)) {
+                            res.normal = ld3(pr.n); res.matID = pr.matID; res.prim = pi; res.dist = distance; any = true;
+                            bestIsSphere = false;
+                        }
+                    }
+                } else {
+                    /* Sphere::Intersect offers ONE distance -- the nearer root beyond tmin, else the farther one --
+                       whatever res.dist is (if the nearer root fails "< res.dist" so does the farther) */
+                    Isect s; s.dist = 1e36f; s.matID = 0; s.lightID = -1; s.normal = sp3(0.f); s.prim = -1;
+                    if (sph_intersect(pr, pi, ray, s)) {
+                        if (any && near_tie(s.dist, res.dist)) ambiguous = true;
+                        if (s.dist < res.dist || (s.dist == res.dist && any && pi < res.prim)) {
+                            res.normal = s.normal; res.matID = s.matID; res.prim = pi; res.dist = s.dist; any = true;
+                            bestIsSphere = true;
+                        }
+                    }
+                }
+            }
+        }
+        node++;
+    }
+    if (ambiguous) { res = start; return list_intersect(sc, ray, res); }
+    if (any) res.lightID = sc.mat2light[res.matID];
+    return any;
+}
+
+/* Scene::Occluded over the BVH: any hit in (0, tmax) (order-free) */
+VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
+{
+    const V3 invDir = mk3(1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z);
+    bool occluded = false;
+    int node = 0;
+    while (node < sc.nNodes && !occluded) {
+        const BvhNode nd = sc.nodes[node];
+        if (!bvh_box_hit(nd, ray.org, invDir, tmaxp)) { node = nd.escape; continue; }
+        if (nd.leaf >= 0) {
+            const int first = nd.leaf >> 4, count = nd.leaf & 15;
+            for (int k = 0; k < count; k++) {
+                const int pi = sc.leafPrims[first + k];
+                const vcm_prim &pr = sc.prims[pi];
+                if (pr.type == VCM_PRIM_TRIANGLE) {
+                    float distance;
+                    const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
+                    if (inside && (distance > 0.f) && (distance < tmaxp)) occluded = true;
+                } else {
+                    Isect s; s.dist = tmaxp; s.matID = 0; s.lightID = -1; s.normal = sp3(0.f); s.prim = -1;
+                    if (sph_intersect(pr, pi, ray, s)) occluded = true;
+                }
+            }
+        }
+        node++;
+    }
+    return occluded;
+}
+
+/* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78): brute force in list order for
+ * the reference's own scenes (<= 32 primitives; the op index is wave-uniform, so the primitive data comes in through
+ * scalar loads), the BVH for larger ones. */
+VCM_HD bool scene_intersect(const DScene &sc, const Ray &ray, Isect &res)
+{
+    if (sc.nNodes > 0) return bvh_intersect(sc, ray, res);
+    bool any = false;
+    for (int i = 0; i < sc.nOps; i++) {
+        const PrimOp op = sc.ops[i];
+        const bool hit = (op.kind == 0) ? tri_pair_intersect(sc.pairs[op.index], ray, res)
                                         : sph_intersect(sc.prims[op.index], op.index, ray, res);
         if (hit) any = hit;
     }
@@ -474,20 +590,20 @@ VCM_HD bool scene_intersect(const vcm_scene_desc &sc, const Ray &ray, Isect &res
     return any;
 }
 /* Scene::Occluded scene.hxx:72-85 (+ GeometryList::IntersectP geometry.hxx:80-91) */
-VCM_HD bool scene_occluded(const vcm_scene_desc &sc, V3 point, V3 dir, float tmax)
+VCM_HD bool scene_occluded(const DScene &sc, V3 point, V3 dir, float tmax)
 {
-    const SceneDev &sd = scene_dev(sc);
     Ray ray;
     ray.org = point + dir * VCM_EPS_RAY;
     ray.dir = dir;
     ray.tmin = 0;
     const float tmaxp = tmax - 2 * VCM_EPS_RAY;
+    if (sc.nNodes > 0) return bvh_occluded(sc, ray, tmaxp);
     bool occluded = false;
-    for (int i = 0; i < sd.nOps; i++) {
-        const PrimOp op = sd.ops[i];
+    for (int i = 0; i < sc.nOps; i++) {
+        const PrimOp op = sc.ops[i];
         if (!occluded) {
             bool hit;
-            if (op.kind == 0) hit = tri_pair_occluded(sd.pairs[op.index], ray.org, ray.dir, tmaxp);
+            if (op.kind == 0) hit = tri_pair_occluded(sc.pairs[op.index], ray.org, ray.dir, tmaxp);
             else {
                 Isect isect;
                 isect.dist = tmaxp; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
@@ -532,87 +648,30 @@ VCM_HD void bsdf_component_probabilities(Bsdf &b, const vcm_material &m)
         b.contProb = smin(1.f, smax(0.f, b.contProb));
     }
 }
-/* frame and component probabilities of a hit: from the scene's tables where they are constants of the primitive /
- * the material (SceneDev), by Frame::SetFromZ / GetComponentProbabilities otherwise -- the same bits either way.
- * prim < 0: no primitive known. */
-VCM_HD void bsdf_frame(Bsdf &b, V3 normal, int prim, const vcm_scene_desc &sc)
-{
-    const SceneDev &sd = scene_dev(sc);
-    /* VCM_SHADE_TABLES off (default): measured 5.6 % SLOWER at 2048^2 (profiles/r02c_ab_summary.txt) -- the per-lane
-       table gathers sit in dependent chains at the head of every task; kept behind the switch for a rework */
-#if !defined(VCM_SHADE_TABLES)
-    prim = -1;
-#endif
-    if (prim >= 0 && sd.primShade[prim].isTriangle) {
-        const PrimShade &ps = sd.primShade[prim];
-        b.frame.mX = ld3(ps.mX); b.frame.mY = ld3(ps.mY); b.frame.mZ = ld3(ps.mZ);
-    } else {
-        frame_from_z(b.frame, normal);
-    }
-}
-VCM_HD void bsdf_probabilities(Bsdf &b, int matID, const vcm_scene_desc &sc)
-{
-    const SceneDev &sd = scene_dev(sc);
-    const MatShade &ms = sd.matShade[matID];
-#if !defined(VCM_SHADE_TABLES)
-    if (false) {
-#else
-    if (ms.constant) {
-#endif
-        b.diffProb = ms.diffProb; b.phongProb = ms.phongProb; b.reflProb = ms.reflProb; b.refrProb = ms.refrProb;
-        b.contProb = ms.contProb; b.reflectCoeff = ms.reflectCoeff;
-    } else {
-        bsdf_component_probabilities(b, sc.materials[matID]);
-    }
-}
 /* Setup :95-117.  rayDir = the incoming ray direction, normal = isect.normal, prim = isect.prim */
-VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, int prim, const vcm_scene_desc &sc)
+VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, int prim, const DScene &sc)
 {
+    (void)prim;
     b.matID = -1;
-    bsdf_frame(b, normal, prim, sc);
+    frame_from_z(b.frame, normal);
     b.localDirFix = to_local(b.frame, -rayDir);
     if (fabsf(b.localDirFix.z) < VCM_EPS_COSINE) return;
-    bsdf_probabilities(b, matID, sc);
+    bsdf_component_probabilities(b, sc.materials[matID]);
     b.isDelta = (b.diffProb == 0.f) && (b.phongProb == 0.f);
     b.matID = matID;
 }
-/* What a stored vertex keeps of its surface, in the upper 24 bits of the word that holds its path length:
- * matID (8 bits) and prim + 1 (16 bits, 0 = unknown). */
-VCM_HD uint32_t shade_code(int matID, int prim) { return (uint32_t)matID | ((uint32_t)(prim + 1) << 8); }
-/* Rebuild the BSDF of a STORED vertex from (isect.normal, mLocalDirFix, shade code): the same operations Setup
- * ran -- or the same table entries -- hence the same bits. */
-VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, uint32_t code, const vcm_scene_desc &sc)
+/* What a stored vertex keeps of its surface, in the upper 24 bits of the word that holds its path length: matID */
+VCM_HD uint32_t shade_code(int matID, int /*prim*/) { return (uint32_t)matID & 0xffffffu; }
+/* Rebuild the BSDF of a STORED vertex from (isect.normal, mLocalDirFix, matID): the same operations Setup ran,
+ * hence the same bits. */
+VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, uint32_t code, const DScene &sc)
 {
-    const int matID = (int)(code & 0xffu), prim = (int)(code >> 8) - 1;
-    bsdf_frame(b, normal, prim, sc);
+    const int matID = (int)(code & 0xffffffu);
+    frame_from_z(b.frame, normal);
     b.localDirFix = localDirFix;
-    bsdf_probabilities(b, matID, sc);
+    bsdf_component_probabilities(b, sc.materials[matID]);
     b.isDelta = false;
     b.matID = matID;
-}
-inline void scene_dev_build_tables(SceneDev &sd)
-{
-    const vcm_scene_desc &sc = sd.sc;
-    for (int i = 0; i < sc.nPrims && i < VCM_MAX_PRIMS; i++) {
-        PrimShade &ps = sd.primShade[i];
-        ps.isTriangle = sc.prims[i].type == VCM_PRIM_TRIANGLE ? 1 : 0;
-        if (!ps.isTriangle) continue;
-        Frame f;
-        frame_from_z(f, ld3(sc.prims[i].n));   /* Triangle::Intersect reports mNormal itself (geometry.hxx:150) */
-        ps.mX[0] = f.mX.x; ps.mX[1] = f.mX.y; ps.mX[2] = f.mX.z;
-        ps.mY[0] = f.mY.x; ps.mY[1] = f.mY.y; ps.mY[2] = f.mY.z;
-        ps.mZ[0] = f.mZ.x; ps.mZ[1] = f.mZ.y; ps.mZ[2] = f.mZ.z;
-    }
-    for (int i = 0; i < sc.nMaterials && i < VCM_MAX_MATERIALS; i++) {
-        MatShade &ms = sd.matShade[i];
-        ms.constant = sc.materials[i].ior < 0.f ? 1 : 0;   /* FresnelDielectric == 1 whatever the direction */
-        if (!ms.constant) continue;
-        Bsdf b;
-        b.localDirFix = mk3(0.f, 0.f, 1.f);   /* only its z enters, and only through the Fresnel term */
-        bsdf_component_probabilities(b, sc.materials[i]);
-        ms.diffProb = b.diffProb; ms.phongProb = b.phongProb; ms.reflProb = b.reflProb; ms.refrProb = b.refrProb;
-        ms.contProb = b.contProb; ms.reflectCoeff = b.reflectCoeff;
-    }
 }
 VCM_HD V3 bsdf_eval_diffuse(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf)
 {   /* EvaluateDiffuse :393-412 */
@@ -656,7 +715,7 @@ VCM_HD void bsdf_pdf_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *
     if (dirPdf) *dirPdf += pdfW;
     if (revPdf) *revPdf += pdfW;
 }
-VCM_HD V3 bsdf_evaluate(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, float &cosThetaGen,
+VCM_HD V3 bsdf_evaluate(const Bsdf &b, const DScene &sc, V3 worldDirGen, float &cosThetaGen,
                         float *dirPdf, float *revPdf)
 {   /* Evaluate :128-153 */
     V3 result = sp3(0.f);
@@ -670,7 +729,7 @@ VCM_HD V3 bsdf_evaluate(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen,
     result = result + bsdf_eval_phong(b, m, gen, dirPdf, revPdf);
     return result;
 }
-VCM_HD float bsdf_pdf(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, bool evalRev)
+VCM_HD float bsdf_pdf(const Bsdf &b, const DScene &sc, V3 worldDirGen, bool evalRev)
 {   /* Pdf :161-180 */
     const V3 gen = to_local(b.frame, worldDirGen);
     if (gen.z * b.localDirFix.z < 0.f) return 0.f;
@@ -682,7 +741,7 @@ VCM_HD float bsdf_pdf(const Bsdf &b, const vcm_scene_desc &sc, V3 worldDirGen, b
 }
 /* Sample :191-257 with SampleDiffuse :274, SamplePhong :290, SampleReflect :320,
  * SampleRefract :335.  fixIsLight is the reference's template argument. */
-VCM_HD V3 bsdf_sample(const Bsdf &b, const vcm_scene_desc &sc, bool fixIsLight, float r0, float r1, float r2,
+VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0, float r1, float r2,
                       V3 &worldDirGen, float &pdfW, float &cosThetaGen, uint32_t &sampledEvent)
 {
     if (r2 < b.diffProb) sampledEvent = kDiffuse;
@@ -756,13 +815,13 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const vcm_scene_desc &sc, bool fixIsLight, 
 /* ---- lights.hxx ---------------------------------------------------- */
 VCM_HD bool light_is_finite(const vcm_light &l) { return l.type == VCM_LIGHT_AREA || l.type == VCM_LIGHT_POINT; }
 VCM_HD bool light_is_delta(const vcm_light &l) { return l.type == VCM_LIGHT_DIRECTIONAL || l.type == VCM_LIGHT_POINT; }
-VCM_HD const vcm_light &get_light(const vcm_scene_desc &sc, int idx)
+VCM_HD const vcm_light &get_light(const DScene &sc, int idx)
 {   /* Scene::GetLightPtr scene.hxx:98-102 */
     idx = (sc.nLights - 1 < idx) ? sc.nLights - 1 : idx;
     return sc.lights[idx];
 }
 
-VCM_HD V3 light_illuminate(const vcm_light &l, const vcm_scene_desc &sc, V3 recvPos, float rx, float ry,
+VCM_HD V3 light_illuminate(const vcm_light &l, const DScene &sc, V3 recvPos, float rx, float ry,
                            V3 &dirToLight, float &distance, float &directPdfW, float &emissionPdfW,
                            float &cosAtLight)
 {
@@ -806,7 +865,7 @@ VCM_HD V3 light_illuminate(const vcm_light &l, const vcm_scene_desc &sc, V3 recv
     }
 }
 
-VCM_HD V3 light_emit(const vcm_light &l, const vcm_scene_desc &sc, float dx, float dy, float px, float py,
+VCM_HD V3 light_emit(const vcm_light &l, const DScene &sc, float dx, float dy, float px, float py,
                      V3 &position, V3 &direction, float &emissionPdfW, float &directPdfA, float &cosThetaLight)
 {
     if (l.type == VCM_LIGHT_AREA) {   /* AreaLight::Emit :168-198 */
@@ -852,7 +911,7 @@ VCM_HD V3 light_emit(const vcm_light &l, const vcm_scene_desc &sc, float dx, flo
     }
 }
 
-VCM_HD V3 light_get_radiance(const vcm_light &l, const vcm_scene_desc &sc, V3 rayDir,
+VCM_HD V3 light_get_radiance(const vcm_light &l, const DScene &sc, V3 rayDir,
                              float &directPdfA, float &emissionPdfW)
 {
     if (l.type == VCM_LIGHT_AREA) {   /* :200-221 */
@@ -885,7 +944,7 @@ struct SubPathState {
 VCM_HD float mis(float pdf) { return pdf; }   /* :553-557 (balance heuristic) */
 
 /* SampleScattering<tLightSample> :938-1006 */
-VCM_HD bool sample_scattering(const vcm_scene_desc &sc, const IterParams &P, bool lightSample, PathRng &rng,
+VCM_HD bool sample_scattering(const DScene &sc, const IterParams &P, bool lightSample, PathRng &rng,
                               const Bsdf &bsdf, V3 hitPoint, SubPathState &st)
 {
     /* the 3 floats of BSDF::Sample (:944) and the Russian-roulette float (:964), which only counts as drawn if
@@ -925,7 +984,7 @@ VCM_HD bool sample_scattering(const vcm_scene_desc &sc, const IterParams &P, boo
 /* ================= light sub-path (vertexcm.hxx:321-396) ============== */
 
 /* GenerateLightSample :816-858 */
-VCM_HD void generate_light_sample(const vcm_scene_desc &sc, const IterParams &P, PathRng &rng, SubPathState &st)
+VCM_HD void generate_light_sample(const DScene &sc, const IterParams &P, PathRng &rng, SubPathState &st)
 {
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;
@@ -961,7 +1020,7 @@ VCM_HD void generate_light_sample(const vcm_scene_desc &sc, const IterParams &P,
 /* splatOut == NULL: the splat is an fp32 atomic add on fb (strict mode);
  * otherwise *splatOut receives (contrib.rgb, pixel) -- pixel -1 when nothing is
  * splatted -- and k_splat_apply adds the splats of a pixel in vertex order. */
-VCM_HD void connect_to_camera(const vcm_scene_desc &sc, const IterParams &P, const SubPathState &st, V3 hitpoint,
+VCM_HD void connect_to_camera(const DScene &sc, const IterParams &P, const SubPathState &st, V3 hitpoint,
                               const Bsdf &bsdf, float *fb, LaneStats &ls, F4 *splatOut = 0)
 {
     if (splatOut) *splatOut = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
@@ -1011,7 +1070,7 @@ struct LightPath {
     uint32_t lenMask;   /* see LightStore::lenMask */
 };
 
-VCM_HD void light_path_begin(const vcm_scene_desc &sc, const IterParams &P, LightPath &lp, int localPath)
+VCM_HD void light_path_begin(const DScene &sc, const IterParams &P, LightPath &lp, int localPath)
 {
     lp.lp = localPath;
     lp.nStored = 0;
@@ -1024,7 +1083,7 @@ VCM_HD void light_path_begin(const vcm_scene_desc &sc, const IterParams &P, Ligh
  * MODE 1 (wavefront): ConnectToCamera (:380-384) is left to k_connect_camera,
  * which runs it for every stored vertex. */
 template <int MODE>
-VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, LightPath &lp, const LightStore &store,
+VCM_HD bool light_path_step(const DScene &sc, const IterParams &P, LightPath &lp, const LightStore &store,
                             float *fb, LaneStats &ls)
 {
     SubPathState &st = lp.st;
@@ -1065,7 +1124,7 @@ VCM_HD bool light_path_step(const vcm_scene_desc &sc, const IterParams &P, Light
 }
 
 /* ConnectToCamera (:380-384, :862-933) for a STORED light vertex (wavefront mode) */
-VCM_HD void connect_stored_vertex_to_camera(const vcm_scene_desc &sc, const IterParams &P, const LightStore &store,
+VCM_HD void connect_stored_vertex_to_camera(const DScene &sc, const IterParams &P, const LightStore &store,
                                             size_t slot, float *fb, LaneStats &ls, F4 *splatOut)
 {
     const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), c = lv(store, slot, 2), d = lv(store, slot, 3);
@@ -1083,7 +1142,7 @@ VCM_HD void connect_stored_vertex_to_camera(const vcm_scene_desc &sc, const Iter
 /* ================= camera sub-path (vertexcm.hxx:415-545) ============= */
 
 /* GetLightRadiance :617-658 */
-VCM_HD V3 get_light_radiance(const vcm_scene_desc &sc, const IterParams &P, const vcm_light &light,
+VCM_HD V3 get_light_radiance(const DScene &sc, const IterParams &P, const vcm_light &light,
                              const SubPathState &st, V3 rayDir)
 {
     const int lightCount = sc.nLights;
@@ -1101,7 +1160,7 @@ VCM_HD V3 get_light_radiance(const vcm_scene_desc &sc, const IterParams &P, cons
 }
 
 /* DirectIllumination :663-738 */
-VCM_HD V3 direct_illumination(const vcm_scene_desc &sc, const IterParams &P, float rPick, float rx, float ry,
+VCM_HD V3 direct_illumination(const DScene &sc, const IterParams &P, float rPick, float rx, float ry,
                               const SubPathState &st, V3 hitpoint, const Bsdf &bsdf, LaneStats &ls)
 {   /* rPick, rx, ry: the three floats drawn at :672-673 */
     const int lightCount = sc.nLights;
@@ -1131,7 +1190,7 @@ VCM_HD V3 direct_illumination(const vcm_scene_desc &sc, const IterParams &P, flo
 }
 
 /* ConnectVertices :743-809; the light vertex comes from the LightStore */
-VCM_HD V3 connect_vertices(const vcm_scene_desc &sc, const IterParams &P, V3 lvHitpoint, const Bsdf &lvBsdf,
+VCM_HD V3 connect_vertices(const DScene &sc, const IterParams &P, V3 lvHitpoint, const Bsdf &lvBsdf,
                            float lvdVCM, float lvdVC, const Bsdf &cameraBsdf, V3 cameraHitpoint,
                            const SubPathState &st, LaneStats &ls)
 {
@@ -1212,7 +1271,7 @@ struct MergeEval {
     uint32_t pathLength;
     bool cosOk;           /* !(mLocalDirFix.z < EPS_COSINE) */
 };
-VCM_HD void merge_eval_setup(MergeEval &e, const vcm_scene_desc &sc, const IterParams &P, const Bsdf &b,
+VCM_HD void merge_eval_setup(MergeEval &e, const DScene &sc, const IterParams &P, const Bsdf &b,
                              const SubPathState &st)
 {
     const vcm_material &m = sc.materials[b.matID];
@@ -1307,7 +1366,7 @@ VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval
  * lanes active instead of the ~18 % that accept at any one candidate.  Each
  * lane still processes ITS photons in the reference's order, so the sum
  * (:168) is bit-identical. */
-VCM_HD V3 merge_query(const vcm_scene_desc &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
+VCM_HD V3 merge_query(const DScene &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
                       const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms)
 {
     V3 contrib = sp3(0.f);
@@ -1505,7 +1564,7 @@ VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, in
 }
 
 /* GenerateCameraSample :564-606 (+ Camera::GenerateRay camera.hxx:108-117) */
-VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, int localPath)
+VCM_HD void camera_path_begin(const DScene &sc, const IterParams &P, CameraPath &cp, int localPath)
 {
     const vcm_camera &cam = sc.camera;
     const int pathIdx = P.p0 + localPath;
@@ -1550,7 +1609,7 @@ VCM_HD void camera_path_begin(const vcm_scene_desc &sc, const IterParams &P, Cam
 struct CameraWaveQueues { WaveQueue v, di, vc; };   /* wave-uniform allocator state of K3 */
 
 template <int MODE>
-VCM_HD bool camera_path_step(const vcm_scene_desc &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
+VCM_HD bool camera_path_step(const DScene &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
                              const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const VertexStore &vs,
                              CameraWaveQueues &wqs)
 {
@@ -1698,7 +1757,7 @@ struct CamVertex {
     uint32_t lp;
     uint32_t diK;         /* position of DirectIllumination's 3 floats in the path's random stream */
 };
-VCM_HD void load_cam_vertex(const vcm_scene_desc &sc, const VertexStore &vs, int vi, CamVertex &v)
+VCM_HD void load_cam_vertex(const DScene &sc, const VertexStore &vs, int vi, CamVertex &v)
 {
     const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi], e = vs.q4[vi];
     v.hit = mk3(a.x, a.y, a.z);
@@ -1711,7 +1770,7 @@ VCM_HD void load_cam_vertex(const vcm_scene_desc &sc, const VertexStore &vs, int
     v.diK = f2u(e.y);
 }
 /* the addend of :491  (color += throughput * DirectIllumination(...)) */
-VCM_HD V3 eval_di_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls,
+VCM_HD V3 eval_di_task(const DScene &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls,
                        size_t &pathSlot)
 {
     CamVertex v;
@@ -1724,7 +1783,7 @@ VCM_HD V3 eval_di_task(const vcm_scene_desc &sc, const IterParams &P, const Vert
     return v.throughput * direct_illumination(sc, P, rnd[0], rnd[1], rnd[2], v.st, v.hit, v.bsdf, ls);
 }
 /* the addend of :523  (color += throughput * lightVertex.mThroughput * ConnectVertices(...)) */
-VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const LightStore &store,
+VCM_HD V3 eval_vc_task(const DScene &sc, const IterParams &P, const VertexStore &vs, const LightStore &store,
                        int vi, int j, LaneStats &ls)
 {
     CamVertex v;
@@ -1737,7 +1796,7 @@ VCM_HD V3 eval_vc_task(const vcm_scene_desc &sc, const IterParams &P, const Vert
            connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, v.bsdf, v.hit, v.st, ls);
 }
 /* the addend of :534  (color += throughput * mVmNormalization * query.GetContrib()) */
-VCM_HD V3 eval_merge_task(const vcm_scene_desc &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
+VCM_HD V3 eval_merge_task(const DScene &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
                           int vi, LaneStats &ls, const MergeScratch &ms, size_t &pathSlot)
 {
     const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
@@ -1796,7 +1855,7 @@ struct PtPath {
     int lp;
 };
 VCM_HD float mis2(float samplePdf, float otherPdf) { return mis(samplePdf) / (mis(samplePdf) + mis(otherPdf)); }   /* :226-231 */
-VCM_HD void pt_path_begin(const vcm_scene_desc &sc, const IterParams &P, PtPath &pp, int localPath)
+VCM_HD void pt_path_begin(const DScene &sc, const IterParams &P, PtPath &pp, int localPath)
 {
     const vcm_camera &cam = sc.camera;
     const int pathIdx = P.p0 + localPath;
@@ -1817,7 +1876,7 @@ VCM_HD void pt_path_begin(const vcm_scene_desc &sc, const IterParams &P, PtPath 
     pp.lastPdfW = 1.f;
 }
 /* one turn of the for(;; ++pathLength) at :71-213; false when the path ends */
-VCM_HD bool pt_path_step(const vcm_scene_desc &sc, const IterParams &P, PtPath &pp, LaneStats &ls)
+VCM_HD bool pt_path_step(const DScene &sc, const IterParams &P, PtPath &pp, LaneStats &ls)
 {
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;   /* :48-49 */
@@ -1909,7 +1968,7 @@ VCM_HD bool pt_path_step(const vcm_scene_desc &sc, const IterParams &P, PtPath &
 
 /* ================= EyeLight::RunIteration (eyelight.hxx:46-77) ================= */
 /* returns the colour and the jittered sample; hit = false: nothing is added (:68) */
-VCM_HD bool eyelight_path(const vcm_scene_desc &sc, const IterParams &P, int localPath, V3 &color, float &sx, float &sy,
+VCM_HD bool eyelight_path(const DScene &sc, const IterParams &P, int localPath, V3 &color, float &sx, float &sy,
                           uint32_t &floatsDrawn, LaneStats &ls)
 {
     const vcm_camera &cam = sc.camera;

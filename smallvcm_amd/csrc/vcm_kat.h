@@ -11,7 +11,7 @@
 
 namespace vcm {
 
-VCM_HD void kat_eval(const vcm_scene_desc &sc, int op, const float *in, float *out)
+VCM_HD void kat_eval(const DScene &sc, int op, const float *in, float *out)
 {
     for (int i = 0; i < VCM_KAT_FLOATS; i++) out[i] = 0.f;
     switch (op) {

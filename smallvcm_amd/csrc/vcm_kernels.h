@@ -78,11 +78,11 @@ __device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long l
 /* ---------------- K1: light sub-paths (vertexcm.hxx:321-396) ------------ */
 template <int MODE>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
-k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, float *fb,
+k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, float *fb,
               unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
     int next = wave * chunk;                              /* wave-uniform */
@@ -117,11 +117,11 @@ k_light_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore s
  * MODE 0 ("strict"): everything inside the path. */
 template <int MODE>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
-k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store, GridStore grid, VertexStore vs,
+k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, GridStore grid, VertexStore vs,
                F4 *camOut, uint32_t *camMask, unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
     int next = wave * chunk;
@@ -170,11 +170,11 @@ k_camera_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore 
 /* Same shape as K3: persistent waves, one lane per pixel, dead lanes refilled by ballot + prefix popcount.
  * The colour of a path goes to camOut with the pixel of its jittered sample; k_resolve adds it in path order. */
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
-k_path_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
+k_path_trace(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
              unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
     int next = wave * chunk;
@@ -202,11 +202,11 @@ k_path_trace(const vcm_scene_desc *__restrict__ scp, IterParams P, F4 *camOut, u
 }
 
 __global__ void __launch_bounds__(256)
-k_eye_light(const vcm_scene_desc *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
+k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
             unsigned long long *gstats, StampArgs st)
 {
     stamp_entry(st);
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     LaneStats ls; lane_stats_zero(ls);
     for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < P.nLocal; lp += gridDim.x * blockDim.x) {
         V3 color = sp3(0.f);
@@ -226,11 +226,11 @@ k_eye_light(const vcm_scene_desc *__restrict__ scp, IterParams P, F4 *camOut, un
  * lane and at 23 % lane utilisation (profiles/r01b_pmc_*). */
 #define VCM_TASK_BLOCK 256
 __global__ void __launch_bounds__(VCM_TASK_BLOCK)
-k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats,
+k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats,
              const int *__restrict__ bucketStart, int *sortedVertex, StampArgs st)
 {
     stamp_entry(st);
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int n = vs.count[1];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
@@ -248,10 +248,10 @@ k_connect_di(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore v
 }
 
 __global__ void __launch_bounds__(VCM_TASK_BLOCK)
-k_connect_vc(const vcm_scene_desc *__restrict__ scp, IterParams P, VertexStore vs, LightStore store,
+k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, LightStore store,
              unsigned long long *gstats)
 {
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int n = vs.count[2];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
@@ -318,11 +318,11 @@ __global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, con
 /* 104 VGPRs = 4 waves/SIMD.  Forcing 5 / 6 / 8 waves (amdgpu_waves_per_eu) was measured: 5.66 / 6.9 / 10.8 ms
  * against 5.4 ms on the same box -- the spills cost more than the occupancy buys. */
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK)
-k_merge_lane(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
+k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
              const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int nQ = *nSorted;
     __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_MERGE_BLOCK];
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK; ms.cap = VCM_MERGE_Q;
@@ -423,7 +423,7 @@ __device__ __forceinline__ uint32_t stage_insert(StageLds &L, int cell, int lo, 
 
 /* HashGrid::Process + RangeQuery::Process for one camera vertex, candidates out of LDS where staged.
  * Mirrors merge_query (vcm_core.h) statement by statement; `slots` = the 8 table slots of step A, 10 bits each. */
-__device__ __forceinline__ V3 merge_query_staged(const vcm_scene_desc &sc, const IterParams &P, const GridStore &g,
+__device__ __forceinline__ V3 merge_query_staged(const DScene &sc, const IterParams &P, const GridStore &g,
                                                  const Bsdf &cameraBsdf, const SubPathState &st, V3 queryPos, bool inside,
                                                  int px, int py, int pz, int pxo, int pyo, int pzo,
                                                  uint32_t s0, uint32_t s1, uint32_t s2, const StageLds &L, LaneStats &ls,
@@ -497,12 +497,12 @@ __device__ __forceinline__ V3 merge_query_staged(const vcm_scene_desc &sc, const
 #endif
 
 __global__ void __launch_bounds__(VCM_STAGE_BLOCK)
-k_merge_staged(const vcm_scene_desc *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
+k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
                const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int nQ = *nSorted;
     __shared__ uint32_t accQ[(VCM_STAGE_Q + 1) * VCM_STAGE_BLOCK];
     __shared__ __attribute__((aligned(16))) StageLds L;
@@ -732,11 +732,11 @@ __global__ void k_compact_records(IterParams P, LightStore store, const int *__r
  * order -- bit-identical to the serial loop and reproducible from run to run
  * (fp32 atomics gave an RMSE of 5e-9 and a different image every run). */
 __global__ void __launch_bounds__(256)
-k_connect_camera(const vcm_scene_desc *__restrict__ scp, IterParams P, LightStore store,
+k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
                  const int *__restrict__ slotOfVertex, const int *__restrict__ nVertices, float *fb, F4 *splat,
                  int *pixCount, int *arrival, unsigned long long *gstats)
 {
-    const vcm_scene_desc &sc = *scp;
+    const DScene &sc = *scp;
     const int n = *nVertices;
     LaneStats ls; lane_stats_zero(ls);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

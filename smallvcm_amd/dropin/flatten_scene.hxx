@@ -16,6 +16,7 @@
 #define SMALLVCM_AMD_FLATTEN_SCENE_HXX
 
 #include <string.h>
+#include <vector>
 #include "smallvcm_amd.h"
 
 namespace smallvcm_amd {
@@ -113,6 +114,102 @@ inline int FlattenScene(const Scene &aScene, vcm_scene_desc &oDesc)
     oDesc.sceneRadius       = aScene.mSceneSphere.mSceneRadius;
     oDesc.invSceneRadiusSqr = aScene.mSceneSphere.mInvSceneRadiusSqr;
 
+    const Camera &c = aScene.mCamera;
+    put3(oDesc.camera.position, c.mPosition);
+    put3(oDesc.camera.forward, c.mForward);
+    oDesc.camera.resolution[0] = c.mResolution.x;
+    oDesc.camera.resolution[1] = c.mResolution.y;
+    memcpy(oDesc.camera.rasterToWorld, c.mRasterToWorld.GetPtr(), 16 * sizeof(float));
+    memcpy(oDesc.camera.worldToRaster, c.mWorldToRaster.GetPtr(), 16 * sizeof(float));
+    oDesc.camera.imagePlaneDist = c.mImagePlaneDist;
+    return 0;
+}
+
+// The same into the version-2 description (pointer + count: any number of primitives, materials, lights), for a
+// reference Scene that outgrows the fixed capacities -- e.g. one filled by a scene loader added to the reference.  The
+// arrays live in oStorage, which must outlive the vcm_create2 call (the library copies them).
+struct SceneArrays
+{
+    std::vector<vcm_prim>     prims;
+    std::vector<vcm_material> materials;
+    std::vector<int>          mat2light;
+    std::vector<vcm_light>    lights;
+};
+
+inline int FlattenScene2(const Scene &aScene, SceneArrays &oStorage, vcm_scene_desc2 &oDesc)
+{
+    memset(&oDesc, 0, sizeof(oDesc));
+    const GeometryList *list = dynamic_cast<const GeometryList*>(aScene.mGeometry);
+    if(list == NULL) return -1;
+    oStorage.prims.resize(list->mGeometry.size());
+    for(size_t i = 0; i < list->mGeometry.size(); i++)
+    {
+        vcm_prim &p = oStorage.prims[i];
+        memset(&p, 0, sizeof(p));
+        if(const Triangle *t = dynamic_cast<const Triangle*>(list->mGeometry[i]))
+        {
+            p.type = VCM_PRIM_TRIANGLE; p.matID = t->matID;
+            put3(p.p0, t->p[0]); put3(p.p1, t->p[1]); put3(p.p2, t->p[2]); put3(p.n, t->mNormal);
+        }
+        else if(const Sphere *s = dynamic_cast<const Sphere*>(list->mGeometry[i]))
+        {
+            p.type = VCM_PRIM_SPHERE; p.matID = s->matID;
+            put3(p.p0, s->center); p.p1[0] = s->radius;
+        }
+        else return -3;
+    }
+    oStorage.materials.resize(aScene.mMaterials.size());
+    oStorage.mat2light.assign(aScene.mMaterials.size(), -1);
+    for(size_t i = 0; i < aScene.mMaterials.size(); i++)
+    {
+        const Material &m = aScene.mMaterials[i];
+        vcm_material &d = oStorage.materials[i];
+        put3(d.diffuse, m.mDiffuseReflectance); put3(d.phong, m.mPhongReflectance); d.phongExp = m.mPhongExponent;
+        put3(d.mirror, m.mMirrorReflectance); d.ior = m.mIOR;
+    }
+    for(std::map<int, int>::const_iterator it = aScene.mMaterial2Light.begin(); it != aScene.mMaterial2Light.end(); ++it)
+    {
+        if(it->first < 0 || it->first >= int(oStorage.mat2light.size())) return -5;
+        oStorage.mat2light[it->first] = it->second;
+    }
+    oStorage.lights.resize(aScene.mLights.size());
+    oDesc.backgroundLight = -1;
+    for(size_t i = 0; i < aScene.mLights.size(); i++)
+    {
+        vcm_light &d = oStorage.lights[i];
+        memset(&d, 0, sizeof(d));
+        const AbstractLight *l = aScene.mLights[i];
+        if(const AreaLight *a = dynamic_cast<const AreaLight*>(l))
+        {
+            d.type = VCM_LIGHT_AREA;
+            put3(d.p0, a->p0); put3(d.e1, a->e1); put3(d.e2, a->e2);
+            put3(d.frameX, a->mFrame.mX); put3(d.frameY, a->mFrame.mY); put3(d.frameZ, a->mFrame.mZ);
+            put3(d.intensity, a->mIntensity); d.invArea = a->mInvArea;
+        }
+        else if(const DirectionalLight *dl = dynamic_cast<const DirectionalLight*>(l))
+        {
+            d.type = VCM_LIGHT_DIRECTIONAL;
+            put3(d.frameX, dl->mFrame.mX); put3(d.frameY, dl->mFrame.mY); put3(d.frameZ, dl->mFrame.mZ);
+            put3(d.intensity, dl->mIntensity);
+        }
+        else if(const PointLight *pl = dynamic_cast<const PointLight*>(l))
+        {
+            d.type = VCM_LIGHT_POINT; put3(d.p0, pl->mPosition); put3(d.intensity, pl->mIntensity);
+        }
+        else if(const BackgroundLight *bl = dynamic_cast<const BackgroundLight*>(l))
+        {
+            d.type = VCM_LIGHT_BACKGROUND; put3(d.intensity, bl->mBackgroundColor); d.scale = bl->mScale;
+            if(bl == aScene.mBackground) oDesc.backgroundLight = int(i);
+        }
+        else return -7;
+    }
+    oDesc.nPrims = int(oStorage.prims.size());         oDesc.prims = oStorage.prims.empty() ? NULL : &oStorage.prims[0];
+    oDesc.nMaterials = int(oStorage.materials.size()); oDesc.materials = oStorage.materials.empty() ? NULL : &oStorage.materials[0];
+    oDesc.mat2light = oStorage.mat2light.empty() ? NULL : &oStorage.mat2light[0];
+    oDesc.nLights = int(oStorage.lights.size());       oDesc.lights = oStorage.lights.empty() ? NULL : &oStorage.lights[0];
+    put3(oDesc.sceneCenter, aScene.mSceneSphere.mSceneCenter);
+    oDesc.sceneRadius       = aScene.mSceneSphere.mSceneRadius;
+    oDesc.invSceneRadiusSqr = aScene.mSceneSphere.mInvSceneRadiusSqr;
     const Camera &c = aScene.mCamera;
     put3(oDesc.camera.position, c.mPosition);
     put3(oDesc.camera.forward, c.mForward);

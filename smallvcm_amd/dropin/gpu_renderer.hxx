@@ -38,14 +38,25 @@ public:
     {
         vcm_scene_desc desc;
         const int rc = FlattenScene(aScene, desc);
-        if(rc != 0)
+        if(rc == 0)
         {
-            // same convention as the reference's factory (src/config.hxx:140-141)
-            fprintf(stderr, "smallvcm_amd: scene cannot be flattened (code %d)\n", rc);
-            exit(2);
+            mCtx = vcm_create(&desc, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed);
         }
-
-        mCtx = vcm_create(&desc, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed);
+        else
+        {
+            // more primitives / materials / lights than the reference's built-in boxes have: the version-2
+            // description (traced through a BVH beyond 32 primitives)
+            SceneArrays arrays;
+            vcm_scene_desc2 desc2;
+            const int rc2 = FlattenScene2(aScene, arrays, desc2);
+            if(rc2 != 0)
+            {
+                // same convention as the reference's factory (src/config.hxx:140-141)
+                fprintf(stderr, "smallvcm_amd: scene cannot be flattened (code %d)\n", rc2);
+                exit(2);
+            }
+            mCtx = vcm_create2(&desc2, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed);
+        }
         if(mCtx == NULL)
         {
             fprintf(stderr, "smallvcm_amd: %s\n", vcm_last_error());

@@ -21,7 +21,7 @@ import os
 
 import numpy as np
 
-from ._abi import (SceneDesc, Stats, SCENE_CONFIGS, VCM_MERGE_RECORD_FLOATS, ALGO_LIGHT_TRACE, ALGO_PPM, ALGO_BPM,
+from ._abi import (SceneDesc, SceneDesc2, Stats, SCENE_CONFIGS, VCM_MERGE_RECORD_FLOATS, ALGO_LIGHT_TRACE, ALGO_PPM, ALGO_BPM,
                    ALGO_BPT, ALGO_VCM)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -54,6 +54,9 @@ def load_library(require_gpu=True):
         L.vcm_create_sharded.restype = vp
         L.vcm_create_sharded.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                          C.c_int, C.c_int]
+        L.vcm_create_sharded2.restype = vp
+        L.vcm_create_sharded2.argtypes = [C.POINTER(SceneDesc2), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                          C.c_int, C.c_int]
         L.vcm_destroy.argtypes = [vp]
         L.vcm_destroy.restype = None
         L.vcm_set_stream.argtypes = [vp, vp]
@@ -125,8 +128,8 @@ class HipBackend:
         self.resx = int(scene.camera.resolution[0])
         self.resy = int(scene.camera.resolution[1])
         self.N = self.resx * self.resy
-        self.ctx = self.L.vcm_create_sharded(C.byref(scene), algorithm, radius_factor, radius_alpha, seed, device,
-                                             rank, world)
+        create = self.L.vcm_create_sharded2 if isinstance(scene, SceneDesc2) else self.L.vcm_create_sharded
+        self.ctx = create(C.byref(scene), algorithm, radius_factor, radius_alpha, seed, device, rank, world)
         if not self.ctx:
             raise RuntimeError("smallvcm_amd: vcm_create failed: %s" % self.L.vcm_last_error().decode())
         first, count = C.c_int(), C.c_int()

@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 import numpy as np
-from smallvcm_amd._abi import SceneDesc
+from smallvcm_amd._abi import SceneDesc, SceneDesc2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _E = None
@@ -14,6 +14,8 @@ def emul():
         E = C.CDLL(os.path.join(_HERE, "host_emul", "libemul.so"))
         E.emul_create.restype = C.c_void_p
         E.emul_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+        E.emul_create2.restype = C.c_void_p
+        E.emul_create2.argtypes = [C.POINTER(SceneDesc2), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         E.emul_destroy.argtypes = [C.c_void_p]
         E.emul_run_iteration.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
         E.emul_get_framebuffer.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -37,7 +39,8 @@ def emul():
 class Emul:
     def __init__(self, scene, algo, radius_factor=0.003, radius_alpha=0.75, seed=1234, rank=0, world=1):
         self.E = emul()
-        self.h = self.E.emul_create(C.byref(scene), algo, radius_factor, radius_alpha, seed, rank, world)
+        create = self.E.emul_create2 if isinstance(scene, SceneDesc2) else self.E.emul_create
+        self.h = create(C.byref(scene), algo, radius_factor, radius_alpha, seed, rank, world)
         self.resx = int(scene.camera.resolution[0])
         self.resy = int(scene.camera.resolution[1])
         self.N = self.resx * self.resy

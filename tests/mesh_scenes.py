@@ -1,0 +1,49 @@
+"""Procedural version-2 test scenes (TEST INPUT, deterministic): a Cornell-like room whose floor is a tessellated
+height field -- thousands of triangles, so the product traces it through its BVH while the oracle and the unmodified
+reference walk every primitive (the reference has no acceleration structure, README:208-209)."""
+import numpy as np
+
+from smallvcm_amd.scene2 import SceneBuilder
+
+
+def bumpy_room(grid=24, resx=64, resy=64, spheres=True, sun=False, background=False, seed=5):
+    """2 * grid^2 floor triangles + 8 wall / ceiling triangles + 2 emissive triangles (+ 2 spheres)"""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    white = b.material(diffuse=(0.803922, 0.803922, 0.803922))
+    green = b.material(diffuse=(0.156863, 0.803922, 0.172549))
+    red = b.material(diffuse=(0.803922, 0.152941, 0.152941))
+    glossy = b.material(diffuse=(0.1, 0.1, 0.1), phong=(0.7, 0.7, 0.7), exponent=90.0)
+    mirror = b.material(mirror=(1, 1, 1))
+    glass = b.material(mirror=(1, 1, 1), ior=1.6)
+    lo, hi = -1.25, 1.25
+    # floor: height field z = -1.25 + bumps
+    xs = np.linspace(lo, hi, grid + 1, dtype=np.float32)
+    h = (0.04 * np.sin(3.1 * xs)[:, None] * np.cos(2.3 * xs)[None, :] + 0.01 * rng.random((grid + 1, grid + 1))).astype(np.float32)
+    z = (np.float32(lo) + h).astype(np.float32)
+    for i in range(grid):
+        for j in range(grid):
+            p00, p10 = (xs[i], xs[j], z[i, j]), (xs[i + 1], xs[j], z[i + 1, j])
+            p01, p11 = (xs[i], xs[j + 1], z[i, j + 1]), (xs[i + 1], xs[j + 1], z[i + 1, j + 1])
+            m = glossy if (i + j) % 3 else white
+            b.triangle(p00, p10, p11, m)
+            b.triangle(p11, p01, p00, m)
+    c = [(lo, hi, lo), (hi, hi, lo), (hi, hi, hi), (lo, hi, hi), (lo, lo, lo), (hi, lo, lo), (hi, lo, hi), (lo, lo, hi)]
+    b.triangle(c[0], c[1], c[2], white); b.triangle(c[2], c[3], c[0], white)       # back wall
+    b.triangle(c[3], c[7], c[4], green); b.triangle(c[4], c[0], c[3], green)       # left
+    b.triangle(c[1], c[5], c[6], red); b.triangle(c[6], c[2], c[1], red)           # right
+    if not background:
+        b.triangle(c[2], c[6], c[7], white); b.triangle(c[7], c[3], c[2], white)   # ceiling
+    if spheres:
+        b.sphere((-0.5, 0.3, -0.75), 0.4, mirror)
+        b.sphere((0.55, -0.2, -0.8), 0.35, glass)
+    if sun:
+        b.directional_light((-1.0, 1.5, -1.0), (10.0, 4.0, 0.0))
+    elif background:
+        b.background_light(1.0)
+    else:
+        q = [(-0.25, -0.25, 1.2), (0.25, -0.25, 1.2), (0.25, 0.25, 1.2), (-0.25, 0.25, 1.2)]
+        b.emissive_triangle(q[0], q[1], q[2], (25.0, 25.0, 25.0))
+        b.emissive_triangle(q[2], q[3], q[0], (25.0, 25.0, 25.0))
+    return b.build((-0.0439815, -4.12529, 0.222539), (0.00688625, 0.998505, -0.0542161), (3.73896e-4, 0.0542148, 0.998529), 45.0,
+                   resx, resy)

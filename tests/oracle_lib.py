@@ -4,7 +4,7 @@ import ctypes as C
 import os
 import numpy as np
 
-from smallvcm_amd._abi import SceneDesc, Stats, VCM_MERGE_RECORD_FLOATS
+from smallvcm_amd._abi import SceneDesc, SceneDesc2, Stats, VCM_MERGE_RECORD_FLOATS
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -32,6 +32,8 @@ def oracle():
         L = C.CDLL(ORACLE_SO)
         L.oracle_create.restype = C.c_void_p
         L.oracle_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.oracle_create2.restype = C.c_void_p
+        L.oracle_create2.argtypes = [C.POINTER(SceneDesc2), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         for n in ("oracle_destroy", "oracle_trace_light", "oracle_build_grid", "oracle_trace_camera",
                   "oracle_end_iteration"):
             getattr(L, n).argtypes = [C.c_void_p]
@@ -73,7 +75,8 @@ class Oracle:
     def __init__(self, scene, algo, radius_factor=0.003, radius_alpha=0.75, seed=1234, rank=0, world=1, threads=1):
         self.L = oracle()
         self.scene = scene
-        self.h = self.L.oracle_create(C.byref(scene), algo, radius_factor, radius_alpha, seed, rank, world)
+        create = self.L.oracle_create2 if isinstance(scene, SceneDesc2) else self.L.oracle_create
+        self.h = create(C.byref(scene), algo, radius_factor, radius_alpha, seed, rank, world)
         self.resx = int(scene.camera.resolution[0])
         self.resy = int(scene.camera.resolution[1])
         self.N = self.resx * self.resy
@@ -204,6 +207,30 @@ def ref_run_tape(mask, resx, resy, algo, light_counts, cam_counts, radius_factor
     bad = ref_tape().ref_run_tape(mask, resx, resy, algo, radius_factor, radius_alpha, seed, first_iteration, n_iter,
                                   min_len, max_len, _bptr(lc), _bptr(cc), _fptr(fb), C.byref(consumed))
     return fb, consumed.value, bad
+
+
+def ref_run_tape2(scene2, algo, light_counts, cam_counts, radius_factor=0.003, radius_alpha=0.75, seed=1234,
+                  first_iteration=0, n_iter=1, min_len=0, max_len=10):
+    """ref_run_tape for a version-2 scene: the harness builds a reference Scene from the arrays with the reference's own
+    constructors and refuses (rc <= -100) if a derived member of the description is not what they produce."""
+    L = ref_tape()
+    L.ref_run_tape2.argtypes = [C.POINTER(SceneDesc2), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint,
+                                _u8p, _u8p, _fp, C.POINTER(C.c_longlong)]
+    resx, resy = int(scene2.camera.resolution[0]), int(scene2.camera.resolution[1])
+    lc = np.ascontiguousarray(light_counts, np.uint8)
+    cc = np.ascontiguousarray(cam_counts, np.uint8)
+    assert lc.size == n_iter * resx * resy and cc.size == lc.size
+    fb = np.zeros((resy, resx, 3), np.float32)
+    consumed = C.c_longlong()
+    bad = L.ref_run_tape2(C.byref(scene2), algo, radius_factor, radius_alpha, seed, first_iteration, n_iter, min_len, max_len,
+                          _bptr(lc), _bptr(cc), _fptr(fb), C.byref(consumed))
+    return fb, consumed.value, bad
+
+
+def ref_check_scene2(scene2):
+    L = ref_tape()
+    L.ref_check_scene2.argtypes = [C.POINTER(SceneDesc2)]
+    return L.ref_check_scene2(C.byref(scene2))
 
 
 def ref_render_stock(mask, resx, resy, algo, iterations=1, threads=1, seed=1234, min_len=0, max_len=10,

@@ -1,0 +1,195 @@
+"""Version-2 scenes (vcm_scene_desc2): any number of primitives, traced through a BVH.
+
+not gpu
+  * the library's constructors (vcm_make_*) build, bit for bit, what the REFERENCE's constructors build;
+  * the oracle (brute force over every primitive, like the reference) equals the unmodified reference run on a Scene the
+    harness assembles from the same arrays;
+  * the product's device functions compiled for the host -- INCLUDING the BVH traversal -- equal the oracle: closest
+    hit with the reference's tie rule, occlusion, whole iterations.
+gpu: the same on the device, with a scene of more than 10 000 triangles."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from emul_lib import Emul, emul
+from mesh_scenes import bumpy_room
+from oracle_lib import Oracle
+from smallvcm_amd._abi import Camera, Light, Prim, SceneDesc2
+
+needs_ref = pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+_fp = C.POINTER(C.c_float)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+@needs_ref
+def test_constructors_equal_the_reference_constructors():
+    from smallvcm_amd.renderer import load_library
+    L, R = load_library(require_gpu=False), oracle_lib.ref_tape()
+    for lib, pre in ((L, "vcm_make_"), (R, "ref_make_")):
+        getattr(lib, pre + "triangle").argtypes = [_fp, _fp, _fp, C.c_int, C.POINTER(Prim)]
+        getattr(lib, pre + "area_light").argtypes = [_fp, _fp, _fp, _fp, C.POINTER(Light)]
+        getattr(lib, pre + "directional_light").argtypes = [_fp, _fp, C.POINTER(Light)]
+        getattr(lib, pre + "camera").argtypes = [_fp, _fp, _fp, C.c_float, C.c_int, C.c_int, C.POINTER(Camera)]
+    rng = np.random.default_rng(11)
+    for _ in range(2000):
+        p = (rng.random((3, 3)) * 4 - 2).astype(np.float32)
+        a, b = Prim(), Prim()
+        L.vcm_make_triangle(_f3(p[0]), _f3(p[1]), _f3(p[2]), 3, C.byref(a))
+        R.ref_make_triangle(_f3(p[0]), _f3(p[1]), _f3(p[2]), 3, C.byref(b))
+        assert bytes(a) == bytes(b)
+        la, lb = Light(), Light()
+        L.vcm_make_area_light(_f3(p[0]), _f3(p[1]), _f3(p[2]), _f3((1, 2, 3)), C.byref(la))
+        R.ref_make_area_light(_f3(p[0]), _f3(p[1]), _f3(p[2]), _f3((1, 2, 3)), C.byref(lb))
+        assert bytes(la) == bytes(lb)
+        L.vcm_make_directional_light(_f3(p[0]), _f3((1, 2, 3)), C.byref(la))
+        R.ref_make_directional_light(_f3(p[0]), _f3((1, 2, 3)), C.byref(lb))
+        assert bytes(la) == bytes(lb)
+    for _ in range(200):
+        pos, fwd = (rng.random(3) * 6 - 3).astype(np.float32), (rng.random(3) * 2 - 1).astype(np.float32)
+        up = np.float32([0.01, 0.02, 1.0])
+        ca, cb = Camera(), Camera()
+        fov, rx, ry = float(rng.random() * 60 + 20), int(rng.integers(16, 2048)), int(rng.integers(16, 2048))
+        assert L.vcm_make_camera(_f3(pos), _f3(fwd), _f3(up), fov, rx, ry, C.byref(ca)) == 0
+        R.ref_make_camera(_f3(pos), _f3(fwd), _f3(up), fov, rx, ry, C.byref(cb))
+        assert bytes(ca) == bytes(cb)
+
+
+@needs_ref
+def test_a_built_scene_is_what_the_reference_would_hold():
+    for kw in ({}, {"sun": True}, {"background": True, "spheres": False}):
+        assert oracle_lib.ref_check_scene2(bumpy_room(grid=6, **kw)) == 0
+
+
+def _kat_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    a = np.zeros((n, 16), np.float32)
+    a[:, 0:3] = (rng.random((n, 3)) * 2.3 - 1.15).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    a[:, 3:6] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    k = n // 6   # grid-aligned origins and axis-parallel directions: shared edges and vertices of the floor mesh
+    a[:k, 0:2] = np.round(a[:k, 0:2] * 12) / 12 * np.float32(1.25 / 1.0)
+    a[k:2 * k, 3:6] = np.float32([0, 0, -1])
+    return a
+
+
+@needs_ref
+@pytest.mark.parametrize("op,name", [(0, "intersect"), (1, "occluded")])
+def test_bvh_traversal_on_the_host_equals_the_reference_walk(op, name):
+    """Scene::Intersect / Occluded of the unmodified reference (every primitive, list order) against the product's BVH
+    traversal (device functions compiled for the host): hit distance, normal, material, light -- bit for bit, the tie
+    rule at shared edges included."""
+    sc = bumpy_room(grid=20)
+    assert sc.nPrims > 800
+    rays = _kat_rays(30000, 3 + op)
+    if op == 1:
+        rays[:, 6] = (np.random.default_rng(9).random(len(rays)) * 3).astype(np.float32)
+    want, mine = np.zeros_like(rays), np.zeros_like(rays)
+    R, E = oracle_lib.ref_tape(), emul()
+    R.ref_kat2.argtypes = [C.POINTER(SceneDesc2), C.c_int, C.c_int, _fp, _fp]
+    E.emul_kat2.argtypes = [C.POINTER(SceneDesc2), C.c_int, C.c_int, _fp, _fp]
+    assert R.ref_kat2(C.byref(sc), op, len(rays), rays.ctypes.data_as(_fp), want.ctypes.data_as(_fp)) == 0
+    E.emul_kat2(C.byref(sc), op, len(rays), rays.ctypes.data_as(_fp), mine.ctypes.data_as(_fp))
+    bad = np.nonzero((want.view(np.uint32) != mine.view(np.uint32)).any(axis=1))[0]
+    assert len(bad) == 0, (name, len(bad), bad[:5])
+    assert want[:, 0].sum() > 100
+
+
+MESH_CASES = [({"grid": 10}, 4, 48, 2), ({"grid": 12, "sun": True}, 4, 40, 1), ({"grid": 8, "background": True, "spheres": False}, 4, 40, 1),
+              ({"grid": 10}, 2, 40, 1), ({"grid": 10}, 3, 40, 1), ({"grid": 9}, 5, 48, 2), ({"grid": 10}, 0, 40, 1)]
+
+
+@needs_ref
+@pytest.mark.parametrize("kw,algo,res,nit", MESH_CASES)
+def test_oracle_equals_reference_on_mesh_scenes(kw, algo, res, nit):
+    sc = bumpy_room(resx=res, resy=res, **kw)
+    o = Oracle(sc, algo, threads=8)
+    lcs, ccs = [], []
+    for it in range(nit):
+        o.run_iteration(it, 0, 10)
+        a, b = o.counts()
+        lcs.append(a)
+        ccs.append(b)
+    fb, consumed, bad = oracle_lib.ref_run_tape2(sc, algo, np.concatenate(lcs), np.concatenate(ccs), n_iter=nit)
+    assert bad == 0
+    assert np.array_equal(fb.view(np.uint32), o.framebuffer().view(np.uint32))
+    assert fb.max() > 0
+
+
+@pytest.mark.parametrize("kw,algo,res,nit", MESH_CASES)
+def test_device_functions_with_bvh_equal_oracle_on_mesh_scenes(kw, algo, res, nit):
+    sc = bumpy_room(resx=res, resy=res, **kw)
+    o, e = Oracle(sc, algo, threads=8), Emul(sc, algo)
+    for it in range(nit):
+        o.run_iteration(it, 0, 10)
+        e.run_iteration(it, 0, 10)
+    assert np.array_equal(o.framebuffer().view(np.uint32), e.framebuffer().view(np.uint32))
+    for a, b in zip(o.counts(), e.counts()):
+        assert np.array_equal(a, b)
+    so, se = o.stats(), e.stats()
+    for k in se:
+        assert so[k] == se[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,algo,res,nit", [(72, 4, 128, 2), (72, 2, 96, 1), (40, 5, 128, 2), (72, 3, 96, 1)])
+def test_gpu_mesh_scene_through_the_bvh_equals_oracle_and_reference(grid, algo, res, nit):
+    """> 10 000 triangles on the GPU (BVH) against the oracle's brute force -- tape, counters, framebuffer bit for bit --
+    and, through the tape, against the unmodified reference."""
+    from smallvcm_amd.renderer import VertexCM
+    sc = bumpy_room(grid=grid, resx=res, resy=res)
+    assert sc.nPrims > (10000 if grid >= 72 else 3000)
+    import os
+    o = Oracle(sc, algo, threads=os.cpu_count() or 1)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r.mMaxPathLength = 10
+    lcs, ccs = [], []
+    for it in range(nit):
+        o.run_iteration(it, 0, 10)
+        r.RunIteration(it)
+        lc, cc = r.backend.rng_counts()
+        olc, occ = o.counts()
+        assert np.array_equal(lc, olc) and np.array_equal(cc, occ)
+        lcs.append(lc)
+        ccs.append(cc)
+        so, sg = o.stats(), r.stats()
+        for k in ("lightVertices", "lightRays", "cameraRays", "shadowRays", "mergeQueries", "mergeCandidates", "mergeAccepted",
+                  "connections", "lightSplats"):
+            assert so[k] == sg[k], (k, so[k], sg[k])
+    fb = r.framebuffer_sum()
+    r.close()
+    assert np.array_equal(fb.view(np.uint32), o.framebuffer().view(np.uint32))
+    assert fb.max() > 0
+    if oracle_lib.have_ref() and res <= 96:
+        rfb, consumed, bad = oracle_lib.ref_run_tape2(sc, algo, np.concatenate(lcs), np.concatenate(ccs), n_iter=nit)
+        assert bad == 0
+        assert np.array_equal(fb.view(np.uint32), rfb.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_cornell_scenes_through_a_forced_bvh_equal_brute_force():
+    """SMALLVCM_AMD_FORCE_BVH=1 sends the built-in boxes (spheres resting on the floor included) through the BVH: same
+    image as the list walk."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from smallvcm_amd.renderer import VertexCM, cornell_scene\n"
+            "out = []\n"
+            "for sid in range(4):\n"
+            "    r = VertexCM(cornell_scene(sid, 96, 96), 4, 0.003, 0.75, 1234); r.mMaxPathLength = 10\n"
+            "    r.RunIteration(0); r.RunIteration(1); out.append(r.framebuffer_sum()); r.close()\n"
+            "np.save(sys.argv[1], np.stack(out))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    d = tempfile.mkdtemp()
+    imgs = []
+    for force in ("0", "1"):
+        path = os.path.join(d, "fb%s.npy" % force)
+        env = dict(os.environ, SMALLVCM_AMD_FORCE_BVH=force)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        imgs.append(np.load(path))
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
