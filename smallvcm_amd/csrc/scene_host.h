@@ -35,14 +35,16 @@ struct SceneHost {
     std::vector<BvhNode> nodes;
     std::vector<int> leafPrims;
 
-    /* the view the device functions take; pointers into THIS object's arrays (host emulation) */
-    DScene view() const
+    /* the view the device functions take, filled IN PLACE: the arrays are addressed relative to the DScene object
+       itself (vcm_core.h), so `d` must stay where it is while it is in use (host emulation) */
+    void view(DScene &d) const
     {
-        DScene d;
         fill_scalars(d);
-        d.prims = prims.data(); d.materials = materials.data(); d.mat2light = mat2light.data(); d.lights = lights.data();
-        d.ops = ops.data(); d.pairs = pairs.data(); d.nodes = nodes.data(); d.leafPrims = leafPrims.data();
-        return d;
+        const char *base = reinterpret_cast<const char *>(&d);
+        d.offPrims = (const char *)prims.data() - base; d.offMaterials = (const char *)materials.data() - base;
+        d.offMat2light = (const char *)mat2light.data() - base; d.offLights = (const char *)lights.data() - base;
+        d.offOps = (const char *)ops.data() - base; d.offPairs = (const char *)pairs.data() - base;
+        d.offNodes = (const char *)nodes.data() - base; d.offLeafPrims = (const char *)leafPrims.data() - base;
     }
     void fill_scalars(DScene &d) const
     {

@@ -110,6 +110,12 @@ static std::atomic<unsigned long long> g_threadCounter{0};
 static thread_local unsigned long long g_threadId = 0;
 static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_threadCounter; return g_threadId; }
 
+/* Kernels that cast rays exist once per kind of scene (vcm_core.h SceneList / SceneBvh); the launch picks. */
+#define LAUNCH_SC(c, K, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<SceneBvh>), __VA_ARGS__); \
+                                  else hipLaunchKernelGGL((K<SceneList>), __VA_ARGS__); } while (0)
+#define LAUNCH_SC_MODE(c, K, M, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<M, SceneBvh>), __VA_ARGS__); \
+                                          else hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); } while (0)
+
 struct vcm_ctx : Scratch {
     SceneHost *scene;                 /* host copy of the scene + the structure the intersection code walks */
     bool useVM, useVC, lightTraceOnly, ppm;
@@ -129,8 +135,8 @@ struct vcm_ctx : Scratch {
     Arena *arena; bool holdsArena;    /* the arena of the current / last iteration */
 
     /* per context: survives the iteration */
-    DScene *dScene;                   /* the scene view in device memory (pointers into dSceneBlob) */
-    char *dSceneBlob;                 /* primitives, materials, lights, pairs / BVH: one allocation */
+    DScene *dScene;                   /* the scene header in device memory = the start of dSceneBlob */
+    char *dSceneBlob;                 /* header, primitives, materials, lights, pairs / BVH: one allocation */
     float *dFb;                       /* N*3, running sum (mFramebuffer, renderer.hxx:68) */
     unsigned char *dRngLight, *dRngCam;   /* the random-number tape of the last iteration */
     GridHeader *dHdr;
@@ -392,25 +398,25 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evBbox, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
-        {   /* scene arrays in ONE device allocation, then the view of device pointers */
+        {   /* the scene in ONE device allocation: the DScene header, then the arrays it addresses by offset */
             const SceneHost &h = *c->scene;
             struct Part { const void *src; size_t bytes; size_t off; } parts[8] = {
                 { h.prims.data(), h.prims.size() * sizeof(vcm_prim), 0 }, { h.materials.data(), h.materials.size() * sizeof(vcm_material), 0 },
                 { h.mat2light.data(), h.mat2light.size() * sizeof(int), 0 }, { h.lights.data(), h.lights.size() * sizeof(vcm_light), 0 },
                 { h.ops.data(), h.ops.size() * sizeof(PrimOp), 0 }, { h.pairs.data(), h.pairs.size() * sizeof(TriPair), 0 },
                 { h.nodes.data(), h.nodes.size() * sizeof(BvhNode), 0 }, { h.leafPrims.data(), h.leafPrims.size() * sizeof(int), 0 } };
-            size_t total = 0;
+            size_t total = (sizeof(DScene) + 255) & ~(size_t)255;
             for (Part &p : parts) { p.off = total; total += (p.bytes + 255) & ~(size_t)255; }
             if (dalloc(&c->dSceneBlob, total + 256)) return -1;
             for (const Part &p : parts)
                 if (p.bytes) HIPCHK(hipMemcpy(c->dSceneBlob + p.off, p.src, p.bytes, hipMemcpyHostToDevice));
             DScene view;
             h.fill_scalars(view);
-            view.prims = (const vcm_prim *)(c->dSceneBlob + parts[0].off); view.materials = (const vcm_material *)(c->dSceneBlob + parts[1].off);
-            view.mat2light = (const int *)(c->dSceneBlob + parts[2].off); view.lights = (const vcm_light *)(c->dSceneBlob + parts[3].off);
-            view.ops = (const PrimOp *)(c->dSceneBlob + parts[4].off); view.pairs = (const TriPair *)(c->dSceneBlob + parts[5].off);
-            view.nodes = (const BvhNode *)(c->dSceneBlob + parts[6].off); view.leafPrims = (const int *)(c->dSceneBlob + parts[7].off);
-            if (dalloc(&c->dScene, 1)) return -1;
+            view.offPrims = (long long)parts[0].off; view.offMaterials = (long long)parts[1].off;
+            view.offMat2light = (long long)parts[2].off; view.offLights = (long long)parts[3].off;
+            view.offOps = (long long)parts[4].off; view.offPairs = (long long)parts[5].off;
+            view.offNodes = (long long)parts[6].off; view.offLeafPrims = (long long)parts[7].off;
+            c->dScene = reinterpret_cast<DScene *>(c->dSceneBlob);
             HIPCHK(hipMemcpy(c->dScene, &view, sizeof(DScene), hipMemcpyHostToDevice));
         }
         if (dalloc(&c->dFb, (size_t)c->N * 3)) return -1;
@@ -709,7 +715,7 @@ void vcm_destroy(vcm_ctx *c)
     delete c->scene;
     c->scene = NULL;
     if (c->deviceReady) {
-        DFREE(c->dScene); DFREE(c->dSceneBlob); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
+        c->dScene = NULL; DFREE(c->dSceneBlob); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         (void)hipStreamSynchronize(c->side);
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
@@ -831,7 +837,7 @@ static int flush_light_splats(vcm_ctx *c)
         int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart;
         F4 *list = (F4 *)c->dUnsorted;   /* 16-byte elements, like the cell list it is later used for */
         HIPCHK(hipMemsetAsync(pixCount, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
+        LAUNCH_SC(c, k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
                            arrival, c->dStats);
         if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
@@ -862,10 +868,10 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     if (mark(c, EV_LIGHT_K0)) return -1;
     const bool wf = !c->strictOrder;
     if (wf)
-        hipLaunchKernelGGL(k_light_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
+        LAUNCH_SC_MODE(c, k_light_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
                            c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream));
     else
-        hipLaunchKernelGGL(k_light_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
+        LAUNCH_SC_MODE(c, k_light_trace, 0, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
                            c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream));
     HIPCHK(hipGetLastError());
     if (mark(c, EV_LIGHT_K1)) return -1;
@@ -1086,10 +1092,10 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     if (mark(c, EV_CAMERA_K0)) return -1;
     if (c->renderer) {   /* PathTracer / EyeLight: colour + jittered pixel per path; K5 adds them in path order */
         if (c->renderer == 1)
-            hipLaunchKernelGGL(k_path_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->dCamOut,
+            LAUNCH_SC(c, k_path_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->dCamOut,
                                c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         else
-            hipLaunchKernelGGL(k_eye_light, dim3(2048), dim3(256), 0, c->stream, c->dScene, c->P, c->dCamOut, c->dRngCam,
+            LAUNCH_SC(c, k_eye_light, dim3(2048), dim3(256), 0, c->stream, c->dScene, c->P, c->dCamOut, c->dRngCam,
                                c->dStats, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
         if (mark(c, EV_CAMERA_K1)) return -1;
@@ -1105,7 +1111,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
         if (c->countedInCamera) HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)c->P.nBuckets + 1) * sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_camera_trace<1>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+        LAUNCH_SC_MODE(c, k_camera_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
@@ -1113,16 +1119,16 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
-            hipLaunchKernelGGL(k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+            LAUNCH_SC(c, k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
                                c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
-            hipLaunchKernelGGL(k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+            LAUNCH_SC(c, k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->store, c->dStats);
         }
         if (mark(c, EV_CONNECT_K1)) return -1;
     } else {
         if (c->useVM && !c->gridBuilt) return fail("vcm_trace_camera", "strict mode merges inside the camera pass: call vcm_build_grid first");
-        hipLaunchKernelGGL(k_camera_trace<0>, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
+        LAUNCH_SC_MODE(c, k_camera_trace, 0, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (mark(c, EV_CONNECT_K1)) return -1;
@@ -1449,13 +1455,14 @@ __global__ void k_numeric_spec(int op, int n, const float *a, const float *b, fl
     }
     out[i] = r;
 }
+template <class SC>
 __global__ void k_kat(const DScene *__restrict__ scp, int op, int n, const float *in, float *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float a[VCM_KAT_FLOATS], r[VCM_KAT_FLOATS];
     for (int k = 0; k < VCM_KAT_FLOATS; k++) a[k] = in[(size_t)i * VCM_KAT_FLOATS + k];
-    kat_eval(*scp, op, a, r);
+    kat_eval(*static_cast<const SC *>(scp), op, a, r);
     for (int k = 0; k < VCM_KAT_FLOATS; k++) out[(size_t)i * VCM_KAT_FLOATS + k] = r[k];
 }
 __global__ void k_philox_spec(uint32_t seed, uint32_t iter, uint32_t kind, int nPaths, int nFloats, float *out)
@@ -1494,7 +1501,7 @@ int vcm_debug_kat(vcm_ctx *c, int op, int n, const float *in, float *out)
     HIPCHK(hipMalloc((void **)&din, bytes));
     HIPCHK(hipMalloc((void **)&dout, bytes));
     HIPCHK(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat, dim3((n + 63) / 64), dim3(64), 0, 0, (const DScene *)c->dScene, op, n, (const float *)din, dout);
+    LAUNCH_SC(c, k_kat, dim3((n + 63) / 64), dim3(64), 0, 0, (const DScene *)c->dScene, op, n, (const float *)din, dout);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(din); (void)hipFree(dout);

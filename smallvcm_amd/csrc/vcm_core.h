@@ -202,26 +202,39 @@ struct alignas(16) BvhNode {
     float bmax[3]; int leaf;          /* -1: inner node; else (first << 4) | count into leafPrims, count <= 15 */
 };
 
-/* The scene as the device functions see it.  Member names are those of vcm_scene_desc (the C-ABI struct the scene
- * arrives in), but primitives, materials and lights are POINTERS: the same code serves the reference's built-in
- * boxes (<= 32 primitives, brute force in list order over packed triangle pairs) and arbitrary scenes
- * (vcm_scene_desc2: any counts, BVH).  Built by scene_host.h, uploaded once per context. */
+/* The scene as the device functions see it.  Scalars are those of vcm_scene_desc (the C-ABI struct the scene arrives
+ * in); primitives, materials, lights and the structure the intersection code walks are arrays of any length, so the
+ * same code serves the reference's built-in boxes (<= 32 primitives, brute force in list order over packed triangle
+ * pairs) and arbitrary scenes (vcm_scene_desc2: any counts, BVH).  Built by scene_host.h, uploaded once per context.
+ *
+ * The arrays are addressed as BYTE OFFSETS FROM THIS STRUCT, not through stored pointers: a kernel gets the scene as
+ * `const DScene *__restrict__`, and only addresses derived from that argument carry its no-alias guarantee.  With
+ * pointer members the compiler has to assume that any store of the kernel may overwrite the triangle data, so it
+ * re-reads it with per-lane VECTOR loads into VGPRs instead of scalar loads into SGPRs (the list index is
+ * wave-uniform): K3 122 -> 133 registers, 4 -> 3 waves per SIMD, 713 -> 576 Mpaths/s on the same box (r02g). */
 struct DScene {
     int nPrims, nMaterials, nLights, backgroundLight;
-    const vcm_prim *prims;
-    const vcm_material *materials;
-    const int *mat2light;
-    const vcm_light *lights;
     float sceneCenter[3], sceneRadius, invSceneRadiusSqr;
     vcm_camera camera;
-    /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0) */
+    /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0); BVH: nNodes > 0 */
     int nOps, nNodes;
-    const PrimOp *ops;
-    const TriPair *pairs;
-    /* BVH (nNodes > 0) */
-    const BvhNode *nodes;
-    const int *leafPrims;
+    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims;
+    template <class T> VCM_HD const T *at(long long off) const { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(this) + off); }
+    VCM_HD const vcm_prim *prims() const { return at<vcm_prim>(offPrims); }
+    VCM_HD const vcm_material *materials() const { return at<vcm_material>(offMaterials); }
+    VCM_HD const int *mat2light() const { return at<int>(offMat2light); }
+    VCM_HD const vcm_light *lights() const { return at<vcm_light>(offLights); }
+    VCM_HD const PrimOp *ops() const { return at<PrimOp>(offOps); }
+    VCM_HD const TriPair *pairs() const { return at<TriPair>(offPairs); }
+    VCM_HD const BvhNode *nodes() const { return at<BvhNode>(offNodes); }
+    VCM_HD const int *leafPrims() const { return at<int>(offLeafPrims); }
 };
+/* Which of the two a scene carries, as a TYPE: every kernel that casts rays exists once per kind (the launch picks by
+ * nNodes), so the brute-force kernels hold no traversal code and the BVH kernels no list loop.  Compiled together the
+ * two paths cost the headline kernels 11-27 VGPRs, i.e. a wave per SIMD (K3 122 -> 133 registers: 713 -> 576
+ * Mpaths/s on the same box, profiles/r02g_*).  Functions that cast rays take `const SC &`, the rest `const DScene &`. */
+struct SceneList : DScene { static constexpr bool kBvh = false; };
+struct SceneBvh : DScene { static constexpr bool kBvh = true; };
 
 /* ---- utils.hxx ---------------------------------------------------- */
 VCM_HD float luminance(V3 c)
@@ -476,7 +489,7 @@ VCM_HD bool list_intersect(const DScene &sc, const Ray &ray, Isect &res)
 {
     bool any = false;
     for (int pi = 0; pi < sc.nPrims; pi++) {
-        const vcm_prim &pr = sc.prims[pi];
+        const vcm_prim &pr = sc.prims()[pi];
         if (pr.type == VCM_PRIM_TRIANGLE) {
             float distance;
             const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
@@ -485,7 +498,7 @@ VCM_HD bool list_intersect(const DScene &sc, const Ray &ray, Isect &res)
             }
         } else if (sph_intersect(pr, pi, ray, res)) any = true;
     }
-    if (any) res.lightID = sc.mat2light[res.matID];
+    if (any) res.lightID = sc.mat2light()[res.matID];
     return any;
 }
 
@@ -506,13 +519,13 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
     bool any = false, ambiguous = false, bestIsSphere = false;
     int node = 0;
     while (node < sc.nNodes) {
-        const BvhNode nd = sc.nodes[node];
+        const BvhNode nd = sc.nodes()[node];
         if (!bvh_box_hit(nd, ray.org, invDir, res.dist)) { node = nd.escape; continue; }
         if (nd.leaf >= 0) {
             const int first = nd.leaf >> 4, count = nd.leaf & 15;
             for (int k = 0; k < count; k++) {
-                const int pi = sc.leafPrims[first + k];
-                const vcm_prim &pr = sc.prims[pi];
+                const int pi = sc.leafPrims()[first + k];
+                const vcm_prim &pr = sc.prims()[pi];
                 if (pr.type == VCM_PRIM_TRIANGLE) {
                     float distance;
                     const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
@@ -540,7 +553,7 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
         node++;
     }
     if (ambiguous) { res = start; return list_intersect(sc, ray, res); }
-    if (any) res.lightID = sc.mat2light[res.matID];
+    if (any) res.lightID = sc.mat2light()[res.matID];
     return any;
 }
 
@@ -551,13 +564,13 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
     bool occluded = false;
     int node = 0;
     while (node < sc.nNodes && !occluded) {
-        const BvhNode nd = sc.nodes[node];
+        const BvhNode nd = sc.nodes()[node];
         if (!bvh_box_hit(nd, ray.org, invDir, tmaxp)) { node = nd.escape; continue; }
         if (nd.leaf >= 0) {
             const int first = nd.leaf >> 4, count = nd.leaf & 15;
             for (int k = 0; k < count; k++) {
-                const int pi = sc.leafPrims[first + k];
-                const vcm_prim &pr = sc.prims[pi];
+                const int pi = sc.leafPrims()[first + k];
+                const vcm_prim &pr = sc.prims()[pi];
                 if (pr.type == VCM_PRIM_TRIANGLE) {
                     float distance;
                     const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
@@ -576,38 +589,40 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
 /* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78): brute force in list order for
  * the reference's own scenes (<= 32 primitives; the op index is wave-uniform, so the primitive data comes in through
  * scalar loads), the BVH for larger ones. */
-VCM_HD bool scene_intersect(const DScene &sc, const Ray &ray, Isect &res)
+template <class SC>
+VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
 {
-    if (sc.nNodes > 0) return bvh_intersect(sc, ray, res);
+    if constexpr (SC::kBvh) return bvh_intersect(sc, ray, res);
     bool any = false;
     for (int i = 0; i < sc.nOps; i++) {
-        const PrimOp op = sc.ops[i];
-        const bool hit = (op.kind == 0) ? tri_pair_intersect(sc.pairs[op.index], ray, res)
-                                        : sph_intersect(sc.prims[op.index], op.index, ray, res);
+        const PrimOp op = sc.ops()[i];
+        const bool hit = (op.kind == 0) ? tri_pair_intersect(sc.pairs()[op.index], ray, res)
+                                        : sph_intersect(sc.prims()[op.index], op.index, ray, res);
         if (hit) any = hit;
     }
-    if (any) res.lightID = sc.mat2light[res.matID];
+    if (any) res.lightID = sc.mat2light()[res.matID];
     return any;
 }
 /* Scene::Occluded scene.hxx:72-85 (+ GeometryList::IntersectP geometry.hxx:80-91) */
-VCM_HD bool scene_occluded(const DScene &sc, V3 point, V3 dir, float tmax)
+template <class SC>
+VCM_HD bool scene_occluded(const SC &sc, V3 point, V3 dir, float tmax)
 {
     Ray ray;
     ray.org = point + dir * VCM_EPS_RAY;
     ray.dir = dir;
     ray.tmin = 0;
     const float tmaxp = tmax - 2 * VCM_EPS_RAY;
-    if (sc.nNodes > 0) return bvh_occluded(sc, ray, tmaxp);
+    if constexpr (SC::kBvh) return bvh_occluded(sc, ray, tmaxp);
     bool occluded = false;
     for (int i = 0; i < sc.nOps; i++) {
-        const PrimOp op = sc.ops[i];
+        const PrimOp op = sc.ops()[i];
         if (!occluded) {
             bool hit;
-            if (op.kind == 0) hit = tri_pair_occluded(sc.pairs[op.index], ray.org, ray.dir, tmaxp);
+            if (op.kind == 0) hit = tri_pair_occluded(sc.pairs()[op.index], ray.org, ray.dir, tmaxp);
             else {
                 Isect isect;
                 isect.dist = tmaxp; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
-                hit = sph_intersect(sc.prims[op.index], op.index, ray, isect);
+                hit = sph_intersect(sc.prims()[op.index], op.index, ray, isect);
             }
             if (hit) occluded = true;
         }
@@ -656,7 +671,7 @@ VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, int prim, const
     frame_from_z(b.frame, normal);
     b.localDirFix = to_local(b.frame, -rayDir);
     if (fabsf(b.localDirFix.z) < VCM_EPS_COSINE) return;
-    bsdf_component_probabilities(b, sc.materials[matID]);
+    bsdf_component_probabilities(b, sc.materials()[matID]);
     b.isDelta = (b.diffProb == 0.f) && (b.phongProb == 0.f);
     b.matID = matID;
 }
@@ -669,7 +684,7 @@ VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, uint32_t code, cons
     const int matID = (int)(code & 0xffffffu);
     frame_from_z(b.frame, normal);
     b.localDirFix = localDirFix;
-    bsdf_component_probabilities(b, sc.materials[matID]);
+    bsdf_component_probabilities(b, sc.materials()[matID]);
     b.isDelta = false;
     b.matID = matID;
 }
@@ -724,7 +739,7 @@ VCM_HD V3 bsdf_evaluate(const Bsdf &b, const DScene &sc, V3 worldDirGen, float &
     const V3 gen = to_local(b.frame, worldDirGen);
     if (gen.z * b.localDirFix.z < 0.f) return result;
     cosThetaGen = fabsf(gen.z);
-    const vcm_material &m = sc.materials[b.matID];
+    const vcm_material &m = sc.materials()[b.matID];
     result = result + bsdf_eval_diffuse(b, m, gen, dirPdf, revPdf);
     result = result + bsdf_eval_phong(b, m, gen, dirPdf, revPdf);
     return result;
@@ -733,7 +748,7 @@ VCM_HD float bsdf_pdf(const Bsdf &b, const DScene &sc, V3 worldDirGen, bool eval
 {   /* Pdf :161-180 */
     const V3 gen = to_local(b.frame, worldDirGen);
     if (gen.z * b.localDirFix.z < 0.f) return 0.f;
-    const vcm_material &m = sc.materials[b.matID];
+    const vcm_material &m = sc.materials()[b.matID];
     float directPdfW = 0.f, reversePdfW = 0.f;
     bsdf_pdf_diffuse(b, gen, &directPdfW, &reversePdfW);
     bsdf_pdf_phong(b, m, gen, &directPdfW, &reversePdfW);
@@ -749,7 +764,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0
     else if (r2 < b.diffProb + b.phongProb + b.reflProb) sampledEvent = kReflect;
     else sampledEvent = kRefract;
 
-    const vcm_material &m = sc.materials[b.matID];
+    const vcm_material &m = sc.materials()[b.matID];
     pdfW = 0.f;
     V3 result = sp3(0.f);
     V3 gen = sp3(0.f);
@@ -818,7 +833,7 @@ VCM_HD bool light_is_delta(const vcm_light &l) { return l.type == VCM_LIGHT_DIRE
 VCM_HD const vcm_light &get_light(const DScene &sc, int idx)
 {   /* Scene::GetLightPtr scene.hxx:98-102 */
     idx = (sc.nLights - 1 < idx) ? sc.nLights - 1 : idx;
-    return sc.lights[idx];
+    return sc.lights()[idx];
 }
 
 VCM_HD V3 light_illuminate(const vcm_light &l, const DScene &sc, V3 recvPos, float rx, float ry,
@@ -1020,7 +1035,8 @@ VCM_HD void generate_light_sample(const DScene &sc, const IterParams &P, PathRng
 /* splatOut == NULL: the splat is an fp32 atomic add on fb (strict mode);
  * otherwise *splatOut receives (contrib.rgb, pixel) -- pixel -1 when nothing is
  * splatted -- and k_splat_apply adds the splats of a pixel in vertex order. */
-VCM_HD void connect_to_camera(const DScene &sc, const IterParams &P, const SubPathState &st, V3 hitpoint,
+template <class SC>
+VCM_HD void connect_to_camera(const SC &sc, const IterParams &P, const SubPathState &st, V3 hitpoint,
                               const Bsdf &bsdf, float *fb, LaneStats &ls, F4 *splatOut = 0)
 {
     if (splatOut) *splatOut = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
@@ -1082,8 +1098,8 @@ VCM_HD void light_path_begin(const DScene &sc, const IterParams &P, LightPath &l
 /* one iteration of the for(;;) at :328-393; returns false when the path ends.
  * MODE 1 (wavefront): ConnectToCamera (:380-384) is left to k_connect_camera,
  * which runs it for every stored vertex. */
-template <int MODE>
-VCM_HD bool light_path_step(const DScene &sc, const IterParams &P, LightPath &lp, const LightStore &store,
+template <int MODE, class SC>
+VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, const LightStore &store,
                             float *fb, LaneStats &ls)
 {
     SubPathState &st = lp.st;
@@ -1124,7 +1140,8 @@ VCM_HD bool light_path_step(const DScene &sc, const IterParams &P, LightPath &lp
 }
 
 /* ConnectToCamera (:380-384, :862-933) for a STORED light vertex (wavefront mode) */
-VCM_HD void connect_stored_vertex_to_camera(const DScene &sc, const IterParams &P, const LightStore &store,
+template <class SC>
+VCM_HD void connect_stored_vertex_to_camera(const SC &sc, const IterParams &P, const LightStore &store,
                                             size_t slot, float *fb, LaneStats &ls, F4 *splatOut)
 {
     const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), c = lv(store, slot, 2), d = lv(store, slot, 3);
@@ -1160,7 +1177,8 @@ VCM_HD V3 get_light_radiance(const DScene &sc, const IterParams &P, const vcm_li
 }
 
 /* DirectIllumination :663-738 */
-VCM_HD V3 direct_illumination(const DScene &sc, const IterParams &P, float rPick, float rx, float ry,
+template <class SC>
+VCM_HD V3 direct_illumination(const SC &sc, const IterParams &P, float rPick, float rx, float ry,
                               const SubPathState &st, V3 hitpoint, const Bsdf &bsdf, LaneStats &ls)
 {   /* rPick, rx, ry: the three floats drawn at :672-673 */
     const int lightCount = sc.nLights;
@@ -1190,7 +1208,8 @@ VCM_HD V3 direct_illumination(const DScene &sc, const IterParams &P, float rPick
 }
 
 /* ConnectVertices :743-809; the light vertex comes from the LightStore */
-VCM_HD V3 connect_vertices(const DScene &sc, const IterParams &P, V3 lvHitpoint, const Bsdf &lvBsdf,
+template <class SC>
+VCM_HD V3 connect_vertices(const SC &sc, const IterParams &P, V3 lvHitpoint, const Bsdf &lvBsdf,
                            float lvdVCM, float lvdVC, const Bsdf &cameraBsdf, V3 cameraHitpoint,
                            const SubPathState &st, LaneStats &ls)
 {
@@ -1274,7 +1293,7 @@ struct MergeEval {
 VCM_HD void merge_eval_setup(MergeEval &e, const DScene &sc, const IterParams &P, const Bsdf &b,
                              const SubPathState &st)
 {
-    const vcm_material &m = sc.materials[b.matID];
+    const vcm_material &m = sc.materials()[b.matID];
     e.frame = b.frame;
     e.refl = reflect_local(b.localDirFix);
     e.diffuseVal = ld3(m.diffuse) * VCM_INV_PI_F;
@@ -1608,8 +1627,8 @@ VCM_HD void camera_path_begin(const DScene &sc, const IterParams &P, CameraPath 
  *         tasks.  Returns false when the path ends. */
 struct CameraWaveQueues { WaveQueue v, di, vc; };   /* wave-uniform allocator state of K3 */
 
-template <int MODE>
-VCM_HD bool camera_path_step(const DScene &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
+template <int MODE, class SC>
+VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
                              const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const VertexStore &vs,
                              CameraWaveQueues &wqs)
 {
@@ -1620,7 +1639,7 @@ VCM_HD bool camera_path_step(const DScene &sc, const IterParams &P, CameraPath &
     if (!scene_intersect(sc, ray, isect)) {   /* :434-447 */
         if (sc.backgroundLight >= 0) {
             if (st.pathLength >= P.minLen)
-                cp.color = cp.color + st.throughput * get_light_radiance(sc, P, sc.lights[sc.backgroundLight], st, ray.dir);
+                cp.color = cp.color + st.throughput * get_light_radiance(sc, P, sc.lights()[sc.backgroundLight], st, ray.dir);
         }
         return false;
     }
@@ -1770,7 +1789,8 @@ VCM_HD void load_cam_vertex(const DScene &sc, const VertexStore &vs, int vi, Cam
     v.diK = f2u(e.y);
 }
 /* the addend of :491  (color += throughput * DirectIllumination(...)) */
-VCM_HD V3 eval_di_task(const DScene &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls,
+template <class SC>
+VCM_HD V3 eval_di_task(const SC &sc, const IterParams &P, const VertexStore &vs, int vi, LaneStats &ls,
                        size_t &pathSlot)
 {
     CamVertex v;
@@ -1783,7 +1803,8 @@ VCM_HD V3 eval_di_task(const DScene &sc, const IterParams &P, const VertexStore 
     return v.throughput * direct_illumination(sc, P, rnd[0], rnd[1], rnd[2], v.st, v.hit, v.bsdf, ls);
 }
 /* the addend of :523  (color += throughput * lightVertex.mThroughput * ConnectVertices(...)) */
-VCM_HD V3 eval_vc_task(const DScene &sc, const IterParams &P, const VertexStore &vs, const LightStore &store,
+template <class SC>
+VCM_HD V3 eval_vc_task(const SC &sc, const IterParams &P, const VertexStore &vs, const LightStore &store,
                        int vi, int j, LaneStats &ls)
 {
     CamVertex v;
@@ -1876,7 +1897,8 @@ VCM_HD void pt_path_begin(const DScene &sc, const IterParams &P, PtPath &pp, int
     pp.lastPdfW = 1.f;
 }
 /* one turn of the for(;; ++pathLength) at :71-213; false when the path ends */
-VCM_HD bool pt_path_step(const DScene &sc, const IterParams &P, PtPath &pp, LaneStats &ls)
+template <class SC>
+VCM_HD bool pt_path_step(const SC &sc, const IterParams &P, PtPath &pp, LaneStats &ls)
 {
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;   /* :48-49 */
@@ -1887,7 +1909,7 @@ VCM_HD bool pt_path_step(const DScene &sc, const IterParams &P, PtPath &pp, Lane
         if (pp.pathLength < P.minLen) return false;
         if (sc.backgroundLight < 0) return false;
         float directPdfW = 0.f, emissionPdfW = 0.f;
-        const V3 contrib = light_get_radiance(sc.lights[sc.backgroundLight], sc, ray.dir, directPdfW, emissionPdfW);
+        const V3 contrib = light_get_radiance(sc.lights()[sc.backgroundLight], sc, ray.dir, directPdfW, emissionPdfW);
         if (iszero(contrib)) return false;
         float misWeight = 1.f;
         if (pp.pathLength > 1 && !pp.lastSpecular) misWeight = mis2(pp.lastPdfW, directPdfW * lightPickProb);
@@ -1968,7 +1990,8 @@ VCM_HD bool pt_path_step(const DScene &sc, const IterParams &P, PtPath &pp, Lane
 
 /* ================= EyeLight::RunIteration (eyelight.hxx:46-77) ================= */
 /* returns the colour and the jittered sample; hit = false: nothing is added (:68) */
-VCM_HD bool eyelight_path(const DScene &sc, const IterParams &P, int localPath, V3 &color, float &sx, float &sy,
+template <class SC>
+VCM_HD bool eyelight_path(const SC &sc, const IterParams &P, int localPath, V3 &color, float &sx, float &sy,
                           uint32_t &floatsDrawn, LaneStats &ls)
 {
     const vcm_camera &cam = sc.camera;

@@ -11,7 +11,8 @@
 
 namespace vcm {
 
-VCM_HD void kat_eval(const DScene &sc, int op, const float *in, float *out)
+template <class SC>
+VCM_HD void kat_eval(const SC &sc, int op, const float *in, float *out)
 {
     for (int i = 0; i < VCM_KAT_FLOATS; i++) out[i] = 0.f;
     switch (op) {

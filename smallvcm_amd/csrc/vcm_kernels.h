@@ -76,13 +76,13 @@ __device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long l
 }
 
 /* ---------------- K1: light sub-paths (vertexcm.hxx:321-396) ------------ */
-template <int MODE>
+template <int MODE, class SC>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
 k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, float *fb,
               unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
-    const DScene &sc = *scp;
+    const SC &sc = *static_cast<const SC *>(scp);
     const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
     int next = wave * chunk;                              /* wave-uniform */
@@ -115,13 +115,13 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
 /* MODE 1 (default, "wavefront"): trace + scatter only; DI / VC / merge become
  *        records and tasks for K3b / K3c / K4, k_resolve replays the additions;
  * MODE 0 ("strict"): everything inside the path. */
-template <int MODE>
+template <int MODE, class SC>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
 k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, GridStore grid, VertexStore vs,
                F4 *camOut, uint32_t *camMask, unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
-    const DScene &sc = *scp;
+    const SC &sc = *static_cast<const SC *>(scp);
     const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
     int next = wave * chunk;
@@ -169,12 +169,13 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
 /* ---------------- PathTracer / EyeLight (pathtracer.hxx:45-215, eyelight.hxx:46-77) ---------------- */
 /* Same shape as K3: persistent waves, one lane per pixel, dead lanes refilled by ballot + prefix popcount.
  * The colour of a path goes to camOut with the pixel of its jittered sample; k_resolve adds it in path order. */
+template <class SC>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
 k_path_trace(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
              unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
-    const DScene &sc = *scp;
+    const SC &sc = *static_cast<const SC *>(scp);
     const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
     int next = wave * chunk;
@@ -201,12 +202,13 @@ k_path_trace(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned 
     flush_stats(ls, gstats);
 }
 
+template <class SC>
 __global__ void __launch_bounds__(256)
 k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
             unsigned long long *gstats, StampArgs st)
 {
     stamp_entry(st);
-    const DScene &sc = *scp;
+    const SC &sc = *static_cast<const SC *>(scp);
     LaneStats ls; lane_stats_zero(ls);
     for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < P.nLocal; lp += gridDim.x * blockDim.x) {
         V3 color = sp3(0.f);
@@ -225,12 +227,13 @@ k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned c
  * not offer: there the connection loop ran at the trip count of the busiest
  * lane and at 23 % lane utilisation (profiles/r01b_pmc_*). */
 #define VCM_TASK_BLOCK 256
+template <class SC>
 __global__ void __launch_bounds__(VCM_TASK_BLOCK)
 k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats,
              const int *__restrict__ bucketStart, int *sortedVertex, StampArgs st)
 {
     stamp_entry(st);
-    const DScene &sc = *scp;
+    const SC &sc = *static_cast<const SC *>(scp);
     const int n = vs.count[1];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
@@ -247,11 +250,12 @@ k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsig
     flush_stats(ls, gstats);
 }
 
+template <class SC>
 __global__ void __launch_bounds__(VCM_TASK_BLOCK)
 k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, LightStore store,
              unsigned long long *gstats)
 {
-    const DScene &sc = *scp;
+    const SC &sc = *static_cast<const SC *>(scp);
     const int n = vs.count[2];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
@@ -731,12 +735,13 @@ __global__ void k_compact_records(IterParams P, LightStore store, const int *__r
  * rounding, so the splats are written out and K1d adds them per pixel in that
  * order -- bit-identical to the serial loop and reproducible from run to run
  * (fp32 atomics gave an RMSE of 5e-9 and a different image every run). */
+template <class SC>
 __global__ void __launch_bounds__(256)
 k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
                  const int *__restrict__ slotOfVertex, const int *__restrict__ nVertices, float *fb, F4 *splat,
                  int *pixCount, int *arrival, unsigned long long *gstats)
 {
-    const DScene &sc = *scp;
+    const SC &sc = *static_cast<const SC *>(scp);
     const int n = *nVertices;
     LaneStats ls; lane_stats_zero(ls);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

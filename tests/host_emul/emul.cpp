@@ -12,9 +12,17 @@
 
 using namespace vcm;
 
+/* the ray-casting functions are instantiated per kind of scene (vcm_core.h SceneList / SceneBvh): pick like the
+   product's launches do */
+template <class F> static void with_scene(const DScene &sc, F &&f)
+{
+    if (sc.nNodes > 0) f(static_cast<const SceneBvh &>(sc));
+    else f(static_cast<const SceneList &>(sc));
+}
+
 struct Emul {
     SceneHost host;   /* owned scene arrays + packed pairs / BVH */
-    DScene sc;        /* what the device functions see: pointers into `host` */
+    DScene sc;        /* what the device functions see: offsets from THIS object into `host` (an Emul never moves) */
     bool useVM, useVC, lightTraceOnly, ppm;
     int renderer;
     float baseRadius, radiusAlpha;
@@ -52,7 +60,7 @@ void *emul_create2(const vcm_scene_desc2 *scene, int algorithm, float radiusFact
 static void *emul_finish_create(Emul *e, int algorithm, float radiusFactor, float radiusAlpha, int seed, int rank, int world)
 {
     scene_host_build_accel(e->host, scene_host_force_bvh());
-    e->sc = e->host.view();
+    e->host.view(e->sc);
     const SceneHost *scene = &e->host;
     e->useVM = e->useVC = e->lightTraceOnly = e->ppm = false;
     e->renderer = 0;
@@ -120,12 +128,13 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             if (e.renderer == 1) {
                 PtPath path;
                 pt_path_begin(e.sc, P, path, lp);
-                while (pt_path_step(e.sc, P, path, e.ls)) {}
+                with_scene(e.sc, [&](const auto &sc) { while (pt_path_step(sc, P, path, e.ls)) {} });
                 e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)raster_target(P, path.sx, path.sy)));
                 e.rngC[lp] = (unsigned char)path.rng.k;
             } else {
                 V3 color = sp3(0.f); float sx, sy; uint32_t drawn;
-                const bool hit = eyelight_path(e.sc, P, lp, color, sx, sy, drawn, e.ls);
+                bool hit = false;
+                with_scene(e.sc, [&](const auto &sc) { hit = eyelight_path(sc, P, lp, color, sx, sy, drawn, e.ls); });
                 e.camOut[lp] = mk4(color.x, color.y, color.z, u2f((uint32_t)(hit ? raster_target(P, sx, sy) : -1)));
                 e.rngC[lp] = (unsigned char)drawn;
             }
@@ -150,7 +159,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     for (int lp = 0; lp < e.nLocal; lp++) {
         LightPath path;
         light_path_begin(e.sc, P, path, lp);
-        while (light_path_step<0>(e.sc, P, path, store, e.fb.data(), e.ls)) {}
+        with_scene(e.sc, [&](const auto &sc) { while (light_path_step<0>(sc, P, path, store, e.fb.data(), e.ls)) {} });
         e.count[lp] = (unsigned char)path.nStored;
         lenMask[lp] = path.lenMask;
         e.rngL[lp] = (unsigned char)path.rng.k;
@@ -209,7 +218,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             VertexStore vs; memset(&vs, 0, sizeof(vs));
             int wqState[6] = {0, 0, 0, 0, 0, 0};
             CameraWaveQueues wqs; wqs.v.p = wqState; wqs.di.p = wqState + 2; wqs.vc.p = wqState + 4;
-            while (camera_path_step<0>(e.sc, P, path, store, grid, e.ls, ms, vs, wqs)) {}
+            with_scene(e.sc, [&](const auto &sc) { while (camera_path_step<0>(sc, P, path, store, grid, e.ls, ms, vs, wqs)) {} });
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;
         }
@@ -257,8 +266,11 @@ void emul_kat(const vcm_scene_desc *scene, int op, int n, const float *in, float
     std::string err;
     if (!scene_host_from_desc(*scene, h, err)) return;
     scene_host_build_accel(h, scene_host_force_bvh());
-    const DScene sc = h.view();
-    for (int i = 0; i < n; i++) kat_eval(sc, op, in + (size_t)i * VCM_KAT_FLOATS, out + (size_t)i * VCM_KAT_FLOATS);
+    DScene view;
+    h.view(view);
+    with_scene(view, [&](const auto &sc) {
+        for (int i = 0; i < n; i++) kat_eval(sc, op, in + (size_t)i * VCM_KAT_FLOATS, out + (size_t)i * VCM_KAT_FLOATS);
+    });
 }
 /* the same over a version-2 scene (BVH for more than VCM_MAX_PRIMS primitives) */
 void emul_kat2(const vcm_scene_desc2 *scene, int op, int n, const float *in, float *out)
@@ -267,8 +279,11 @@ void emul_kat2(const vcm_scene_desc2 *scene, int op, int n, const float *in, flo
     std::string err;
     if (!scene_host_from_desc2(*scene, h, err)) return;
     scene_host_build_accel(h, scene_host_force_bvh());
-    const DScene sc = h.view();
-    for (int i = 0; i < n; i++) kat_eval(sc, op, in + (size_t)i * VCM_KAT_FLOATS, out + (size_t)i * VCM_KAT_FLOATS);
+    DScene view;
+    h.view(view);
+    with_scene(view, [&](const auto &sc) {
+        for (int i = 0; i < n; i++) kat_eval(sc, op, in + (size_t)i * VCM_KAT_FLOATS, out + (size_t)i * VCM_KAT_FLOATS);
+    });
 }
 
 } // extern "C"
