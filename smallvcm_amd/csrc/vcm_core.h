@@ -192,6 +192,22 @@ struct alignas(8) TriPair {
 };
 struct PrimOp { int kind; int index; };   /* kind 0: TriPair pairs[index]; kind 1: sphere prims[index] */
 
+/* One primitive of the brute-force list as the CERTIFIED FILTER sees it (scene_intersect / scene_occluded below), in
+ * GeometryList order: entry i belongs to prims[i].  Triangle: the plane in Hessian form and the three edge functions
+ * of Triangle::Intersect (geometry.hxx:133-142) in Pluecker form,
+ *     Dot(Cross(Q - o, P - o), dir)  =  Dot(dir, Cross(Q, P)) + Dot(Cross(o, dir), P - Q),
+ * so that an edge costs six fused multiply-adds on the ray's direction and moment instead of the reference's
+ * two vertex offsets, a cross product and a dot product.  Sphere: centre and radius. */
+struct alignas(16) FastPrim {
+    int   kind;        /* 0 triangle, 1 sphere */
+    int   reuse;       /* triangle: its edge function 2 is MINUS edge function 2 of the previous entry (shared edge,
+                          opposite orientation: the two triangles of a quad); the entry still holds its own N2/E2 */
+    float p0[3];       /* triangle: vertex 0 | sphere: centre */
+    float n[3];        /* triangle: Triangle::mNormal | sphere: radius, -, - */
+    float N0[3], E0[3], N1[3], E1[3], N2[3], E2[3];   /* edge k: W_k = Dot(dir, N_k) + Dot(Cross(o, dir), E_k) */
+    float pad[2];
+};
+
 /* One node of the bounding-volume hierarchy used for scenes with more primitives than the brute-force loop is
  * meant for (the reference has no acceleration structure: README:208-209, Scene::Intersect scene.hxx:53-70).
  * Nodes are stored in depth-first order and THREADED: a traversal needs no stack -- when the ray meets a node's box
@@ -218,7 +234,9 @@ struct DScene {
     vcm_camera camera;
     /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0); BVH: nNodes > 0 */
     int nOps, nNodes;
-    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims;
+    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFast;
+    /* scene constants of the filter's error bounds: max |vertex|^2 over the triangles; a sphere around their vertices */
+    float fastRw2, fastCenter[3], fastRadius;
     template <class T> VCM_HD const T *at(long long off) const { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(this) + off); }
     VCM_HD const vcm_prim *prims() const { return at<vcm_prim>(offPrims); }
     VCM_HD const vcm_material *materials() const { return at<vcm_material>(offMaterials); }
@@ -228,6 +246,7 @@ struct DScene {
     VCM_HD const TriPair *pairs() const { return at<TriPair>(offPairs); }
     VCM_HD const BvhNode *nodes() const { return at<BvhNode>(offNodes); }
     VCM_HD const int *leafPrims() const { return at<int>(offLeafPrims); }
+    VCM_HD const FastPrim *fast() const { return at<FastPrim>(offFast); }
 };
 /* Which of the two a scene carries, as a TYPE: every kernel that casts rays exists once per kind (the launch picks by
  * nNodes), so the brute-force kernels hold no traversal code and the BVH kernels no list loop.  Compiled together the
@@ -586,13 +605,10 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
     return occluded;
 }
 
-/* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78): brute force in list order for
- * the reference's own scenes (<= 32 primitives; the op index is wave-uniform, so the primitive data comes in through
- * scalar loads), the BVH for larger ones. */
-template <class SC>
-VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
+/* GeometryList::Intersect (geometry.hxx:65-78) over the packed pairs: the reference's operations, every primitive
+ * in list order (the op index is wave-uniform, so the primitive data comes in through scalar loads). */
+VCM_HD bool pairs_intersect(const DScene &sc, const Ray &ray, Isect &res)
 {
-    if constexpr (SC::kBvh) return bvh_intersect(sc, ray, res);
     bool any = false;
     for (int i = 0; i < sc.nOps; i++) {
         const PrimOp op = sc.ops()[i];
@@ -603,16 +619,9 @@ VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
     if (any) res.lightID = sc.mat2light()[res.matID];
     return any;
 }
-/* Scene::Occluded scene.hxx:72-85 (+ GeometryList::IntersectP geometry.hxx:80-91) */
-template <class SC>
-VCM_HD bool scene_occluded(const SC &sc, V3 point, V3 dir, float tmax)
+/* GeometryList::IntersectP (geometry.hxx:80-91) over the packed pairs */
+VCM_HD bool pairs_occluded(const DScene &sc, const Ray &ray, float tmaxp)
 {
-    Ray ray;
-    ray.org = point + dir * VCM_EPS_RAY;
-    ray.dir = dir;
-    ray.tmin = 0;
-    const float tmaxp = tmax - 2 * VCM_EPS_RAY;
-    if constexpr (SC::kBvh) return bvh_occluded(sc, ray, tmaxp);
     bool occluded = false;
     for (int i = 0; i < sc.nOps; i++) {
         const PrimOp op = sc.ops()[i];
@@ -628,6 +637,254 @@ VCM_HD bool scene_occluded(const SC &sc, V3 point, V3 dir, float tmax)
         }
     }
     return occluded;
+}
+
+/* ---- certified filters in front of the reference's intersection arithmetic ---------------------------------------
+ * What has to come out of Scene::Intersect is WHICH primitive the reference's loop ends up holding and the distance,
+ * normal and material it computed for it; of Scene::Occluded only a boolean.  The reference's expression trees
+ * (offsets, cross products, dot products per triangle; binary64 roots per sphere) DEFINE those answers, but for all
+ * but a vanishing fraction of the rays the answers do not depend on the last bits: a ray either passes an edge at a
+ * distance far above every rounding error or it does not.  So every primitive is first put through a cheap
+ * approximation with a RIGOROUS error bound (u = 2^-24; Lw = max(|o|, max |vertex|), Lo >= the distance from the
+ * ray's origin to every triangle vertex; |dir| = 1 up to rounding, the bounds are scaled by max(1, |dir|^2)):
+ *
+ *   edge function   W  = fma chain of Dot(dir, N) + Dot(Cross(o, dir), E)                      6 fma
+ *                   |W - exact| <= 29 u Lw^2  (N, E rounded once from binary64; the moment; six roundings of the chain)
+ *                   |reference's v0d - exact| <= 14 u Lo^2  (three rounded offsets, cross, dot: standard forward bound)
+ *                   => |W| > tauW = u (64 Lw^2 + 32 Lo^2)  (twice the sum) : the reference's sign is the sign of W
+ *   plane distance  the reference's own two operands num = Dot(n, p0 - o), den = Dot(n, dir) (same trees, geometry.hxx
+ *                   :144-147: 13 operations), then t = num * rcp(den) instead of the correctly rounded division:
+ *                   |t - reference's distance| <= eps = 8 u |t|.  (A Hessian-form plane, 6 fma, was measured first:
+ *                   its ABSOLUTE error of ~1e-6 cannot tell on which side of a surface a shadow ray starts that
+ *                   leaves it at a grazing angle -- 0.5 % of the shadow rays, a quarter of the waves, fell back.)
+ *   sphere roots    the reference's own binary32 A, B, C and discriminant (same tree, geometry.hxx:205-211; "no real
+ *                   root" is therefore exact), then the roots in binary32 instead of binary64 (:216-220):
+ *                   |root - reference's| <= 64 u |root|  (no cancellation: -B and the square root are added with
+ *                   equal signs; the factor covers the two roots changing places when they nearly coincide)
+ *
+ * A primitive is then classified as certainly hit / certainly missed / unknown, and
+ *   closest hit:  the winner is certain when the candidate with the smallest lower bound t - eps is a certain hit and
+ *                 its upper bound t + eps lies below the lower bound of every other candidate; the reference's own
+ *                 arithmetic then runs for THAT primitive only (plane distance of one triangle, or the binary64
+ *                 roots of one sphere), so distance and normal are the reference's bits;
+ *   any hit:      one certain hit decides "occluded", all primitives certainly missed decides "free".
+ * Whenever a lane of the wave is left without a certain answer (a ray within ~1e-5 of an edge, of a tangent, of two
+ * surfaces meeting) the WAVE re-does the query with the reference's arithmetic over the whole list -- the loops
+ * above, which are also what the filter replaced.  Results are therefore bit-identical to the brute-force loop by
+ * construction; the parity tests compare full frames (tests/test_gpu_parity.py).  Measured: DESIGN.md section 5. */
+#if defined(__HIP_DEVICE_COMPILE__)
+VCM_HD float approx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     /* 1 ulp */
+VCM_HD float approx_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   /* 1 ulp */
+#else
+VCM_HD float approx_rcp(float x) { return 1.f / x; }
+VCM_HD float approx_sqrt(float x) { return sqrtf(x); }
+/* how often the filter hands a ray to the reference loop (host emulation only: tests/test_core_emul.py reports it) */
+struct FilterStats { unsigned long long isect, isectExact, occl, occlExact; };
+inline FilterStats g_filterStats = { 0, 0, 0, 0 };
+#endif
+#define VCM_FILTER_U 5.9604645e-8f          /* 2^-24 */
+#define VCM_FILTER_INF 3.0e38f
+struct FastRay { V3 o, d, m; float tauW; };
+VCM_HD void fast_ray_setup(const DScene &sc, V3 org, V3 dir, FastRay &r)
+{
+    r.o = org; r.d = dir;
+    r.m = mk3(__builtin_fmaf(org.y, dir.z, -(org.z * dir.y)), __builtin_fmaf(org.z, dir.x, -(org.x * dir.z)),
+              __builtin_fmaf(org.x, dir.y, -(org.y * dir.x)));
+    const float oo = __builtin_fmaf(org.x, org.x, __builtin_fmaf(org.y, org.y, org.z * org.z));
+    const float dd = fmaxf(1.f, __builtin_fmaf(dir.x, dir.x, __builtin_fmaf(dir.y, dir.y, dir.z * dir.z)));
+    const float lw2 = fmaxf(oo, sc.fastRw2);
+    const V3 oc = org - ld3(sc.fastCenter);
+    const float lo = approx_sqrt(__builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, oc.z * oc.z))) * 1.00001f + sc.fastRadius;
+    r.tauW = (VCM_FILTER_U * dd) * __builtin_fmaf(64.f, lw2, 32.f * (lo * lo));
+}
+struct FastHit { float L, U; bool certIn, certOut; };
+VCM_HD void fast_tri_plane(const FastPrim &p, const FastRay &r, FastHit &h, float &num, float &den)
+{
+    const V3 n = ld3(p.n);
+    num = dot(n, ld3(p.p0) - r.o);           /* the reference's operands, bit for bit */
+    den = dot(n, r.d);
+    const float t = num * approx_rcp(den);
+    const float eps = (VCM_FILTER_U * 8.f) * fabsf(t);
+    const bool known = fabsf(t) < 1e30f;      /* false for inf / NaN (den = 0 or denormal, overflow) */
+    h.L = known ? t - eps : -VCM_FILTER_INF;
+    h.U = known ? t + eps : VCM_FILTER_INF;
+}
+VCM_HD float fast_edge(const float *N, const float *E, const FastRay &r)
+{
+    return __builtin_fmaf(r.d.x, N[0], __builtin_fmaf(r.d.y, N[1], __builtin_fmaf(r.d.z, N[2],
+           __builtin_fmaf(r.m.x, E[0], __builtin_fmaf(r.m.y, E[1], r.m.z * E[2])))));
+}
+/* prevW2 / prevValid: edge function 2 of the previous list entry, if it was evaluated (wave-uniform) */
+VCM_HD void fast_tri_edges(const FastPrim &p, const FastRay &r, float &prevW2, bool &prevValid, FastHit &h)
+{
+    const float w0 = fast_edge(p.N0, p.E0, r), w1 = fast_edge(p.N1, p.E1, r);
+    const float w2 = (p.reuse && prevValid) ? -prevW2 : fast_edge(p.N2, p.E2, r);
+    prevW2 = w2; prevValid = true;
+    const bool n0 = w0 < -r.tauW, n1 = w1 < -r.tauW, n2 = w2 < -r.tauW;
+    const bool p0 = w0 > r.tauW, p1 = w1 > r.tauW, p2 = w2 > r.tauW;
+    h.certIn = (n0 && n1 && n2) || (p0 && p1 && p2);     /* geometry.hxx:141-142, signs certain */
+    h.certOut = (n0 || n1 || n2) && (p0 || p1 || p2);
+}
+/* the reference's binary32 part of Sphere::Intersect (geometry.hxx:205-211), then its roots approximately.
+ * ok = false: roots unknown (degenerate q).  noRoot: exact. */
+struct FastRoots { float lo, hi, eLo, eHi; bool noRoot, ok; };
+VCM_HD void fast_sphere(const FastPrim &p, V3 org, V3 dir, FastRoots &fr)
+{
+    const V3 to = org - ld3(p.p0);
+    const float radius = p.n[0];
+    const float A = dot(dir, dir);
+    const float B = 2 * dot(dir, to);
+    const float C = dot(to, to) - (radius * radius);
+    const float discF = B * B - 4 * A * C;
+    fr.noRoot = discF < 0;
+    const float s = approx_sqrt(fmaxf(discF, 0.f));
+    const float q = (B < 0) ? (-B + s) * 0.5f : (-B - s) * 0.5f;
+    const float t0 = q * approx_rcp(A), t1 = C * approx_rcp(q);
+    fr.ok = (fabsf(q) > 1e-30f) && (A > 1e-30f) && (fabsf(t0) < 1e30f) && (fabsf(t1) < 1e30f);   /* false for NaN */
+    fr.lo = fminf(t0, t1); fr.hi = fmaxf(t0, t1);
+    fr.eLo = (VCM_FILTER_U * 64.f) * fabsf(fr.lo) + 1e-30f;
+    fr.eHi = (VCM_FILTER_U * 64.f) * fabsf(fr.hi) + 1e-30f;
+}
+
+/* Scene::Intersect over the list with the filter in front.  `certain` = this lane's answer is final. */
+VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res, bool &certain)
+{
+    FastRay r;
+    fast_ray_setup(sc, ray.org, ray.dir, r);
+    float minL1 = VCM_FILTER_INF, minL2 = VCM_FILTER_INF, bestU = VCM_FILTER_INF;
+    int best = -1;
+    bool bestCertain = false;
+    float prevW2 = 0.f;
+    bool prevValid = false;
+    for (int pi = 0; pi < sc.nPrims; pi++) {
+        const FastPrim &p = sc.fast()[pi];
+        float L, U;
+        bool cand, cert;
+        if (p.kind == 0) {
+            FastHit h;
+            float num, den;
+            fast_tri_plane(p, r, h, num, den);
+            fast_tri_edges(p, r, prevW2, prevValid, h);
+            cand = !h.certOut && !(h.U <= ray.tmin) && !(h.L >= res.dist);
+            cert = h.certIn && (h.L > ray.tmin) && (h.U < res.dist);
+            L = h.L; U = h.U;
+        } else {
+            prevValid = false;
+            FastRoots fr;
+            fast_sphere(p, ray.org, ray.dir, fr);
+            /* Sphere::Intersect offers the first root beyond tmin (:226-234) */
+            const bool loValid = fr.lo - fr.eLo > ray.tmin, loInvalid = fr.lo + fr.eLo <= ray.tmin;
+            const float t = loInvalid ? fr.hi : fr.lo, e = loInvalid ? fr.eHi : fr.eLo;
+            L = fr.ok ? t - e : -VCM_FILTER_INF;
+            U = fr.ok ? t + e : VCM_FILTER_INF;
+            cand = !fr.noRoot && !(fr.ok && loInvalid && (fr.hi + fr.eHi <= ray.tmin)) && !(L >= res.dist);
+            cert = !fr.noRoot && fr.ok && (loValid || (loInvalid && (fr.hi - fr.eHi > ray.tmin))) && (U < res.dist);
+        }
+        const float Lc = cand ? L : VCM_FILTER_INF;
+        const bool isBest = Lc < minL1;
+        minL2 = fminf(minL2, isBest ? minL1 : Lc);
+        minL1 = isBest ? Lc : minL1;
+        best = isBest ? pi : best;
+        bestU = isBest ? U : bestU;
+        bestCertain = isBest ? cert : bestCertain;
+    }
+    if (best < 0) { certain = true; return false; }   /* every primitive certainly missed */
+    certain = bestCertain && (minL2 > bestU);
+    if (!certain) return false;
+    /* the reference's arithmetic for the winner alone (per-lane index: vector loads, once per ray) */
+    const vcm_prim &pr = sc.prims()[best];
+    bool hit;
+    if (pr.type == VCM_PRIM_TRIANGLE) {
+        const V3 n = ld3(pr.n);
+        const V3 ao = ld3(pr.p0) - ray.org;
+        const float distance = dot(n, ao) / dot(n, ray.dir);                 /* geometry.hxx:144-147 */
+        hit = (distance > ray.tmin) && (distance < res.dist);               /* certified to hold */
+        if (hit) { res.normal = n; res.matID = pr.matID; res.prim = best; res.dist = distance; }
+        else certain = false;                                               /* cannot happen; the wave would re-do it */
+    } else {
+        hit = sph_intersect(pr, best, ray, res);
+        if (!hit) certain = false;
+    }
+    if (hit) res.lightID = sc.mat2light()[res.matID];
+    return hit;
+}
+/* Scene::Occluded over the list with the filter in front */
+VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp, bool &certain)
+{
+    FastRay r;
+    fast_ray_setup(sc, ray.org, ray.dir, r);
+    bool occ = false, unknown = false;
+    float prevW2 = 0.f;
+    bool prevValid = false;
+    for (int pi = 0; pi < sc.nPrims; pi++) {
+        const FastPrim &p = sc.fast()[pi];
+        if (p.kind == 0) {
+            FastHit h;
+            float num, den;
+            fast_tri_plane(p, r, h, num, den);
+            /* can the plane part report a hit in (0, tmax) at all?  Exact (see tri_pair_occluded): fl(num / den) > 0
+               needs equal signs, < tmax needs |num| < tmax |den| up to the rounding of this test's own products */
+            const bool reach = (((f2u(num) ^ f2u(den)) & 0x80000000u) == 0u) && !(fabsf(num) >= 1.000001f * (tmaxp * fabsf(den)));
+            if (wave_any(reach && !occ)) {
+                fast_tri_edges(p, r, prevW2, prevValid, h);
+                const bool hitC = reach && h.certIn && (h.L > 0.f) && (h.U < tmaxp);
+                const bool missC = !reach || h.certOut;
+                occ = occ || hitC;
+                unknown = unknown || !(hitC || missC);
+            } else prevValid = false;
+        } else {
+            prevValid = false;
+            FastRoots fr;
+            fast_sphere(p, ray.org, ray.dir, fr);
+            /* geometry.hxx:226-234 with res.dist = tmax: a hit iff one of the roots lies in (0, tmax) */
+            const bool hitLo = (fr.lo - fr.eLo > 0.f) && (fr.lo + fr.eLo < tmaxp), hitHi = (fr.hi - fr.eHi > 0.f) && (fr.hi + fr.eHi < tmaxp);
+            const bool missLo = (fr.lo + fr.eLo <= 0.f) || (fr.lo - fr.eLo >= tmaxp), missHi = (fr.hi + fr.eHi <= 0.f) || (fr.hi - fr.eHi >= tmaxp);
+            const bool hitC = !fr.noRoot && fr.ok && (hitLo || hitHi);
+            const bool missC = fr.noRoot || (fr.ok && missLo && missHi);
+            occ = occ || hitC;
+            unknown = unknown || !(hitC || missC);
+        }
+    }
+    certain = occ || !unknown;
+    return occ;
+}
+
+/* Scene::Intersect scene.hxx:53-70 (+ GeometryList::Intersect geometry.hxx:65-78): brute force in list order for
+ * the reference's own scenes (<= 32 primitives), the BVH for larger ones. */
+template <class SC>
+VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
+{
+    if constexpr (SC::kBvh) return bvh_intersect(sc, ray, res);
+#if !defined(VCM_NO_FILTER)
+    bool certain;
+    Isect fast = res;
+    const bool hit = list_intersect_filtered(sc, ray, fast, certain);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    g_filterStats.isect++; if (!certain) g_filterStats.isectExact++;
+#endif
+    if (!wave_any(!certain)) { res = fast; return hit; }
+#endif
+    return pairs_intersect(sc, ray, res);
+}
+/* Scene::Occluded scene.hxx:72-85 (+ GeometryList::IntersectP geometry.hxx:80-91) */
+template <class SC>
+VCM_HD bool scene_occluded(const SC &sc, V3 point, V3 dir, float tmax)
+{
+    Ray ray;
+    ray.org = point + dir * VCM_EPS_RAY;
+    ray.dir = dir;
+    ray.tmin = 0;
+    const float tmaxp = tmax - 2 * VCM_EPS_RAY;
+    if constexpr (SC::kBvh) return bvh_occluded(sc, ray, tmaxp);
+#if !defined(VCM_NO_FILTER)
+    bool certain;
+    const bool occ = list_occluded_filtered(sc, ray, tmaxp, certain);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    g_filterStats.occl++; if (!certain) g_filterStats.occlExact++;
+#endif
+    if (!wave_any(!certain)) return occ;
+#endif
+    return pairs_occluded(sc, ray, tmaxp);
 }
 
 /* ---- BSDF: bsdf.hxx:61-576 ---------------------------------------- */

@@ -258,6 +258,12 @@ float emul_path_float(uint32_t seed, uint32_t iter, uint32_t path, uint32_t kind
     for (uint32_t i = 0; i <= k; i++) f = rng_float(r);
     return f;
 }
+/* how often the certified filter handed a ray to the reference loop (per ray here; a GPU wave does it for 64) */
+void emul_filter_stats(unsigned long long *out4, int reset)
+{
+    out4[0] = g_filterStats.isect; out4[1] = g_filterStats.isectExact; out4[2] = g_filterStats.occl; out4[3] = g_filterStats.occlExact;
+    if (reset) g_filterStats = FilterStats{ 0, 0, 0, 0 };
+}
 int emul_scene_cornell(int resX, int resY, unsigned mask, vcm_scene_desc *out);
 /* function-level known answers: the product's device functions, one call per record (vcm_kat.h) */
 void emul_kat(const vcm_scene_desc *scene, int op, int n, const float *in, float *out)
