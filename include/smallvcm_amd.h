@@ -215,6 +215,14 @@ int vcm_set_strict_order(vcm_ctx *ctx, int on);
  * host asks this to know whether vcm_trace_camera may run before vcm_build_grid. */
 int vcm_is_wavefront(vcm_ctx *ctx, unsigned maxPathLength);
 
+/* Which kernel evaluates the range merges (HashGrid::Process, hashgrid.hxx:110-169) in wavefront mode: all three
+ * produce the same bits, they differ in how a wave walks the cell lists (vcm_kernels.h; measured in DESIGN.md 5).
+ * The environment variable SMALLVCM_AMD_MERGE=lane|staged|walk sets the default. */
+#define VCM_MERGE_LANE   0   /* the 8 cells in lockstep, per-lane global loads */
+#define VCM_MERGE_STAGED 1   /* a workgroup stages the cell lists of its queries through LDS */
+#define VCM_MERGE_WALK   2   /* every lane walks its own non-empty runs back to back */
+int vcm_set_merge_kernel(vcm_ctx *ctx, int kind);
+
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all
  * work of this context; NULL = the context's own stream. */
 int vcm_set_stream(vcm_ctx *ctx, void *hipStream);

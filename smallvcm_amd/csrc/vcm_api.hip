@@ -116,6 +116,9 @@ static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_t
 #define LAUNCH_SC_MODE(c, K, M, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<M, SceneBvh>), __VA_ARGS__); \
                                           else hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); } while (0)
 
+#ifndef VCM_MERGE_DEFAULT
+#define VCM_MERGE_DEFAULT VCM_MERGE_LANE
+#endif
 struct vcm_ctx : Scratch {
     SceneHost *scene;                 /* host copy of the scene + the structure the intersection code walks */
     bool useVM, useVC, lightTraceOnly, ppm;
@@ -149,6 +152,7 @@ struct vcm_ctx : Scratch {
     bool importedRecords;
     bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI, bboxPreset;
     bool strictOrder;
+    int mergeKind;                    /* VCM_MERGE_* */
     IterParams P;
     bool inIteration;
     hipEvent_t ev[EV_COUNT];
@@ -618,6 +622,8 @@ static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor
     }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
+    { const char *e = getenv("SMALLVCM_AMD_MERGE");
+      c->mergeKind = (e && !strcmp(e, "staged")) ? VCM_MERGE_STAGED : (e && !strcmp(e, "walk")) ? VCM_MERGE_WALK : (e && !strcmp(e, "lane")) ? VCM_MERGE_LANE : VCM_MERGE_DEFAULT; }
     return c;
 }
 
@@ -732,6 +738,15 @@ int vcm_set_strict_order(vcm_ctx *c, int on)
     if (!c) return fail("vcm_set_strict_order", "ctx is NULL");
     if (c->inIteration) return fail("vcm_set_strict_order", "iteration in progress");
     c->strictOrder = on != 0;
+    return 0;
+}
+
+int vcm_set_merge_kernel(vcm_ctx *c, int kind)
+{
+    if (!c) return fail("vcm_set_merge_kernel", "ctx is NULL");
+    if (c->inIteration) return fail("vcm_set_merge_kernel", "iteration in progress");
+    if (kind != VCM_MERGE_LANE && kind != VCM_MERGE_STAGED && kind != VCM_MERGE_WALK) return fail("vcm_set_merge_kernel", "unknown kernel");
+    c->mergeKind = kind;
     return 0;
 }
 
@@ -1173,9 +1188,11 @@ static int vcm_merge_impl(vcm_ctx *c)
                (SMALLVCM_AMD_MERGE=staged): the workgroup stages the cell lists of its queries through LDS -- 27 % less
                HBM traffic (13.7 -> 9.9 GB per launch) but 4 % slower (profiles/r02c_ab_summary.txt): the kernel is bound
                by VALU issue, not by the candidate loads, and the staging adds instructions and barriers. */
-            static int mergeStaged = -1;
-            if (mergeStaged < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE"); mergeStaged = (e && !strcmp(e, "staged")) ? 1 : 0; }
-            if (mergeStaged) {
+            const int mergeStaged = c->mergeKind;
+            if (mergeStaged == 2)
+                hipLaunchKernelGGL(k_merge_walk, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
+            else if (mergeStaged) {
                 int ch = mergeChunk * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK;
                 if (ch < 1) ch = 1;
                 hipLaunchKernelGGL(k_merge_staged, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,

@@ -355,6 +355,140 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
     flush_stats(ls, gstats);
 }
 
+/* ---------------- K4 (walk): every lane walks ITS candidate runs without waiting for the others ---------------- */
+/* merge_query (k_merge_lane) visits the 8 cells in lockstep: in step j every lane scans its j-th cell and the wave
+ * iterates until the LONGEST of the 64 runs is done -- measured 40 % of the candidate slots of a step hold a candidate
+ * (48.6 M ds_write per launch = 12.1 M wave steps x 256 slots for 1.25 G candidates, profiles/r01u_pmc_sq.json), and
+ * both halves of the scan, the per-lane loads (TA-bound) and the distance arithmetic, pay for the empty ones.
+ * Here a lane first writes the (at most 8) NON-EMPTY runs of its query to LDS -- all 8 hashes and 16 range words in
+ * flight together -- and then walks them back to back: when its run ends it takes its next one in the same step,
+ * whatever the other lanes are doing.  The wave iterates until the lane with the most candidates IN TOTAL is done,
+ * and the lanes of a wave are neighbours in space with similar totals.  The order in which a lane meets its
+ * candidates -- cells in the reference's order (hashgrid.hxx:142-155), vertices in index order inside a cell -- is
+ * unchanged, so the per-query sum is the same bits. */
+#define VCM_WALK_Q 16   /* accepted-index queue per lane: 17 rows + 8 run rows of 8 bytes = 33 KB per block, like k_merge_lane */
+#if defined(__HIP_DEVICE_COMPILE__)
+struct alignas(8) WalkRun { int lo, hi; };
+__device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
+                                               const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms,
+                                               WalkRun *runs /* [k * stride + thread] */, int stride)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    V3 contrib = sp3(0.f);
+    int n = 0;
+    {   /* hashgrid.hxx:116-155: bbox test, the 8 cells toward the nearer faces */
+        const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
+        const V3 distMin = queryPos - bmin, distMax = bmax - queryPos;
+        const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
+                              distMin.z < 0.f || distMax.z < 0.f);
+        const V3 cellPt = P.invCellSize * distMin;
+        const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+        const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
+        const V3 fractCoord = cellPt - coordF;
+        const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+        const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+        const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+        int lo[8], hi[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            lo[j] = 0; hi[j] = 0;
+            if (inside) {
+                const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
+                lo[j] = g.cellStart[cell];
+                hi[j] = g.cellStart[cell + 1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]);   /* one distance test per entry (:162-165) */
+            if (hi[j] > lo[j]) { WalkRun r; r.lo = lo[j]; r.hi = hi[j]; runs[n * stride] = r; n++; }
+        }
+    }
+    MergeEval ev;
+    merge_eval_setup(ev, sc, P, cameraBsdf, st);
+    const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
+    int qn = 0, k = 0;
+    WalkRun cur, nxt;
+    cur.lo = 0; cur.hi = 0; nxt = cur;
+    if (n > 0) cur = runs[0];
+    if (n > 1) nxt = runs[stride];
+    f4u X = *(const f4u *)(g.gx + cur.lo), Y = *(const f4u *)(g.gy + cur.lo), Z = *(const f4u *)(g.gz + cur.lo);
+    while (wave_any(cur.lo < cur.hi)) {
+        const int stepEnd = cur.lo + VCM_MERGE_UNROLL;
+        const bool last = stepEnd >= cur.hi;            /* this step finishes the lane's run (or the lane has none left) */
+        const int aNext = last ? nxt.lo : stepEnd;      /* software-pipelined: the candidates of the NEXT step */
+        const f4u Xn = *(const f4u *)(g.gx + aNext), Yn = *(const f4u *)(g.gy + aNext), Zn = *(const f4u *)(g.gz + aNext);
+        float distSqr[VCM_MERGE_UNROLL];
+        {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */
+            const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
+            const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
+            const f2 da = dxa * dxa + dya * dya + dza * dza;
+            const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
+            distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
+        }
+        X = Xn; Y = Yn; Z = Zn;
+#pragma unroll
+        for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
+            const int idx = cur.lo + u;
+            const bool acc = (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
+            ms.q[qn * ms.stride] = (uint32_t)idx;
+            qn += acc ? 1 : 0;
+        }
+        if (last) {   /* on to this lane's next run; the one after it comes out of LDS while this one is scanned */
+            cur = nxt;
+            k++;
+            nxt.lo = 0; nxt.hi = 0;
+            if (k + 1 < n) nxt = runs[(k + 1) * stride];
+        } else cur.lo = stepEnd;
+        if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
+            ls.mergeAccepted += (uint32_t)qn;
+            merge_drain(P, g, ev, ms, qn, contrib);
+            qn = 0;
+        }
+    }
+    ls.mergeAccepted += (uint32_t)qn;
+    merge_drain(P, g, ev, ms, qn, contrib);
+    return contrib;
+}
+#endif
+
+__global__ void __launch_bounds__(VCM_MERGE_BLOCK)
+k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
+             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
+{
+    stamp_entry(st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const DScene &sc = *scp;
+    const int nQ = *nSorted;
+    __shared__ uint32_t accQ[(VCM_WALK_Q + 1) * VCM_MERGE_BLOCK];
+    __shared__ WalkRun runs[8 * VCM_MERGE_BLOCK];
+    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK; ms.cap = VCM_WALK_Q;
+    LaneStats ls; lane_stats_zero(ls);
+    /* batches of the cell-sorted queries are dealt to the XCDs in chunks, as in k_merge_lane */
+    const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
+    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
+    for (int t = wgOfXcd;; t += wgPerXcd) {
+        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
+        if ((t / chunk) * 8 * chunk >= nBatches) break;
+        if (b >= nBatches) continue;
+        const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
+        if (q < nQ) {   /* the runs of a lane are private to it: no barrier */
+            const int vi = sortedVertex[q];
+            const F4 a = vs.q0[vi], bq = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+            const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
+            Bsdf bsdf;
+            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
+            SubPathState sps;
+            sps.pathLength = f2u(bq.w) & 0xffu; sps.dVCM = c.w; sps.dVM = d.w;
+            const V3 contrib = merge_query_walk(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK);
+            const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+        }
+    }
+    flush_stats(ls, gstats);
+#endif
+}
+
 /* ---------------- K4 (default): range-merge with the cell lists staged through LDS ---------------- */
 /* HashGrid::Process walks 8 hashed cells per query (hashgrid.hxx:142-167).  k_merge_lane reads the candidates of
  * those cells with per-lane global loads: three 16-byte loads per lane and step, each touching as many cache lines

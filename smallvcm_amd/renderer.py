@@ -61,6 +61,7 @@ def load_library(require_gpu=True):
         L.vcm_destroy.restype = None
         L.vcm_set_stream.argtypes = [vp, vp]
         L.vcm_set_strict_order.argtypes = [vp, C.c_int]
+        L.vcm_set_merge_kernel.argtypes = [vp, C.c_int]
         L.vcm_is_wavefront.argtypes = [vp, C.c_uint]
         L.vcm_set_arena_limit.argtypes = [C.c_int, C.c_int]
         L.vcm_run_iteration.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
@@ -164,6 +165,12 @@ class HipBackend:
     def set_strict_order(self, on):
         """True: DI / VC / merge inside the camera path as the reference does (slower, same bits)."""
         _check(self.L, self.L.vcm_set_strict_order(self.ctx, 1 if on else 0), "vcm_set_strict_order")
+
+    MERGE_KERNELS = {"lane": 0, "staged": 1, "walk": 2}
+
+    def set_merge_kernel(self, kind):
+        """which kernel evaluates the range merges: 'lane', 'staged' or 'walk' (same bits; include/smallvcm_amd.h)"""
+        _check(self.L, self.L.vcm_set_merge_kernel(self.ctx, self.MERGE_KERNELS[kind]), "vcm_set_merge_kernel")
 
     def set_stream(self, stream_handle):
         _check(self.L, self.L.vcm_set_stream(self.ctx, stream_handle), "vcm_set_stream")

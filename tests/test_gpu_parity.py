@@ -102,6 +102,25 @@ def test_hip_equals_oracle(sid, algo, res, nit, mn, mx, strict):
     r.close()
 
 
+@pytest.mark.parametrize("kind", ["lane", "staged", "walk"])
+@pytest.mark.parametrize("sid,algo,res,nit,mx", [(1, 4, 256, 3, 10), (3, 2, 192, 2, 10), (0, 1, 128, 2, 6), (2, 4, 64, 1, 10), (1, 4, 40, 1, 10)])
+def test_merge_kernels_equal_oracle(sid, algo, res, nit, mx, kind):
+    """The three range-merge kernels (vcm_set_merge_kernel) walk the cell lists differently and give the same bits."""
+    sc = cornell_scene(sid, res, res)
+    o = Oracle(sc, algo, threads=8)
+    r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+    r.backend.set_merge_kernel(kind)
+    r.mMaxPathLength = mx
+    for it in range(nit):
+        o.run_iteration(it, 0, mx)
+        r.RunIteration(it)
+        so, sg = o.stats(), r.stats()
+        for k in ("mergeQueries", "mergeCandidates", "mergeAccepted"):
+            assert so[k] == sg[k], (k, so[k], sg[k])
+    assert np.array_equal(r.framebuffer_sum().view(np.uint32), o.framebuffer().astype(np.float32).view(np.uint32))
+    r.close()
+
+
 @pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not shipped")
 @pytest.mark.parametrize("sid,algo,res,nit", [(1, 4, 128, 2), (3, 4, 128, 1), (0, 2, 96, 1), (2, 1, 96, 2), (1, 3, 96, 1)])
 @pytest.mark.parametrize("strict", [False, True], ids=["wavefront", "strict"])
