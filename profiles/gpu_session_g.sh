@@ -16,6 +16,11 @@ for lib in smallvcm_amd/csrc/libsmallvcm_amd_*.so; do
   run $n SMALLVCM_AMD_LIB=$lib $B
 done
 run base2 $B
+run walk SMALLVCM_AMD_MERGE=walk $B
+run staged SMALLVCM_AMD_MERGE=staged $B
+run walk2 SMALLVCM_AMD_MERGE=walk $B
+run walk-bpm SMALLVCM_AMD_MERGE=walk $B --algo bpm
+run walk-512 SMALLVCM_AMD_MERGE=walk $B --res 512
 run base-512 $B --res 512
 run base-s3 $B --scene 3 --res 1024
 run base-bpm $B --algo bpm

@@ -32,7 +32,8 @@ struct SceneHost {
     vcm_camera camera;
     std::vector<PrimOp> ops;
     std::vector<TriPair> pairs;
-    std::vector<FastPrim> fast;       /* the filter's view of the list (vcm_core.h), one entry per primitive */
+    std::vector<FastPair> fastPairs;      /* the filter's view of the list (vcm_core.h): triangles two by two, */
+    std::vector<FastSphere> fastSpheres;  /* and the spheres */
     float fastRw2, fastCenter[3], fastRadius;
     std::vector<BvhNode> nodes;
     std::vector<int> leafPrims;
@@ -47,7 +48,7 @@ struct SceneHost {
         d.offMat2light = (const char *)mat2light.data() - base; d.offLights = (const char *)lights.data() - base;
         d.offOps = (const char *)ops.data() - base; d.offPairs = (const char *)pairs.data() - base;
         d.offNodes = (const char *)nodes.data() - base; d.offLeafPrims = (const char *)leafPrims.data() - base;
-        d.offFast = (const char *)fast.data() - base;
+        d.offFastPairs = (const char *)fastPairs.data() - base; d.offFastSpheres = (const char *)fastSpheres.data() - base;
     }
     void fill_scalars(DScene &d) const
     {
@@ -58,6 +59,7 @@ struct SceneHost {
         d.camera = camera;
         d.nOps = (int)ops.size(); d.nNodes = (int)nodes.size();
         d.fastRw2 = fastRw2; d.fastRadius = fastRadius;
+        d.nFastPairs = (int)fastPairs.size(); d.nFastSpheres = (int)fastSpheres.size();
         for (int k = 0; k < 3; k++) d.fastCenter[k] = fastCenter[k];
     }
 };
@@ -139,60 +141,62 @@ inline void scene_host_build_pairs(SceneHost &s)
 inline void scene_host_build_fast(SceneHost &s)
 {
     const int n = (int)s.prims.size();
-    s.fast.assign((size_t)n, FastPrim());
+    s.fastPairs.clear(); s.fastSpheres.clear();
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 }, rw2 = 0.0;
-    auto edge = [](const float *P, const float *Q, float *N, float *E) {   /* V(P, Q) = Dot(dir, P x Q) + Dot(o x dir, Q - P) */
+    auto edge = [](const float *P, const float *Q, float *NE) {   /* V(P, Q) = Dot(dir, P x Q) + Dot(o x dir, Q - P) */
         const double p[3] = { P[0], P[1], P[2] }, q[3] = { Q[0], Q[1], Q[2] };
-        N[0] = (float)(p[1] * q[2] - p[2] * q[1]); N[1] = (float)(p[2] * q[0] - p[0] * q[2]); N[2] = (float)(p[0] * q[1] - p[1] * q[0]);
-        for (int k = 0; k < 3; k++) E[k] = (float)(q[k] - p[k]);
+        NE[0] = (float)(p[1] * q[2] - p[2] * q[1]); NE[1] = (float)(p[2] * q[0] - p[0] * q[2]); NE[2] = (float)(p[0] * q[1] - p[1] * q[0]);
+        for (int k = 0; k < 3; k++) NE[3 + k] = (float)(q[k] - p[k]);
     };
     auto same = [](const float *a, const float *b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; };
-    bool prevFree = false;   /* the previous entry is a triangle whose slot 2 is not tied to ITS predecessor */
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; ) {
         const vcm_prim &t = s.prims[i];
-        FastPrim &f = s.fast[i];
-        std::memset(&f, 0, sizeof(f));
         if (t.type != VCM_PRIM_TRIANGLE) {
-            f.kind = 1;
-            for (int k = 0; k < 3; k++) f.p0[k] = t.p0[k];
-            f.n[0] = t.p1[0];
-            prevFree = false;
+            FastSphere f;
+            std::memset(&f, 0, sizeof(f));
+            for (int k = 0; k < 3; k++) f.c[k] = t.p0[k];
+            f.radius = t.p1[0]; f.prim = i;
+            s.fastSpheres.push_back(f);
+            i++;
             continue;
         }
-        f.kind = 0;
-        for (int k = 0; k < 3; k++) { f.n[k] = t.n[k]; f.p0[k] = t.p0[k]; }
-        /* the reference's three edge functions (geometry.hxx:133-139): v0 = V(c, b), v1 = V(b, a), v2 = V(a, c) */
-        const float *ends[3][2] = { { t.p2, t.p1 }, { t.p1, t.p0 }, { t.p0, t.p2 } };
-        int order[3] = { 0, 1, 2 };
-        if (prevFree) {   /* an edge of this triangle that is an edge of the previous one, reversed? */
-            const vcm_prim &u = s.prims[i - 1];
-            const float *uends[3][2] = { { u.p2, u.p1 }, { u.p1, u.p0 }, { u.p0, u.p2 } };
-            for (int a = 0; a < 3 && !f.reuse; a++)
-                for (int b = 0; b < 3 && !f.reuse; b++)
-                    if (same(ends[a][0], uends[b][1]) && same(ends[a][1], uends[b][0])) {
-                        /* previous entry: edge b into slot 2; this entry: edge a into slot 2 (the sign test is symmetric in the slots) */
-                        FastPrim &g = s.fast[i - 1];
-                        const int uo[3] = { (b + 1) % 3, (b + 2) % 3, b };
-                        edge(uends[uo[0]][0], uends[uo[0]][1], g.N0, g.E0);
-                        edge(uends[uo[1]][0], uends[uo[1]][1], g.N1, g.E1);
-                        edge(uends[uo[2]][0], uends[uo[2]][1], g.N2, g.E2);
-                        order[0] = (a + 1) % 3; order[1] = (a + 2) % 3; order[2] = a;
-                        f.reuse = 1;
-                    }
+        const bool two = (i + 1 < n) && s.prims[i + 1].type == VCM_PRIM_TRIANGLE;
+        const vcm_prim &u = s.prims[two ? i + 1 : i];
+        FastPair f;
+        std::memset(&f, 0, sizeof(f));
+        for (int k = 0; k < 3; k++) { f.p0[0][k] = t.p0[k]; f.n[0][k] = t.n[k]; f.p0[1][k] = u.p0[k]; f.n[1][k] = u.n[k]; }
+        f.prim[0] = i; f.prim[1] = two ? i + 1 : i;
+        f.flags = two ? 1 : 0;
+        /* the reference's three edge functions (geometry.hxx:133-139): v0 = V(c, b), v1 = V(b, a), v2 = V(a, c);
+           the sign test is symmetric in them, so each triangle may list them in any order */
+        const float *te[3][2] = { { t.p2, t.p1 }, { t.p1, t.p0 }, { t.p0, t.p2 } };
+        const float *ue[3][2] = { { u.p2, u.p1 }, { u.p1, u.p0 }, { u.p0, u.p2 } };
+        int ta = 2, ub = 2;
+        bool shared = false;
+        if (two)
+            for (int a = 0; a < 3 && !shared; a++)
+                for (int b = 0; b < 3 && !shared; b++)
+                    if (same(te[a][0], ue[b][1]) && same(te[a][1], ue[b][0])) { ta = a; ub = b; shared = true; }
+        const int to[3] = { (ta + 1) % 3, (ta + 2) % 3, ta }, uo[3] = { (ub + 1) % 3, (ub + 2) % 3, ub };
+        for (int k = 0; k < 3; k++) edge(te[to[k]][0], te[to[k]][1], f.NE[k]);
+        edge(ue[uo[0]][0], ue[uo[0]][1], f.NE[3]);
+        edge(ue[uo[1]][0], ue[uo[1]][1], f.NE[4]);
+        edge(ue[uo[2]][0], ue[uo[2]][1], f.NE5);
+        if (shared) f.flags |= 2;
+        s.fastPairs.push_back(f);
+        for (int w = 0; w < (two ? 2 : 1); w++) {
+            const vcm_prim &q = s.prims[i + w];
+            const float *vs[3] = { q.p0, q.p1, q.p2 };
+            for (int v = 0; v < 3; v++) {
+                double l2 = 0.0;
+                for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)vs[v][k]); hi[k] = std::max(hi[k], (double)vs[v][k]); l2 += (double)vs[v][k] * vs[v][k]; }
+                rw2 = std::max(rw2, l2);
+            }
         }
-        edge(ends[order[0]][0], ends[order[0]][1], f.N0, f.E0);
-        edge(ends[order[1]][0], ends[order[1]][1], f.N1, f.E1);
-        edge(ends[order[2]][0], ends[order[2]][1], f.N2, f.E2);
-        prevFree = !f.reuse;
-        const float *vs[3] = { t.p0, t.p1, t.p2 };
-        for (int v = 0; v < 3; v++) {
-            double l2 = 0.0;
-            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)vs[v][k]); hi[k] = std::max(hi[k], (double)vs[v][k]); l2 += (double)vs[v][k] * vs[v][k]; }
-            rw2 = std::max(rw2, l2);
-        }
+        i += two ? 2 : 1;
     }
     double c[3] = { 0, 0, 0 }, r2 = 0.0;
-    if (rw2 > 0.0 || lo[0] <= hi[0]) for (int k = 0; k < 3; k++) c[k] = lo[0] <= hi[0] ? 0.5 * (lo[k] + hi[k]) : 0.0;
+    if (lo[0] <= hi[0]) for (int k = 0; k < 3; k++) c[k] = 0.5 * (lo[k] + hi[k]);
     for (int i = 0; i < n; i++) {
         const vcm_prim &t = s.prims[i];
         if (t.type != VCM_PRIM_TRIANGLE) continue;
@@ -315,7 +319,7 @@ inline void scene_host_build_bvh(SceneHost &s)
 /* what the intersection code walks: the packed list for the reference's own scenes, the BVH beyond */
 inline void scene_host_build_accel(SceneHost &s, bool forceBvh)
 {
-    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.leafPrims.clear(); s.fast.clear();
+    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.leafPrims.clear(); s.fastPairs.clear(); s.fastSpheres.clear();
     s.fastRw2 = s.fastRadius = 0.f; s.fastCenter[0] = s.fastCenter[1] = s.fastCenter[2] = 0.f;
     if ((int)s.prims.size() > VCM_MAX_PRIMS || (forceBvh && !s.prims.empty())) scene_host_build_bvh(s);
     else { scene_host_build_pairs(s); scene_host_build_fast(s); }

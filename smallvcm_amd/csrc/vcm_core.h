@@ -192,21 +192,24 @@ struct alignas(8) TriPair {
 };
 struct PrimOp { int kind; int index; };   /* kind 0: TriPair pairs[index]; kind 1: sphere prims[index] */
 
-/* One primitive of the brute-force list as the CERTIFIED FILTER sees it (scene_intersect / scene_occluded below), in
- * GeometryList order: entry i belongs to prims[i].  Triangle: the plane in Hessian form and the three edge functions
- * of Triangle::Intersect (geometry.hxx:133-142) in Pluecker form,
- *     Dot(Cross(Q - o, P - o), dir)  =  Dot(dir, Cross(Q, P)) + Dot(Cross(o, dir), P - Q),
- * so that an edge costs six fused multiply-adds on the ray's direction and moment instead of the reference's
- * two vertex offsets, a cross product and a dot product.  Sphere: centre and radius. */
-struct alignas(16) FastPrim {
-    int   kind;        /* 0 triangle, 1 sphere */
-    int   reuse;       /* triangle: its edge function 2 is MINUS edge function 2 of the previous entry (shared edge,
-                          opposite orientation: the two triangles of a quad); the entry still holds its own N2/E2 */
-    float p0[3];       /* triangle: vertex 0 | sphere: centre */
-    float n[3];        /* triangle: Triangle::mNormal | sphere: radius, -, - */
-    float N0[3], E0[3], N1[3], E1[3], N2[3], E2[3];   /* edge k: W_k = Dot(dir, N_k) + Dot(Cross(o, dir), E_k) */
-    float pad[2];
+/* The brute-force list as the CERTIFIED FILTER sees it (scene_intersect / scene_occluded below): the triangles in
+ * GeometryList order, two per entry, and the spheres.  Per triangle the vertex and normal the reference's plane part
+ * reads, and the three edge functions of Triangle::Intersect (geometry.hxx:133-142) in Pluecker form,
+ *     Dot(Cross(P - o, Q - o), dir)  =  Dot(dir, Cross(P, Q)) + Dot(Cross(o, dir), Q - P),
+ * so that an edge costs six fused multiply-adds on the ray's direction and moment instead of the reference's two
+ * vertex offsets, a cross product and a dot product.  The two triangles of a quad share their diagonal with opposite
+ * orientation: the second triangle's third edge function is MINUS the first one's third (exactly: every term changes
+ * sign), so a pair takes five edge evaluations.  One entry = one burst of scalar loads (the index is wave-uniform)
+ * and one wait: the loop is bound by that latency as much as by its arithmetic. */
+struct alignas(16) FastPair {
+    float p0[2][3], n[2][3];    /* vertex 0 and Triangle::mNormal of the two triangles */
+    float NE[5][6];             /* {N, E} of edges A0 A1 A2 B0 B1:  W = Dot(dir, N) + Dot(Cross(o, dir), E) */
+    float NE5[6];               /* edge B2 when it is not -A2 */
+    int   prim[2];              /* indices in prims[] */
+    int   flags;                /* bit 0: triangle B present; bit 1: B2 = -A2 */
+    int   pad;
 };
+struct alignas(16) FastSphere { float c[3], radius; int prim; int pad[3]; };
 
 /* One node of the bounding-volume hierarchy used for scenes with more primitives than the brute-force loop is
  * meant for (the reference has no acceleration structure: README:208-209, Scene::Intersect scene.hxx:53-70).
@@ -234,9 +237,10 @@ struct DScene {
     vcm_camera camera;
     /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0); BVH: nNodes > 0 */
     int nOps, nNodes;
-    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFast;
+    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFastPairs, offFastSpheres;
     /* scene constants of the filter's error bounds: max |vertex|^2 over the triangles; a sphere around their vertices */
     float fastRw2, fastCenter[3], fastRadius;
+    int nFastPairs, nFastSpheres;
     template <class T> VCM_HD const T *at(long long off) const { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(this) + off); }
     VCM_HD const vcm_prim *prims() const { return at<vcm_prim>(offPrims); }
     VCM_HD const vcm_material *materials() const { return at<vcm_material>(offMaterials); }
@@ -246,7 +250,8 @@ struct DScene {
     VCM_HD const TriPair *pairs() const { return at<TriPair>(offPairs); }
     VCM_HD const BvhNode *nodes() const { return at<BvhNode>(offNodes); }
     VCM_HD const int *leafPrims() const { return at<int>(offLeafPrims); }
-    VCM_HD const FastPrim *fast() const { return at<FastPrim>(offFast); }
+    VCM_HD const FastPair *fastPairs() const { return at<FastPair>(offFastPairs); }
+    VCM_HD const FastSphere *fastSpheres() const { return at<FastSphere>(offFastSpheres); }
 };
 /* Which of the two a scene carries, as a TYPE: every kernel that casts rays exists once per kind (the launch picks by
  * nNodes), so the brute-force kernels hold no traversal code and the BVH kernels no list loop.  Compiled together the
@@ -658,9 +663,8 @@ VCM_HD bool pairs_occluded(const DScene &sc, const Ray &ray, float tmaxp)
  *                   its ABSOLUTE error of ~1e-6 cannot tell on which side of a surface a shadow ray starts that
  *                   leaves it at a grazing angle -- 0.5 % of the shadow rays, a quarter of the waves, fell back.)
  *   sphere roots    the reference's own binary32 A, B, C and discriminant (same tree, geometry.hxx:205-211; "no real
- *                   root" is therefore exact), then the roots in binary32 instead of binary64 (:216-220):
- *                   |root - reference's| <= 64 u |root|  (no cancellation: -B and the square root are added with
- *                   equal signs; the factor covers the two roots changing places when they nearly coincide)
+ *                   root" is therefore exact), then its roots in binary32 instead of binary64 (:216-220) with the
+ *                   error of every step carried along: fast_sphere below
  *
  * A primitive is then classified as certainly hit / certainly missed / unknown, and
  *   closest hit:  the winner is certain when the candidate with the smallest lower bound t - eps is a certain hit and
@@ -698,10 +702,11 @@ VCM_HD void fast_ray_setup(const DScene &sc, V3 org, V3 dir, FastRay &r)
     r.tauW = (VCM_FILTER_U * dd) * __builtin_fmaf(64.f, lw2, 32.f * (lo * lo));
 }
 struct FastHit { float L, U; bool certIn, certOut; };
-VCM_HD void fast_tri_plane(const FastPrim &p, const FastRay &r, FastHit &h, float &num, float &den)
+/* plane part: the reference's operands num = Dot(n, p0 - o), den = Dot(n, dir), bit for bit; t = num * rcp(den) */
+VCM_HD void fast_tri_plane(const float *p0, const float *nrm, const FastRay &r, FastHit &h, float &num, float &den)
 {
-    const V3 n = ld3(p.n);
-    num = dot(n, ld3(p.p0) - r.o);           /* the reference's operands, bit for bit */
+    const V3 n = ld3(nrm);
+    num = dot(n, ld3(p0) - r.o);
     den = dot(n, r.d);
     const float t = num * approx_rcp(den);
     const float eps = (VCM_FILTER_U * 8.f) * fabsf(t);
@@ -709,100 +714,122 @@ VCM_HD void fast_tri_plane(const FastPrim &p, const FastRay &r, FastHit &h, floa
     h.L = known ? t - eps : -VCM_FILTER_INF;
     h.U = known ? t + eps : VCM_FILTER_INF;
 }
-VCM_HD float fast_edge(const float *N, const float *E, const FastRay &r)
+VCM_HD float fast_edge(const float *NE, const FastRay &r)
 {
-    return __builtin_fmaf(r.d.x, N[0], __builtin_fmaf(r.d.y, N[1], __builtin_fmaf(r.d.z, N[2],
-           __builtin_fmaf(r.m.x, E[0], __builtin_fmaf(r.m.y, E[1], r.m.z * E[2])))));
+    return __builtin_fmaf(r.d.x, NE[0], __builtin_fmaf(r.d.y, NE[1], __builtin_fmaf(r.d.z, NE[2],
+           __builtin_fmaf(r.m.x, NE[3], __builtin_fmaf(r.m.y, NE[4], r.m.z * NE[5])))));
 }
-/* prevW2 / prevValid: edge function 2 of the previous list entry, if it was evaluated (wave-uniform) */
-VCM_HD void fast_tri_edges(const FastPrim &p, const FastRay &r, float &prevW2, bool &prevValid, FastHit &h)
+VCM_HD void fast_classify(float w0, float w1, float w2, float tau, FastHit &h)
 {
-    const float w0 = fast_edge(p.N0, p.E0, r), w1 = fast_edge(p.N1, p.E1, r);
-    const float w2 = (p.reuse && prevValid) ? -prevW2 : fast_edge(p.N2, p.E2, r);
-    prevW2 = w2; prevValid = true;
-    const bool n0 = w0 < -r.tauW, n1 = w1 < -r.tauW, n2 = w2 < -r.tauW;
-    const bool p0 = w0 > r.tauW, p1 = w1 > r.tauW, p2 = w2 > r.tauW;
+    const bool n0 = w0 < -tau, n1 = w1 < -tau, n2 = w2 < -tau;
+    const bool p0 = w0 > tau, p1 = w1 > tau, p2 = w2 > tau;
     h.certIn = (n0 && n1 && n2) || (p0 && p1 && p2);     /* geometry.hxx:141-142, signs certain */
     h.certOut = (n0 || n1 || n2) && (p0 || p1 || p2);
 }
-/* the reference's binary32 part of Sphere::Intersect (geometry.hxx:205-211), then its roots approximately.
- * ok = false: roots unknown (degenerate q).  noRoot: exact. */
-struct FastRoots { float lo, hi, eLo, eHi; bool noRoot, ok; };
-VCM_HD void fast_sphere(const FastPrim &p, V3 org, V3 dir, FastRoots &fr)
+/* the edge functions of both triangles of an entry */
+VCM_HD void fast_pair_edges(const FastPair &p, const FastRay &r, FastHit &ha, FastHit &hb)
 {
-    const V3 to = org - ld3(p.p0);
-    const float radius = p.n[0];
+    const float a0 = fast_edge(p.NE[0], r), a1 = fast_edge(p.NE[1], r), a2 = fast_edge(p.NE[2], r);
+    const float b0 = fast_edge(p.NE[3], r), b1 = fast_edge(p.NE[4], r);
+    const float b2 = (p.flags & 2) ? -a2 : fast_edge(p.NE5, r);
+    fast_classify(a0, a1, a2, r.tauW, ha);
+    fast_classify(b0, b1, b2, r.tauW, hb);
+}
+/* The reference's binary32 part of Sphere::Intersect (geometry.hxx:205-211: A, B, C and the discriminant, same
+ * trees, so "no real root" is exact), then ITS two roots approximately.  They are not simply the roots of the
+ * quadratic: the reference takes q = (-B - sqrt(disc)) / 2 for B < 0 and (-B + sqrt(disc)) / 2 otherwise (:217) --
+ * the CANCELLING combination -- in binary64, from a discriminant that was rounded to binary32, and t0 = q / A,
+ * t1 = C / q.  The far root C / q therefore carries the relative error of B*B - disc against 4AC, up to ~1e-5 for a
+ * ray that starts on the sphere (C small): a feature of the reference, reproduced here.  In binary32 the
+ * cancellation is avoided algebraically, q = +-(B*B - disc) / (2 (|B| + sqrt(disc))), with B*B - disc evaluated
+ * without loss (B*B as an exact two-term product, the subtraction exact by Sterbenz or harmless), and the error of
+ * every step is carried along: |root - reference's| <= e = (rel + 16 u) |root|, rel = 2 u (|e1| + |lo|) / |D|.
+ * ok = false: roots unknown (q = 0, overflow, NaN).  The factor 4 on e covers the two roots changing places when
+ * they nearly coincide (geometry.hxx:222). */
+struct FastRoots { float lo, hi, eLo, eHi; bool noRoot, ok; };
+VCM_HD void fast_sphere(const FastSphere &p, V3 org, V3 dir, FastRoots &fr)
+{
+    const V3 to = org - ld3(p.c);
+    const float radius = p.radius;
     const float A = dot(dir, dir);
     const float B = 2 * dot(dir, to);
     const float C = dot(to, to) - (radius * radius);
     const float discF = B * B - 4 * A * C;
     fr.noRoot = discF < 0;
     const float s = approx_sqrt(fmaxf(discF, 0.f));
-    const float q = (B < 0) ? (-B + s) * 0.5f : (-B - s) * 0.5f;
+    const float b = fabsf(B);
+    const float hi = b * b, lo = __builtin_fmaf(b, b, -hi);   /* b*b = hi + lo exactly */
+    const float e1 = hi - discF;
+    const float D = e1 + lo;                                  /* B*B - disc */
+    const float rel = (VCM_FILTER_U * 2.f) * (fabsf(e1) + fabsf(lo)) * approx_rcp(fabsf(D)) + VCM_FILTER_U * 16.f;
+    const float qa = D * approx_rcp(2.f * (b + s));
+    const float q = (B < 0) ? qa : -qa;
     const float t0 = q * approx_rcp(A), t1 = C * approx_rcp(q);
-    fr.ok = (fabsf(q) > 1e-30f) && (A > 1e-30f) && (fabsf(t0) < 1e30f) && (fabsf(t1) < 1e30f);   /* false for NaN */
+    fr.ok = (fabsf(q) > 1e-30f) && (A > 1e-30f) && (fabsf(t0) < 1e30f) && (fabsf(t1) < 1e30f) && (rel < 0.01f);   /* false for NaN */
     fr.lo = fminf(t0, t1); fr.hi = fmaxf(t0, t1);
-    fr.eLo = (VCM_FILTER_U * 64.f) * fabsf(fr.lo) + 1e-30f;
-    fr.eHi = (VCM_FILTER_U * 64.f) * fabsf(fr.hi) + 1e-30f;
+    fr.eLo = (4.f * rel) * fabsf(fr.lo) + 1e-30f;
+    fr.eHi = (4.f * rel) * fabsf(fr.hi) + 1e-30f;
 }
 
+/* running choice of the closest-hit filter: the candidate with the smallest lower bound, and the second smallest */
+struct FastBest { float minL1, minL2, bestU; int best; bool bestCertain; };
+VCM_HD void fast_offer(FastBest &fb, bool cand, bool cert, float L, float U, int prim)
+{
+    const float Lc = cand ? L : VCM_FILTER_INF;
+    const bool isBest = Lc < fb.minL1;
+    fb.minL2 = fminf(fb.minL2, isBest ? fb.minL1 : Lc);
+    fb.minL1 = isBest ? Lc : fb.minL1;
+    fb.best = isBest ? prim : fb.best;
+    fb.bestU = isBest ? U : fb.bestU;
+    fb.bestCertain = isBest ? cert : fb.bestCertain;
+}
 /* Scene::Intersect over the list with the filter in front.  `certain` = this lane's answer is final. */
 VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res, bool &certain)
 {
     FastRay r;
     fast_ray_setup(sc, ray.org, ray.dir, r);
-    float minL1 = VCM_FILTER_INF, minL2 = VCM_FILTER_INF, bestU = VCM_FILTER_INF;
-    int best = -1;
-    bool bestCertain = false;
-    float prevW2 = 0.f;
-    bool prevValid = false;
-    for (int pi = 0; pi < sc.nPrims; pi++) {
-        const FastPrim &p = sc.fast()[pi];
-        float L, U;
-        bool cand, cert;
-        if (p.kind == 0) {
-            FastHit h;
-            float num, den;
-            fast_tri_plane(p, r, h, num, den);
-            fast_tri_edges(p, r, prevW2, prevValid, h);
-            cand = !h.certOut && !(h.U <= ray.tmin) && !(h.L >= res.dist);
-            cert = h.certIn && (h.L > ray.tmin) && (h.U < res.dist);
-            L = h.L; U = h.U;
-        } else {
-            prevValid = false;
-            FastRoots fr;
-            fast_sphere(p, ray.org, ray.dir, fr);
-            /* Sphere::Intersect offers the first root beyond tmin (:226-234) */
-            const bool loValid = fr.lo - fr.eLo > ray.tmin, loInvalid = fr.lo + fr.eLo <= ray.tmin;
-            const float t = loInvalid ? fr.hi : fr.lo, e = loInvalid ? fr.eHi : fr.eLo;
-            L = fr.ok ? t - e : -VCM_FILTER_INF;
-            U = fr.ok ? t + e : VCM_FILTER_INF;
-            cand = !fr.noRoot && !(fr.ok && loInvalid && (fr.hi + fr.eHi <= ray.tmin)) && !(L >= res.dist);
-            cert = !fr.noRoot && fr.ok && (loValid || (loInvalid && (fr.hi - fr.eHi > ray.tmin))) && (U < res.dist);
-        }
-        const float Lc = cand ? L : VCM_FILTER_INF;
-        const bool isBest = Lc < minL1;
-        minL2 = fminf(minL2, isBest ? minL1 : Lc);
-        minL1 = isBest ? Lc : minL1;
-        best = isBest ? pi : best;
-        bestU = isBest ? U : bestU;
-        bestCertain = isBest ? cert : bestCertain;
+    FastBest fb;
+    fb.minL1 = fb.minL2 = fb.bestU = VCM_FILTER_INF; fb.best = -1; fb.bestCertain = false;
+    for (int i = 0; i < sc.nFastPairs; i++) {
+        const FastPair &p = sc.fastPairs()[i];
+        FastHit ha, hb;
+        float num, den;
+        fast_tri_plane(p.p0[0], p.n[0], r, ha, num, den);
+        fast_tri_plane(p.p0[1], p.n[1], r, hb, num, den);
+        fast_pair_edges(p, r, ha, hb);
+        const bool two = (p.flags & 1) != 0;
+        fast_offer(fb, !ha.certOut && !(ha.U <= ray.tmin) && !(ha.L >= res.dist),
+                   ha.certIn && (ha.L > ray.tmin) && (ha.U < res.dist), ha.L, ha.U, p.prim[0]);
+        fast_offer(fb, two && !hb.certOut && !(hb.U <= ray.tmin) && !(hb.L >= res.dist),
+                   hb.certIn && (hb.L > ray.tmin) && (hb.U < res.dist), hb.L, hb.U, p.prim[1]);
     }
-    if (best < 0) { certain = true; return false; }   /* every primitive certainly missed */
-    certain = bestCertain && (minL2 > bestU);
+    for (int i = 0; i < sc.nFastSpheres; i++) {
+        const FastSphere &p = sc.fastSpheres()[i];
+        FastRoots fr;
+        fast_sphere(p, ray.org, ray.dir, fr);
+        /* Sphere::Intersect offers the first root beyond tmin (:226-234) */
+        const bool loValid = fr.lo - fr.eLo > ray.tmin, loInvalid = fr.lo + fr.eLo <= ray.tmin;
+        const float t = loInvalid ? fr.hi : fr.lo, e = loInvalid ? fr.eHi : fr.eLo;
+        const float L = fr.ok ? t - e : -VCM_FILTER_INF, U = fr.ok ? t + e : VCM_FILTER_INF;
+        const bool cand = !fr.noRoot && !(fr.ok && loInvalid && (fr.hi + fr.eHi <= ray.tmin)) && !(L >= res.dist);
+        const bool cert = !fr.noRoot && fr.ok && (loValid || (loInvalid && (fr.hi - fr.eHi > ray.tmin))) && (U < res.dist);
+        fast_offer(fb, cand, cert, L, U, p.prim);
+    }
+    if (fb.best < 0) { certain = true; return false; }   /* every primitive certainly missed */
+    certain = fb.bestCertain && (fb.minL2 > fb.bestU);
     if (!certain) return false;
     /* the reference's arithmetic for the winner alone (per-lane index: vector loads, once per ray) */
-    const vcm_prim &pr = sc.prims()[best];
+    const vcm_prim &pr = sc.prims()[fb.best];
     bool hit;
     if (pr.type == VCM_PRIM_TRIANGLE) {
         const V3 n = ld3(pr.n);
         const V3 ao = ld3(pr.p0) - ray.org;
         const float distance = dot(n, ao) / dot(n, ray.dir);                 /* geometry.hxx:144-147 */
         hit = (distance > ray.tmin) && (distance < res.dist);               /* certified to hold */
-        if (hit) { res.normal = n; res.matID = pr.matID; res.prim = best; res.dist = distance; }
+        if (hit) { res.normal = n; res.matID = pr.matID; res.prim = fb.best; res.dist = distance; }
         else certain = false;                                               /* cannot happen; the wave would re-do it */
     } else {
-        hit = sph_intersect(pr, best, ray, res);
+        hit = sph_intersect(pr, fb.best, ray, res);
         if (!hit) certain = false;
     }
     if (hit) res.lightID = sc.mat2light()[res.matID];
@@ -814,36 +841,35 @@ VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp
     FastRay r;
     fast_ray_setup(sc, ray.org, ray.dir, r);
     bool occ = false, unknown = false;
-    float prevW2 = 0.f;
-    bool prevValid = false;
-    for (int pi = 0; pi < sc.nPrims; pi++) {
-        const FastPrim &p = sc.fast()[pi];
-        if (p.kind == 0) {
-            FastHit h;
-            float num, den;
-            fast_tri_plane(p, r, h, num, den);
-            /* can the plane part report a hit in (0, tmax) at all?  Exact (see tri_pair_occluded): fl(num / den) > 0
-               needs equal signs, < tmax needs |num| < tmax |den| up to the rounding of this test's own products */
-            const bool reach = (((f2u(num) ^ f2u(den)) & 0x80000000u) == 0u) && !(fabsf(num) >= 1.000001f * (tmaxp * fabsf(den)));
-            if (wave_any(reach && !occ)) {
-                fast_tri_edges(p, r, prevW2, prevValid, h);
-                const bool hitC = reach && h.certIn && (h.L > 0.f) && (h.U < tmaxp);
-                const bool missC = !reach || h.certOut;
-                occ = occ || hitC;
-                unknown = unknown || !(hitC || missC);
-            } else prevValid = false;
-        } else {
-            prevValid = false;
-            FastRoots fr;
-            fast_sphere(p, ray.org, ray.dir, fr);
-            /* geometry.hxx:226-234 with res.dist = tmax: a hit iff one of the roots lies in (0, tmax) */
-            const bool hitLo = (fr.lo - fr.eLo > 0.f) && (fr.lo + fr.eLo < tmaxp), hitHi = (fr.hi - fr.eHi > 0.f) && (fr.hi + fr.eHi < tmaxp);
-            const bool missLo = (fr.lo + fr.eLo <= 0.f) || (fr.lo - fr.eLo >= tmaxp), missHi = (fr.hi + fr.eHi <= 0.f) || (fr.hi - fr.eHi >= tmaxp);
-            const bool hitC = !fr.noRoot && fr.ok && (hitLo || hitHi);
-            const bool missC = fr.noRoot || (fr.ok && missLo && missHi);
-            occ = occ || hitC;
-            unknown = unknown || !(hitC || missC);
+    for (int i = 0; i < sc.nFastPairs; i++) {
+        const FastPair &p = sc.fastPairs()[i];
+        FastHit ha, hb;
+        float numA, denA, numB, denB;
+        fast_tri_plane(p.p0[0], p.n[0], r, ha, numA, denA);
+        fast_tri_plane(p.p0[1], p.n[1], r, hb, numB, denB);
+        /* can the plane part report a hit in (0, tmax) at all?  Exact (see tri_pair_occluded): fl(num / den) > 0
+           needs equal signs, < tmax needs |num| < tmax |den| up to the rounding of this test's own products */
+        const bool reachA = (((f2u(numA) ^ f2u(denA)) & 0x80000000u) == 0u) && !(fabsf(numA) >= 1.000001f * (tmaxp * fabsf(denA)));
+        const bool reachB = (p.flags & 1) && (((f2u(numB) ^ f2u(denB)) & 0x80000000u) == 0u) && !(fabsf(numB) >= 1.000001f * (tmaxp * fabsf(denB)));
+        if (wave_any((reachA || reachB) && !occ)) {
+            fast_pair_edges(p, r, ha, hb);
+            const bool hitA = reachA && ha.certIn && (ha.L > 0.f) && (ha.U < tmaxp), missA = !reachA || ha.certOut;
+            const bool hitB = reachB && hb.certIn && (hb.L > 0.f) && (hb.U < tmaxp), missB = !reachB || hb.certOut;
+            occ = occ || hitA || hitB;
+            unknown = unknown || !(hitA || missA) || !(hitB || missB);
         }
+    }
+    for (int i = 0; i < sc.nFastSpheres; i++) {
+        const FastSphere &p = sc.fastSpheres()[i];
+        FastRoots fr;
+        fast_sphere(p, ray.org, ray.dir, fr);
+        /* geometry.hxx:226-234 with res.dist = tmax: a hit iff one of the roots lies in (0, tmax) */
+        const bool hitLo = (fr.lo - fr.eLo > 0.f) && (fr.lo + fr.eLo < tmaxp), hitHi = (fr.hi - fr.eHi > 0.f) && (fr.hi + fr.eHi < tmaxp);
+        const bool missLo = (fr.lo + fr.eLo <= 0.f) || (fr.lo - fr.eLo >= tmaxp), missHi = (fr.hi + fr.eHi <= 0.f) || (fr.hi - fr.eHi >= tmaxp);
+        const bool hitC = !fr.noRoot && fr.ok && (hitLo || hitHi);
+        const bool missC = fr.noRoot || (fr.ok && missLo && missHi);
+        occ = occ || hitC;
+        unknown = unknown || !(hitC || missC);
     }
     certain = occ || !unknown;
     return occ;
@@ -861,6 +887,15 @@ VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
     const bool hit = list_intersect_filtered(sc, ray, fast, certain);
 #if !defined(__HIP_DEVICE_COMPILE__)
     g_filterStats.isect++; if (!certain) g_filterStats.isectExact++;
+#endif
+#if defined(VCM_FILTER_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    if (certain) {
+        Isect ex = res;
+        const bool eh = pairs_intersect(sc, ray, ex);
+        if (eh != hit || (hit && (ex.dist != fast.dist || ex.prim != fast.prim || ex.matID != fast.matID)))
+            printf("FILTER MISMATCH isect: org %.9g %.9g %.9g dir %.9g %.9g %.9g tmin %g | exact hit %d prim %d dist %.9g | fast hit %d prim %d dist %.9g\n",
+                   ray.org.x, ray.org.y, ray.org.z, ray.dir.x, ray.dir.y, ray.dir.z, ray.tmin, (int)eh, ex.prim, ex.dist, (int)hit, fast.prim, fast.dist);
+    }
 #endif
     if (!wave_any(!certain)) { res = fast; return hit; }
 #endif
@@ -881,6 +916,11 @@ VCM_HD bool scene_occluded(const SC &sc, V3 point, V3 dir, float tmax)
     const bool occ = list_occluded_filtered(sc, ray, tmaxp, certain);
 #if !defined(__HIP_DEVICE_COMPILE__)
     g_filterStats.occl++; if (!certain) g_filterStats.occlExact++;
+#endif
+#if defined(VCM_FILTER_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    if (certain && pairs_occluded(sc, ray, tmaxp) != occ)
+        printf("FILTER MISMATCH occluded: org %.9g %.9g %.9g dir %.9g %.9g %.9g tmax %.9g | fast %d\n",
+               ray.org.x, ray.org.y, ray.org.z, ray.dir.x, ray.dir.y, ray.dir.z, tmaxp, (int)occ);
 #endif
     if (!wave_any(!certain)) return occ;
 #endif
