@@ -181,7 +181,7 @@ inline void scene_host_build_fast(SceneHost &s)
         for (int k = 0; k < 3; k++) edge(te[to[k]][0], te[to[k]][1], f.NE[k]);
         edge(ue[uo[0]][0], ue[uo[0]][1], f.NE[3]);
         edge(ue[uo[1]][0], ue[uo[1]][1], f.NE[4]);
-        edge(ue[uo[2]][0], ue[uo[2]][1], f.NE5);
+        edge(ue[uo[2]][0], ue[uo[2]][1], f.NE[5]);
         if (shared) f.flags |= 2;
         s.fastPairs.push_back(f);
         for (int w = 0; w < (two ? 2 : 1); w++) {

@@ -117,7 +117,7 @@ static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_t
                                           else hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); } while (0)
 
 #ifndef VCM_MERGE_DEFAULT
-#define VCM_MERGE_DEFAULT VCM_MERGE_LANE
+#define VCM_MERGE_DEFAULT VCM_MERGE_WALK
 #endif
 struct vcm_ctx : Scratch {
     SceneHost *scene;                 /* host copy of the scene + the structure the intersection code walks */
@@ -536,7 +536,7 @@ static int launch_scan(vcm_ctx *c, const T *in, int n, int *out, int *totalOut, 
     return launch_scan_on<T>(c->stream, c->dTileSums, in, n, out, totalOut, writeTotalAtN, take_stamps(c, c->stream));
 }
 
-static void trace_launch_shape(int nLocal, int *blocks, int *chunk)
+static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPass = false)
 {
     /* persistent waves: enough to fill 256 CUs several times over, each wave
        owning a contiguous chunk of paths (>= 64) */
@@ -544,6 +544,8 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk)
     static const char *tw = getenv("SMALLVCM_AMD_TRACE_WAVES");
     /* 4096 = 16 waves per CU: measured best (fewer, longer-lived waves leave fewer partly used queue blocks) */
     int maxWaves = (tw && atoi(tw) > 0) ? atoi(tw) : 256 * 16;
+    static const char *lw = getenv("SMALLVCM_AMD_LIGHT_WAVES");   /* K1 needs fewer registers than K3: 5 waves per SIMD fit */
+    if (lightPass && lw && atoi(lw) > 0) maxWaves = atoi(lw);
     if (maxWaves > VCM_MAX_TRACE_WAVES) maxWaves = VCM_MAX_TRACE_WAVES;   /* the queue buffers hold one spare block per wave */
     if (waves > maxWaves) waves = maxWaves;
     if (waves < 1) waves = 1;
@@ -881,7 +883,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         return 0;
     }
     int blocks, chunk;
-    trace_launch_shape(c->nLocal, &blocks, &chunk);
+    trace_launch_shape(c->nLocal, &blocks, &chunk, true);
     if (mark(c, EV_LIGHT_K0)) return -1;
     const bool wf = !c->strictOrder;
     if (wf)
@@ -1184,10 +1186,12 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (join_grid(c)) return -1;
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
-            /* Two kernels, same bits.  k_merge_lane (default): per-lane gathers of the candidates.  k_merge_staged
-               (SMALLVCM_AMD_MERGE=staged): the workgroup stages the cell lists of its queries through LDS -- 27 % less
-               HBM traffic (13.7 -> 9.9 GB per launch) but 4 % slower (profiles/r02c_ab_summary.txt): the kernel is bound
-               by VALU issue, not by the candidate loads, and the staging adds instructions and barriers. */
+            /* Three kernels, same bits (vcm_set_merge_kernel).  k_merge_walk (default): every lane walks its own
+               non-empty runs back to back -- 3.51 ms against 3.93 for k_merge_lane, which visits the 8 cells in
+               lockstep (profiles/r02j_ab_summary.txt).  k_merge_staged: the workgroup stages the cell lists of its
+               queries through LDS -- 27 % less HBM traffic than k_merge_lane (13.7 -> 9.9 GB per launch,
+               profiles/r02c_ab_summary.txt) but slower: the kernel is not bound by the candidate loads, and the
+               staging adds instructions and barriers. */
             const int mergeStaged = c->mergeKind;
             if (mergeStaged == 2)
                 hipLaunchKernelGGL(k_merge_walk, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),

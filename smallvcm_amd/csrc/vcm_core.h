@@ -203,10 +203,10 @@ struct PrimOp { int kind; int index; };   /* kind 0: TriPair pairs[index]; kind 
  * and one wait: the loop is bound by that latency as much as by its arithmetic. */
 struct alignas(16) FastPair {
     float p0[2][3], n[2][3];    /* vertex 0 and Triangle::mNormal of the two triangles */
-    float NE[5][6];             /* {N, E} of edges A0 A1 A2 B0 B1:  W = Dot(dir, N) + Dot(Cross(o, dir), E) */
-    float NE5[6];               /* edge B2 when it is not -A2 */
+    float NE[6][6];             /* {N, E} of edges A0 A1 A2 B0 B1 B2:  W = Dot(dir, N) + Dot(Cross(o, dir), E) */
     int   prim[2];              /* indices in prims[] */
-    int   flags;                /* bit 0: triangle B present; bit 1: B2 = -A2 */
+    int   flags;                /* bit 0: triangle B present; bit 1: B2 = -A2 (the entry holds B2 all the same: testing
+                                   the bit would split the burst of loads in two and cost more than six fma) */
     int   pad;
 };
 struct alignas(16) FastSphere { float c[3], radius; int prim; int pad[3]; };
@@ -730,8 +730,7 @@ VCM_HD void fast_classify(float w0, float w1, float w2, float tau, FastHit &h)
 VCM_HD void fast_pair_edges(const FastPair &p, const FastRay &r, FastHit &ha, FastHit &hb)
 {
     const float a0 = fast_edge(p.NE[0], r), a1 = fast_edge(p.NE[1], r), a2 = fast_edge(p.NE[2], r);
-    const float b0 = fast_edge(p.NE[3], r), b1 = fast_edge(p.NE[4], r);
-    const float b2 = (p.flags & 2) ? -a2 : fast_edge(p.NE5, r);
+    const float b0 = fast_edge(p.NE[3], r), b1 = fast_edge(p.NE[4], r), b2 = fast_edge(p.NE[5], r);
     fast_classify(a0, a1, a2, r.tauW, ha);
     fast_classify(b0, b1, b2, r.tauW, hb);
 }
@@ -851,7 +850,11 @@ VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp
            needs equal signs, < tmax needs |num| < tmax |den| up to the rounding of this test's own products */
         const bool reachA = (((f2u(numA) ^ f2u(denA)) & 0x80000000u) == 0u) && !(fabsf(numA) >= 1.000001f * (tmaxp * fabsf(denA)));
         const bool reachB = (p.flags & 1) && (((f2u(numB) ^ f2u(denB)) & 0x80000000u) == 0u) && !(fabsf(numB) >= 1.000001f * (tmaxp * fabsf(denB)));
+#if defined(VCM_FILTER_NOSKIP)
+        {
+#else
         if (wave_any((reachA || reachB) && !occ)) {
+#endif
             fast_pair_edges(p, r, ha, hb);
             const bool hitA = reachA && ha.certIn && (ha.L > 0.f) && (ha.U < tmaxp), missA = !reachA || ha.certOut;
             const bool hitB = reachB && hb.certIn && (hb.L > 0.f) && (hb.U < tmaxp), missB = !reachB || hb.certOut;
