@@ -47,9 +47,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-KERNEL_KEYS = {"k_light_trace": ["vcm::k_light_trace<1>"], "k_camera_trace": ["vcm::k_camera_trace<1>"],
+# kernel-name PREFIXES as rocprofv3 prints them (the ray-casting kernels are templates over the kind of scene:
+# "vcm::k_camera_trace<1, vcm::SceneList>")
+KERNEL_KEYS = {"k_light_trace": ["vcm::k_light_trace<1"], "k_camera_trace": ["vcm::k_camera_trace<1"],
                "k_connect_di+vc": ["vcm::k_connect_di", "vcm::k_connect_vc"],
-               "k_merge": ["vcm::k_merge_staged", "vcm::k_merge_lane"]}
+               "k_merge": ["vcm::k_merge_walk", "vcm::k_merge_staged", "vcm::k_merge_lane"]}
+
+
+def _is_kernel(name, prefixes):
+    return any(name.startswith(p) for p in prefixes)
 KERNEL_SOURCES = ["vcm_api.hip", "vcm_kernels.h", "vcm_core.h", "vcm_math.h", "detmath.h", "philox.h", "Makefile"]
 # BASELINE.json configs that fit one GPU, besides the headline (C4 at one GPU)
 # (name, scene, algorithm, resolution, renderers in flight): "x4" = four renderers (seeds 1234..1237, the reference's
@@ -75,7 +81,7 @@ def recorded_traffic(kernel):
             if d.get("kernel_src_sha16") != want:
                 continue
             t = d["kernels"]
-            tot = sum(t[k]["fetch_bytes_x2"] + t[k]["write_bytes"] for k in KERNEL_KEYS[kernel] if k in t)
+            tot = sum(v["fetch_bytes_x2"] + v["write_bytes"] for k, v in t.items() if _is_kernel(k, KERNEL_KEYS[kernel]))
             if tot > 0:
                 return int(tot), os.path.relpath(path, ROOT)
         except Exception:
@@ -88,7 +94,7 @@ def _pmc_mean(csv_path, kernel_names, counter, skip):
     seen, vals = {}, []
     for r in csv.DictReader(open(csv_path)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if k not in kernel_names or r["Counter_Name"] != counter:
+        if not _is_kernel(k, kernel_names) or r["Counter_Name"] != counter:
             continue
         seen[k] = seen.get(k, 0) + 1
         if seen[k] > skip:

@@ -63,11 +63,13 @@ json.dump({"kernel_src_sha16": kernel_source_hash(),
                    "avg_us is the duration under counter collection (serialised dispatches)",
            "kernels": kernels}, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 sq = {}
-for p in ("sq1", "sq2"):
+for p in ("sq1", "sq2", "sq3", "sq4"):
+    if p in ("sq3", "sq4") and not glob.glob(os.path.join(src, "%s_%s/*/*counter_collection.csv" % (tag, p))):
+        continue
     c, _ = per_kernel(one("%s_%s/*/*counter_collection.csv" % (tag, p)))
     for k, d in c.items():
         if k.startswith("vcm::"):
             sq.setdefault(k, {}).update({n: int(v) for n, v in d.items()})
-json.dump({"note": "rocprofv3 --pmc SQ_* (two passes), mean per dispatch after the first two", "kernels": sq},
+json.dump({"note": "rocprofv3 --pmc SQ_* (one pass per group of counters), mean per dispatch after the first two", "kernels": sq},
           open(os.path.join(dst, "%s_pmc_sq.json" % tag), "w"), indent=1)
 print("wrote profiles/%s_kernel_stats.csv, %s_traffic.json, %s_pmc_sq.json" % (tag, tag, tag))
