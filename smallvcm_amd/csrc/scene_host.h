@@ -60,6 +60,9 @@ struct SceneHost {
         d.nOps = (int)ops.size(); d.nNodes = (int)nodes.size();
         d.fastRw2 = fastRw2; d.fastRadius = fastRadius;
         d.nFastPairs = (int)fastPairs.size(); d.nFastSpheres = (int)fastSpheres.size();
+        d.fastOnePlane = 1;
+        for (const FastPair &f : fastPairs) if (!(f.flags & 4)) d.fastOnePlane = 0;
+        { const char *e = getenv("SMALLVCM_AMD_NO_ONEPLANE"); if (e && e[0] == '1') d.fastOnePlane = 0; }   /* measurement switch */
         for (int k = 0; k < 3; k++) d.fastCenter[k] = fastCenter[k];
     }
 };
@@ -183,6 +186,11 @@ inline void scene_host_build_fast(SceneHost &s)
         edge(ue[uo[1]][0], ue[uo[1]][1], f.NE[4]);
         edge(ue[uo[2]][0], ue[uo[2]][1], f.NE[5]);
         if (shared) f.flags |= 2;
+        if (two) {   /* one plane part for both? (FastPair::flags bit 2) */
+            bool same = true;
+            for (int k = 0; k < 3; k++) same = same && (t.n[k] == u.n[k]) && (t.n[k] == 0.f || t.p0[k] == u.p0[k]);
+            if (same) f.flags |= 4;
+        }
         s.fastPairs.push_back(f);
         for (int w = 0; w < (two ? 2 : 1); w++) {
             const vcm_prim &q = s.prims[i + w];

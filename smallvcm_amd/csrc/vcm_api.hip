@@ -112,8 +112,10 @@ static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_t
 
 /* Kernels that cast rays exist once per kind of scene (vcm_core.h SceneList / SceneBvh); the launch picks. */
 #define LAUNCH_SC(c, K, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<SceneBvh>), __VA_ARGS__); \
+                                  else if ((c)->sceneQuads) hipLaunchKernelGGL((K<SceneQuads>), __VA_ARGS__); \
                                   else hipLaunchKernelGGL((K<SceneList>), __VA_ARGS__); } while (0)
 #define LAUNCH_SC_MODE(c, K, M, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<M, SceneBvh>), __VA_ARGS__); \
+                                          else if ((c)->sceneQuads) hipLaunchKernelGGL((K<M, SceneQuads>), __VA_ARGS__); \
                                           else hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); } while (0)
 
 #ifndef VCM_MERGE_DEFAULT
@@ -153,6 +155,7 @@ struct vcm_ctx : Scratch {
     bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI, bboxPreset;
     bool strictOrder;
     int mergeKind;                    /* VCM_MERGE_* */
+    bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
     IterParams P;
     bool inIteration;
     hipEvent_t ev[EV_COUNT];
@@ -214,7 +217,7 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
     DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
-    DFREE(s.vs.q0); DFREE(s.vs.q1); DFREE(s.vs.q2); DFREE(s.vs.q3); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
+    DFREE(s.vs.q); DFREE(s.vs.meta); DFREE(s.vs.count);
     DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
     DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryArrival);
     a->allocated = false;
@@ -264,8 +267,8 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const size_t vslots = vitems + vitems / 3 + maxWaves * VCM_QBLOCK_VERTEX;
     const size_t vcPerPath = (cL >= 3) ? (size_t)(cL - 1) * (size_t)(cL - 2) / 2 : 1;
     const size_t vcslots = 2 * vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
-    if (dalloc(&s.vs.q0, vslots) || dalloc(&s.vs.q1, vslots) || dalloc(&s.vs.q2, vslots) ||
-        dalloc(&s.vs.q3, vslots) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
+    s.vs.qcap = vslots;
+    if (dalloc(&s.vs.q, vslots * 5) || dalloc(&s.vs.meta, vslots) ||
         dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.diOut, vslots) ||
         dalloc(&s.vs.mergeOut, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
         dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;
@@ -417,6 +420,7 @@ static int ensure_device(vcm_ctx *c)
                 if (p.bytes) HIPCHK(hipMemcpy(c->dSceneBlob + p.off, p.src, p.bytes, hipMemcpyHostToDevice));
             DScene view;
             h.fill_scalars(view);
+            c->sceneQuads = h.nodes.empty() && view.fastOnePlane != 0;
             view.offPrims = (long long)parts[0].off; view.offMaterials = (long long)parts[1].off;
             view.offMat2light = (long long)parts[2].off; view.offLights = (long long)parts[3].off;
             view.offOps = (long long)parts[4].off; view.offPairs = (long long)parts[5].off;
@@ -483,6 +487,42 @@ static __global__ void k_set_bbox(GridHeader *hdr, float x0, float y0, float z0,
 }
 static __global__ void k_note_grid_vertices(const GridHeader *hdr, unsigned long long *out, StampArgs st) { stamp_entry(st); *out = (unsigned long long)hdr->nRecords; }
 static __global__ void k_stamp_many(StampArgs st) { stamp_entry(st); }
+/* Zeroing up to four device ranges in ONE launch (16-byte stores plus a tail of 4-byte ones; every range starts
+ * 16-byte aligned and is a whole number of 4-byte words, except byte tables, whose size is rounded up to 4: they are
+ * allocated in larger units).  hipMemsetAsync reached 380 GB/s on the 16 MB tables and cost a launch per
+ * range: nine of them were 0.43 ms of an 11 ms iteration (profiles/r02k_kernel_stats.csv). */
+struct ZeroArgs { void *p[4]; unsigned long long n16[4]; unsigned tail4[4]; };
+static __global__ void __launch_bounds__(256) k_zero_ranges(ZeroArgs z)
+{
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint4 *q = (uint4 *)z.p[r];
+        for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < z.n16[r]; i += (unsigned long long)gridDim.x * blockDim.x) q[i] = zero;
+        if (blockIdx.x == 0 && threadIdx.x < z.tail4[r]) ((unsigned *)(q + z.n16[r]))[threadIdx.x] = 0u;
+    }
+}
+static int zero_ranges(hipStream_t stream, void *p0, size_t b0, void *p1 = NULL, size_t b1 = 0, void *p2 = NULL, size_t b2 = 0, void *p3 = NULL, size_t b3 = 0)
+{
+    ZeroArgs z;
+    void *p[4] = { p0, p1, p2, p3 };
+    const size_t b[4] = { b0, b1, b2, b3 };
+    size_t most = 0;
+    for (int r = 0; r < 4; r++) {
+        z.p[r] = p[r]; z.n16[r] = p[r] ? b[r] / 16 : 0; z.tail4[r] = p[r] ? (unsigned)((b[r] % 16 + 3) / 4) : 0u;
+        if (z.n16[r] + 1 > most && p[r] && b[r]) most = z.n16[r] + 1;
+    }
+    if (!most) return 0;
+#if defined(VCM_HIP_MEMSET)   /* measurement switch: one hipMemsetAsync per range, as before */
+    for (int r = 0; r < 4; r++) if (p[r] && b[r]) HIPCHK(hipMemsetAsync(p[r], 0, b[r], stream));
+    return 0;
+#endif
+    size_t blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_zero_ranges, dim3((unsigned)blocks), dim3(256), 0, stream, z);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static StampArgs take_stamps(vcm_ctx *c, hipStream_t stream)
 {
     const int w = (stream == c->side) ? 1 : 0;
@@ -833,9 +873,8 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     if (mark(c, EV_START)) return -1;
     c->dStats = c->dStatsRing + (size_t)(c->iterations % VCM_STAMP_RING) * VCM_STAT_SLOTS;
     c->radiusRing[c->iterations % VCM_STAMP_RING] = radius;
-    HIPCHK(hipMemsetAsync(c->dStats, 0, VCM_STAT_SLOTS * sizeof(unsigned long long), c->stream));
-    HIPCHK(hipMemsetAsync(c->store.count, 0, (size_t)c->nLocal, c->stream));   /* :311-312 */
-    HIPCHK(hipMemsetAsync(c->vs.count, 0, 4 * sizeof(int), c->stream));
+    if (zero_ranges(c->stream, c->dStats, VCM_STAT_SLOTS * sizeof(unsigned long long), c->store.count, (size_t)c->nLocal /* :311-312 */,
+                    c->vs.count, 4 * sizeof(int))) return -1;
     c->importedRecords = false;
     c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->bboxPreset = false;
     c->inIteration = true;
@@ -855,7 +894,7 @@ static int flush_light_splats(vcm_ctx *c)
         /* scratch shared with the grid build / query sort, which run later */
         int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart;
         F4 *list = (F4 *)c->dUnsorted;   /* 16-byte elements, like the cell list it is later used for */
-        HIPCHK(hipMemsetAsync(pixCount, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
+        if (zero_ranges(c->stream, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
         LAUNCH_SC(c, k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
                            arrival, c->dStats);
@@ -1060,7 +1099,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         recs.slotOfVertex = c->dSlotOfVertex;
         const int nCells = c->P.nCells;
         const dim3 g(2048), b(256);
-        HIPCHK(hipMemsetAsync(c->dCellCount, 0, ((size_t)nCells + 1) * sizeof(int), q));
+        if (zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
         if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
             hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr, take_stamps(c, q));
             hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
@@ -1129,7 +1168,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
-        if (c->countedInCamera) HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)c->P.nBuckets + 1) * sizeof(int), c->stream));
+        if (c->countedInCamera && zero_ranges(c->stream, c->dQueryCount, ((size_t)c->P.nBuckets + 1) * sizeof(int))) return -1;
         LAUNCH_SC_MODE(c, k_camera_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
@@ -1169,7 +1208,7 @@ static int vcm_merge_impl(vcm_ctx *c)
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
             const int nb = c->P.nBuckets;
             if (!c->countedInCamera) {
-                HIPCHK(hipMemsetAsync(c->dQueryCount, 0, ((size_t)nb + 1) * sizeof(int), c->stream));
+                if (zero_ranges(c->stream, c->dQueryCount, ((size_t)nb + 1) * sizeof(int))) return -1;
                 hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
                                    (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount, take_stamps(c, c->stream));
             }

@@ -92,11 +92,16 @@ struct GridStore {
  * every path in the reference's order. */
 struct alignas(16) I4 { int x, y, z, w; };
 struct VertexStore {
-    F4 *q0;          /* hitpoint.xyz | local path index                          */
-    F4 *q1;          /* isect.normal.xyz | pathLength (bits 0-7), matID (8-15)   */
-    F4 *q2;          /* localDirFix.xyz | dVCM                                   */
-    F4 *q3;          /* throughput.xyz | dVM                                     */
-    F4 *q4;          /* dVC | the 3 random floats of DirectIllumination (:672-673) */
+    /* the record of camera vertex i: five 16-byte fields, CONTIGUOUS (80 B): q[i * 5 + k].  As five separate arrays
+       (round 1) a wave's append was five partly written cache lines per step and every consumer's gather touched
+       five lines: K4 3.55 -> 3.39 ms, K3 unchanged (profiles/r02r_ab_summary.txt)
+         k=0 hitpoint.xyz | local path index
+         k=1 isect.normal.xyz | pathLength (bits 0-7), matID (8-15)
+         k=2 localDirFix.xyz | dVCM
+         k=3 throughput.xyz | dVM
+         k=4 dVC | the position of the 3 random floats of DirectIllumination (:672-673) in the path's stream */
+    F4 *q;
+    size_t qcap;     /* records allocated (the SoA measurement build indexes q[k * qcap + i]) */
     I4 *meta;        /* per PATH SLOT: DI task (-1: none) | first VC task | number of VC tasks | 0 */
     int *count;      /* [0] vertices  [1] DI tasks  [2] VC tasks                  */
     int *diTask;     /* DI task -> vertex                                         */
@@ -112,6 +117,11 @@ struct VertexStore {
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
 };
+#if defined(VCM_VS_SOA)   /* measurement switch: five arrays */
+VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return vs.q[(size_t)k * vs.qcap + i]; }
+#else
+VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return vs.q[i * 5 + (size_t)k]; }
+#endif
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
@@ -206,7 +216,10 @@ struct alignas(16) FastPair {
     float NE[6][6];             /* {N, E} of edges A0 A1 A2 B0 B1 B2:  W = Dot(dir, N) + Dot(Cross(o, dir), E) */
     int   prim[2];              /* indices in prims[] */
     int   flags;                /* bit 0: triangle B present; bit 1: B2 = -A2 (the entry holds B2 all the same: testing
-                                   the bit would split the burst of loads in two and cost more than six fma) */
+                                   the bit would split the burst of loads in two and cost more than six fma);
+                                   bit 2: B's plane operands Dot(n, p0 - o), Dot(n, dir) equal A's for EVERY ray (same
+                                   normal up to the sign of zeros, and p0 differs only along axes where the normal is
+                                   zero: the two triangles of an axis-aligned quad) -- one plane part serves both */
     int   pad;
 };
 struct alignas(16) FastSphere { float c[3], radius; int prim; int pad[3]; };
@@ -241,6 +254,7 @@ struct DScene {
     /* scene constants of the filter's error bounds: max |vertex|^2 over the triangles; a sphere around their vertices */
     float fastRw2, fastCenter[3], fastRadius;
     int nFastPairs, nFastSpheres;
+    int fastOnePlane;   /* every FastPair has flags bit 2: the loops then contain no per-entry branch (one burst of loads) */
     template <class T> VCM_HD const T *at(long long off) const { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(this) + off); }
     VCM_HD const vcm_prim *prims() const { return at<vcm_prim>(offPrims); }
     VCM_HD const vcm_material *materials() const { return at<vcm_material>(offMaterials); }
@@ -257,8 +271,11 @@ struct DScene {
  * nNodes), so the brute-force kernels hold no traversal code and the BVH kernels no list loop.  Compiled together the
  * two paths cost the headline kernels 11-27 VGPRs, i.e. a wave per SIMD (K3 122 -> 133 registers: 713 -> 576
  * Mpaths/s on the same box, profiles/r02g_*).  Functions that cast rays take `const SC &`, the rest `const DScene &`. */
-struct SceneList : DScene { static constexpr bool kBvh = false; };
-struct SceneBvh : DScene { static constexpr bool kBvh = true; };
+struct SceneList : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = false; };
+struct SceneBvh : DScene { static constexpr bool kBvh = true; static constexpr bool kOnePlane = false; };
+/* a list whose triangle pairs all share their plane part (FastPair::flags bit 2: axis-aligned quads, i.e. the reference's
+   Cornell boxes): its kernels carry only that loop */
+struct SceneQuads : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; };
 
 /* ---- utils.hxx ---------------------------------------------------- */
 VCM_HD float luminance(V3 c)
@@ -783,24 +800,41 @@ VCM_HD void fast_offer(FastBest &fb, bool cand, bool cert, float L, float U, int
     fb.bestCertain = isBest ? cert : fb.bestCertain;
 }
 /* Scene::Intersect over the list with the filter in front.  `certain` = this lane's answer is final. */
+template <bool ONE_PLANE>
 VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res, bool &certain)
 {
     FastRay r;
     fast_ray_setup(sc, ray.org, ray.dir, r);
     FastBest fb;
     fb.minL1 = fb.minL2 = fb.bestU = VCM_FILTER_INF; fb.best = -1; fb.bestCertain = false;
-    for (int i = 0; i < sc.nFastPairs; i++) {
-        const FastPair &p = sc.fastPairs()[i];
-        FastHit ha, hb;
-        float num, den;
-        fast_tri_plane(p.p0[0], p.n[0], r, ha, num, den);
-        fast_tri_plane(p.p0[1], p.n[1], r, hb, num, den);
-        fast_pair_edges(p, r, ha, hb);
-        const bool two = (p.flags & 1) != 0;
-        fast_offer(fb, !ha.certOut && !(ha.U <= ray.tmin) && !(ha.L >= res.dist),
-                   ha.certIn && (ha.L > ray.tmin) && (ha.U < res.dist), ha.L, ha.U, p.prim[0]);
-        fast_offer(fb, two && !hb.certOut && !(hb.U <= ray.tmin) && !(hb.L >= res.dist),
-                   hb.certIn && (hb.L > ray.tmin) && (hb.U < res.dist), hb.L, hb.U, p.prim[1]);
+    if (ONE_PLANE) {
+        for (int i = 0; i < sc.nFastPairs; i++) {
+            const FastPair &p = sc.fastPairs()[i];
+            FastHit ha, hb;
+            float num, den;
+            fast_tri_plane(p.p0[0], p.n[0], r, ha, num, den);
+            /* one plane, two triangles: the same distance bounds for both; at most one of them contains the point */
+            hb.L = ha.L; hb.U = ha.U;
+            fast_pair_edges(p, r, ha, hb);
+            const bool reach = !(ha.U <= ray.tmin) && !(ha.L >= res.dist), sure = (ha.L > ray.tmin) && (ha.U < res.dist);
+            const bool candA = reach && !ha.certOut, candB = reach && !hb.certOut;
+            const bool certA = sure && ha.certIn && hb.certOut, certB = sure && hb.certIn && ha.certOut;
+            fast_offer(fb, candA || candB, certA || certB, ha.L, ha.U, certB ? p.prim[1] : p.prim[0]);
+        }
+    } else {
+        for (int i = 0; i < sc.nFastPairs; i++) {
+            const FastPair &p = sc.fastPairs()[i];
+            FastHit ha, hb;
+            float num, den;
+            fast_tri_plane(p.p0[0], p.n[0], r, ha, num, den);
+            fast_tri_plane(p.p0[1], p.n[1], r, hb, num, den);
+            fast_pair_edges(p, r, ha, hb);
+            const bool two = (p.flags & 1) != 0;
+            fast_offer(fb, !ha.certOut && !(ha.U <= ray.tmin) && !(ha.L >= res.dist),
+                       ha.certIn && (ha.L > ray.tmin) && (ha.U < res.dist), ha.L, ha.U, p.prim[0]);
+            fast_offer(fb, two && !hb.certOut && !(hb.U <= ray.tmin) && !(hb.L >= res.dist),
+                       hb.certIn && (hb.L > ray.tmin) && (hb.U < res.dist), hb.L, hb.U, p.prim[1]);
+        }
     }
     for (int i = 0; i < sc.nFastSpheres; i++) {
         const FastSphere &p = sc.fastSpheres()[i];
@@ -834,22 +868,23 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
     if (hit) res.lightID = sc.mat2light()[res.matID];
     return hit;
 }
-/* Scene::Occluded over the list with the filter in front */
-VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp, bool &certain)
+/* the triangle entries of Scene::Occluded; ONE_PLANE: every entry's two triangles share the plane part (no branch
+ * inside the loop: the loads of an entry stay one burst) */
+template <bool ONE_PLANE>
+VCM_HD void occluded_pairs(const DScene &sc, const FastRay &r, float tmaxp, bool &occ, bool &unknown)
 {
-    FastRay r;
-    fast_ray_setup(sc, ray.org, ray.dir, r);
-    bool occ = false, unknown = false;
     for (int i = 0; i < sc.nFastPairs; i++) {
         const FastPair &p = sc.fastPairs()[i];
         FastHit ha, hb;
         float numA, denA, numB, denB;
         fast_tri_plane(p.p0[0], p.n[0], r, ha, numA, denA);
-        fast_tri_plane(p.p0[1], p.n[1], r, hb, numB, denB);
+        if (ONE_PLANE) { hb.L = ha.L; hb.U = ha.U; numB = numA; denB = denA; }
+        else fast_tri_plane(p.p0[1], p.n[1], r, hb, numB, denB);
         /* can the plane part report a hit in (0, tmax) at all?  Exact (see tri_pair_occluded): fl(num / den) > 0
            needs equal signs, < tmax needs |num| < tmax |den| up to the rounding of this test's own products */
         const bool reachA = (((f2u(numA) ^ f2u(denA)) & 0x80000000u) == 0u) && !(fabsf(numA) >= 1.000001f * (tmaxp * fabsf(denA)));
-        const bool reachB = (p.flags & 1) && (((f2u(numB) ^ f2u(denB)) & 0x80000000u) == 0u) && !(fabsf(numB) >= 1.000001f * (tmaxp * fabsf(denB)));
+        const bool reachB = ONE_PLANE ? reachA
+                                      : ((p.flags & 1) && (((f2u(numB) ^ f2u(denB)) & 0x80000000u) == 0u) && !(fabsf(numB) >= 1.000001f * (tmaxp * fabsf(denB))));
 #if defined(VCM_FILTER_NOSKIP)
         {
 #else
@@ -862,6 +897,15 @@ VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp
             unknown = unknown || !(hitA || missA) || !(hitB || missB);
         }
     }
+}
+/* Scene::Occluded over the list with the filter in front */
+template <bool ONE_PLANE>
+VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp, bool &certain)
+{
+    FastRay r;
+    fast_ray_setup(sc, ray.org, ray.dir, r);
+    bool occ = false, unknown = false;
+    occluded_pairs<ONE_PLANE>(sc, r, tmaxp, occ, unknown);
     for (int i = 0; i < sc.nFastSpheres; i++) {
         const FastSphere &p = sc.fastSpheres()[i];
         FastRoots fr;
@@ -887,7 +931,7 @@ VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
 #if !defined(VCM_NO_FILTER)
     bool certain;
     Isect fast = res;
-    const bool hit = list_intersect_filtered(sc, ray, fast, certain);
+    const bool hit = list_intersect_filtered<SC::kOnePlane>(sc, ray, fast, certain);
 #if !defined(__HIP_DEVICE_COMPILE__)
     g_filterStats.isect++; if (!certain) g_filterStats.isectExact++;
 #endif
@@ -916,7 +960,7 @@ VCM_HD bool scene_occluded(const SC &sc, V3 point, V3 dir, float tmax)
     if constexpr (SC::kBvh) return bvh_occluded(sc, ray, tmaxp);
 #if !defined(VCM_NO_FILTER)
     bool certain;
-    const bool occ = list_occluded_filtered(sc, ray, tmaxp, certain);
+    const bool occ = list_occluded_filtered<SC::kOnePlane>(sc, ray, tmaxp, certain);
 #if !defined(__HIP_DEVICE_COMPILE__)
     g_filterStats.occl++; if (!certain) g_filterStats.occlExact++;
 #endif
@@ -1925,7 +1969,13 @@ VCM_HD void camera_path_begin(const DScene &sc, const IterParams &P, CameraPath 
  * MODE 1 ("wavefront", default): the path only traces and scatters; per
  *         non-delta vertex it appends a VertexStore record and its DI / VC
  *         tasks.  Returns false when the path ends. */
-struct CameraWaveQueues { WaveQueue v, di, vc; };   /* wave-uniform allocator state of K3 */
+struct CameraWaveQueues {   /* wave-uniform allocator state of K3 */
+    WaveQueue v, di, vc;
+    /* per lane: the place a vertex took in its query-sort bucket (a RETURNING atomic, issued when the vertex is
+       appended) is written to sortArrival by the caller AFTER the step: stored on the spot, the wave waited for the
+       atomic's round trip -- and with it for every store of the record it had just issued -- once per bounce */
+    int pendingVertex, pendingArrival;
+};
 
 template <int MODE, class SC>
 VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
@@ -1993,25 +2043,29 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
             const int vi = wave_queue_alloc(wqs.v, &vs.count[0], P.qblockVertex, 1,
                 [&](int first, int cnt, int rank, int na) {
                     for (int i = rank; i < cnt; i += na) {
-                        vs.q0[first + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+                        vq(vs, 0, first + i) = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
                         if (vs.sortKey) vs.sortKey[first + i] = -1;
                     } });
             const int di = wave_queue_alloc(wqs.di, &vs.count[1], P.qblockDI, hasDI,
                 [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.diTask[first + i] = -1; });
             const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], P.qblockVC, nvc,
                 [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.vcTask[2 * (first + i)] = -1; });
-            vs.q0[vi] = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
-            vs.q1[vi] = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | (shade_code(bsdf.matID, isect.prim) << 8)));
-            vs.q2[vi] = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
-            vs.q3[vi] = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
-            vs.q4[vi] = mk4(st.dVC, u2f(diK), 0.f, 0.f);
+            vq(vs, 0, vi) = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
+            vq(vs, 1, vi) = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | (shade_code(bsdf.matID, isect.prim) << 8)));
+            vq(vs, 2, vi) = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);
+            vq(vs, 3, vi) = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
+            vq(vs, 4, vi) = mk4(st.dVC, u2f(diK), 0.f, 0.f);
             I4 m; m.x = hasDI ? di : -1; m.y = vc0; m.z = nvc; m.w = 0;
             vs.meta[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = m;
 #if defined(__HIP_DEVICE_COMPILE__)
             if (vs.sortKey && P.useVM) {   /* K4a's histogram pass, here (see VertexStore) */
                 const int k = query_sort_key(P, vs.sortHdr, hitPoint);
                 vs.sortKey[vi] = k;
+#if defined(VCM_NO_DEFER)   /* measurement switch: store on the spot */
                 if (k >= 0) vs.sortArrival[vi] = atomicAdd(&vs.bucketCount[k], 1);
+#else
+                if (k >= 0) { wqs.pendingVertex = vi; wqs.pendingArrival = atomicAdd(&vs.bucketCount[k], 1); }
+#endif
                 else vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
             }
 #endif
@@ -2078,7 +2132,7 @@ struct CamVertex {
 };
 VCM_HD void load_cam_vertex(const DScene &sc, const VertexStore &vs, int vi, CamVertex &v)
 {
-    const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi], e = vs.q4[vi];
+    const F4 a = vq(vs, 0, vi), b = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi), e = vq(vs, 4, vi);
     v.hit = mk3(a.x, a.y, a.z);
     v.lp = f2u(a.w);
     bsdf_restore(v.bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(b.w) >> 8, sc);
@@ -2120,7 +2174,7 @@ VCM_HD V3 eval_vc_task(const SC &sc, const IterParams &P, const VertexStore &vs,
 VCM_HD V3 eval_merge_task(const DScene &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
                           int vi, LaneStats &ls, const MergeScratch &ms, size_t &pathSlot)
 {
-    const F4 a = vs.q0[vi], b = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+    const F4 a = vq(vs, 0, vi), b = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
     pathSlot = path_slot(P, f2u(b.w) & 0xffu, f2u(a.w));
     Bsdf bsdf;
     bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(b.w) >> 8, sc);

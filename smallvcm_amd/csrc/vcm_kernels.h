@@ -76,8 +76,13 @@ __device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long l
 }
 
 /* ---------------- K1: light sub-paths (vertexcm.hxx:321-396) ------------ */
+#if defined(VCM_K1_WAVES)
+#define VCM_K1_ATTR __attribute__((amdgpu_waves_per_eu(VCM_K1_WAVES, VCM_K1_WAVES)))
+#else
+#define VCM_K1_ATTR
+#endif
 template <int MODE, class SC>
-__global__ void __launch_bounds__(VCM_TRACE_BLOCK)
+__global__ void __launch_bounds__(VCM_TRACE_BLOCK) VCM_K1_ATTR
 k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, float *fb,
               unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st)
 {
@@ -115,8 +120,13 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
 /* MODE 1 (default, "wavefront"): trace + scatter only; DI / VC / merge become
  *        records and tasks for K3b / K3c / K4, k_resolve replays the additions;
  * MODE 0 ("strict"): everything inside the path. */
+#if defined(VCM_K3_WAVES)   /* experiment: cap K3's registers for more waves per SIMD (spills go to scratch) */
+#define VCM_K3_ATTR __attribute__((amdgpu_waves_per_eu(VCM_K3_WAVES, VCM_K3_WAVES)))
+#else
+#define VCM_K3_ATTR
+#endif
 template <int MODE, class SC>
-__global__ void __launch_bounds__(VCM_TRACE_BLOCK)
+__global__ void __launch_bounds__(VCM_TRACE_BLOCK) VCM_K3_ATTR
 k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, GridStore grid, VertexStore vs,
                F4 *camOut, uint32_t *camMask, unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st)
 {
@@ -134,6 +144,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
     if (lane < 6) myState[lane] = 0;
     CameraWaveQueues wqs;
     wqs.v.p = myState; wqs.di.p = myState + 2; wqs.vc.p = myState + 4;
+    wqs.pendingVertex = -1; wqs.pendingArrival = 0;
     CameraPath path;
     bool alive = false;
     for (;;) {
@@ -146,6 +157,9 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
         if (!__any(alive)) break;
         if (alive) {
             alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs);
+#if !defined(VCM_NO_DEFER)
+            if (MODE == 1 && wqs.pendingVertex >= 0) { vs.sortArrival[wqs.pendingVertex] = wqs.pendingArrival; wqs.pendingVertex = -1; }
+#endif
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
@@ -157,7 +171,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
     if (MODE == 1) {   /* mark the unused tails of this wave's last blocks as holes */
         const int vb = wqs.v.p[0], vl = wqs.v.p[1], db = wqs.di.p[0], dl = wqs.di.p[1], cb = wqs.vc.p[0], cl = wqs.vc.p[1];
         for (int i = (int)lane; i < vl; i += VCM_WAVE) {
-            vs.q0[vb + i] = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+            vq(vs, 0, vb + i) = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
             if (vs.sortKey) vs.sortKey[vb + i] = -1;
         }
         for (int i = (int)lane; i < dl; i += VCM_WAVE) vs.diTask[db + i] = -1;
@@ -286,12 +300,12 @@ __global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__
     stamp_entry(st);
     const int nQ = vs.count[0];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nQ; q += gridDim.x * blockDim.x) {
-        const F4 r0 = vs.q0[q];
+        const F4 r0 = vq(vs, 0, q);
         int k = -1;
         if (f2u(r0.w) != 0xffffffffu) {
             k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
             if (k < 0)   /* empty query: contrib = 0 */
-                vs.mergeOut[path_slot(P, f2u(vs.q1[q].w) & 0xffu, f2u(r0.w))] = mk4(0.f, 0.f, 0.f, 0.f);
+                vs.mergeOut[path_slot(P, f2u(vq(vs, 1, q).w) & 0xffu, f2u(r0.w))] = mk4(0.f, 0.f, 0.f, 0.f);
         }
         key[q] = k;
         /* the value the atomic returns is the vertex's place in its bucket: the scatter needs no second atomic */
@@ -366,7 +380,14 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
  * and the lanes of a wave are neighbours in space with similar totals.  The order in which a lane meets its
  * candidates -- cells in the reference's order (hashgrid.hxx:142-155), vertices in index order inside a cell -- is
  * unchanged, so the per-query sum is the same bits. */
+#if defined(VCM_K4_WAVES)
+#define VCM_K4_ATTR __attribute__((amdgpu_waves_per_eu(VCM_K4_WAVES, VCM_K4_WAVES)))
+#else
+#define VCM_K4_ATTR
+#endif
+#ifndef VCM_WALK_Q
 #define VCM_WALK_Q 16   /* accepted-index queue per lane: 17 rows + 8 run rows of 8 bytes = 33 KB per block, like k_merge_lane */
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 struct alignas(8) WalkRun { int lo, hi; };
 __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
@@ -452,7 +473,7 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
 }
 #endif
 
-__global__ void __launch_bounds__(VCM_MERGE_BLOCK)
+__global__ void __launch_bounds__(VCM_MERGE_BLOCK) VCM_K4_ATTR
 k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
              const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
 {
@@ -474,7 +495,7 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
         const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
         if (q < nQ) {   /* the runs of a lane are private to it: no barrier */
             const int vi = sortedVertex[q];
-            const F4 a = vs.q0[vi], bq = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+            const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
             const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
             Bsdf bsdf;
             bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
@@ -669,7 +690,7 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
         uint32_t s0 = 0u, s1 = 0u, s2 = 0u;
         if (active) {
             vi = sortedVertex[q];
-            const F4 a = vs.q0[vi];
+            const F4 a = vq(vs, 0, vi);
             pos = mk3(a.x, a.y, a.z);
             const V3 distMin = pos - bmin, distMax = bmax - pos;
             inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
@@ -718,7 +739,7 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
         __syncthreads();
         /* ---- C: scan + evaluate (eval_merge_task with the staged scan) */
         if (active) {
-            const F4 a = vs.q0[vi], bq = vs.q1[vi], c = vs.q2[vi], d = vs.q3[vi];
+            const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
             const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
             Bsdf bsdf;
             bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
@@ -800,18 +821,20 @@ __global__ void __launch_bounds__(VCM_SCAN_BLOCK) k_scan_tile_sums(const T *__re
     if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
 }
 
+/* one block: every thread sums a contiguous run of tile sums, ONE block scan over the 256 partial sums, then the
+ * thread writes its run's offsets.  (The first version scanned 256 tiles per trip with a block scan each: 8 trips
+ * of 16 barriers for the 4.2 M-entry bucket table of a 512^2 frame = 47 us per call, 190 us = 12 % of that
+ * iteration, profiles/r02m_trace512_summary.txt.) */
 __global__ void __launch_bounds__(VCM_SCAN_BLOCK) k_scan_tile_offsets(int *tileSums, int nTiles, int *totalOut)
 {
-    int carry = 0;
-    for (int base = 0; base < nTiles; base += VCM_SCAN_BLOCK) {
-        const int i = base + threadIdx.x;
-        const int v = (i < nTiles) ? tileSums[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, &total);
-        if (i < nTiles) tileSums[i] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0 && totalOut) *totalOut = carry;
+    const int per = (nTiles + VCM_SCAN_BLOCK - 1) / VCM_SCAN_BLOCK;
+    const int lo = min(nTiles, (int)threadIdx.x * per), hi = min(nTiles, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += tileSums[i];
+    int total;
+    int run = block_exclusive_scan(sum, &total);
+    for (int i = lo; i < hi; i++) { const int v = tileSums[i]; tileSums[i] = run; run += v; }
+    if (threadIdx.x == 0 && totalOut) *totalOut = total;
 }
 
 template <typename T>
@@ -878,12 +901,18 @@ k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
     const SC &sc = *static_cast<const SC *>(scp);
     const int n = *nVertices;
     LaneStats ls; lane_stats_zero(ls);
+    /* the place of a splat in its pixel's list comes back from a returning atomic: it is stored one task later, so
+       that the wave does not wait for the round trip at the end of every task */
+    int pendI = -1, pendArrival = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         F4 sp;
         connect_stored_vertex_to_camera(sc, P, store, (size_t)slotOfVertex[i], fb, ls, &sp);
+        if (pendI >= 0) arrival[pendI] = pendArrival;
+        pendI = -1;
         splat[i] = sp;
-        if (f2u(sp.w) != 0xffffffffu) arrival[i] = atomicAdd(&pixCount[f2u(sp.w)], 1);
+        if (f2u(sp.w) != 0xffffffffu) { pendI = i; pendArrival = atomicAdd(&pixCount[f2u(sp.w)], 1); }
     }
+    if (pendI >= 0) arrival[pendI] = pendArrival;
     flush_stats(ls, gstats);
 }
 

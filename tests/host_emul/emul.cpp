@@ -17,6 +17,7 @@ using namespace vcm;
 template <class F> static void with_scene(const DScene &sc, F &&f)
 {
     if (sc.nNodes > 0) f(static_cast<const SceneBvh &>(sc));
+    else if (sc.fastOnePlane) f(static_cast<const SceneQuads &>(sc));
     else f(static_cast<const SceneList &>(sc));
 }
 
@@ -217,7 +218,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             camera_path_begin(e.sc, P, path, lp);
             VertexStore vs; memset(&vs, 0, sizeof(vs));
             int wqState[6] = {0, 0, 0, 0, 0, 0};
-            CameraWaveQueues wqs; wqs.v.p = wqState; wqs.di.p = wqState + 2; wqs.vc.p = wqState + 4;
+            CameraWaveQueues wqs; wqs.v.p = wqState; wqs.di.p = wqState + 2; wqs.vc.p = wqState + 4; wqs.pendingVertex = -1; wqs.pendingArrival = 0;
             with_scene(e.sc, [&](const auto &sc) { while (camera_path_step<0>(sc, P, path, store, grid, e.ls, ms, vs, wqs)) {} });
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;

@@ -47,3 +47,44 @@ def bumpy_room(grid=24, resx=64, resy=64, spheres=True, sun=False, background=Fa
         b.emissive_triangle(q[2], q[3], q[0], (25.0, 25.0, 25.0))
     return b.build((-0.0439815, -4.12529, 0.222539), (0.00688625, 0.998505, -0.0542161), (3.73896e-4, 0.0542148, 0.998529), 45.0,
                    resx, resy)
+
+
+def tilted_room(resx=64, resy=64, angle=0.37, sun=False):
+    """A Cornell-like room of at most 32 primitives whose every vertex is rotated about a skew axis: NO triangle pair is
+    axis-aligned, so the brute-force list takes its general path (two plane parts per entry) instead of the one the
+    reference's own boxes take; it also holds a lone triangle between two spheres (an entry with one triangle), two
+    consecutive unrelated triangles (an entry whose triangles share no edge) and a sphere resting on the floor."""
+    axis = np.array([0.3, -0.5, 0.81], np.float64)
+    axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+    def rot(p):
+        return tuple(float(x) for x in np.float32(R @ np.array(p, np.float64)))
+    b = SceneBuilder()
+    white = b.material(diffuse=(0.803922, 0.803922, 0.803922))
+    green = b.material(diffuse=(0.156863, 0.803922, 0.172549))
+    red = b.material(diffuse=(0.803922, 0.152941, 0.152941))
+    glossy = b.material(diffuse=(0.1, 0.1, 0.1), phong=(0.7, 0.7, 0.7), exponent=90.0)
+    mirror = b.material(mirror=(1, 1, 1))
+    glass = b.material(mirror=(1, 1, 1), ior=1.6)
+    lo, hi = -1.25, 1.25
+    c = [rot(v) for v in [(lo, hi, lo), (hi, hi, lo), (hi, hi, hi), (lo, hi, hi), (lo, lo, lo), (hi, lo, lo), (hi, lo, hi), (lo, lo, hi)]]
+    b.triangle(c[0], c[4], c[5], glossy); b.triangle(c[5], c[1], c[0], glossy)     # floor
+    b.triangle(c[0], c[1], c[2], white); b.triangle(c[2], c[3], c[0], white)       # back wall
+    b.triangle(c[3], c[7], c[4], green); b.triangle(c[4], c[0], c[3], green)       # left
+    b.triangle(c[1], c[5], c[6], red); b.triangle(c[6], c[2], c[1], red)           # right
+    b.triangle(c[2], c[6], c[7], white); b.triangle(c[7], c[3], c[2], white)       # ceiling
+    b.sphere(rot((-0.5, 0.3, lo + 0.4)), 0.4, mirror)                              # resting on the floor
+    b.triangle(rot((0.1, 0.2, -0.3)), rot((0.7, 0.5, -0.2)), rot((0.3, 0.6, 0.4)), red)   # a lone triangle
+    b.sphere(rot((0.55, -0.2, -0.8)), 0.35, glass)
+    b.triangle(rot((-0.9, 0.8, -0.6)), rot((-0.4, 0.9, -0.5)), rot((-0.7, 0.7, 0.1)), green)   # two unrelated triangles
+    b.triangle(rot((0.2, -0.6, 0.5)), rot((0.8, -0.4, 0.6)), rot((0.5, -0.7, 0.9)), white)
+    if sun:
+        b.directional_light(rot((-1.0, 1.5, -1.0)), (10.0, 4.0, 0.0))
+    else:
+        q = [rot(v) for v in [(-0.25, -0.25, 1.2), (0.25, -0.25, 1.2), (0.25, 0.25, 1.2), (-0.25, 0.25, 1.2)]]
+        b.emissive_triangle(q[0], q[1], q[2], (25.0, 25.0, 25.0))
+        b.emissive_triangle(q[2], q[3], q[0], (25.0, 25.0, 25.0))
+    return b.build(rot((-0.0439815, -4.12529, 0.222539)), rot((0.00688625, 0.998505, -0.0542161)), rot((3.73896e-4, 0.0542148, 0.998529)),
+                   45.0, resx, resy)
