@@ -61,7 +61,10 @@ KERNEL_SOURCES = ["vcm_api.hip", "vcm_kernels.h", "vcm_core.h", "vcm_math.h", "d
 # (name, scene, algorithm, resolution, renderers in flight): "x4" = four renderers (seeds 1234..1237, the reference's
 # iteration-parallel threads, smallvcm.cxx:61-108) taking turns on the one GPU, their iterations overlapping
 OTHER_CONFIGS = [("C1", 1, "vcm", 512, 1), ("C1x4", 1, "vcm", 512, 4), ("C2", 3, "vcm", 1024, 1), ("C2x2", 3, "vcm", 1024, 2),
-                 ("C3", 1, "bpm", 2048, 1), ("C4x2", 1, "vcm", 2048, 2)]
+                 ("C3", 1, "bpm", 2048, 1), ("C4x2", 1, "vcm", 2048, 2),
+                 # not a BASELINE config: SURVEY 8(f) #3, a scene beyond the Cornell boxes through the BVH
+                 # (tests/mesh_scenes.py bumpy_room: a tessellated height-field floor, 10 380 primitives)
+                 ("M1", "mesh:72", "vcm", 1024, 1)]
 
 
 def kernel_source_hash():
@@ -171,6 +174,10 @@ def roofline_block(st, n_local, n_paths):
 
 
 def workload_name(scene, algo, res, replicas, first, last):
+    if isinstance(scene, str):
+        scene_txt = "tests/mesh_scenes.py bumpy_room(grid=%s), BVH," % scene.split(":")[1]
+        return ("%s -a %s %dx%d maxPathLength 10 minPathLength 0 radiusFactor 0.003 radiusAlpha 0.75 seed 1234, iterations %d..%d timed"
+                % (scene_txt, algo, res, res, first, last))
     return ("scene %d -a %s %dx%d maxPathLength 10 minPathLength 0 radiusFactor 0.003 radiusAlpha 0.75 seed 1234%s, "
             "iterations %d..%d timed" % (scene, algo, res, res, "..%d" % (1234 + replicas - 1) if replicas > 1 else "", first, last))
 
@@ -292,7 +299,12 @@ def main():
         torch.cuda.synchronize()
 
     def make_farm(scene, algo_name, res, shards, inflight):
-        sc = cornell_scene(scene, res, res)
+        if isinstance(scene, str):   # "mesh:<grid>": a version-2 scene (any number of primitives, BVH)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from mesh_scenes import bumpy_room
+            sc = bumpy_room(grid=int(scene.split(":")[1]), resx=res, resy=res)
+        else:
+            sc = cornell_scene(scene, res, res)
         algo = ALGO_BY_NAME[algo_name]
         farm = RenderFarm(lambda seed, s, S: HipBackend(sc, algo, 0.003, 0.75, seed, device=local_rank, rank=s, world=S),
                           1234, rank, world, shards=shards, dist=dist, inflight=inflight)
@@ -351,7 +363,7 @@ def main():
                        "parallelism": "%d renderer(s) (iteration-parallel, smallvcm.cxx:61-108), each on %d path-index shard(s) "
                                       "(RCCL all-gather of light vertices), %d renderer(s) in flight per GPU group"
                                       % (replicas, shards, inflight_used),
-                       "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "lane")},
+                       "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "walk")},
             "roofline": roof,
             "counters": {k: int(st[k]) for k in ("lightVertices", "gridVertices", "mergeQueries", "mergeCandidates",
                                                  "mergeAccepted", "connections", "lightSplats", "lightRays", "cameraRays",

@@ -900,9 +900,13 @@ static int flush_light_splats(vcm_ctx *c)
                            arrival, c->dStats);
         if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
         hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, c->stream, (const F4 *)c->dSplat,
-                           (const int *)c->dLocalTotal, (const int *)pixStart, (const int *)arrival, list);
+                           (const int *)c->dLocalTotal, (const int *)pixStart, (const int *)arrival, list, pixCount);
+        /* pixels with more than VCM_SPLAT_REG splats are queued (pixCount[0] = their number, `arrival` = the queue:
+           both dead since the scatter) and handled by one wave each; `sorted` = the vertex-ordered splat array */
         hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const int *)pixStart,
-                           (const F4 *)list, c->dFb);
+                           (const F4 *)list, c->dFb, arrival, pixCount);
+        hipLaunchKernelGGL(k_splat_apply_long, dim3(1024), dim3(256), 0, c->stream, (const int *)pixStart, (const F4 *)list,
+                           c->dSplat, c->dFb, (const int *)arrival, (const int *)pixCount);
         HIPCHK(hipGetLastError());
     }
     return 0;

@@ -504,9 +504,13 @@ VCM_HD bool tri_inside(const vcm_prim &t, V3 org, V3 dir, float &distance)
     const V3 ao = ld3(t.p0) - org, bo = ld3(t.p1) - org, co = ld3(t.p2) - org;
     const V3 v0 = cross(co, bo), v1 = cross(bo, ao), v2 = cross(ao, co);
     const float v0d = dot(v0, dir), v1d = dot(v1, dir), v2d = dot(v2, dir);
-    const V3 n = ld3(t.n);
-    distance = dot(n, ao) / dot(n, dir);
-    return ((v0d < 0.f) && (v1d < 0.f) && (v2d < 0.f)) || ((v0d >= 0.f) && (v1d >= 0.f) && (v2d >= 0.f));
+    const bool inside = ((v0d < 0.f) && (v1d < 0.f) && (v2d < 0.f)) || ((v0d >= 0.f) && (v1d >= 0.f) && (v2d >= 0.f));
+    distance = 0.f;
+    if (inside) {   /* the reference divides only here too (:144-147); a wave skips it when no lane is inside */
+        const V3 n = ld3(t.n);
+        distance = dot(n, ao) / dot(n, dir);
+    }
+    return inside;
 }
 
 /* Does the ray meet the node's box within [0, tmax]?  The boxes are grown at build time by far more than the
@@ -553,45 +557,115 @@ VCM_HD bool list_intersect(const DScene &sc, const Ray &ray, Isect &res)
  * within 1e-7 of each other along it: the contact point of a sphere resting on the floor) is re-done by the
  * list walk. */
 VCM_HD bool near_tie(float a, float b) { const int d = (int)f2u(a) - (int)f2u(b); return d >= -2 && d <= 2; }
+/* entry distance of the ray into the node's box (bvh_box_hit's tnear); hit = the box is met within [0, tmax] */
+VCM_HD bool bvh_box_near(const BvhNode &nd, V3 org, V3 invDir, float tmax, float &tnear)
+{
+    const float ax = (nd.bmin[0] - org.x) * invDir.x, bx = (nd.bmax[0] - org.x) * invDir.x;
+    const float ay = (nd.bmin[1] - org.y) * invDir.y, by = (nd.bmax[1] - org.y) * invDir.y;
+    const float az = (nd.bmin[2] - org.z) * invDir.z, bz = (nd.bmax[2] - org.z) * invDir.z;
+    tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+    const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return tnear <= tfar * 1.0000004f;
+}
+/* the primitives of one leaf against the hit held so far: lexicographic on (distance, list index), see below */
+VCM_HD void bvh_leaf(const DScene &sc, const BvhNode &nd, const Ray &ray, Isect &res, bool &any, bool &ambiguous, bool &bestIsSphere)
+{
+    const int first = nd.leaf >> 4, count = nd.leaf & 15;
+    for (int k = 0; k < count; k++) {
+        const int pi = sc.leafPrims()[first + k];
+        const vcm_prim &pr = sc.prims()[pi];
+        if (pr.type == VCM_PRIM_TRIANGLE) {
+            float distance;
+            const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
+            if (inside && (distance > ray.tmin)) {
+                if (any && bestIsSphere && near_tie(distance, res.dist)) ambiguous = true;
+                if (distance < res.dist || (distance == res.dist && any && pi < res.prim)) {
+                    res.normal = ld3(pr.n); res.matID = pr.matID; res.prim = pi; res.dist = distance; any = true;
+                    bestIsSphere = false;
+                }
+            }
+        } else {
+            /* Sphere::Intersect offers ONE distance -- the nearer root beyond tmin, else the farther one --
+               whatever res.dist is (if the nearer root fails "< res.dist" so does the farther) */
+            Isect s; s.dist = 1e36f; s.matID = 0; s.lightID = -1; s.normal = sp3(0.f); s.prim = -1;
+            if (sph_intersect(pr, pi, ray, s)) {
+                if (any && near_tie(s.dist, res.dist)) ambiguous = true;
+                if (s.dist < res.dist || (s.dist == res.dist && any && pi < res.prim)) {
+                    res.normal = s.normal; res.matID = s.matID; res.prim = pi; res.dist = s.dist; any = true;
+                    bestIsSphere = true;
+                }
+            }
+        }
+    }
+}
+/* Closest hit, ORDERED: at an inner node both children's boxes are tested (the left child is the next node in memory,
+ * the right one the left's escape), the nearer is descended first and the farther goes on a per-lane stack, to be
+ * dropped unvisited if a hit closer than its box has been found by the time it is popped -- the threaded walk
+ * (bvh_occluded below, and the first version of this function) visits the subtrees in memory order whatever the ray's
+ * direction and prunes only by what it happens to have found: 158 -> ... Mpaths/s on the 10 380-triangle room.
+ * The visiting order cannot change the result: the winner is the minimum of (distance, list index), and a
+ * primitive within 2 ulp of the winner is never pruned (the boxes are padded by 1e-4 of the scene, scene_host.h), so
+ * the near-tie rule sees the same pairs.  Stack: 32 levels per lane, in LDS on the device ([level][thread], no bank
+ * conflicts); a deeper tree finishes the lane with the threaded walk. */
+#define VCM_BVH_STACK 32
 VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
 {
     const V3 invDir = mk3(1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z);
     const Isect start = res;
-    bool any = false, ambiguous = false, bestIsSphere = false;
-    int node = 0;
-    while (node < sc.nNodes) {
+    bool any = false, ambiguous = false, bestIsSphere = false, overflow = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int stackNode[VCM_BVH_STACK][256];   /* 32 KB per block: four blocks per CU stay resident */
+    int *sn = &stackNode[0][threadIdx.x];
+    const int stride = 256;
+#else
+    int stackNode[VCM_BVH_STACK];
+    int *sn = stackNode;
+    const int stride = 1;
+#endif
+    int sp = 0, node = -1;
+#if defined(VCM_BVH_THREADED)   /* measurement switch: the threaded walk only */
+    overflow = true;
+#else
+    if (sc.nNodes > 0) {
+        float t;
+        if (bvh_box_near(sc.nodes()[0], ray.org, invDir, res.dist, t)) node = 0;
+    }
+#endif
+    while (node >= 0) {
         const BvhNode nd = sc.nodes()[node];
-        if (!bvh_box_hit(nd, ray.org, invDir, res.dist)) { node = nd.escape; continue; }
         if (nd.leaf >= 0) {
-            const int first = nd.leaf >> 4, count = nd.leaf & 15;
-            for (int k = 0; k < count; k++) {
-                const int pi = sc.leafPrims()[first + k];
-                const vcm_prim &pr = sc.prims()[pi];
-                if (pr.type == VCM_PRIM_TRIANGLE) {
-                    float distance;
-                    const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
-                    if (inside && (distance > ray.tmin)) {
-                        if (any && bestIsSphere && near_tie(distance, res.dist)) ambiguous = true;
-                        if (distance < res.dist || (distance == res.dist && any && pi < res.prim)) {
-                            res.normal = ld3(pr.n); res.matID = pr.matID; res.prim = pi; res.dist = distance; any = true;
-                            bestIsSphere = false;
-                        }
-                    }
-                } else {
-                    /* Sphere::Intersect offers ONE distance -- the nearer root beyond tmin, else the farther one --
-                       whatever res.dist is (if the nearer root fails "< res.dist" so does the farther) */
-                    Isect s; s.dist = 1e36f; s.matID = 0; s.lightID = -1; s.normal = sp3(0.f); s.prim = -1;
-                    if (sph_intersect(pr, pi, ray, s)) {
-                        if (any && near_tie(s.dist, res.dist)) ambiguous = true;
-                        if (s.dist < res.dist || (s.dist == res.dist && any && pi < res.prim)) {
-                            res.normal = s.normal; res.matID = s.matID; res.prim = pi; res.dist = s.dist; any = true;
-                            bestIsSphere = true;
-                        }
-                    }
-                }
-            }
+            bvh_leaf(sc, nd, ray, res, any, ambiguous, bestIsSphere);
+            node = -1;
+        } else {
+            const int l = node + 1;
+            const BvhNode nl = sc.nodes()[l];
+            const int r = nl.escape;
+            const BvhNode nr = sc.nodes()[r];
+            float tl, tr;
+            const bool hl = bvh_box_near(nl, ray.org, invDir, res.dist, tl), hr = bvh_box_near(nr, ray.org, invDir, res.dist, tr);
+            if (hl && hr) {
+                const bool leftFirst = tl <= tr;
+                if (sp < VCM_BVH_STACK) { sn[sp * stride] = leftFirst ? r : l; sp++; }
+                else overflow = true;
+                node = leftFirst ? l : r;
+            } else node = hl ? l : (hr ? r : -1);
         }
-        node++;
+        while (node < 0 && sp > 0) {   /* next pending subtree that can still hold a closer (or equal: the tie rule) hit:
+                                          its box is tested again against the distance held NOW */
+            sp--;
+            const int cand = sn[sp * stride];
+            float t;
+            if (bvh_box_near(sc.nodes()[cand], ray.org, invDir, res.dist, t)) node = cand;
+        }
+    }
+    if (overflow) {   /* deeper than the stack: the threaded walk over the whole tree (order-free, same result) */
+        int nodeT = 0;
+        while (nodeT < sc.nNodes) {
+            const BvhNode nd = sc.nodes()[nodeT];
+            if (!bvh_box_hit(nd, ray.org, invDir, res.dist)) { nodeT = nd.escape; continue; }
+            if (nd.leaf >= 0) bvh_leaf(sc, nd, ray, res, any, ambiguous, bestIsSphere);
+            nodeT++;
+        }
     }
     if (ambiguous) { res = start; return list_intersect(sc, ray, res); }
     if (any) res.lightID = sc.mat2light()[res.matID];

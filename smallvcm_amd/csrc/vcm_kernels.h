@@ -920,8 +920,9 @@ k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
 /* the scatter moves the splat VALUE (rgb | vertex index) into its pixel's segment, so that k_splat_apply reads
  * one contiguous run per pixel instead of gathering 16 bytes per splat from all over the vertex-ordered array */
 __global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restrict__ nVertices,
-                                const int *__restrict__ pixStart, const int *__restrict__ arrival, F4 *list)
+                                const int *__restrict__ pixStart, const int *__restrict__ arrival, F4 *list, int *longCount)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *longCount = 0;   /* k_splat_apply's queue of long lists (the word is dead by now) */
     const int n = *nVertices;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const F4 s = splat[i];
@@ -932,55 +933,93 @@ __global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restr
 
 /* one lane per pixel: its splats in increasing vertex index.  A pixel holds 1.7 splats on average and the
  * kernel is pure latency (the busiest of a wave's 64 pixels has ~7): up to VCM_SPLAT_REG entries are loaded
- * ONCE, all loads in flight together, and ordered in registers by rank (number of smaller indices); longer
- * lists take the selection loop. */
+ * ONCE, all loads in flight together, and ordered in registers by rank (number of smaller indices).  Longer lists
+ * -- the pixels a caustic lands on: a thousand and more splats -- go to k_splat_apply_long, one WAVE per pixel.
+ * (They used to take a per-lane selection loop here, quadratic in the list length on ONE lane: 5.2 of the 11.5 ms of an
+ * iteration of the 10 380-triangle room, profiles/r02w.) */
 #define VCM_SPLAT_REG 8
-__global__ void k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb)
+__global__ void k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb,
+                              int *longPix, int *longCount)
 {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
         const int lo = pixStart[p], hi = pixStart[p + 1];
         const int k = hi - lo;
         if (k == 0) continue;
+        if (k > VCM_SPLAT_REG) { longPix[atomicAdd(longCount, 1)] = p; continue; }
         float r = fb[(size_t)p * 3 + 0], g = fb[(size_t)p * 3 + 1], b = fb[(size_t)p * 3 + 2];
-        if (k <= VCM_SPLAT_REG) {
-            F4 e[VCM_SPLAT_REG];
+        F4 e[VCM_SPLAT_REG];
 #pragma unroll
-            for (int j = 0; j < VCM_SPLAT_REG; j++) e[j] = (j < k) ? list[lo + j] : mk4(0.f, 0.f, 0.f, u2f(0x7fffffffu));
-            int rank[VCM_SPLAT_REG];
+        for (int j = 0; j < VCM_SPLAT_REG; j++) e[j] = (j < k) ? list[lo + j] : mk4(0.f, 0.f, 0.f, u2f(0x7fffffffu));
+        int rank[VCM_SPLAT_REG];
 #pragma unroll
-            for (int j = 0; j < VCM_SPLAT_REG; j++) {
-                int c = 0;
+        for (int j = 0; j < VCM_SPLAT_REG; j++) {
+            int c = 0;
 #pragma unroll
-                for (int m = 0; m < VCM_SPLAT_REG; m++) c += ((int)f2u(e[m].w) < (int)f2u(e[j].w)) ? 1 : 0;
-                rank[j] = c;   /* indices are distinct, padding sorts last */
-            }
+            for (int m = 0; m < VCM_SPLAT_REG; m++) c += ((int)f2u(e[m].w) < (int)f2u(e[j].w)) ? 1 : 0;
+            rank[j] = c;   /* indices are distinct, padding sorts last */
+        }
 #pragma unroll
-            for (int t = 0; t < VCM_SPLAT_REG; t++) {
-                if (t < k) {
-                    float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int t = 0; t < VCM_SPLAT_REG; t++) {
+            if (t < k) {
+                float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
-                    for (int j = 0; j < VCM_SPLAT_REG; j++) {
-                        const bool me = rank[j] == t;
-                        sx = me ? e[j].x : sx; sy = me ? e[j].y : sy; sz = me ? e[j].z : sz;
-                    }
-                    r = r + sx; g = g + sy; b = b + sz;   /* framebuffer.hxx:56 */
+                for (int j = 0; j < VCM_SPLAT_REG; j++) {
+                    const bool me = rank[j] == t;
+                    sx = me ? e[j].x : sx; sy = me ? e[j].y : sy; sz = me ? e[j].z : sz;
                 }
-            }
-        } else {
-            int last = -1;
-            for (int t = lo; t < hi; t++) {
-                int best = 0x7fffffff, at = lo;
-                for (int q = lo; q < hi; q++) {
-                    const int v = (int)f2u(list[q].w);
-                    if (v > last && v < best) { best = v; at = q; }
-                }
-                const F4 s = list[at];
-                r = r + s.x; g = g + s.y; b = b + s.z;
-                last = best;
+                r = r + sx; g = g + sy; b = b + sz;   /* framebuffer.hxx:56 */
             }
         }
         fb[(size_t)p * 3 + 0] = r; fb[(size_t)p * 3 + 1] = g; fb[(size_t)p * 3 + 2] = b;
     }
+}
+
+/* One wave per pixel with a long list: (1) every entry's rank = the number of entries of the list with a smaller
+ * vertex index -- lane l ranks entries l, l + 64, ... against the list, read 64 keys at a time and passed round with
+ * v_readlane, k^2 / 64 comparisons per lane instead of k^2 on one lane; (2) the entry goes to its place in `sorted`
+ * (the vertex-ordered splat array, dead since the scatter); (3) the sum in that order -- Framebuffer::AddColor in
+ * the order of the serial light loop (vertexcm.hxx:931) -- 64 entries per load, added one after the other. */
+__global__ void __launch_bounds__(256) k_splat_apply_long(const int *__restrict__ pixStart, const F4 *__restrict__ list, F4 *sorted,
+                                                        float *fb, const int *__restrict__ longPix, const int *__restrict__ longCount)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int nLong = *longCount;
+    const int lane = (int)lane_id();
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) / VCM_WAVE), nWaves = (int)(gridDim.x * blockDim.x / VCM_WAVE);
+    for (int w = wave; w < nLong; w += nWaves) {
+        const int p = longPix[w];
+        const int lo = pixStart[p], k = pixStart[p + 1] - lo;
+        for (int jb = 0; jb < k; jb += VCM_WAVE) {
+            const int j = jb + lane;
+            F4 ej = mk4(0.f, 0.f, 0.f, 0.f);
+            if (j < k) ej = list[lo + j];
+            const int vj = (j < k) ? (int)f2u(ej.w) : 0x7fffffff;
+            int rank = 0;
+            for (int mb = 0; mb < k; mb += VCM_WAVE) {
+                const int m = mb + lane;
+                const int vm = (m < k) ? (int)f2u(list[lo + m].w) : 0x7fffffff;   /* padding is smaller than nothing */
+#pragma unroll
+                for (int t = 0; t < VCM_WAVE; t++) rank += (__builtin_amdgcn_readlane(vm, t) < vj) ? 1 : 0;
+            }
+            if (j < k) sorted[lo + rank] = ej;
+        }
+        __threadfence();   /* the wave reads back what its lanes wrote */
+        float r = fb[(size_t)p * 3 + 0], g = fb[(size_t)p * 3 + 1], b = fb[(size_t)p * 3 + 2];
+        for (int cb = 0; cb < k; cb += VCM_WAVE) {
+            F4 e = mk4(0.f, 0.f, 0.f, 0.f);
+            if (cb + lane < k) {   /* after the fence: not from a stale L1 line */
+                typedef float vf4 __attribute__((ext_vector_type(4)));
+                const vf4 v = __builtin_nontemporal_load((const vf4 *)&sorted[lo + cb + lane]);
+                e = mk4(v.x, v.y, v.z, v.w);
+            }
+            const int cnt = min(VCM_WAVE, k - cb);
+            for (int t = 0; t < cnt; t++) {   /* framebuffer.hxx:56, in vertex order; every lane keeps the same sum */
+                r = r + __shfl(e.x, t, VCM_WAVE); g = g + __shfl(e.y, t, VCM_WAVE); b = b + __shfl(e.z, t, VCM_WAVE);
+            }
+        }
+        if (lane == 0) { fb[(size_t)p * 3 + 0] = r; fb[(size_t)p * 3 + 1] = g; fb[(size_t)p * 3 + 2] = b; }
+    }
+#endif
 }
 
 __global__ void k_set_counts(GridHeader *hdr, const int *localTotal, int useLocalAsGlobal, int globalTotal, StampArgs st)
