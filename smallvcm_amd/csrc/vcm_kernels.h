@@ -933,11 +933,14 @@ __global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restr
 
 /* one lane per pixel: its splats in increasing vertex index.  A pixel holds 1.7 splats on average and the
  * kernel is pure latency (the busiest of a wave's 64 pixels has ~7): up to VCM_SPLAT_REG entries are loaded
- * ONCE, all loads in flight together, and ordered in registers by rank (number of smaller indices).  Longer lists
- * -- the pixels a caustic lands on: a thousand and more splats -- go to k_splat_apply_long, one WAVE per pixel.
+ * ONCE, all loads in flight together, and ordered in registers by rank (number of smaller indices); up to
+ * VCM_SPLAT_LONG the lane selects the next index k times; longer lists -- the pixels a caustic lands on: a thousand
+ * and more splats -- go to k_splat_apply_long, one WAVE per pixel (sending every list above 8 there cost 0.7 ms at
+ * 2048^2, r02y: a wave per pixel and a fence per pixel for lists of a dozen).
  * (They used to take a per-lane selection loop here, quadratic in the list length on ONE lane: 5.2 of the 11.5 ms of an
  * iteration of the 10 380-triangle room, profiles/r02w.) */
 #define VCM_SPLAT_REG 8
+#define VCM_SPLAT_LONG 48   /* up to here a lane orders its list by selection (k^2 / 2 loads that hit the cache) */
 __global__ void k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb,
                               int *longPix, int *longCount)
 {
@@ -945,8 +948,23 @@ __global__ void k_splat_apply(int N, const int *__restrict__ pixStart, const F4 
         const int lo = pixStart[p], hi = pixStart[p + 1];
         const int k = hi - lo;
         if (k == 0) continue;
-        if (k > VCM_SPLAT_REG) { longPix[atomicAdd(longCount, 1)] = p; continue; }
+        if (k > VCM_SPLAT_LONG) { longPix[atomicAdd(longCount, 1)] = p; continue; }
         float r = fb[(size_t)p * 3 + 0], g = fb[(size_t)p * 3 + 1], b = fb[(size_t)p * 3 + 2];
+        if (k > VCM_SPLAT_REG) {   /* selection: the next larger vertex index, k times */
+            int last = -1;
+            for (int t = lo; t < hi; t++) {
+                int best = 0x7fffffff, at = lo;
+                for (int q = lo; q < hi; q++) {
+                    const int v = (int)f2u(list[q].w);
+                    if (v > last && v < best) { best = v; at = q; }
+                }
+                const F4 s = list[at];
+                r = r + s.x; g = g + s.y; b = b + s.z;
+                last = best;
+            }
+            fb[(size_t)p * 3 + 0] = r; fb[(size_t)p * 3 + 1] = g; fb[(size_t)p * 3 + 2] = b;
+            continue;
+        }
         F4 e[VCM_SPLAT_REG];
 #pragma unroll
         for (int j = 0; j < VCM_SPLAT_REG; j++) e[j] = (j < k) ? list[lo + j] : mk4(0.f, 0.f, 0.f, u2f(0x7fffffffu));
