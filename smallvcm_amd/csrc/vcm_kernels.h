@@ -386,7 +386,8 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #define VCM_K4_ATTR
 #endif
 #ifndef VCM_WALK_Q
-#define VCM_WALK_Q 16   /* accepted-index queue per lane: 17 rows + 8 run rows of 8 bytes = 33 KB per block, like k_merge_lane */
+#define VCM_WALK_Q 20   /* accepted-index queue per lane: 21 rows + 8 run rows of 8 bytes = 37 KB per block, four blocks per CU
+                           (12 / 16 / 20 entries: 3.51 / 3.40 / 3.35 ms, profiles/r03a_ab_summary.txt) */
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 struct alignas(8) WalkRun { int lo, hi; };
