@@ -353,7 +353,9 @@ def main():
             "metric": "Mpaths/sec (light+camera), %s scene %d at %d^2" % (args.algo.upper(), args.scene, res),
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong" if replicas == 1 else "weak",
+            # the default decomposition keeps the work per GPU fixed as N grows (one renderer-iteration per GPU and step:
+            # 1 renderer at N = 1, N renderers on N / 2 pairs at N > 1); --shards N at N > 1 is the strong one
+            "scaling": "strong" if (replicas == 1 and world > 1) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (reference's built-in Cornell box scene %d)" % args.scene,
             "config": {"workload": workload_name(args.scene, args.algo, res, replicas, args.warmup * replicas,
                                                  (args.warmup + args.steps) * replicas - 1),
