@@ -903,8 +903,10 @@ static int flush_light_splats(vcm_ctx *c)
                            (const int *)c->dLocalTotal, (const int *)pixStart, (const int *)arrival, list, pixCount);
         /* pixels with more than VCM_SPLAT_REG splats are queued (pixCount[0] = their number, `arrival` = the queue:
            both dead since the scatter) and handled by one wave each; `sorted` = the vertex-ordered splat array */
+        static int splatLong = -1;   /* SMALLVCM_AMD_SPLAT_LONG: tests send short lists down the one-wave-per-pixel path too */
+        if (splatLong < 0) { const char *e = getenv("SMALLVCM_AMD_SPLAT_LONG"); splatLong = (e && atoi(e) >= VCM_SPLAT_REG) ? atoi(e) : VCM_SPLAT_LONG; }
         hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const int *)pixStart,
-                           (const F4 *)list, c->dFb, arrival, pixCount);
+                           (const F4 *)list, c->dFb, arrival, pixCount, splatLong);
         hipLaunchKernelGGL(k_splat_apply_long, dim3(1024), dim3(256), 0, c->stream, (const int *)pixStart, (const F4 *)list,
                            c->dSplat, c->dFb, (const int *)arrival, (const int *)pixCount);
         HIPCHK(hipGetLastError());

@@ -943,13 +943,13 @@ __global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restr
 #define VCM_SPLAT_REG 8
 #define VCM_SPLAT_LONG 48   /* up to here a lane orders its list by selection (k^2 / 2 loads that hit the cache) */
 __global__ void k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb,
-                              int *longPix, int *longCount)
+                              int *longPix, int *longCount, int longThreshold /* VCM_SPLAT_LONG; tests lower it */)
 {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
         const int lo = pixStart[p], hi = pixStart[p + 1];
         const int k = hi - lo;
         if (k == 0) continue;
-        if (k > VCM_SPLAT_LONG) { longPix[atomicAdd(longCount, 1)] = p; continue; }
+        if (k > longThreshold) { longPix[atomicAdd(longCount, 1)] = p; continue; }
         float r = fb[(size_t)p * 3 + 0], g = fb[(size_t)p * 3 + 1], b = fb[(size_t)p * 3 + 2];
         if (k > VCM_SPLAT_REG) {   /* selection: the next larger vertex index, k times */
             int last = -1;

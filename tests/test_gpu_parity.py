@@ -102,6 +102,40 @@ def test_hip_equals_oracle(sid, algo, res, nit, mn, mx, strict):
     r.close()
 
 
+def test_long_splat_lists_one_wave_per_pixel():
+    """Pixels that receive many light splats in one iteration (a caustic) are ordered by k_splat_apply_long, one wave per
+    pixel; with SMALLVCM_AMD_SPLAT_LONG=8 every pixel with more than 8 splats goes that way, at sizes the oracle checks
+    in seconds: light tracing and VCM on the point-light / glass-sphere scene at 48^2 (many splats per pixel) and on
+    scene 1, framebuffer bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from smallvcm_amd.renderer import VertexCM, cornell_scene\n"
+            "out = []\n"
+            "for sid, algo, res, nit in ((2, 0, 48, 3), (2, 4, 48, 2), (1, 4, 96, 2), (0, 3, 64, 2)):\n"
+            "    r = VertexCM(cornell_scene(sid, res, res), algo, 0.003, 0.75, 1234); r.mMaxPathLength = 10\n"
+            "    for it in range(nit): r.RunIteration(it)\n"
+            "    out.append(r.framebuffer_sum().ravel()); r.close()\n"
+            "np.save(sys.argv[1], np.concatenate(out))\n") % root
+    path = os.path.join(tempfile.mkdtemp(), "fb.npy")
+    r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SMALLVCM_AMD_SPLAT_LONG="8"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(path)
+    want = []
+    for sid, algo, res, nit in ((2, 0, 48, 3), (2, 4, 48, 2), (1, 4, 96, 2), (0, 3, 64, 2)):
+        o = Oracle(cornell_scene(sid, res, res), algo, threads=8)
+        for it in range(nit):
+            o.run_iteration(it, 0, 10)
+        want.append(o.framebuffer().astype(np.float32).ravel())
+    want = np.concatenate(want)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert got.max() > 0
+
+
 @pytest.mark.parametrize("kind", ["lane", "staged", "walk"])
 @pytest.mark.parametrize("sid,algo,res,nit,mx", [(1, 4, 256, 3, 10), (3, 2, 192, 2, 10), (0, 1, 128, 2, 6), (2, 4, 64, 1, 10), (1, 4, 40, 1, 10)])
 def test_merge_kernels_equal_oracle(sid, algo, res, nit, mx, kind):
