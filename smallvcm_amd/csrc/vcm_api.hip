@@ -255,7 +255,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dGx, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dGy, allRecs + VCM_MERGE_UNROLL) ||
         dalloc(&s.dGz, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
         dalloc(&s.dG3, allRecs) || dalloc(&s.dSortedIndex, allRecs)) return -1;
-    if (dalloc(&s.dCamOut, cl) || dalloc(&s.dCamMask, cl) || dalloc(&s.vs.count, 4)) return -1;
+    if (dalloc(&s.dCamOut, cl) || dalloc(&s.dCamMask, cl) || dalloc(&s.vs.count, 32)) return -1;
     /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l connects to
        light vertices of length <= L-1-l, so <= (L-1)(L-2)/2 VC tasks per path; + one partly used
        block per wave (holes) */
@@ -592,8 +592,14 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPa
     const int wavesPerBlock = VCM_TRACE_BLOCK / VCM_WAVE;
     *blocks = (waves + wavesPerBlock - 1) / wavesPerBlock;
     const int totalWaves = *blocks * wavesPerBlock;
-    *chunk = (nLocal + totalWaves - 1) / totalWaves;
-    if (*chunk < 1) *chunk = 1;
+    /* indices are dealt out in chunks (vcm_kernels.h wave_work_take): the first chunk of a wave is fixed, the rest
+       comes from a counter.  Up to 1024^2 a wave gets everything in its first chunk (64 .. 256 paths: no atomics, as
+       before); above, chunks of 256 -- four per wave at 2048^2.  Smaller chunks balance no better and cost a grab
+       every step where paths are short (environment light: K1 0.24 -> 0.34 ms at 1024^2 with 64-path chunks, r03f) */
+    int ch = nLocal / totalWaves;
+    static const char *ce = getenv("SMALLVCM_AMD_TRACE_CHUNK");
+    if (ce && atoi(ce) > 0) ch = atoi(ce);
+    *chunk = ch < 64 ? 64 : (ch > 256 && !(ce && atoi(ce) > 0) ? 256 : ch);
 }
 
 extern "C" {
@@ -874,7 +880,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     c->dStats = c->dStatsRing + (size_t)(c->iterations % VCM_STAMP_RING) * VCM_STAT_SLOTS;
     c->radiusRing[c->iterations % VCM_STAMP_RING] = radius;
     if (zero_ranges(c->stream, c->dStats, VCM_STAT_SLOTS * sizeof(unsigned long long), c->store.count, (size_t)c->nLocal /* :311-312 */,
-                    c->vs.count, 4 * sizeof(int))) return -1;
+                    c->vs.count, 32 * sizeof(int) /* queue counts [0..2]; chunk counter of K3 / k_path_trace [8] and of K1 [16] */)) return -1;
     c->importedRecords = false;
     c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->bboxPreset = false;
     c->inIteration = true;
@@ -933,10 +939,10 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     const bool wf = !c->strictOrder;
     if (wf)
         LAUNCH_SC_MODE(c, k_light_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream));
+                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16);
     else
         LAUNCH_SC_MODE(c, k_light_trace, 0, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream));
+                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16);
     HIPCHK(hipGetLastError());
     if (mark(c, EV_LIGHT_K1)) return -1;
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
@@ -1095,7 +1101,9 @@ static int vcm_build_grid_impl(vcm_ctx *c)
            (K3, K3b, K3c) is VALU-bound and does not read the grid: the build runs on a side stream next to it.
            Main waits for the bounding box only (K3 derives the query-sort keys from it); vcm_merge waits for the
            rest.  Strict mode merges inside K3 and waits at once. */
-        hipStream_t q = c->side;
+        static int noSide = -1;   /* SMALLVCM_AMD_NO_SIDE=1 (measurement switch): the build in line on the main stream */
+        if (noSide < 0) { const char *e = getenv("SMALLVCM_AMD_NO_SIDE"); noSide = (e && e[0] == '1') ? 1 : 0; }
+        hipStream_t q = noSide ? c->stream : c->side;
         HIPCHK(hipEventRecord(c->evFork, c->stream));
         HIPCHK(hipStreamWaitEvent(q, c->evFork, 0));
         if (mark_on(c, EV_GRID_K0, q)) return -1;
@@ -1157,7 +1165,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     if (c->renderer) {   /* PathTracer / EyeLight: colour + jittered pixel per path; K5 adds them in path order */
         if (c->renderer == 1)
             LAUNCH_SC(c, k_path_trace, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->dCamOut,
-                               c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
+                               c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 8);
         else
             LAUNCH_SC(c, k_eye_light, dim3(2048), dim3(256), 0, c->stream, c->dScene, c->P, c->dCamOut, c->dRngCam,
                                c->dStats, take_stamps(c, c->stream));

@@ -75,6 +75,44 @@ __device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long l
     }
 }
 
+/* Path indices for the persistent waves of K1 / K3.  A wave takes CHUNKS of `chunk` consecutive indices from a global
+ * counter (one atomic per chunk, lane 0) and hands them to its dead lanes with ballot + prefix popcount; when the
+ * chunk cannot serve every dead lane the rest comes out of the next one in the same step.  The first version gave
+ * every wave ONE fixed range: the waves of K3 that start late -- the grid build on the side stream holds part of the
+ * chip when K3 is launched -- then finish late by the whole length of their range: K3 took 2.35 ms next to the build
+ * against 1.71 ms alone (profiles/r03d_ab_summary.txt).  Which wave traces which path does not matter: every path has
+ * its own random stream and its own slots in the stores. */
+struct WaveWork { int next, end, dynBase; bool exhausted; };
+/* the FIRST chunk of every wave is fixed (chunk number = wave number): 4096 waves asking one counter word at the same
+   moment wait ~50 us for it (it sustains ~88 returning atomics per microsecond), which a 512^2 frame -- one chunk per
+   wave, 0.2 ms per kernel -- cannot afford; the counter deals out the chunks after those */
+__device__ __forceinline__ void wave_work_init(WaveWork &w, int chunk, int total)
+{
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) / VCM_WAVE), nWaves = (int)(gridDim.x * blockDim.x / VCM_WAVE);
+    w.next = min(total, wave * chunk); w.end = min(total, w.next + chunk);
+    w.dynBase = nWaves * chunk;
+    w.exhausted = w.dynBase >= total;
+}
+/* returns the path index for this lane (dead lanes only; -1: none left for it in this step) */
+__device__ __forceinline__ int wave_work_take(WaveWork &w, int *counter, int chunk, int total, unsigned long long need, unsigned lane)
+{
+    const int want = __popcll(need);                                   /* wave-uniform */
+    const int rank = __popcll(need & ((1ull << lane) - 1ull));
+    const int rem = max(w.end - w.next, 0);
+    int idx = (rank < rem) ? w.next + rank : -1;
+    if (want > rem && !w.exhausted) {                                  /* wave-uniform branch */
+        int base = 0;
+        /* (one counter per XCD was measured too: the XCDs then finish at different times, K3 2.07 instead of 1.98 ms) */
+        if (lane == 0) base = atomicAdd(counter, chunk);
+        base = w.dynBase + __builtin_amdgcn_readfirstlane(base);
+        if (base >= total) w.exhausted = true;
+        const int nend = min(total, base + chunk);
+        if (rank >= rem) { const int i2 = base + (rank - rem); idx = (i2 < nend) ? i2 : -1; }
+        w.next = base + (want - rem); w.end = nend;
+    } else w.next += want;
+    return idx;
+}
+
 /* ---------------- K1: light sub-paths (vertexcm.hxx:321-396) ------------ */
 #if defined(VCM_K1_WAVES)
 #define VCM_K1_ATTR __attribute__((amdgpu_waves_per_eu(VCM_K1_WAVES, VCM_K1_WAVES)))
@@ -84,26 +122,23 @@ __device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long l
 template <int MODE, class SC>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK) VCM_K1_ATTR
 k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, float *fb,
-              unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st)
+              unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st, int *work)
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
-    const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
-    int next = wave * chunk;                              /* wave-uniform */
-    const int end = min(P.nLocal, next + chunk);
+    WaveWork ww; wave_work_init(ww, chunk, P.nLocal);
     LaneStats ls; lane_stats_zero(ls);
     LightPath path;
     bool alive = false;
     for (;;) {
         /* refill dead lanes: ballot + prefix popcount over the wave */
         const unsigned long long need = __ballot(!alive);
-        if (!alive) {
-            const int idx = next + __popcll(need & ((1ull << lane) - 1ull));
-            if (idx < end) { light_path_begin(sc, P, path, idx); alive = true; }
+        if (need) {
+            const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
+            if (!alive && idx >= 0) { light_path_begin(sc, P, path, idx); alive = true; }
         }
-        next += __popcll(need);
-        if (!__any(alive)) break;
+        if (!__any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = light_path_step<MODE>(sc, P, path, store, fb, ls);
             if (!alive) {
@@ -132,10 +167,9 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
-    const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
-    int next = wave * chunk;
-    const int end = min(P.nLocal, next + chunk);
+    WaveWork ww; wave_work_init(ww, chunk, P.nLocal);
+    int *work = vs.count + 8;   /* the chunk counter of this launch (zeroed with the queue counts) */
     LaneStats ls; lane_stats_zero(ls);
     __shared__ uint32_t accQ[MODE == 1 ? 1 : (VCM_MERGE_Q + 1) * VCM_TRACE_BLOCK];   /* [entry][thread]: conflict-free */
     MergeScratch ms; ms.q = accQ + (MODE == 1 ? 0 : threadIdx.x); ms.stride = VCM_TRACE_BLOCK; ms.cap = VCM_MERGE_Q;
@@ -149,12 +183,11 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
     bool alive = false;
     for (;;) {
         const unsigned long long need = __ballot(!alive);
-        if (!alive) {
-            const int idx = next + __popcll(need & ((1ull << lane) - 1ull));
-            if (idx < end) { camera_path_begin(sc, P, path, idx); alive = true; }
+        if (need) {
+            const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
+            if (!alive && idx >= 0) { camera_path_begin(sc, P, path, idx); alive = true; }
         }
-        next += __popcll(need);
-        if (!__any(alive)) break;
+        if (!__any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs);
 #if !defined(VCM_NO_DEFER)
@@ -186,25 +219,22 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
 template <class SC>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK)
 k_path_trace(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned char *rngCount,
-             unsigned long long *gstats, int chunk, StampArgs st)
+             unsigned long long *gstats, int chunk, StampArgs st, int *work)
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
-    const int wave = (blockIdx.x * VCM_TRACE_BLOCK + threadIdx.x) / VCM_WAVE;
     const unsigned lane = lane_id();
-    int next = wave * chunk;
-    const int end = min(P.nLocal, next + chunk);
+    WaveWork ww; wave_work_init(ww, chunk, P.nLocal);
     LaneStats ls; lane_stats_zero(ls);
     PtPath path;
     bool alive = false;
     for (;;) {
         const unsigned long long need = __ballot(!alive);
-        if (!alive) {
-            const int idx = next + __popcll(need & ((1ull << lane) - 1ull));
-            if (idx < end) { pt_path_begin(sc, P, path, idx); alive = true; }
+        if (need) {
+            const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
+            if (!alive && idx >= 0) { pt_path_begin(sc, P, path, idx); alive = true; }
         }
-        next += __popcll(need);
-        if (!__any(alive)) break;
+        if (!__any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = pt_path_step(sc, P, path, ls);
             if (!alive) {
