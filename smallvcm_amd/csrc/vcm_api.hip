@@ -892,6 +892,16 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
  * order (vertexcm.hxx:373-378 -> :863-934).  A sharded context defers this until the host has
  * started the all-gather of the light records (they are complete after K1b), so that the
  * exchange overlaps it; it must run before the grid build, whose scratch it borrows. */
+/* workgroups of the dense task kernels (K1c, K3b, K3c: grid-stride loops over the tasks).  At 70-80 VGPRs 1536 of them
+ * are resident (6 waves per SIMD); the 2048 of round 1 meant a second round that occupied a third of the chip.
+ * Measured (1024 / 1536 / 1792 / 2048 / 3072 / 4608 / 8192): K3b+c 2.16 / 1.96 / 2.06 / 1.99 / 1.83 / 1.82 / 1.88 ms
+ * next to the tail of the grid build (profiles/r03j_ab_summary.txt). */
+static int task_blocks()
+{
+    static int n = 0;
+    if (!n) { const char *e = getenv("SMALLVCM_AMD_TASK_BLOCKS"); n = (e && atoi(e) > 0) ? atoi(e) : 256 * 12; }
+    return n;
+}
 static int flush_light_splats(vcm_ctx *c)
 {
     if (!c->splatsPending) return 0;
@@ -901,7 +911,7 @@ static int flush_light_splats(vcm_ctx *c)
         int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart;
         F4 *list = (F4 *)c->dUnsorted;   /* 16-byte elements, like the cell list it is later used for */
         if (zero_ranges(c->stream, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
-        LAUNCH_SC(c, k_connect_camera, dim3(256 * 8), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
+        LAUNCH_SC(c, k_connect_camera, dim3(task_blocks()), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
                            arrival, c->dStats);
         if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
@@ -1191,10 +1201,10 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
-            LAUNCH_SC(c, k_connect_di, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+            LAUNCH_SC(c, k_connect_di, dim3(task_blocks()), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
                                c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
-            LAUNCH_SC(c, k_connect_vc, dim3(256 * 8), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+            LAUNCH_SC(c, k_connect_vc, dim3(task_blocks()), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->store, c->dStats);
         }
         if (mark(c, EV_CONNECT_K1)) return -1;
