@@ -896,11 +896,24 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
  * are resident (6 waves per SIMD); the 2048 of round 1 meant a second round that occupied a third of the chip.
  * Measured (1024 / 1536 / 1792 / 2048 / 3072 / 4608 / 8192): K3b+c 2.16 / 1.96 / 2.06 / 1.99 / 1.83 / 1.82 / 1.88 ms
  * next to the tail of the grid build (profiles/r03j_ab_summary.txt). */
-static int task_blocks()
+static int task_blocks(int nLocal)
 {
-    static int n = 0;
-    if (!n) { const char *e = getenv("SMALLVCM_AMD_TASK_BLOCKS"); n = (e && atoi(e) > 0) ? atoi(e) : 256 * 12; }
-    return n;
+    static int n = -1;
+    if (n < 0) { const char *e = getenv("SMALLVCM_AMD_TASK_BLOCKS"); n = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    /* frames up to 1024^2 keep the 2048 of round 1: with a task or two per thread more workgroups only cost their
+       dispatch (512^2: K3b+c 0.31 -> 0.38 ms with 3072, profiles/r03m_ab_summary.txt) */
+    return n ? n : (nLocal >= (1 << 21) ? 256 * 12 : 256 * 8);
+}
+/* workgroups of k_merge_walk (multiple of 8: they are dealt to the XCDs).  1024 are resident (126 VGPRs, 37 KB of
+ * LDS); with 2048 every workgroup walked ~20 batches of 256 queries and the last ones to finish set the kernel's time,
+ * with 16384 it is two or three batches each: 3.29 -> 3.15 ms; beyond that the launch itself shows (32768: 3.63 ms;
+ * profiles/r03k, r03l). */
+static int merge_blocks(int nLocal)
+{
+    static int n = -1;
+    if (n < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_BLOCKS"); n = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 0; }
+    /* smaller frames have fewer batches than that: 2048 as before (16384 at 1024^2: 0.40 -> 1.08 ms, r03m) */
+    return n ? n : (nLocal >= (1 << 21) ? 16384 : 256 * 8);
 }
 static int flush_light_splats(vcm_ctx *c)
 {
@@ -911,7 +924,7 @@ static int flush_light_splats(vcm_ctx *c)
         int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart;
         F4 *list = (F4 *)c->dUnsorted;   /* 16-byte elements, like the cell list it is later used for */
         if (zero_ranges(c->stream, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
-        LAUNCH_SC(c, k_connect_camera, dim3(task_blocks()), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
+        LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
                            arrival, c->dStats);
         if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
@@ -1201,10 +1214,10 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
-            LAUNCH_SC(c, k_connect_di, dim3(task_blocks()), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+            LAUNCH_SC(c, k_connect_di, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
                                c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
-            LAUNCH_SC(c, k_connect_vc, dim3(task_blocks()), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+            LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->store, c->dStats);
         }
         if (mark(c, EV_CONNECT_K1)) return -1;
@@ -1257,7 +1270,7 @@ static int vcm_merge_impl(vcm_ctx *c)
                staging adds instructions and barriers. */
             const int mergeStaged = c->mergeKind;
             if (mergeStaged == 2)
-                hipLaunchKernelGGL(k_merge_walk, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                hipLaunchKernelGGL(k_merge_walk, dim3(merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
                                    c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
             else if (mergeStaged) {
                 int ch = mergeChunk * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK;
