@@ -686,7 +686,9 @@ __device__ __forceinline__ V3 merge_query_staged(const DScene &sc, const IterPar
 }
 #endif
 
-__global__ void __launch_bounds__(VCM_STAGE_BLOCK)
+/* 4 waves per SIMD = two 512-thread workgroups per CU: at 129 registers (one too many) only ONE fitted, 6.4 instead of
+ * 4.2 ms (r02j-r03o) */
+__global__ void __launch_bounds__(VCM_STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
                const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
 {
