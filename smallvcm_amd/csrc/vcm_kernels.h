@@ -271,8 +271,13 @@ k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned c
  * not offer: there the connection loop ran at the trip count of the busiest
  * lane and at 23 % lane utilisation (profiles/r01b_pmc_*). */
 #define VCM_TASK_BLOCK 256
+#if defined(VCM_TASK_WAVES)   /* experiment: cap the registers of K3b / K3c for more waves per SIMD */
+#define VCM_TASK_ATTR __attribute__((amdgpu_waves_per_eu(VCM_TASK_WAVES, VCM_TASK_WAVES)))
+#else
+#define VCM_TASK_ATTR
+#endif
 template <class SC>
-__global__ void __launch_bounds__(VCM_TASK_BLOCK)
+__global__ void __launch_bounds__(VCM_TASK_BLOCK) VCM_TASK_ATTR
 k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats,
              const int *__restrict__ bucketStart, int *sortedVertex, StampArgs st)
 {
@@ -295,7 +300,7 @@ k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsig
 }
 
 template <class SC>
-__global__ void __launch_bounds__(VCM_TASK_BLOCK)
+__global__ void __launch_bounds__(VCM_TASK_BLOCK) VCM_TASK_ATTR
 k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, LightStore store,
              unsigned long long *gstats)
 {
