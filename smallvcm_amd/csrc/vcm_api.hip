@@ -153,6 +153,7 @@ struct vcm_ctx : Scratch {
 
     bool importedRecords;
     bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI, bboxPreset;
+    bool bboxFromLight;               /* K1 of this iteration accumulated the vertices' box into dHdr (single rank) */
     bool strictOrder;
     int mergeKind;                    /* VCM_MERGE_* */
     bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
@@ -880,9 +881,10 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     c->dStats = c->dStatsRing + (size_t)(c->iterations % VCM_STAMP_RING) * VCM_STAT_SLOTS;
     c->radiusRing[c->iterations % VCM_STAMP_RING] = radius;
     if (zero_ranges(c->stream, c->dStats, VCM_STAT_SLOTS * sizeof(unsigned long long), c->store.count, (size_t)c->nLocal /* :311-312 */,
-                    c->vs.count, 32 * sizeof(int) /* queue counts [0..2]; chunk counter of K3 / k_path_trace [8] and of K1 [16] */)) return -1;
+                    c->vs.count, 32 * sizeof(int) /* queue counts [0..2]; chunk counter of K3 / k_path_trace [8] and of K1 [16] */,
+                    c->dHdr, 6 * sizeof(uint32_t) /* bboxMinU / bboxMaxU: K1 accumulates into them with atomicMax */)) return -1;
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->bboxPreset = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->bboxPreset = c->bboxFromLight = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -962,11 +964,16 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     const bool wf = !c->strictOrder;
     if (wf)
         LAUNCH_SC_MODE(c, k_light_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16);
+                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16, c->dHdr);
     else
         LAUNCH_SC_MODE(c, k_light_trace, 0, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
-                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16);
+                           c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16, c->dHdr);
     HIPCHK(hipGetLastError());
+    {   /* SMALLVCM_AMD_NO_K1_BBOX=1 (measurement switch): the grid build computes the box itself, as in round 1 */
+        static int noK1Box = -1;
+        if (noK1Box < 0) { const char *e = getenv("SMALLVCM_AMD_NO_K1_BBOX"); noK1Box = (e && e[0] == '1') ? 1 : 0; }
+        c->bboxFromLight = (c->world == 1) && !noK1Box;
+    }
     if (mark(c, EV_LIGHT_K1)) return -1;
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
        record array in the reference's vertex order */
@@ -1024,7 +1031,7 @@ static int vcm_local_light_bbox_impl(vcm_ctx *c, float *min3, float *max3, long 
     VertexSource src; src.records = NULL; src.store = c->store; src.slotOfVertex = c->dSlotOfVertex;
     hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr, take_stamps(c, c->stream));
     hipLaunchKernelGGL(k_bbox, dim3(512), dim3(256), 0, c->stream, src, c->dHdr);
-    hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr);
+    hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr, 0);
     HIPCHK(hipGetLastError());
     GridHeader h;
     HIPCHK(hipMemcpyAsync(&h, c->dHdr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -1138,9 +1145,13 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         const dim3 g(2048), b(256);
         if (zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
         if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
-            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr, take_stamps(c, q));
-            hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
-            hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr);
+            if (c->bboxFromLight && !recs.records) {   /* K1 left the box of what it stored in the header's key words */
+                hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr, 1);
+            } else {
+                hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr, take_stamps(c, q));
+                hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
+                hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr, 0);
+            }
         }
         HIPCHK(hipEventRecord(c->evBbox, q));
         hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,

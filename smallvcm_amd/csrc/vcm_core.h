@@ -1504,6 +1504,11 @@ struct LightPath {
     uint32_t lenMask;   /* see LightStore::lenMask */
 };
 
+/* bounding box of the vertices a lane has stored (HashGrid::Build takes it over all of them, hashgrid.hxx:50-61):
+ * K1 keeps it while it writes them, so that the grid build does not read every position again */
+struct LaneBox { float mn[3], mx[3]; };
+VCM_HD void lane_box_init(LaneBox &b) { for (int k = 0; k < 3; k++) { b.mn[k] = 3.0e38f; b.mx[k] = -3.0e38f; } }
+
 VCM_HD void light_path_begin(const DScene &sc, const IterParams &P, LightPath &lp, int localPath)
 {
     lp.lp = localPath;
@@ -1518,7 +1523,7 @@ VCM_HD void light_path_begin(const DScene &sc, const IterParams &P, LightPath &l
  * which runs it for every stored vertex. */
 template <int MODE, class SC>
 VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, const LightStore &store,
-                            float *fb, LaneStats &ls)
+                            float *fb, LaneStats &ls, LaneBox &box)
 {
     SubPathState &st = lp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
@@ -1545,6 +1550,8 @@ VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, co
         lv(store, slot, 3) = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
         lv(store, slot, 4) = mk4(wdir.x, wdir.y, wdir.z, bsdf.contProb);
         lp.nStored++;
+        box.mn[0] = fminf(box.mn[0], hitPoint.x); box.mn[1] = fminf(box.mn[1], hitPoint.y); box.mn[2] = fminf(box.mn[2], hitPoint.z);
+        box.mx[0] = fmaxf(box.mx[0], hitPoint.x); box.mx[1] = fmaxf(box.mx[1], hitPoint.y); box.mx[2] = fmaxf(box.mx[2], hitPoint.z);
         lp.lenMask |= (st.pathLength < 32u) ? (1u << st.pathLength) : 0u;
         if (P.useVC || P.useVM) ls.stored++;   /* the reference stores nothing in light-trace mode (:364) */
     }

@@ -75,6 +75,16 @@ __device__ __forceinline__ void flush_stats(const LaneStats &ls, unsigned long l
     }
 }
 
+__device__ __forceinline__ uint32_t float_order_key(float f)
+{   /* order-preserving float -> uint */
+    const uint32_t u = f2u(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_key(uint32_t k)
+{
+    return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 /* Path indices for the persistent waves of K1 / K3.  A wave takes CHUNKS of `chunk` consecutive indices from a global
  * counter (one atomic per chunk, lane 0) and hands them to its dead lanes with ballot + prefix popcount; when the
  * chunk cannot serve every dead lane the rest comes out of the next one in the same step.  The first version gave
@@ -122,13 +132,14 @@ __device__ __forceinline__ int wave_work_take(WaveWork &w, int *counter, int chu
 template <int MODE, class SC>
 __global__ void __launch_bounds__(VCM_TRACE_BLOCK) VCM_K1_ATTR
 k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, float *fb,
-              unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st, int *work)
+              unsigned char *rngCount, unsigned long long *gstats, int chunk, StampArgs st, int *work, GridHeader *hdr)
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
     const unsigned lane = lane_id();
     WaveWork ww; wave_work_init(ww, chunk, P.nLocal);
     LaneStats ls; lane_stats_zero(ls);
+    LaneBox box; lane_box_init(box);
     LightPath path;
     bool alive = false;
     for (;;) {
@@ -140,12 +151,31 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
         }
         if (!__any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
-            alive = light_path_step<MODE>(sc, P, path, store, fb, ls);
+            alive = light_path_step<MODE>(sc, P, path, store, fb, ls, box);
             if (!alive) {
                 store.count[path.lp] = (unsigned char)path.nStored;   /* mPathEnds :395 */
                 store.lenMask[path.lp] = path.lenMask;
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
+        }
+    }
+    {   /* the box of the vertices this block stored -> the grid header, both ends as order keys under atomicMax (the
+           minimum inverted): the words start at zero, which the iteration's zeroing kernel provides */
+        uint32_t key[6];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { key[c] = ~float_order_key(box.mn[c]); key[3 + c] = float_order_key(box.mx[c]); }
+        __shared__ uint32_t sbox[VCM_TRACE_BLOCK / VCM_WAVE][6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) key[c] = max(key[c], (uint32_t)__shfl_xor((int)key[c], o, 64));
+            if (lane == 0) sbox[threadIdx.x / VCM_WAVE][c] = key[c];
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            uint32_t v = sbox[0][threadIdx.x];
+            for (int w = 1; w < VCM_TRACE_BLOCK / VCM_WAVE; w++) v = max(v, sbox[w][threadIdx.x]);
+            if (threadIdx.x < 3) atomicMax(&hdr->bboxMinU[threadIdx.x], v); else atomicMax(&hdr->bboxMaxU[threadIdx.x - 3], v);
         }
     }
     flush_stats(ls, gstats);
@@ -1086,15 +1116,6 @@ __global__ void k_set_counts(GridHeader *hdr, const int *localTotal, int useLoca
 }
 
 /* ---------------- K2: hash-grid build (hashgrid.hxx:41-107) ------------- */
-__device__ __forceinline__ uint32_t float_order_key(float f)
-{   /* order-preserving float -> uint */
-    const uint32_t u = f2u(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float float_from_order_key(uint32_t k)
-{
-    return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
 
 /* Where the grid build reads the light vertices from: the contiguous 13-float merge records (a sharded
  * renderer: the all-gathered array) or, for a single-rank renderer, the slot-major store of K1 itself through
@@ -1153,12 +1174,12 @@ __global__ void __launch_bounds__(256) k_bbox(VertexSource src, GridHeader *hdr)
     }
 }
 
-__global__ void k_bbox_finalize(GridHeader *hdr)
+__global__ void k_bbox_finalize(GridHeader *hdr, int minInverted /* the words K1 left: minimum as ~key */)
 {
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
         if (hdr->nRecords > 0) {
-            hdr->bboxMin[c] = float_from_order_key(hdr->bboxMinU[c]);
+            hdr->bboxMin[c] = float_from_order_key(minInverted ? ~hdr->bboxMinU[c] : hdr->bboxMinU[c]);
             hdr->bboxMax[c] = float_from_order_key(hdr->bboxMaxU[c]);
         } else {   /* :47-48 initial values */
             hdr->bboxMin[c] = 1e36f;

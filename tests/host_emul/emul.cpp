@@ -160,7 +160,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     for (int lp = 0; lp < e.nLocal; lp++) {
         LightPath path;
         light_path_begin(e.sc, P, path, lp);
-        with_scene(e.sc, [&](const auto &sc) { while (light_path_step<0>(sc, P, path, store, e.fb.data(), e.ls)) {} });
+        LaneBox box; lane_box_init(box);
+        with_scene(e.sc, [&](const auto &sc) { while (light_path_step<0>(sc, P, path, store, e.fb.data(), e.ls, box)) {} });
         e.count[lp] = (unsigned char)path.nStored;
         lenMask[lp] = path.lenMask;
         e.rngL[lp] = (unsigned char)path.rng.k;
