@@ -492,6 +492,8 @@ static __global__ void k_stamp_many(StampArgs st) { stamp_entry(st); }
  * 16-byte aligned and is a whole number of 4-byte words, except byte tables, whose size is rounded up to 4: they are
  * allocated in larger units).  hipMemsetAsync reached 380 GB/s on the 16 MB tables and cost a launch per
  * range: nine of them were 0.43 ms of an 11 ms iteration (profiles/r02k_kernel_stats.csv). */
+/* vcm_begin_iteration zeroes the first six words of the grid header: the order keys K1 accumulates the box into */
+static_assert(offsetof(GridHeader, bboxMinU) == 0 && offsetof(GridHeader, bboxMaxU) == 3 * sizeof(uint32_t), "GridHeader layout");
 struct ZeroArgs { void *p[4]; unsigned long long n16[4]; unsigned tail4[4]; };
 static __global__ void __launch_bounds__(256) k_zero_ranges(ZeroArgs z)
 {
