@@ -959,11 +959,12 @@ VCM_HD void occluded_pairs(const DScene &sc, const FastRay &r, float tmaxp, bool
         const bool reachA = (((f2u(numA) ^ f2u(denA)) & 0x80000000u) == 0u) && !(fabsf(numA) >= 1.000001f * (tmaxp * fabsf(denA)));
         const bool reachB = ONE_PLANE ? reachA
                                       : ((p.flags & 1) && (((f2u(numB) ^ f2u(denB)) & 0x80000000u) == 0u) && !(fabsf(numB) >= 1.000001f * (tmaxp * fabsf(denB))));
-#if defined(VCM_FILTER_NOSKIP)
-        {
+#if defined(VCM_FILTER_NOSKIP)   /* measurement switch: the edge functions of every entry */
+        const bool edges = true;
 #else
-        if (wave_any((reachA || reachB) && !occ)) {
+        const bool edges = wave_any((reachA || reachB) && !occ);   /* no lane can report a hit: the wave skips them */
 #endif
+        if (edges) {
             fast_pair_edges(p, r, ha, hb);
             const bool hitA = reachA && ha.certIn && (ha.L > 0.f) && (ha.U < tmaxp), missA = !reachA || ha.certOut;
             const bool hitB = reachB && hb.certIn && (hb.L > 0.f) && (hb.U < tmaxp), missB = !reachB || hb.certOut;
