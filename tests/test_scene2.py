@@ -138,6 +138,25 @@ def test_device_functions_with_bvh_equal_oracle_on_mesh_scenes(kw, algo, res, ni
 TILTED_CASES = [({}, 4, 96, 2), ({"sun": True}, 4, 64, 1), ({}, 2, 64, 1), ({}, 3, 64, 1), ({"angle": 1.1}, 5, 64, 1)]
 
 
+@needs_ref
+@pytest.mark.parametrize("kw,algo,res,nit", TILTED_CASES)
+def test_oracle_equals_reference_on_the_tilted_list_scene(kw, algo, res, nit):
+    """pins the oracle on the scene the general filter path is tested with: the unmodified reference replaying the
+    oracle's tape gives the same framebuffer, bit for bit"""
+    sc = tilted_room(resx=res, resy=res, **kw)
+    o = Oracle(sc, algo, threads=8)
+    lcs, ccs = [], []
+    for it in range(nit):
+        o.run_iteration(it, 0, 10)
+        a, b = o.counts()
+        lcs.append(a)
+        ccs.append(b)
+    fb, consumed, bad = oracle_lib.ref_run_tape2(sc, algo, np.concatenate(lcs), np.concatenate(ccs), n_iter=nit)
+    assert bad == 0
+    assert np.array_equal(fb.view(np.uint32), o.framebuffer().view(np.uint32))
+    assert fb.max() > 0
+
+
 @pytest.mark.parametrize("kw,algo,res,nit", TILTED_CASES)
 def test_device_functions_on_a_tilted_list_scene_equal_oracle(kw, algo, res, nit):
     """<= 32 primitives, none axis-aligned: the brute-force list with its GENERAL filter path (vcm_core.h: two plane
