@@ -181,11 +181,15 @@ const char *vcm_last_error(void);
  * src/renderer.hxx:58, src/smallvcm.cxx:66). */
 vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm,
                     float radiusFactor, float radiusAlpha, int seed);
-/* On a multi-GPU node consecutive vcm_create calls go round-robin over the visible devices (the reference's
- * render() builds one renderer per host core, smallvcm.cxx:61-72: dealt out like this, every GPU renders whole
- * iterations of its share of the renderers and the driver's own framebuffer average is the only reduce).
- * Environment SMALLVCM_AMD_DEVICES: "all" (default), "current" (the calling thread's current HIP device) or a list
- * such as "0,2,5".  vcm_create_sharded takes the device explicitly. */
+/* vcm_create puts the renderer on the calling thread's CURRENT HIP device (a host that hands over its own stream or
+ * device buffers allocated them there).  A renderer-per-host-core host on a multi-GPU node -- the reference's render()
+ * builds one renderer per host core, smallvcm.cxx:61-72 -- asks vcm_next_device() for the device of its next renderer
+ * and passes it to vcm_create_sharded(..., device, 0, 1): round-robin over the visible devices, so that every GPU
+ * renders whole iterations of its share of the renderers and the driver's own framebuffer average is the only reduce
+ * (this is what the drop-in does, smallvcm_amd/dropin/gpu_renderer.hxx).  Environment SMALLVCM_AMD_DEVICES: "all"
+ * (what vcm_next_device deals over by default), "current" or a list such as "0,2,5"; when it is set, vcm_create
+ * follows it too. */
+int vcm_next_device(void);
 
 /* Same, for one rank of a sharded renderer: rank r of worldSize traces light
  * paths and pixels [r*N/W, (r+1)*N/W) on HIP device `device`. */

@@ -306,11 +306,10 @@ static int arena_acquire(vcm_ctx *c, int S, int L)
         std::unique_lock<std::mutex> lk(p->m);
         for (;;) {
             Arena *mine = NULL, *idle = NULL, *lru = NULL;
-            bool allMineBusy = p->count > 0;
+            bool holdsOne = false;
             for (int i = 0; i < p->count; i++) {
                 Arena *x = p->arenas[i];
-                if (x->busy) { if (x->ownerThread != this_thread_id()) allMineBusy = false; continue; }
-                allMineBusy = false;
+                if (x->busy) { if (x->ownerThread == this_thread_id()) holdsOne = true; continue; }
                 if (x->lastUser == c) mine = x;
                 else if (!x->lastValid || hipEventQuery(x->lastUse) == hipSuccess) idle = x;
                 else lru = x;
@@ -320,10 +319,12 @@ static int arena_acquire(vcm_ctx *c, int S, int L)
             if (!a && pool_may_grow(p)) { a = arena_new(p->device, p); p->arenas[p->count++] = a; }
             if (!a) a = lru;
             if (a) break;
-            if (allMineBusy)
-                return fail("vcm_begin_iteration", "this thread is already inside an iteration on every arena of this device: "
-                                                   "single-rank contexts share the iteration scratch, end an iteration first "
-                                                   "(or raise vcm_set_arena_limit)");
+            /* Waiting while holding is the dead-lock: two threads that each hold one arena and each open a second
+               iteration would wait for each other forever once the pool cannot grow.  A thread that holds nothing waits. */
+            if (holdsOne)
+                return fail("vcm_begin_iteration", "this thread is already inside an iteration on this device and no further "
+                                                   "scratch arena is free: single-rank contexts share the iteration scratch, "
+                                                   "end an iteration first (or raise vcm_set_arena_limit)");
             p->cv.wait(lk);
         }
         a->busy = true;
@@ -698,22 +699,25 @@ vcm_ctx *vcm_create_sharded2(const vcm_scene_desc2 *scene, int algorithm, float 
     return create_from_host(h, algorithm, radiusFactor, radiusAlpha, seed, device, rank, worldSize);
 }
 
-/* Which device the next vcm_create goes to.  The reference's driver builds one renderer per host core and runs
- * them concurrently (smallvcm.cxx:61-72, :99-108): on a multi-GPU node they are dealt round-robin over the visible
- * devices -- every GPU renders whole iterations of its renderers (replicas, no per-iteration exchange) and the
- * driver's own framebuffer average (smallvcm.cxx:116-142) is the reduce.  SMALLVCM_AMD_DEVICES = "all" (default),
- * "current" (the calling thread's hipGetDevice, the behaviour of round 1) or a list "0,2,5". */
-static int next_device(void)
+/* Which device a renderer-per-host-core host puts its next renderer on (vcm_next_device).  The reference's driver
+ * builds one renderer per host core and runs them concurrently (smallvcm.cxx:61-72, :99-108): on a multi-GPU node the
+ * drop-in deals them round-robin over the visible devices -- every GPU renders whole iterations of its renderers
+ * (replicas, no per-iteration exchange) and the driver's own framebuffer average (smallvcm.cxx:116-142) is the
+ * reduce.  SMALLVCM_AMD_DEVICES = "all" (default of vcm_next_device), "current" (the calling thread's hipGetDevice)
+ * or a list "0,2,5".  vcm_create itself stays on the caller's CURRENT device unless the variable is set: a host that
+ * passes its own stream or device buffers allocated them there. */
+static int next_device(bool createDefault)
 {
     static std::mutex m;
     static std::vector<int> devs;
     static unsigned long long counter = 0;
-    static bool current = false, init = false;
+    static bool current = false, init = false, envSet = false;
     std::lock_guard<std::mutex> g(m);
     const int n = vcm_device_count();
     if (!init) {
         init = true;
         const char *e = getenv("SMALLVCM_AMD_DEVICES");
+        envSet = e && *e;
         if (e && !strcmp(e, "current")) current = true;
         else if (e && strcmp(e, "all") && *e) {
             for (const char *p = e; *p;) {
@@ -726,17 +730,18 @@ static int next_device(void)
         }
         if (!current && devs.empty()) for (int d = 0; d < n; d++) devs.push_back(d);
     }
-    if (current || devs.empty()) { int dev = 0; if (n > 0) (void)hipGetDevice(&dev); return dev; }
+    if (current || devs.empty() || (createDefault && !envSet)) { int dev = 0; if (n > 0) (void)hipGetDevice(&dev); return dev; }
     return devs[(size_t)(counter++ % devs.size())];
 }
+int vcm_next_device(void) { return next_device(false); }
 
 vcm_ctx *vcm_create(const vcm_scene_desc *scene, int algorithm, float radiusFactor, float radiusAlpha, int seed)
 {
-    return vcm_create_sharded(scene, algorithm, radiusFactor, radiusAlpha, seed, next_device(), 0, 1);
+    return vcm_create_sharded(scene, algorithm, radiusFactor, radiusAlpha, seed, next_device(true), 0, 1);
 }
 vcm_ctx *vcm_create2(const vcm_scene_desc2 *scene, int algorithm, float radiusFactor, float radiusAlpha, int seed)
 {
-    return vcm_create_sharded2(scene, algorithm, radiusFactor, radiusAlpha, seed, next_device(), 0, 1);
+    return vcm_create_sharded2(scene, algorithm, radiusFactor, radiusAlpha, seed, next_device(true), 0, 1);
 }
 
 void vcm_destroy(vcm_ctx *c)
@@ -804,6 +809,13 @@ int vcm_set_merge_kernel(vcm_ctx *c, int kind)
 int vcm_set_stream(vcm_ctx *c, void *hipStream)
 {
     if (!c) return fail("vcm_set_stream", "ctx is NULL");
+    if (c->inIteration) return fail("vcm_set_stream", "iteration in progress");
+    if (hipStream) {   /* kernels of this context are launched with c->device current: the stream must live there */
+        int sdev = -1;
+        const hipError_t e = hipStreamGetDevice((hipStream_t)hipStream, &sdev);
+        (void)hipGetLastError();
+        if (e == hipSuccess && sdev != c->device) return fail("vcm_set_stream", "the stream belongs to another device than the context");
+    }
     if (c->deviceReady) {
         if (use_device(c)) return -1;
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1040,6 +1052,11 @@ static int vcm_local_light_bbox_impl(vcm_ctx *c, float *min3, float *max3, long 
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; i++) { min3[i] = h.bboxMin[i]; max3[i] = h.bboxMax[i]; }
     if (count) *count = h.nLocalRecords;
+    /* the key words K1 left (minimum inverted) have been overwritten by k_grid_init / k_bbox: vcm_build_grid must not
+       finalise them a second time.  On a single rank the box just computed IS the box of all vertices
+       (hashgrid.hxx:50-61); a sharded host still has to call vcm_set_grid_bbox with the box of all ranks. */
+    c->bboxFromLight = false;
+    if (c->world == 1) c->bboxPreset = true;
     return 0;
 }
 
@@ -1357,10 +1374,10 @@ int vcm_build_grid(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, 
 int vcm_trace_camera(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_trace_camera_impl(c)); }
 int vcm_merge(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_merge_impl(c)); }
 
-int vcm_end_iteration(vcm_ctx *c)
+static int vcm_end_iteration_impl(vcm_ctx *c)
 {
-    if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
     if (!c->merged) return fail("vcm_end_iteration", "vcm_merge has not run");
+    if (use_device(c)) return -1;
     if (join_grid(c)) return -1;   /* (a merge-free algorithm never waited) */
     if (flush_stamps(c, c->stream) || (c->deviceReady && flush_stamps(c, c->side))) return -1;
     c->iterations++;   /* :547 */
@@ -1368,6 +1385,12 @@ int vcm_end_iteration(vcm_ctx *c)
     c->evValid = true;
     arena_release(c, true);
     return 0;
+}
+int vcm_end_iteration(vcm_ctx *c)
+{
+    if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
+    g_hipFailed = false;
+    return abort_iteration(c, vcm_end_iteration_impl(c));   /* a failure ends the iteration like every other phase call */
 }
 
 int vcm_run_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)

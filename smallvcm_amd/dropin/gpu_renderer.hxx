@@ -40,7 +40,8 @@ public:
         const int rc = FlattenScene(aScene, desc);
         if(rc == 0)
         {
-            mCtx = vcm_create(&desc, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed);
+            // render() builds one renderer per host core (smallvcm.cxx:61-72): dealt round-robin over the GPUs of the node
+            mCtx = vcm_create_sharded(&desc, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed, vcm_next_device(), 0, 1);
         }
         else
         {
@@ -55,7 +56,7 @@ public:
                 fprintf(stderr, "smallvcm_amd: scene cannot be flattened (code %d)\n", rc2);
                 exit(2);
             }
-            mCtx = vcm_create2(&desc2, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed);
+            mCtx = vcm_create_sharded2(&desc2, aAlgorithm, aRadiusFactor, aRadiusAlpha, aSeed, vcm_next_device(), 0, 1);
         }
         if(mCtx == NULL)
         {

@@ -109,7 +109,7 @@ private:
 class ThreadCollectives : public Collectives {
 public:
     ThreadCollectives(Shared &sh, int ranks) : Collectives(sh, ranks), mSend((size_t)ranks, NULL), mReady((size_t)ranks),
-                                               mDone((size_t)ranks), mHave((size_t)ranks, false), mHost((size_t)ranks)
+                                               mDone((size_t)ranks), mHave((size_t)ranks, 0), mHost((size_t)ranks)
     {
         for (int r = 0; r < ranks; r++) { mReady[(size_t)r] = NULL; mDone[(size_t)r] = NULL; }
     }
@@ -129,7 +129,7 @@ public:
             HIPOK(hipMemcpyAsync(recv + (size_t)r * n, mSend[(size_t)r], n * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
         HIPOK(hipEventRecord(mDone[(size_t)rank], s));
-        mHave[(size_t)rank] = true;
+        mHave[(size_t)rank] = 1;
         return mBar.wait();
     }
     bool sendBufferFree(Shared &sh, int rank, hipStream_t s) override
@@ -163,7 +163,7 @@ private:
     }
     std::vector<const float *> mSend;
     std::vector<hipEvent_t> mReady, mDone;
-    std::vector<bool> mHave;
+    std::vector<char> mHave;   // one byte per rank: the rank threads write their own element concurrently
     std::vector<std::vector<float>> mHost;
 };
 

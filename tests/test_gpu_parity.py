@@ -431,3 +431,47 @@ def test_soak_many_iterations_stay_exact():
     assert np.array_equal(other.framebuffer_sum().view(np.uint32), o2.framebuffer().view(np.uint32))
     r.close()
     other.close()
+
+
+def test_single_rank_local_bbox_before_build_grid():
+    """vcm_local_light_bbox on a single-rank context overwrites the key words K1 left in the grid header; the grid
+    build that follows must take the finalised box, not finalise the words a second time."""
+    sc = cornell_scene(1, 96, 96)
+    o = Oracle(sc, 4, threads=8)
+    r = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    b = r.backend
+    for it in range(2):
+        o.run_iteration(it, 0, 10)
+        b.begin(it, 0, 10)
+        b.trace_light()
+        mn, mx, n = b.local_bbox()
+        b.build_grid()
+        b.trace_camera()
+        b.merge()
+        b.end()
+        ce, idx, bbox = o.grid()
+        cs, sidx, gb = b.grid()
+        assert n == o.stats()["lightVertices"]
+        assert np.array_equal(np.array(mn + mx, np.float32), bbox)
+        assert np.array_equal(gb, bbox)
+        assert np.array_equal(cs[1:], ce) and np.array_equal(sidx, idx)
+    assert np.array_equal(b.framebuffer_sum(), o.framebuffer())
+    r.close()
+
+
+def test_end_iteration_failure_returns_the_arena():
+    """A failing vcm_end_iteration ends the iteration like every other phase call (the scratch arena goes back)."""
+    L = load_library()
+    sc = cornell_scene(1, 32, 32)
+    r = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    b = r.backend
+    b.begin(0, 0, 10)
+    b.trace_light()
+    assert L.vcm_end_iteration(b.ctx) != 0          # vcm_merge has not run
+    assert b"vcm_merge" in L.vcm_last_error()
+    b.clear_framebuffer()                            # what the abandoned iteration had already splatted stays (documented)
+    b.run_iteration(0, 0, 10)                        # the context (and the arena) are usable again
+    o = Oracle(sc, 4, threads=4)
+    o.run_iteration(0, 0, 10)
+    assert np.array_equal(b.framebuffer_sum(), o.framebuffer())
+    r.close()
