@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -34,7 +35,7 @@ private:
     std::mutex mM; std::condition_variable mCv; int mN, mCount; unsigned long long mGen; bool mBroken;
 };
 
-struct Shared {   // one per farm
+struct Shared {   // one per farm_render call
     std::mutex m;
     std::string error;
     std::atomic<bool> failed;
@@ -52,7 +53,10 @@ struct Shared {   // one per farm
 #define NCCLOK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { sh.fail(std::string(#expr) + ": " + ncclGetErrorString(r_)); return false; } } while (0)
 #define VCMOK(expr) do { if ((expr) != 0) { sh.fail(std::string(#expr) + ": " + vcm_last_error()); return false; } } while (0)
 
-// ---- collectives of one communicator (the ranks of a group, or all ranks) ----
+// what the ranks of a group tell each other before the vertices travel: 7 numbers (hashgrid.hxx:47-61)
+struct Xchg { long long n; float mn[3], mx[3]; };
+
+// ---- collectives of one communicator (the ranks of a group, or all ranks); `rank` = rank INSIDE the communicator ----
 class Collectives {
 public:
     virtual ~Collectives() {}
@@ -61,54 +65,129 @@ public:
     virtual bool allReduceSum(Shared &sh, int rank, float *buf, size_t n, hipStream_t s) = 0;
     // before `rank` overwrites a buffer it has handed to allGather as `send`: wait (on s) until nobody reads it any more
     virtual bool sendBufferFree(Shared &sh, int rank, hipStream_t s) = 0;
-    // 7 numbers per rank, host side (the ranks are threads of this process); all: ranks * 7
-    bool exchange7(Shared &sh, int rank, const double *mine, double *all)
-    {
-        for (int i = 0; i < 7; i++) mSmall[(size_t)rank * 7 + i] = mine[i];
+    // all[r] = what rank r passed as `mine`; returns when every rank's numbers are known to the caller (host side)
+    virtual bool exchange(Shared &sh, int rank, const Xchg &mine, Xchg *all, hipStream_t s)
+    {   // the members are threads of this process: host memory and two barrier crossings
+        (void)s; (void)sh;
+        mSmall[(size_t)rank] = mine;
         if (!mBar.wait()) return false;
-        for (size_t i = 0; i < mSmall.size(); i++) all[i] = mSmall[i];
-        if (!mBar.wait()) return false;   // nobody overwrites mSmall before everybody has read it
-        (void)sh;
-        return true;
+        for (int r = 0; r < mRanks; r++) all[r] = mSmall[(size_t)r];
+        return mBar.wait();   // nobody overwrites mSmall before everybody has read it
     }
+    // every member has arrived (and, across processes, its stream s has drained up to here)
+    virtual bool barrier(Shared &sh, int rank, hipStream_t s) { (void)sh; (void)rank; (void)s; return mBar.wait(); }
+    virtual int rcclRanks() const { return 0; }
     int size() const { return mRanks; }
 protected:
-    Collectives(Shared &sh, int ranks) : mRanks(ranks), mBar(ranks), mSmall((size_t)ranks * 7, 0.0) { sh.barriers.push_back(&mBar); }
+    Collectives(Shared &sh, int ranks, int localMembers) : mRanks(ranks), mBar(localMembers), mSmall((size_t)ranks)
+    {
+        sh.barriers.push_back(&mBar);
+    }
     int mRanks;
-    Barrier mBar;
-    std::vector<double> mSmall;
+    Barrier mBar;               // over the members hosted by this process
+    std::vector<Xchg> mSmall;
 };
 
+// RCCL.  One ncclComm_t per member hosted here (ncclCommInitRank inside one group call); members [first, first + n)
+// of the communicator are local.  All collectives of a member are enqueued by its own host thread on the stream the
+// caller passes -- the rank's single communication stream (vcm_farm.hpp: "Collective order").
 class RcclCollectives : public Collectives {
 public:
-    RcclCollectives(Shared &sh, const std::vector<int> &devices) : Collectives(sh, (int)devices.size()), mComms(devices.size())
+    RcclCollectives(Shared &sh, int ranks, int firstLocal, const std::vector<int> &localDevices, const ncclUniqueId *id)
+        : Collectives(sh, ranks, (int)localDevices.size()), mFirst(firstLocal), mAllLocal((int)localDevices.size() == ranks),
+          mComms(localDevices.size(), (ncclComm_t)NULL), mDevices(localDevices), mScratch(localDevices.size(), (uint32_t *)NULL),
+          mPinned(localDevices.size(), (uint32_t *)NULL)
     {
-        const ncclResult_t r = ncclCommInitAll(mComms.data(), (int)devices.size(), devices.data());
-        if (r != ncclSuccess) { sh.fail(std::string("ncclCommInitAll: ") + ncclGetErrorString(r)); mComms.clear(); }
+        ncclUniqueId own;
+        if (!id) {
+            if (!mAllLocal) { sh.fail("RcclCollectives: members in other processes need a shared ncclUniqueId"); mComms.clear(); return; }
+            const ncclResult_t r = ncclGetUniqueId(&own);
+            if (r != ncclSuccess) { sh.fail(std::string("ncclGetUniqueId: ") + ncclGetErrorString(r)); mComms.clear(); return; }
+            id = &own;
+        }
+        ncclResult_t r = ncclGroupStart();
+        for (size_t i = 0; i < localDevices.size() && r == ncclSuccess; i++) {
+            if (hipSetDevice(localDevices[i]) != hipSuccess) { r = ncclUnhandledCudaError; break; }
+            r = ncclCommInitRank(&mComms[i], ranks, *id, firstLocal + (int)i);
+        }
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) { sh.fail(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); mComms.clear(); }
     }
-    ~RcclCollectives() { for (ncclComm_t c : mComms) ncclCommDestroy(c); }
+    ~RcclCollectives()
+    {
+        for (size_t i = 0; i < mComms.size(); i++) if (mComms[i]) ncclCommDestroy(mComms[i]);
+        for (size_t i = 0; i < mScratch.size(); i++) {
+            if (mScratch[i]) { (void)hipSetDevice(mDevices[i]); (void)hipFree(mScratch[i]); }
+            if (mPinned[i]) (void)hipHostFree(mPinned[i]);
+        }
+    }
     bool allGather(Shared &sh, int rank, const float *send, float *recv, size_t n, hipStream_t s) override
     {
         if (mComms.empty()) return false;
-        NCCLOK(ncclAllGather(send, recv, n, ncclFloat, mComms[(size_t)rank], s));
+        NCCLOK(ncclAllGather(send, recv, n, ncclFloat, mComms[(size_t)(rank - mFirst)], s));
         return true;
     }
     bool allReduceSum(Shared &sh, int rank, float *buf, size_t n, hipStream_t s) override
     {
         if (mComms.empty()) return false;
-        NCCLOK(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, mComms[(size_t)rank], s));
+        NCCLOK(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, mComms[(size_t)(rank - mFirst)], s));
         return true;
     }
     bool sendBufferFree(Shared &, int, hipStream_t) override { return true; }   // RCCL reads `send` in stream order
+    bool exchange(Shared &sh, int rank, const Xchg &mine, Xchg *all, hipStream_t s) override
+    {
+        if (mAllLocal) return Collectives::exchange(sh, rank, mine, all, s);
+        // members in other processes: 8 words per rank through a tiny ncclAllGather (bit patterns, no conversion)
+        if (mComms.empty() || !scratch(sh, rank)) return false;
+        const size_t i = (size_t)(rank - mFirst);
+        uint32_t *host = mPinned[i], *dev = mScratch[i];
+        host[0] = (uint32_t)((unsigned long long)mine.n & 0xffffffffu); host[7] = (uint32_t)((unsigned long long)mine.n >> 32);
+        memcpy(host + 1, mine.mn, 12); memcpy(host + 4, mine.mx, 12);
+        HIPOK(hipMemcpyAsync(dev, host, 32, hipMemcpyHostToDevice, s));
+        NCCLOK(ncclAllGather(dev, dev + 8, 8, ncclUint32, mComms[i], s));
+        HIPOK(hipMemcpyAsync(host + 8, dev + 8, 32 * (size_t)mRanks, hipMemcpyDeviceToHost, s));
+        HIPOK(hipStreamSynchronize(s));
+        for (int r = 0; r < mRanks; r++) {
+            const uint32_t *w = host + 8 + 8 * (size_t)r;
+            all[r].n = (long long)((unsigned long long)w[0] | ((unsigned long long)w[7] << 32));
+            memcpy(all[r].mn, w + 1, 12); memcpy(all[r].mx, w + 4, 12);
+        }
+        return true;
+    }
+    bool barrier(Shared &sh, int rank, hipStream_t s) override
+    {
+        if (mAllLocal) return mBar.wait();
+        if (mComms.empty() || !scratch(sh, rank)) return false;
+        const size_t i = (size_t)(rank - mFirst);
+        NCCLOK(ncclAllReduce(mScratch[i], mScratch[i], 1, ncclUint32, ncclSum, mComms[i], s));
+        HIPOK(hipStreamSynchronize(s));
+        return true;
+    }
+    int rcclRanks() const override { return mRanks; }
 private:
+    bool scratch(Shared &sh, int rank)
+    {
+        const size_t i = (size_t)(rank - mFirst);
+        if (!mScratch[i]) {   // the calling rank thread has its device current
+            HIPOK(hipMalloc((void **)&mScratch[i], 32 * (size_t)(mRanks + 1)));
+            HIPOK(hipMemset(mScratch[i], 0, 32 * (size_t)(mRanks + 1)));
+            HIPOK(hipHostMalloc((void **)&mPinned[i], 32 * (size_t)(mRanks + 1), hipHostMallocDefault));
+        }
+        return true;
+    }
+    int mFirst;
+    bool mAllLocal;
     std::vector<ncclComm_t> mComms;
+    std::vector<int> mDevices;
+    std::vector<uint32_t *> mScratch, mPinned;
 };
 
 // Stand-in for tests on one GPU (RCCL refuses two ranks on one device): the ranks are threads of this process, data
 // moves with device-to-device copies ordered by events.  Same interface, same call pattern as the RCCL class.
 class ThreadCollectives : public Collectives {
 public:
-    ThreadCollectives(Shared &sh, int ranks) : Collectives(sh, ranks), mSend((size_t)ranks, NULL), mReady((size_t)ranks),
+    ThreadCollectives(Shared &sh, int ranks) : Collectives(sh, ranks, ranks), mSend((size_t)ranks, NULL), mReady((size_t)ranks),
                                                mDone((size_t)ranks), mHave((size_t)ranks, 0), mHost((size_t)ranks)
     {
         for (int r = 0; r < ranks; r++) { mReady[(size_t)r] = NULL; mDone[(size_t)r] = NULL; }
@@ -174,57 +253,79 @@ void static_schedule(int iterations, int threads, int tid, int *first, int *coun
     *first = tid * q + std::min(tid, r);
     *count = q + (tid < r ? 1 : 0);
 }
+// the iterations of renderer `rid` in the timed region
+void renderer_schedule(const FarmConfig &cfg, int R, int rid, int *first, int *count)
+{
+    if (cfg.sameWindow) { *first = cfg.warmup; *count = cfg.iterations / R; }   // every renderer the same radius window
+    else static_schedule(cfg.iterations, R, rid, first, count);
+}
 
 // one renderer as seen by ONE of its ranks
 struct Slot {
     vcm_ctx *ctx;
     Collectives *group;          // NULL when shards == 1
-    hipStream_t stream, commStream;
+    hipStream_t stream;          // the renderer's kernels
+    hipStream_t commStream;      // the RANK's communication stream (shared by its slots)
     hipEvent_t evRecords, evGathered;
     float *local, *gathered;     // slabs: stride records / shards * stride records
     size_t capRecords;
     int first, count;            // iterations of this renderer
     std::vector<long long> counts;
-    long long stride;
-    bool exchanging;
+    long long stride, nLocal;
+    bool exchanging, live;
+    Xchg mine;
     Slot() : ctx(NULL), group(NULL), stream(NULL), commStream(NULL), evRecords(NULL), evGathered(NULL), local(NULL), gathered(NULL),
-             capRecords(0), first(0), count(0), stride(0), exchanging(false) {}
+             capRecords(0), first(0), count(0), stride(0), nLocal(0), exchanging(false), live(false) {}
 };
 
 struct RankArgs {
     const FarmConfig *cfg;
     Shared *sh;
     int rank, device, group, shard;
-    std::vector<Collectives *> groupComms;   // per slot
+    Collectives *groupComm;      // NULL when shards == 1
     Collectives *world;
-    Barrier *startLine;
+    Barrier *startLine;          // the ranks hosted by this process
     FarmResult *result;
-    double *wall;
+    std::mutex *resultMutex;
 };
 
-bool slot_start(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard, int iteration)
-{   // light pass, start of the exchange, the part of the camera pass that does not need the other ranks' vertices
+// ---- one step of a rank: every in-flight renderer advances by one iteration.  Four passes over the slots, so that
+// (a) every collective is enqueued in the same order on every rank of the group (vcm_farm.hpp), (b) the host waits of
+// one renderer (the 7 numbers) find the other renderers' light passes already queued on the GPU, and (c) the small
+// exchanges never queue behind a large all-gather of the same step. ----
+bool step_light(Shared &sh, const FarmConfig &cfg, Slot &sl, int iteration)
+{   // light pass (vertexcm.hxx:321-396)
     VCMOK(vcm_begin_iteration(sl.ctx, iteration, cfg.minLen, cfg.maxLen));
     VCMOK(vcm_trace_light(sl.ctx));
     sl.exchanging = false;
+    return true;
+}
+bool step_counts(Shared &sh, Slot &sl, int shard)
+{   // this rank's 7 numbers (one stream synchronisation), then everybody's
     if (!sl.group) return true;
     const int S = sl.group->size();
-    float mn[3], mx[3];
+    if (S > VCM_FARM_MAX_RANKS) { sh.fail("too many shards"); return false; }
     long long n = 0;
-    VCMOK(vcm_local_light_bbox(sl.ctx, mn, mx, &n));   // synchronises the stream: the one host wait of an iteration
-    double mine[7] = { (double)n, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2] }, all[7 * 64];
-    if (S > 64) { sh.fail("more than 64 shards"); return false; }
-    if (!sl.group->exchange7(sh, shard, mine, all)) return false;
+    VCMOK(vcm_local_light_bbox(sl.ctx, sl.mine.mn, sl.mine.mx, &n));
+    sl.mine.n = n; sl.nLocal = n;
+    Xchg all[VCM_FARM_MAX_RANKS];
+    if (!sl.group->exchange(sh, shard, sl.mine, all, sl.commStream)) return false;
     sl.counts.assign((size_t)S, 0);
     sl.stride = 1;
     float gmn[3] = { 1e36f, 1e36f, 1e36f }, gmx[3] = { -1e36f, -1e36f, -1e36f };   // hashgrid.hxx:47-48
     for (int r = 0; r < S; r++) {
-        sl.counts[(size_t)r] = (long long)all[r * 7];
-        sl.stride = std::max(sl.stride, sl.counts[(size_t)r]);
-        if (sl.counts[(size_t)r] > 0)
-            for (int k = 0; k < 3; k++) { gmn[k] = std::min(gmn[k], (float)all[r * 7 + 1 + k]); gmx[k] = std::max(gmx[k], (float)all[r * 7 + 4 + k]); }
+        sl.counts[(size_t)r] = all[r].n;
+        sl.stride = std::max(sl.stride, all[r].n);
+        if (all[r].n > 0)
+            for (int k = 0; k < 3; k++) { gmn[k] = std::min(gmn[k], all[r].mn[k]); gmx[k] = std::max(gmx[k], all[r].mx[k]); }
     }
     VCMOK(vcm_set_grid_bbox(sl.ctx, gmn, gmx));
+    return true;
+}
+bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard)
+{   // start of the all-gather; the part of the camera pass that does not need the other ranks' vertices
+    if (!sl.group) return true;
+    const int S = sl.group->size();
     if ((size_t)sl.stride > sl.capRecords) {   // grow the slabs (rare: the counts vary by a fraction of a percent)
         HIPOK(hipStreamSynchronize(sl.stream));
         HIPOK(hipStreamSynchronize(sl.commStream));
@@ -235,8 +336,8 @@ bool slot_start(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard, int iter
         HIPOK(hipMalloc((void **)&sl.gathered, sl.capRecords * (size_t)S * VCM_MERGE_RECORD_FLOATS * sizeof(float)));
     }
     if (!sl.group->sendBufferFree(sh, shard, sl.stream)) return false;
-    VCMOK(vcm_export_light_records(sl.ctx, sl.local, n));
-    // the all-gather runs on the second stream, behind the export and next to the camera pass
+    VCMOK(vcm_export_light_records(sl.ctx, sl.local, sl.nLocal));
+    // the all-gather runs on the communication stream, behind the export and next to the camera pass
     HIPOK(hipEventRecord(sl.evRecords, sl.stream));
     HIPOK(hipStreamWaitEvent(sl.commStream, sl.evRecords, 0));
     if (!sl.group->allGather(sh, shard, sl.local, sl.gathered, (size_t)sl.stride * VCM_MERGE_RECORD_FLOATS, sl.commStream)) return false;
@@ -245,8 +346,7 @@ bool slot_start(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard, int iter
     if (vcm_is_wavefront(sl.ctx, cfg.maxLen)) VCMOK(vcm_trace_camera(sl.ctx));   // needs only the local light vertices
     return true;
 }
-
-bool slot_finish(Shared &sh, const FarmConfig &cfg, Slot &sl)
+bool step_finish(Shared &sh, const FarmConfig &cfg, Slot &sl)
 {   // wait for the exchange, grid build, (camera pass,) merge, resolve
     if (sl.exchanging) {
         HIPOK(hipStreamWaitEvent(sl.stream, sl.evGathered, 0));
@@ -259,13 +359,35 @@ bool slot_finish(Shared &sh, const FarmConfig &cfg, Slot &sl)
     return true;
 }
 
-bool run_steps(Shared &sh, const FarmConfig &cfg, std::vector<Slot> &slots, int shard, int offset, int steps)
-{   // renderers advance in lock-step; a step = one iteration half of every in-flight renderer, then the other half
+bool run_steps(Shared &sh, const FarmConfig &cfg, std::vector<Slot> &slots, int shard, bool warm, int steps)
+{   // renderers advance in lock-step; warm-up steps use the iteration indices 0 .. steps - 1
     for (int t = 0; t < steps; t++) {
-        for (Slot &sl : slots) if (t < sl.count || offset < 0) { if (!slot_start(sh, cfg, sl, shard, offset < 0 ? t : sl.first + t)) return false; }
-        for (Slot &sl : slots) if (t < sl.count || offset < 0) { if (!slot_finish(sh, cfg, sl)) return false; }
+        for (Slot &sl : slots) sl.live = warm || t < sl.count;
+        for (Slot &sl : slots) if (sl.live && !step_light(sh, cfg, sl, warm ? t : sl.first + t)) return false;
+        for (Slot &sl : slots) if (sl.live && !step_counts(sh, sl, shard)) return false;
+        for (Slot &sl : slots) if (sl.live && !step_exchange_camera(sh, cfg, sl, shard)) return false;
+        for (Slot &sl : slots) if (sl.live && !step_finish(sh, cfg, sl)) return false;
     }
     return true;
+}
+
+void stats_accumulate(vcm_stats &acc, const vcm_stats &s)
+{
+    acc.lightVertices += s.lightVertices; acc.gridVertices += s.gridVertices; acc.lightRays += s.lightRays; acc.cameraRays += s.cameraRays;
+    acc.shadowRays += s.shadowRays; acc.mergeQueries += s.mergeQueries; acc.mergeCandidates += s.mergeCandidates;
+    acc.mergeAccepted += s.mergeAccepted; acc.connections += s.connections; acc.lightSplats += s.lightSplats;
+    acc.msLight += s.msLight; acc.msGrid += s.msGrid; acc.msCamera += s.msCamera; acc.msTotal += s.msTotal;
+    acc.msLightKernel += s.msLightKernel; acc.msCameraKernel += s.msCameraKernel; acc.msMergeKernel += s.msMergeKernel;
+    acc.msQuerySort += s.msQuerySort; acc.msConnectKernels += s.msConnectKernels; acc.radius += s.radius;
+}
+void stats_scale(vcm_stats &a, int n)
+{
+    if (n <= 0) return;
+    a.lightVertices /= n; a.gridVertices /= n; a.lightRays /= n; a.cameraRays /= n; a.shadowRays /= n; a.mergeQueries /= n;
+    a.mergeCandidates /= n; a.mergeAccepted /= n; a.connections /= n; a.lightSplats /= n;
+    const float f = 1.f / (float)n;
+    a.msLight *= f; a.msGrid *= f; a.msCamera *= f; a.msTotal *= f; a.msLightKernel *= f; a.msCameraKernel *= f; a.msMergeKernel *= f;
+    a.msQuerySort *= f; a.msConnectKernels *= f; a.radius *= f;
 }
 
 bool rank_main(RankArgs &a)
@@ -275,6 +397,8 @@ bool rank_main(RankArgs &a)
     HIPOK(hipSetDevice(a.device));
     const int groups = cfg.ranks / cfg.shards, R = groups * cfg.inflight;
     std::vector<Slot> slots((size_t)cfg.inflight);
+    hipStream_t commStream = NULL;
+    HIPOK(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking));
     int maxCount = 0;
     for (int k = 0; k < cfg.inflight; k++) {
         Slot &sl = slots[(size_t)k];
@@ -283,36 +407,74 @@ bool rank_main(RankArgs &a)
                                     a.shard, cfg.shards);   // seed: smallvcm.cxx:68
         if (!sl.ctx) { sh.fail(std::string("vcm_create_sharded: ") + vcm_last_error()); return false; }
         HIPOK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-        HIPOK(hipStreamCreateWithFlags(&sl.commStream, hipStreamNonBlocking));
+        sl.commStream = commStream;
         HIPOK(hipEventCreateWithFlags(&sl.evRecords, hipEventDisableTiming));
         HIPOK(hipEventCreateWithFlags(&sl.evGathered, hipEventDisableTiming));
         VCMOK(vcm_set_stream(sl.ctx, sl.stream));
         VCMOK(vcm_reserve(sl.ctx, cfg.maxLen));
-        sl.group = cfg.shards > 1 ? a.groupComms[(size_t)k] : NULL;
-        static_schedule(cfg.iterations, R, rid, &sl.first, &sl.count);
+        sl.group = cfg.shards > 1 ? a.groupComm : NULL;
+        renderer_schedule(cfg, R, rid, &sl.first, &sl.count);
         maxCount = std::max(maxCount, sl.count);
     }
+    // everybody arrives (threads of this process, then the other processes), the rank's streams drained
+    auto line = [&]() -> bool {
+        for (Slot &sl : slots) VCMOK(vcm_synchronize(sl.ctx));
+        HIPOK(hipStreamSynchronize(commStream));
+        if (!a.startLine->wait()) return false;
+        return a.world->barrier(sh, a.rank, commStream);
+    };
     if (cfg.warmup > 0) {   // untimed: iterations 0..warmup-1 of every renderer, then the framebuffers start over
-        if (!run_steps(sh, cfg, slots, a.shard, -1, cfg.warmup)) return false;
+        if (!run_steps(sh, cfg, slots, a.shard, true, cfg.warmup)) return false;
         for (Slot &sl : slots) VCMOK(vcm_clear_framebuffer(sl.ctx));
     }
-    for (Slot &sl : slots) VCMOK(vcm_synchronize(sl.ctx));
-    if (!a.startLine->wait()) return false;
+    if (!line()) return false;
     const auto t0 = std::chrono::steady_clock::now();
-    if (!run_steps(sh, cfg, slots, a.shard, 0, maxCount)) return false;
-    for (Slot &sl : slots) { VCMOK(vcm_synchronize(sl.ctx)); HIPOK(hipStreamSynchronize(sl.commStream)); }
-    if (!a.startLine->wait()) return false;
-    if (a.rank == 0) *a.wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!run_steps(sh, cfg, slots, a.shard, false, maxCount)) return false;
+    for (Slot &sl : slots) VCMOK(vcm_synchronize(sl.ctx));
+    HIPOK(hipStreamSynchronize(commStream));
+    const double mine = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!line()) return false;
+
+    // per-rank figures: device time of an iteration of the first renderer (its own stamps), counters on rank 0
+    float iterMs = 0.f;
+    {
+        const int n = std::min(slots[0].count, 64);
+        vcm_stats acc; memset(&acc, 0, sizeof(acc));
+        for (int ago = 0; ago < n; ago++) { vcm_stats st; VCMOK(vcm_get_stats_at(slots[0].ctx, ago, &st)); stats_accumulate(acc, st); }
+        stats_scale(acc, n);
+        iterMs = acc.msTotal;
+        if (a.rank == 0) { std::lock_guard<std::mutex> g(*a.resultMutex); a.result->meanStats = acc; }
+    }
+    {   // wall = max over ranks, iteration ms per rank: one small all-reduce of a table every rank fills its row of
+        const size_t n = 2 * (size_t)cfg.ranks;
+        float *dev = NULL;
+        std::vector<float> host(n, 0.f);
+        host[(size_t)a.rank] = (float)mine; host[(size_t)cfg.ranks + (size_t)a.rank] = iterMs;
+        HIPOK(hipMalloc((void **)&dev, n * sizeof(float)));
+        HIPOK(hipMemcpyAsync(dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice, commStream));
+        if (a.world->size() > 1 && !a.world->allReduceSum(sh, a.rank, dev, n, commStream)) return false;
+        HIPOK(hipMemcpyAsync(host.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, commStream));
+        HIPOK(hipStreamSynchronize(commStream));
+        (void)hipFree(dev);
+        if (a.rank == cfg.firstRank) {
+            std::lock_guard<std::mutex> g(*a.resultMutex);
+            double wall = 0;
+            for (int r = 0; r < cfg.ranks; r++) wall = std::max(wall, (double)host[(size_t)r]);
+            a.result->wallSeconds = wall;
+            a.result->rankIterationMs.assign(host.begin() + cfg.ranks, host.end());
+        }
+    }
 
     // read-out (smallvcm.cxx:116-142): mean over the used renderers of (running sum / own iterations); a renderer's
     // shards hold partial sums of it, so ONE all-reduce over all ranks does both sums
     int used = 0;
-    for (int rid = 0; rid < R; rid++) { int f, c; static_schedule(cfg.iterations, R, rid, &f, &c); if (c > 0) used++; }
+    for (int rid = 0; rid < R; rid++) { int f, c; renderer_schedule(cfg, R, rid, &f, &c); if (c > 0) used++; }
     const size_t n3 = (size_t)((int)cfg.scene.camera.resolution[0]) * (size_t)((int)cfg.scene.camera.resolution[1]) * 3;
     float *acc = NULL, *tmp = NULL;
     HIPOK(hipMalloc((void **)&acc, n3 * sizeof(float)));
     HIPOK(hipMalloc((void **)&tmp, n3 * sizeof(float)));
     HIPOK(hipMemsetAsync(acc, 0, n3 * sizeof(float), slots[0].stream));
+    HIPOK(hipStreamSynchronize(slots[0].stream));
     std::vector<float> hostAcc(n3, 0.f), hostTmp(n3);
     bool any = false;
     for (Slot &sl : slots) {
@@ -328,24 +490,25 @@ bool rank_main(RankArgs &a)
         }
         any = true;
     }
-    HIPOK(hipStreamSynchronize(slots[0].stream));
     if (a.world->size() > 1) {
-        if (!a.world->allReduceSum(sh, a.rank, acc, n3, slots[0].stream)) return false;
-        HIPOK(hipStreamSynchronize(slots[0].stream));
+        if (!a.world->allReduceSum(sh, a.rank, acc, n3, commStream)) return false;
+        HIPOK(hipStreamSynchronize(commStream));
     }
     if (a.rank == 0) {
+        std::lock_guard<std::mutex> g(*a.resultMutex);
         a.result->image.resize(n3);
         HIPOK(hipMemcpy(a.result->image.data(), acc, n3 * sizeof(float), hipMemcpyDeviceToHost));
     }
     (void)hipFree(acc); (void)hipFree(tmp);
-    if (!a.startLine->wait()) return false;   // nobody tears a communicator's peer down while a collective runs
+    if (!line()) return false;   // nobody tears a communicator's peer down while a collective runs
     for (Slot &sl : slots) {
         vcm_destroy(sl.ctx);
         if (sl.local) (void)hipFree(sl.local);
         if (sl.gathered) (void)hipFree(sl.gathered);
         (void)hipEventDestroy(sl.evRecords); (void)hipEventDestroy(sl.evGathered);
-        (void)hipStreamDestroy(sl.commStream); (void)hipStreamDestroy(sl.stream);
+        (void)hipStreamDestroy(sl.stream);
     }
+    (void)hipStreamDestroy(commStream);
     return true;
 }
 
@@ -356,39 +519,101 @@ FarmResult farm_render(const FarmConfig &cfg)
     FarmResult res;
     res.wallSeconds = 0;
     res.renderers = 0;
-    if (cfg.ranks < 1 || cfg.shards < 1 || cfg.ranks % cfg.shards || cfg.inflight < 1 || (int)cfg.devices.size() != cfg.ranks) {
-        res.error = "ranks must be a multiple of shards, one device per rank, inflight >= 1";
+    res.rcclRanks = 0;
+    memset(&res.meanStats, 0, sizeof(res.meanStats));
+    const bool multiProcess = cfg.localRanks != cfg.ranks;
+    if (cfg.ranks < 1 || cfg.ranks > VCM_FARM_MAX_RANKS || cfg.shards < 1 || cfg.ranks % cfg.shards || cfg.inflight < 1 ||
+        cfg.localRanks < 1 || cfg.firstRank < 0 || cfg.firstRank + cfg.localRanks > cfg.ranks || (int)cfg.devices.size() != cfg.localRanks) {
+        res.error = "ranks must be a multiple of shards (at most 64), one device per local rank, inflight >= 1";
+        return res;
+    }
+    const int groups = cfg.ranks / cfg.shards;
+    res.renderers = groups * cfg.inflight;
+    if (cfg.sameWindow && cfg.iterations % res.renderers) { res.error = "sameWindow: iterations must be a multiple of the renderer count"; return res; }
+    if (multiProcess && !cfg.rccl) { res.error = "the in-process stand-in for the collectives needs every rank in one process"; return res; }
+    if ((multiProcess || !cfg.uniqueIds.empty()) && cfg.uniqueIds.size() != (size_t)(1 + groups) * sizeof(ncclUniqueId)) {
+        res.error = "one process per GPU: pass 1 + ranks / shards ids of vcm_farm_unique_ids";
         return res;
     }
     Shared sh;
-    const int groups = cfg.ranks / cfg.shards;
-    res.renderers = groups * cfg.inflight;
-    Barrier startLine(cfg.ranks);
+    Barrier startLine(cfg.localRanks);
     sh.barriers.push_back(&startLine);
-    // communicators: one per (group, in-flight slot) -- collectives of one communicator execute in order, and the
-    // small count exchange of one renderer must not queue behind the large all-gather of the other -- plus the world
-    std::vector<std::vector<Collectives *>> groupComms((size_t)groups);
+    const ncclUniqueId *ids = cfg.uniqueIds.empty() ? NULL : reinterpret_cast<const ncclUniqueId *>(cfg.uniqueIds.data());   // shipped ids are used even when every rank is local
+    // communicators: the world's and ONE per group (vcm_farm.hpp: "Collective order")
+    std::vector<Collectives *> groupComms((size_t)groups, (Collectives *)NULL);
+    const int lo = cfg.firstRank, hi = cfg.firstRank + cfg.localRanks;
     for (int g = 0; g < groups && cfg.shards > 1; g++) {
-        std::vector<int> devs(cfg.devices.begin() + g * cfg.shards, cfg.devices.begin() + (g + 1) * cfg.shards);
-        for (int k = 0; k < cfg.inflight; k++)
-            groupComms[(size_t)g].push_back(cfg.rccl ? (Collectives *)new RcclCollectives(sh, devs) : (Collectives *)new ThreadCollectives(sh, cfg.shards));
+        const int g0 = g * cfg.shards, g1 = g0 + cfg.shards;
+        const int a = std::max(lo, g0), b = std::min(hi, g1);   // members of group g hosted here: world ranks [a, b)
+        if (a >= b) continue;
+        std::vector<int> devs(cfg.devices.begin() + (a - lo), cfg.devices.begin() + (b - lo));
+        groupComms[(size_t)g] = cfg.rccl ? (Collectives *)new RcclCollectives(sh, cfg.shards, a - g0, devs, ids ? ids + 1 + g : NULL)
+                                         : (Collectives *)new ThreadCollectives(sh, cfg.shards);
     }
-    Collectives *world = cfg.rccl ? (Collectives *)new RcclCollectives(sh, cfg.devices) : (Collectives *)new ThreadCollectives(sh, cfg.ranks);
-    double wall = 0;
-    std::vector<RankArgs> args((size_t)cfg.ranks);
+    Collectives *world = cfg.rccl ? (Collectives *)new RcclCollectives(sh, cfg.ranks, cfg.firstRank, cfg.devices, ids)
+                                  : (Collectives *)new ThreadCollectives(sh, cfg.ranks);
+    res.rcclRanks = world->rcclRanks();
+    std::mutex resultMutex;
+    std::vector<RankArgs> args((size_t)cfg.localRanks);
     std::vector<std::thread> threads;
     if (!sh.failed) {
-        for (int r = 0; r < cfg.ranks; r++) {
-            RankArgs &a = args[(size_t)r];
-            a.cfg = &cfg; a.sh = &sh; a.rank = r; a.device = cfg.devices[(size_t)r]; a.group = r / cfg.shards; a.shard = r % cfg.shards;
-            a.groupComms = groupComms[(size_t)a.group]; a.world = world; a.startLine = &startLine; a.result = &res; a.wall = &wall;
+        for (int i = 0; i < cfg.localRanks; i++) {
+            RankArgs &a = args[(size_t)i];
+            const int r = cfg.firstRank + i;
+            a.cfg = &cfg; a.sh = &sh; a.rank = r; a.device = cfg.devices[(size_t)i]; a.group = r / cfg.shards; a.shard = r % cfg.shards;
+            a.groupComm = groupComms[(size_t)a.group]; a.world = world; a.startLine = &startLine; a.result = &res; a.resultMutex = &resultMutex;
             threads.emplace_back([&a, &sh] { if (!rank_main(a)) sh.fail("rank failed"); });
         }
         for (std::thread &t : threads) t.join();
     }
-    for (auto &v : groupComms) for (Collectives *c : v) delete c;
+    for (Collectives *c : groupComms) delete c;
     delete world;
-    res.wallSeconds = wall;
     res.error = sh.error;
     return res;
 }
+
+// ---- C-ABI (include/smallvcm_amd_farm.h) ----
+static thread_local std::string g_farmError;
+
+extern "C" {
+
+const char *vcm_farm_last_error(void) { return g_farmError.c_str(); }
+
+int vcm_farm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+unsigned vcm_farm_sizeof_config(void) { return (unsigned)sizeof(vcm_farm_config); }
+unsigned vcm_farm_sizeof_result(void) { return (unsigned)sizeof(vcm_farm_result); }
+
+int vcm_farm_unique_ids(void *out, int n)
+{
+    if (!out || n < 1) { g_farmError = "vcm_farm_unique_ids: bad argument"; return -1; }
+    for (int i = 0; i < n; i++) {
+        ncclUniqueId id;
+        const ncclResult_t r = ncclGetUniqueId(&id);
+        if (r != ncclSuccess) { g_farmError = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return -1; }
+        memcpy((char *)out + (size_t)i * sizeof(id), &id, sizeof(id));
+    }
+    return 0;
+}
+
+int vcm_farm_render(const vcm_farm_config *c, vcm_farm_result *out, float *imageOut)
+{
+    if (!c || !out) { g_farmError = "vcm_farm_render: NULL argument"; return -1; }
+    memset(out, 0, sizeof(*out));
+    if (c->localRanks < 1 || c->localRanks > VCM_FARM_MAX_RANKS) { g_farmError = "vcm_farm_render: localRanks out of range"; return -1; }
+    FarmConfig fc;
+    fc.scene = c->scene; fc.algorithm = c->algorithm; fc.radiusFactor = c->radiusFactor; fc.radiusAlpha = c->radiusAlpha;
+    fc.baseSeed = c->baseSeed; fc.minLen = c->minLen; fc.maxLen = c->maxLen; fc.iterations = c->iterations; fc.warmup = c->warmup;
+    fc.sameWindow = c->sameWindow != 0; fc.ranks = c->ranks; fc.firstRank = c->firstRank; fc.localRanks = c->localRanks;
+    fc.devices.assign(c->devices, c->devices + c->localRanks);
+    fc.shards = c->shards; fc.inflight = c->inflight; fc.rccl = c->collectives == 0;
+    if (c->uniqueIds && c->nUniqueIds > 0)
+        fc.uniqueIds.assign((const char *)c->uniqueIds, (const char *)c->uniqueIds + (size_t)c->nUniqueIds * sizeof(ncclUniqueId));
+    const FarmResult r = farm_render(fc);
+    if (!r.error.empty()) { g_farmError = r.error; return -1; }
+    out->wallSeconds = r.wallSeconds; out->renderers = r.renderers; out->rcclRanks = r.rcclRanks; out->meanStats = r.meanStats;
+    for (size_t i = 0; i < r.rankIterationMs.size() && i < VCM_FARM_MAX_RANKS; i++) out->rankIterationMs[i] = r.rankIterationMs[i];
+    if (imageOut && !r.image.empty()) memcpy(imageOut, r.image.data(), r.image.size() * sizeof(float));
+    return 0;
+}
+
+} // extern "C"

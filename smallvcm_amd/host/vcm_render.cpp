@@ -10,7 +10,7 @@
 //              [--res W H] [--seed S] [--minlen A] [--maxlen B]
 //              [--renderers R] [--radius-factor F] [--radius-alpha A]
 //              [--device D] [--strict] [--warmup W] [-o out.pfm] [--json]
-//              [--gpus N [--shards S] [--inflight K] [--devices 0,1,..] [--collectives rccl|threads]]
+//              [--gpus N [--shards S] [--inflight K] [--devices 0,1,..] [--collectives rccl|threads] [--same-window]]
 //
 // --gpus N: the multi-GPU host (vcm_farm.hpp): N ranks = N host threads, one per GPU, cut into N / S groups; a
 // renderer lives on a group (S path-index shards, RCCL all-gather of the light vertices every iteration), K
@@ -64,7 +64,8 @@ int main(int argc, char **argv)
     int sceneID = 0, algorithm = VCM_ALGO_VCM, iterations = 1, resX = 512, resY = 512, seed = 1234;   // config.hxx:233-240
     unsigned minLen = 0, maxLen = 10;
     int renderers = 1, device = 0, warmup = 0, strict = 0, json = 0;
-    int gpus = 0, shards = 0, inflight = 0, rccl = 1;
+    int gpus = 0, shards = 0, inflight = 0, rccl = 1, sameWindow = 0, rcclRanks = 0;
+    std::vector<float> rankMs;
     std::vector<int> devices;
     float radiusFactor = 0.003f, radiusAlpha = 0.75f;
     std::string out, algoName = "vcm";
@@ -89,6 +90,7 @@ int main(int argc, char **argv)
         else if (a == "--inflight") { need(1); inflight = atoi(argv[++i]); }
         else if (a == "--collectives") { need(1); rccl = std::string(argv[++i]) == "threads" ? 0 : 1; }
         else if (a == "--devices") { need(1); for (const char *p = argv[++i]; *p;) { char *e; devices.push_back((int)strtol(p, &e, 10)); p = (*e == ',') ? e + 1 : e; if (e == p && *p) break; } }
+        else if (a == "--same-window") sameWindow = 1;   // benchmark schedule: every renderer runs the iteration indices warmup ..
         else if (a == "--strict") strict = 1;
         else if (a == "--json") json = 1;
         else { fprintf(stderr, "vcm_render: unknown option %s (see the header of vcm_render.cpp)\n", a.c_str()); return 2; }
@@ -114,6 +116,8 @@ int main(int argc, char **argv)
         fc.shards = shards > 0 ? shards : ((gpus % 2 == 0) ? 2 : gpus);
         fc.inflight = inflight > 0 ? inflight : (fc.shards > 1 ? 2 : 1);
         fc.rccl = rccl != 0; fc.warmup = warmup;
+        fc.firstRank = 0; fc.localRanks = gpus;   // every rank is a thread of this process
+        fc.sameWindow = sameWindow != 0;
         const int visible = vcm_device_count();
         if (visible <= 0) { fprintf(stderr, "vcm_render: no HIP device available (this program has no CPU path)\n"); return 2; }
         for (int k = 0; k < gpus; k++) fc.devices.push_back(k < (int)devices.size() ? devices[(size_t)k] : (fc.rccl ? k : k % visible));
@@ -123,6 +127,9 @@ int main(int argc, char **argv)
         fb = fr.image;
         wall = fr.wallSeconds;
         renderers = fr.renderers;
+        rcclRanks = fr.rcclRanks;
+        rankMs = fr.rankIterationMs;
+        st = fr.meanStats;
     } else {
     // render(): one renderer per "thread", seed base + i (smallvcm.cxx:61-72)
     r.assign((size_t)renderers, (vcm_ctx *)NULL);
@@ -221,11 +228,16 @@ int main(int argc, char **argv)
     double mean[3] = { 0, 0, 0 };
     for (size_t i = 0; i < n3; i++) mean[i % 3] += fb[i];
     const double paths = (algorithm == VCM_ALGO_PATH_TRACE || algorithm == VCM_ALGO_EYE_LIGHT ? 1.0 : 2.0) * resX * resY * iterations;
-    if (json)
+    if (json) {
+        std::string ms = "[";
+        for (size_t i = 0; i < rankMs.size(); i++) { char b[32]; snprintf(b, sizeof(b), "%s%.3f", i ? ", " : "", rankMs[i]); ms += b; }
+        ms += "]";
         printf("{\"scene\": %d, \"algorithm\": \"%s\", \"res\": [%d, %d], \"iterations\": %d, \"renderers\": %d, \"seed\": %d, "
-               "\"gpus\": %d, \"wall_s\": %.6f, \"Mpaths_s\": %.3f, \"image_mean\": [%.6f, %.6f, %.6f], \"last_iteration_ms\": %.3f}\n",
-               sceneID, algoName.c_str(), resX, resY, iterations, renderers, seed, gpus > 0 ? gpus : 1, wall, paths / wall / 1e6,
-               mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal);
+               "\"gpus\": %d, \"rccl_ranks\": %d, \"wall_s\": %.6f, \"Mpaths_s\": %.3f, \"image_mean\": [%.6f, %.6f, %.6f], "
+               "\"last_iteration_ms\": %.3f, \"rank_iteration_ms\": %s}\n",
+               sceneID, algoName.c_str(), resX, resY, iterations, renderers, seed, gpus > 0 ? gpus : 1, rcclRanks, wall, paths / wall / 1e6,
+               mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal, ms.c_str());
+    }
     else
         printf("scene %d, %s, %dx%d, %d iteration(s) on %d renderer(s): %.3f s wall clock, %.2f Mpaths/s\n", sceneID,
                algoName.c_str(), resX, resY, iterations, renderers, wall, paths / wall / 1e6);

@@ -46,6 +46,36 @@ def test_every_exported_symbol_is_declared():
     assert not [n for n in _declared_symbols("smallvcm_amd.h") if n.startswith(("vcm_debug_", "vcm_host_", "vcm_sizeof_"))]
 
 
+def test_farm_library_exports_what_its_header_declares():
+    """include/smallvcm_amd_farm.h = the multi-GPU host's boundary (smallvcm_amd/host/libsmallvcm_amd_farm.so); loads
+    without a GPU, exports exactly the declared entry points, PODs as the ctypes mirror assumes"""
+    from smallvcm_amd import farm
+    L = farm.load_farm_library()
+    declared = [n for n in _declared_symbols("smallvcm_amd_farm.h") if n.startswith("vcm_farm_")]
+    assert len(declared) >= 6
+    out = subprocess.run(["nm", "-D", "--defined-only", farm.FARM_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and l.split()[2].startswith("vcm_"))
+    assert exported == sorted(declared), (exported, declared)
+    assert L.vcm_farm_sizeof_config() == C.sizeof(farm.FarmConfig)
+    assert L.vcm_farm_sizeof_result() == C.sizeof(farm.FarmResult)
+    assert L.vcm_farm_unique_id_bytes() == 128
+
+
+def test_farm_rejects_bad_configurations_without_a_gpu():
+    """argument errors are reported before anything touches a device"""
+    from smallvcm_amd import farm
+    from smallvcm_amd.renderer import cornell_scene
+    sc = cornell_scene(1, 16, 16)
+    with pytest.raises(RuntimeError, match="multiple of shards"):
+        farm.farm_render(sc, 4, iterations=4, ranks=3, shards=2, inflight=1, devices=[0, 0, 0], collectives="threads")
+    with pytest.raises(RuntimeError, match="sameWindow"):
+        farm.farm_render(sc, 4, iterations=3, ranks=2, shards=1, inflight=1, devices=[0, 0], collectives="threads", same_window=True)
+    with pytest.raises(RuntimeError, match="stand-in"):
+        farm.farm_render(sc, 4, iterations=2, ranks=2, shards=2, inflight=1, devices=[0], first_rank=0, collectives="threads")
+    with pytest.raises(RuntimeError, match="ids"):
+        farm.farm_render(sc, 4, iterations=2, ranks=2, shards=2, inflight=1, devices=[0], first_rank=1, collectives="rccl")
+
+
 def test_pod_sizes_match_ctypes_mirror():
     L = load_library(require_gpu=False)
     assert L.vcm_sizeof_scene_desc() == C.sizeof(_abi.SceneDesc)

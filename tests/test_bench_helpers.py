@@ -33,3 +33,47 @@ def test_recorded_traffic_needs_the_same_kernel_sources(tmp_path, monkeypatch):
 def test_workload_names():
     assert "scene 1 -a vcm 2048x2048" in bench.workload_name(1, "vcm", 2048, 1, 2, 9)
     assert "bumpy_room(grid=72)" in bench.workload_name("mesh:72", "vcm", 1024, 1, 2, 9)
+
+
+def _stats(**kw):
+    st = {k: 0 for k in ("lightVertices", "gridVertices", "mergeQueries", "mergeCandidates", "mergeAccepted", "connections",
+                         "lightSplats", "lightRays", "cameraRays", "shadowRays")}
+    st.update({k: 0.0 for k in ("msLight", "msGrid", "msCamera", "msTotal", "msLightKernel", "msCameraKernel", "msMergeKernel",
+                                "msQuerySort", "msConnectKernels", "radius")})
+    st.update(kw)
+    return st
+
+
+def test_roofline_flags_a_model_that_exceeds_the_peak():
+    """SURVEY 8(d) prices every merge candidate as an HBM read; when that exceeds 8 TB/s the line says so"""
+    st = _stats(lightVertices=9_000_000, gridVertices=9_000_000, mergeQueries=10_000_000, mergeCandidates=1_250_000_000,
+                mergeAccepted=210_000_000, connections=19_000_000, lightSplats=7_000_000, msLightKernel=1.0, msCameraKernel=2.0,
+                msConnectKernels=1.8, msMergeKernel=3.0, msTotal=9.8)
+    dom, roof = bench.roofline_block(st, 2048 * 2048, 2048 * 2048)
+    assert dom == "k_merge" and roof["frac"] > 1.0 and roof["frac_model_invalid"] is True
+    assert 0 < roof["frac_design"] < 1.0 and roof["design_bytes_per_launch"] == 100 * 10_000_000 + 52 * 9_000_000
+    # the camera kernel's byte model is what the design writes (records, task queues), not 24 bytes per pixel
+    assert roof["per_kernel"]["k_camera_trace"]["design_bytes"] > 1_000_000_000
+    st["msMergeKernel"] = 30.0
+    assert bench.roofline_block(st, 2048 * 2048, 2048 * 2048)[1]["frac_model_invalid"] is False
+
+
+def test_valu_roofline_and_traffic_from_profiler_rows(tmp_path):
+    """the --pmc child runs' CSV rows -> per-kernel counters -> VALU issue roofline and calibrated traffic"""
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    d = 0
+    for it in range(8):   # 2 warm-up + 6 timed iterations
+        for name, insts in (("void vcm::k_merge_walk(vcm::DScene const*)", 1.5e9), ("void vcm::k_camera_trace<1, vcm::SceneQuads>(int)", 0.8e9)):
+            for c, v in (("SQ_INSTS_VALU", insts), ("SQ_ACTIVE_INST_VALU", insts), ("SQ_THREAD_CYCLES_VALU", insts * 64 * 0.5)):
+                rows.append("%d,\"%s\",%s,%f,%d,%d" % (d, name, c, v if it >= 2 else 0, 1000 * d, 1000 * d + 3000000))
+            d += 1
+    f = tmp_path / "x_counter_collection.csv"
+    f.write_text("\n".join(rows))
+    t = bench._pmc_table(str(f), 2 / 8.0)
+    assert t["vcm::k_merge_walk"]["SQ_INSTS_VALU"] == 1.5e9 and t["vcm::k_camera_trace"]["_n"] == 8
+    v = bench.valu_block(t, bench.KERNEL_KEYS["k_merge"], 3.0)
+    assert v["lane_util"] == 0.5 and abs(v["frac"] - (1.5e9 * 4 / (1024 * 2.4e9)) / 3e-3) < 1e-3
+    assert abs(v["frac_useful_lanes"] - v["frac"] * 0.5) < 1e-3
+    assert bench.valu_block(t, ["vcm::k_resolve"], 1.0) is None
+    fac, src = bench.fetch_factor("k_merge")
+    assert fac > 0 and "runs" in src

@@ -517,3 +517,59 @@ def test_cpp_farm_thread_ranks_equal_single_gpu_renderers(tmp_path, ranks, shard
     ref, _ = _farm(tmp_path, "r", "--renderers", str(renderers), iters=iters, algo=algo)
     assert np.allclose(img, ref, rtol=3e-6, atol=2e-7)
     assert img.max() > 0
+
+
+# ---- the same host behind its C-ABI (include/smallvcm_amd_farm.h), as bench.py --gpus N drives it ---------------------
+def test_farm_binding_equals_the_command_line_host(tmp_path):
+    """smallvcm_amd.farm (ctypes onto libsmallvcm_amd_farm.so) and vcm_render --gpus run the same C++ farm: same image,
+    bit for bit; per-rank iteration times and rank 0's counters come back"""
+    from smallvcm_amd import farm
+    sc = cornell_scene(1, 96, 80)
+    r = farm.farm_render(sc, 4, iterations=6, ranks=4, shards=2, inflight=2, devices=[0, 0, 0, 0], collectives="threads")
+    img, info = _farm(tmp_path, "cli", "--gpus", "4", "--shards", "2", "--inflight", "2", "--collectives", "threads", iters=6)
+    assert r["renderers"] == info["renderers"] == 4 and r["rccl_ranks"] == 0
+    assert np.array_equal(r["image"].view(np.uint32), img.view(np.uint32))
+    assert len(r["rank_iteration_ms"]) == 4 and min(r["rank_iteration_ms"]) > 0
+    assert r["stats"]["lightVertices"] > 0 and r["stats"]["msTotal"] > 0 and r["wall_s"] > 0
+
+
+def test_farm_over_rccl_with_shipped_ids():
+    """the one-process-per-GPU path as far as one GPU can take it: the RCCL communicators come from ids made by
+    vcm_farm_unique_ids and passed in as bytes (what bench.py broadcasts under torch.distributed.run); one rank, image =
+    the single renderer's, bit for bit; the benchmark schedule gives every renderer the same iteration window"""
+    from smallvcm_amd import farm
+    sc = cornell_scene(1, 64, 64)
+    ids = farm.unique_ids(2)
+    assert len(ids) == 256 and ids[:128] != ids[128:]
+    r = farm.farm_render(sc, 4, iterations=3, ranks=1, shards=1, inflight=1, devices=[0], collectives="rccl", ids=ids, warmup=2,
+                         same_window=True)
+    assert r["rccl_ranks"] == 1 and r["renderers"] == 1
+    v = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    v.mMaxPathLength = 10
+    for it in range(2):          # the farm's warm-up: iterations 0, 1, framebuffer cleared afterwards
+        v.RunIteration(it)
+    v.backend.clear_framebuffer()
+    v.mIterations = 0
+    for it in (2, 3, 4):         # same window: warmup .. warmup + n - 1
+        v.RunIteration(it)
+    assert np.array_equal(r["image"].view(np.uint32), v.GetFramebuffer().view(np.uint32))
+    v.close()
+
+
+def test_bench_line_for_several_gpus_runs_as_typed():
+    """`python bench.py --gpus N` (no torch.distributed.run) drives the C++ farm in-process and prints ONE line with the
+    default and the strong decomposition; --collectives threads lets the two ranks share this box's one GPU"""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--collectives", "threads", "--res", "256",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert "C++" in d["config"]["host"] and d["config"]["rccl_ranks"] == 0
+    assert len(d["rank_iteration_ms"]) == 2 and min(d["rank_iteration_ms"]) > 0
+    assert d["strong_decomposition"]["scaling"] == "strong" and d["strong_decomposition"]["value"] > 0
+    assert d["config"]["paths_per_step"] == 2 * 256 * 256 * 2       # two renderers on the pair, two in flight
+    assert d["roofline"]["per_kernel"]["k_merge"]["ms"] > 0
