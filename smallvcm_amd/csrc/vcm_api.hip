@@ -54,8 +54,11 @@ struct Scratch {
     LightStore store;                 /* S*nLocal slots (+ count[nLocal]) */
     int *dPathStart;                  /* nLocal+1 */
     int *dLocalTotal;                 /* 1 */
-    int *dTileSums;                   /* scan scratch */
-    int *dTileSumsSide;               /* scan scratch of the side stream (grid build) */
+    unsigned long long *dScanState[3]; /* per-tile words of the single-pass scan: [0] main stream, [1] side stream (grid build), [2] splat stream */
+    unsigned *dScanTicket;            /* [0..2]: tile ticket counters; never reset (Arena::scanTickets is their value) */
+    int *dPixCount, *dPixStart;       /* N+2 each: light splats per pixel, and the start of every pixel's list (K1d) */
+    int *dSplatArrival;               /* per light vertex: the place of its splat in its pixel's list */
+    F4 *dSplatList;                   /* per light vertex: the splats grouped by pixel */
     float *dRecordsLocal;             /* S*nLocal records */
     int *dSlotOfVertex;               /* S*nLocal: dense vertex index -> slot in the light store */
     F4 *dSplat;                       /* S*nLocal: splat of each light vertex (rgb | pixel) */
@@ -95,6 +98,7 @@ struct Arena {
     bool allocated;
     hipEvent_t lastUse; bool eventReady, lastValid;
     vcm_ctx *lastUser;                /* whose iteration the buffers still hold (NULL: nobody's) */
+    unsigned scanEpoch[3], scanTickets[3];   /* k_scan_onepass: launches so far / tickets handed out so far, per stream */
 };
 #define VCM_MAX_ARENAS 8
 struct ArenaPool {
@@ -135,6 +139,9 @@ struct vcm_ctx : Scratch {
     hipStream_t side;                 /* the grid build runs here, next to the camera pass on `stream` */
     hipEvent_t evFork, evBbox, evGrid; /* main -> side, side -> main (bbox known), side -> main (grid complete) */
     bool gridInFlight;
+    hipStream_t splat;                /* small frames: K1c / K1d (light splats) run here, next to the camera pass */
+    hipEvent_t evSplatFork, evSplatDone;
+    bool splatInFlight;
     bool deviceReady;
     ArenaPool *pool;                  /* the device's shared arenas (NULL: sharded context with a private one) */
     Arena *arena; bool holdsArena;    /* the arena of the current / last iteration */
@@ -154,6 +161,7 @@ struct vcm_ctx : Scratch {
     bool importedRecords;
     bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI, bboxPreset;
     bool bboxFromLight;               /* K1 of this iteration accumulated the vertices' box into dHdr (single rank) */
+    bool bboxFinal;                   /* ... and k_compact_records has turned it into floats already */
     bool strictOrder;
     int mergeKind;                    /* VCM_MERGE_* */
     bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
@@ -213,7 +221,8 @@ static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
     DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
-    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums); DFREE(s.dTileSumsSide);
+    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dScanState[0]); DFREE(s.dScanState[1]); DFREE(s.dScanState[2]); DFREE(s.dScanTicket);
+    DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
     DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
@@ -247,9 +256,19 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
-    if (dalloc(&s.dTileSums, maxScan / VCM_SCAN_TILE + 2) || dalloc(&s.dTileSumsSide, maxScan / VCM_SCAN_TILE + 2)) return -1;
+    {   /* the scan's tile words and ticket counters start at zero ONCE: epochs and ticket bases take it from there */
+        const size_t tiles = maxScan / VCM_SCAN_TILE + 2;
+        if (dalloc(&s.dScanTicket, 4)) return -1;
+        HIPCHK(hipMemset(s.dScanTicket, 0, 4 * sizeof(unsigned)));
+        for (int w = 0; w < 3; w++) {
+            if (dalloc(&s.dScanState[w], tiles)) return -1;
+            HIPCHK(hipMemset(s.dScanState[w], 0, tiles * sizeof(unsigned long long)));
+            a->scanEpoch[w] = 0u; a->scanTickets[w] = 0u;
+        }
+    }
     if (dalloc(&s.dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dSlotOfVertex, slots) || dalloc(&s.dSplat, slots)) return -1;
+    if (dalloc(&s.dPixCount, cn + 2) || dalloc(&s.dPixStart, cn + 2) || dalloc(&s.dSplatArrival, slots) || dalloc(&s.dSplatList, slots)) return -1;
     if (sh && dalloc(&s.dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dCellCount, cn + 2) || dalloc(&s.dCellStart, cn + 2)) return -1;
     if (dalloc(&s.dCellId, allRecs) || dalloc(&s.dUnsorted, allRecs)) return -1;
@@ -373,8 +392,9 @@ static int abort_iteration(vcm_ctx *c, int rc)
     if (rc != 0 && c && c->inIteration && c->holdsArena) {
         const std::string keep = g_err;   /* the message of the failure, not of the clean-up */
         (void)hipStreamSynchronize(c->stream);
-        if (c->deviceReady) (void)hipStreamSynchronize(c->side);
+        if (c->deviceReady) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->splat); }
         c->gridInFlight = false;
+        c->splatInFlight = false;
         c->inIteration = false;
         arena_release(c, false);
         g_err = keep;
@@ -404,6 +424,9 @@ static int ensure_device(vcm_ctx *c)
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
         HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->evSplatFork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evSplatDone, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evBbox, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
@@ -562,22 +585,32 @@ static int mark_on(vcm_ctx *c, int ev, hipStream_t stream)
 }
 static int mark(vcm_ctx *c, int ev) { return mark_on(c, ev, c->stream); }
 
-/* exclusive scan of n ints/bytes on the context's stream */
+/* exclusive scan of n ints/bytes: one launch (k_scan_onepass); `which` = 0 main stream, 1 side stream -- each has its
+   own tile words and ticket counter in the arena, because the two scans may run at the same time */
 template <typename T>
-static int launch_scan_on(hipStream_t stream, int *tileSums, const T *in, int n, int *out, int *totalOut, int writeTotalAtN,
+static int launch_scan_on(vcm_ctx *c, int which, hipStream_t stream, const T *in, int n, int *out, int *totalOut, int writeTotalAtN,
                           StampArgs st)
 {
+    if (n <= 0) return fail("launch_scan", "empty scan");
+    Arena *a = c->arena;
     const int nTiles = (n + VCM_SCAN_TILE - 1) / VCM_SCAN_TILE;
-    hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums, st);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(VCM_SCAN_BLOCK), 0, stream, tileSums, nTiles, totalOut);
-    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums, out, writeTotalAtN);
+    ScanCtl ctl;
+    ctl.state = c->dScanState[which]; ctl.ticket = c->dScanTicket + which;
+    ctl.ticketBase = a->scanTickets[which];
+    unsigned epoch = (a->scanEpoch[which] + 1u) & 0x3fffffffu;
+    if (epoch == 0u) epoch = 1u;   /* 0 = the freshly zeroed words */
+    ctl.epoch = epoch;
+    hipLaunchKernelGGL((k_scan_onepass<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, out, totalOut, writeTotalAtN, ctl, st);
     HIPCHK(hipGetLastError());
+    /* only a launch that went out moves the device's ticket counter: keep the host's copy in step with it */
+    a->scanEpoch[which] = epoch;
+    a->scanTickets[which] += (unsigned)nTiles;   /* wraps like the device counter */
     return 0;
 }
 template <typename T>
 static int launch_scan(vcm_ctx *c, const T *in, int n, int *out, int *totalOut, int writeTotalAtN)
 {
-    return launch_scan_on<T>(c->stream, c->dTileSums, in, n, out, totalOut, writeTotalAtN, take_stamps(c, c->stream));
+    return launch_scan_on<T>(c, 0, c->stream, in, n, out, totalOut, writeTotalAtN, take_stamps(c, c->stream));
 }
 
 static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPass = false)
@@ -782,8 +815,11 @@ void vcm_destroy(vcm_ctx *c)
         c->dScene = NULL; DFREE(c->dSceneBlob); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         (void)hipStreamSynchronize(c->side);
+        (void)hipStreamSynchronize(c->splat);
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
+        (void)hipEventDestroy(c->evSplatFork); (void)hipEventDestroy(c->evSplatDone);
         (void)hipStreamDestroy(c->side);
+        (void)hipStreamDestroy(c->splat);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -898,7 +934,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
                     c->vs.count, 32 * sizeof(int) /* queue counts [0..2]; chunk counter of K3 / k_path_trace [8] and of K1 [16] */,
                     c->dHdr, 6 * sizeof(uint32_t) /* bboxMinU / bboxMaxU: K1 accumulates into them with atomicMax */)) return -1;
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->bboxPreset = c->bboxFromLight = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->splatInFlight = c->bboxPreset = c->bboxFromLight = c->bboxFinal = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -931,30 +967,55 @@ static int merge_blocks(int nLocal)
     /* smaller frames have fewer batches than that: 2048 as before (16384 at 1024^2: 0.40 -> 1.08 ms, r03m) */
     return n ? n : (nLocal >= (1 << 21) ? 16384 : 256 * 8);
 }
+/* the main stream continues only after the splat stream's K1c / K1d (before anything else touches the framebuffer) */
+static int join_splats(vcm_ctx *c)
+{
+    if (!c->splatInFlight) return 0;
+    HIPCHK(hipStreamWaitEvent(c->stream, c->evSplatDone, 0));
+    c->splatInFlight = false;
+    return 0;
+}
 static int flush_light_splats(vcm_ctx *c)
 {
     if (!c->splatsPending) return 0;
     c->splatsPending = false;
     {
-        /* scratch shared with the grid build / query sort, which run later */
-        int *pixCount = c->dCellCount, *arrival = c->dCellId, *pixStart = c->dQueryStart;
-        F4 *list = (F4 *)c->dUnsorted;   /* 16-byte elements, like the cell list it is later used for */
-        if (zero_ranges(c->stream, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
-        LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, c->stream, c->dScene, c->P, c->store,
+        /* K1c / K1d only read the light-vertex store and add to the framebuffer; nothing of the camera pass touches the
+           framebuffer before K5.  On frames too small to fill the chip (up to 1024^2: one path per lane, latency-bound
+           kernels) they run on a stream of their own next to the grid build and the camera pass and are joined before
+           K5; at 2048^2 every kernel fills the chip by itself and the overlap buys nothing (measured in round 1).
+           SMALLVCM_AMD_SPLAT_STREAM=0 / 1 forces it off / on. */
+        static int force = -2;
+        if (force == -2) { const char *e = getenv("SMALLVCM_AMD_SPLAT_STREAM"); force = e ? (e[0] == '1' ? 1 : 0) : -1; }
+        const bool overlap = (force >= 0 ? force == 1 : c->nLocal < (1 << 21)) && c->world == 1 && !c->strictOrder;
+        hipStream_t q = overlap ? c->splat : c->stream;
+        const StampArgs none = { { NULL, NULL, NULL, NULL } };
+        if (overlap) {
+            HIPCHK(hipEventRecord(c->evSplatFork, c->stream));
+            HIPCHK(hipStreamWaitEvent(q, c->evSplatFork, 0));
+        }
+        int *pixCount = c->dPixCount, *arrival = c->dSplatArrival, *pixStart = c->dPixStart;
+        F4 *list = c->dSplatList;
+        if (zero_ranges(q, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
+        LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, q, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
                            arrival, c->dStats);
-        if (launch_scan<int>(c, pixCount, c->N, pixStart, NULL, 1)) return -1;
-        hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, c->stream, (const F4 *)c->dSplat,
+        if (launch_scan_on<int>(c, overlap ? 2 : 0, q, pixCount, c->N, pixStart, NULL, 1, overlap ? none : take_stamps(c, q))) return -1;
+        hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, q, (const F4 *)c->dSplat,
                            (const int *)c->dLocalTotal, (const int *)pixStart, (const int *)arrival, list, pixCount);
         /* pixels with more than VCM_SPLAT_REG splats are queued (pixCount[0] = their number, `arrival` = the queue:
            both dead since the scatter) and handled by one wave each; `sorted` = the vertex-ordered splat array */
         static int splatLong = -1;   /* SMALLVCM_AMD_SPLAT_LONG: tests send short lists down the one-wave-per-pixel path too */
         if (splatLong < 0) { const char *e = getenv("SMALLVCM_AMD_SPLAT_LONG"); splatLong = (e && atoi(e) >= VCM_SPLAT_REG) ? atoi(e) : VCM_SPLAT_LONG; }
-        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, c->stream, c->N, (const int *)pixStart,
+        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, q, c->N, (const int *)pixStart,
                            (const F4 *)list, c->dFb, arrival, pixCount, splatLong);
-        hipLaunchKernelGGL(k_splat_apply_long, dim3(1024), dim3(256), 0, c->stream, (const int *)pixStart, (const F4 *)list,
+        hipLaunchKernelGGL(k_splat_apply_long, dim3(1024), dim3(256), 0, q, (const int *)pixStart, (const F4 *)list,
                            c->dSplat, c->dFb, (const int *)arrival, (const int *)pixCount);
         HIPCHK(hipGetLastError());
+        if (overlap) {
+            HIPCHK(hipEventRecord(c->evSplatDone, q));
+            c->splatInFlight = true;
+        }
     }
     return 0;
 }
@@ -992,21 +1053,29 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
        record array in the reference's vertex order */
     if (launch_scan<unsigned char>(c, c->store.count, c->nLocal, c->dPathStart, c->dLocalTotal, 0)) return -1;
+    bool countsSet = false;
     if (c->useVM || wf) {
         /* a sharded renderer ships the records to the other ranks; a single-rank one builds its grid straight
-           from the store and materialises them only when somebody asks (ensure_records) */
+           from the store and materialises them only when somebody asks (ensure_records).  On a single rank the kernel
+           also publishes the counts and the box K1 kept (k_set_counts / k_bbox_finalize folded in). */
         c->recordsValid = c->useVM && c->world > 1;
+        const bool fold = c->world == 1;
         hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
-                           c->dRecordsLocal, c->dSlotOfVertex, c->recordsValid ? 1 : 0);
+                           c->dRecordsLocal, c->dSlotOfVertex, c->recordsValid ? 1 : 0, fold ? c->dHdr : (GridHeader *)NULL,
+                           (const int *)c->dLocalTotal, (fold && c->bboxFromLight) ? 1 : 0);
         HIPCHK(hipGetLastError());
+        countsSet = fold;
+        if (fold && c->bboxFromLight) c->bboxFinal = true;
     }
     if (wf && (c->useVC || c->lightTraceOnly)) {
         c->splatsPending = true;
         if (c->world == 1 && flush_light_splats(c)) return -1;
     }
-    if (mark(c, EV_LIGHT)) return -1;   /* written by the phase's last (one-lane) kernel as it starts */
-    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0, take_stamps(c, c->stream));
-    HIPCHK(hipGetLastError());
+    if (mark(c, EV_LIGHT)) return -1;   /* written by the next kernel of the stream as it starts */
+    if (!countsSet) {
+        hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 1, 0, take_stamps(c, c->stream));
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1015,7 +1084,7 @@ static int ensure_records(vcm_ctx *c)
 {
     if (c->recordsValid || !c->useVM) return 0;
     hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
-                       c->dRecordsLocal, c->dSlotOfVertex, 1);
+                       c->dRecordsLocal, c->dSlotOfVertex, 1, (GridHeader *)NULL, (const int *)c->dLocalTotal, 0);
     HIPCHK(hipGetLastError());
     c->recordsValid = true;
     return 0;
@@ -1165,7 +1234,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         if (zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
         if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
             if (c->bboxFromLight && !recs.records) {   /* K1 left the box of what it stored in the header's key words */
-                hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr, 1);
+                if (!c->bboxFinal) hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr, 1);
             } else {
                 hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr, take_stamps(c, q));
                 hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
@@ -1176,7 +1245,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
                            c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount, take_stamps(c, q));
         HIPCHK(hipGetLastError());
-        if (launch_scan_on<int>(q, c->dTileSumsSide, c->dCellCount, nCells, c->dCellStart, NULL, 1, take_stamps(c, q))) return -1;
+        if (launch_scan_on<int>(c, noSide ? 0 : 1, q, c->dCellCount, nCells, c->dCellStart, NULL, 1, take_stamps(c, q))) return -1;
         hipLaunchKernelGGL(k_cell_scatter, g, b, 0, q, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
                            (const int *)c->dSortedIndex, (const int *)c->dCellStart,
                            recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
@@ -1315,11 +1384,13 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (mark(c, EV_SORT_K1)) return -1;
         }
         if (mark(c, EV_MERGE_K1)) return -1;
-        /* K5 */
+        /* K5: the first kernel since the light splats that touches the framebuffer */
+        if (join_splats(c)) return -1;
         hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
     }
+    if (join_splats(c)) return -1;               /* light tracing alone: nothing else waited for them */
     if (mark(c, EV_CAMERA)) return -1;
     if (flush_stamps(c, c->stream)) return -1;   /* nothing of this iteration follows: the end mark gets its own (one-lane) launch */
     c->merged = true;
@@ -1378,7 +1449,7 @@ static int vcm_end_iteration_impl(vcm_ctx *c)
 {
     if (!c->merged) return fail("vcm_end_iteration", "vcm_merge has not run");
     if (use_device(c)) return -1;
-    if (join_grid(c)) return -1;   /* (a merge-free algorithm never waited) */
+    if (join_grid(c) || join_splats(c)) return -1;   /* (a merge-free algorithm never waited) */
     if (flush_stamps(c, c->stream) || (c->deviceReady && flush_stamps(c, c->side))) return -1;
     c->iterations++;   /* :547 */
     c->inIteration = false;

@@ -476,6 +476,31 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
         const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
         const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
         int lo[8], hi[8];
+        uint32_t far = 0u;
+#if !defined(VCM_WALK_NOSKIP)
+        /* Edge and corner neighbours that cannot hold a photon within the radius are not scanned.  The cell across an
+           edge (two offset axes) or the corner (three) is at least sqrt(ax^2 + ay^2 (+ az^2)) cells away, a = the
+           query's distance to the face on that axis (<= half a cell = one radius): for a query in the middle of its
+           cell that exceeds the radius -- 21 % of the edge probes, 48 % of the corner probes for evenly spread queries.
+           The test is conservative by 1 % of the squared radius, orders of magnitude more than the rounding of the two
+           cell coordinates (~1e-4 of a cell at a thousand cells per axis) and of the reference's own distance
+           (hashgrid.hxx:162-165), so every skipped entry is one the reference rejects.  A probe is only skipped when no
+           other probe of the query hashes to the same bucket: the reference walks a colliding bucket once per probe
+           (:142-155), and the photons of the OTHER cell in it must still be met twice.  Two probes of one
+           bucket have the same range start; so has, harmlessly, an empty bucket right in front of a full one (then
+           nothing is skipped).  The candidate counter keeps counting the skipped entries: it reports the reference's
+           distance tests.  (One mask register across the range loads: the kernel sits two registers below the
+           128 that cost a wave per SIMD.) */
+        {
+            const float ax = fractCoord.x < 0.5f ? fractCoord.x : 1.f - fractCoord.x;
+            const float ay = fractCoord.y < 0.5f ? fractCoord.y : 1.f - fractCoord.y;
+            const float az = fractCoord.z < 0.5f ? fractCoord.z : 1.f - fractCoord.z;
+            const float lim = (P.radiusSqr * 1.01f) * (P.invCellSize * P.invCellSize);   /* in cells^2 */
+            const float xx = ax * ax, yy = ay * ay, zz = az * az;
+            far = (yy + zz > lim ? 1u << 3 : 0u) | (xx + zz > lim ? 1u << 5 : 0u) | (xx + yy > lim ? 1u << 6 : 0u) |
+                  (xx + yy + zz > lim ? 1u << 7 : 0u);
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             lo[j] = 0; hi[j] = 0;
@@ -485,6 +510,18 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
                 hi[j] = g.cellStart[cell + 1];
             }
         }
+#if !defined(VCM_WALK_NOSKIP)
+        if (far) {
+#pragma unroll
+            for (int j = 3; j < 8; j++) {
+                if (j == 4) continue;
+                bool alone = true;
+#pragma unroll
+                for (int k = 0; k < 8; k++) alone = alone && (k == j || lo[k] != lo[j]);
+                if (((far >> j) & 1u) && alone) { ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]); hi[j] = lo[j]; }
+            }
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]);   /* one distance test per entry (:162-165) */
@@ -852,76 +889,91 @@ __global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, const uin
     }
 }
 
-/* ---------------- exclusive scan (ints), 3 launches ---------------------- */
+/* ---------------- exclusive scan (ints): ONE launch, decoupled look-back ---------------- */
+/* A tile = 2048 consecutive items, one workgroup each.  A workgroup takes its tile number from a ticket counter
+ * (so tile t has started before tile t+1 exists: whoever waits, waits for somebody who runs), reduces its tile,
+ * publishes the tile's AGGREGATE, then looks back over its predecessors' words -- 64 at a time, one per lane of wave
+ * 0 -- adding aggregates until it meets a tile whose inclusive PREFIX is known, publishes its own prefix and writes
+ * its 2048 results.  One pass over the data and one launch, where the first version took three launches (tile sums,
+ * one 256-thread block over the tile sums, apply): at 512^2 the four scans of an iteration were 0.31 of 1.54 ms
+ * (profiles/r02n_trace512_summary.txt: 12 launches, the single-block kernel 40 us each).
+ * A tile's word = [epoch:30 | kind:2 | value:32], written and read whole (64-bit atomics): value and flag cannot be
+ * seen apart.  The host passes a fresh epoch per launch (words of earlier launches read as "not there yet") and the
+ * ticket counter's value at launch time, so neither array is ever zeroed again after allocation. */
 #define VCM_SCAN_BLOCK 256
 #define VCM_SCAN_ITEMS 8
 #define VCM_SCAN_TILE (VCM_SCAN_BLOCK * VCM_SCAN_ITEMS)
-
-__device__ __forceinline__ int block_exclusive_scan(int v, int *total)
-{   /* blockDim.x == VCM_SCAN_BLOCK */
-    __shared__ int s[VCM_SCAN_BLOCK];
-    const int t = threadIdx.x;
-    s[t] = v;
-    __syncthreads();
-#pragma unroll
-    for (int o = 1; o < VCM_SCAN_BLOCK; o <<= 1) {
-        const int add = (t >= o) ? s[t - o] : 0;
-        __syncthreads();
-        s[t] += add;
-        __syncthreads();
-    }
-    const int incl = s[t];
-    if (total) *total = s[VCM_SCAN_BLOCK - 1];
-    __syncthreads();
-    return incl - v;
-}
-
-template <typename T>
-__global__ void __launch_bounds__(VCM_SCAN_BLOCK) k_scan_tile_sums(const T *__restrict__ in, int n, int *tileSums, StampArgs st)
+enum { SCAN_KIND_AGG = 1, SCAN_KIND_PREFIX = 2 };
+__device__ __forceinline__ unsigned long long scan_pack(unsigned epoch, unsigned kind, int value)
 {
-    stamp_entry(st);
-    const int base = blockIdx.x * VCM_SCAN_TILE + threadIdx.x * VCM_SCAN_ITEMS;
-    int sum = 0;
-#pragma unroll
-    for (int i = 0; i < VCM_SCAN_ITEMS; i++) if (base + i < n) sum += (int)in[base + i];
-    int total;
-    block_exclusive_scan(sum, &total);
-    if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+    return ((unsigned long long)epoch << 34) | ((unsigned long long)kind << 32) | (unsigned long long)(unsigned)value;
 }
-
-/* one block: every thread sums a contiguous run of tile sums, ONE block scan over the 256 partial sums, then the
- * thread writes its run's offsets.  (The first version scanned 256 tiles per trip with a block scan each: 8 trips
- * of 16 barriers for the 4.2 M-entry bucket table of a 512^2 frame = 47 us per call, 190 us = 12 % of that
- * iteration, profiles/r02m_trace512_summary.txt.) */
-__global__ void __launch_bounds__(VCM_SCAN_BLOCK) k_scan_tile_offsets(int *tileSums, int nTiles, int *totalOut)
-{
-    const int per = (nTiles + VCM_SCAN_BLOCK - 1) / VCM_SCAN_BLOCK;
-    const int lo = min(nTiles, (int)threadIdx.x * per), hi = min(nTiles, lo + per);
-    int sum = 0;
-    for (int i = lo; i < hi; i++) sum += tileSums[i];
-    int total;
-    int run = block_exclusive_scan(sum, &total);
-    for (int i = lo; i < hi; i++) { const int v = tileSums[i]; tileSums[i] = run; run += v; }
-    if (threadIdx.x == 0 && totalOut) *totalOut = total;
-}
+struct ScanCtl { unsigned long long *state; unsigned *ticket; unsigned ticketBase, epoch; };
 
 template <typename T>
 __global__ void __launch_bounds__(VCM_SCAN_BLOCK)
-k_scan_apply(const T *__restrict__ in, int n, const int *__restrict__ tileOffsets, int *out, int writeTotalAtN)
+k_scan_onepass(const T *__restrict__ in, int n, int *out, int *totalOut, int writeTotalAtN, ScanCtl ctl, StampArgs st)
 {
-    const int base = blockIdx.x * VCM_SCAN_TILE + threadIdx.x * VCM_SCAN_ITEMS;
+    stamp_entry(st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int sTile, sPrefix, sWave[VCM_SCAN_BLOCK / VCM_WAVE];
+    const int tid = (int)threadIdx.x, lane = tid & (VCM_WAVE - 1), wave = tid / VCM_WAVE;
+    if (tid == 0) sTile = (int)(atomicAdd(ctl.ticket, 1u) - ctl.ticketBase);
+    __syncthreads();
+    const int tile = sTile;
+    const int base = tile * VCM_SCAN_TILE + tid * VCM_SCAN_ITEMS;
     int v[VCM_SCAN_ITEMS];
     int sum = 0;
 #pragma unroll
     for (int i = 0; i < VCM_SCAN_ITEMS; i++) { v[i] = (base + i < n) ? (int)in[base + i] : 0; sum += v[i]; }
-    int total;
-    int run = block_exclusive_scan(sum, &total) + tileOffsets[blockIdx.x];
+    /* inclusive scan of the thread sums inside the wave, then the four wave totals through LDS */
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < VCM_WAVE; o <<= 1) { const int t = __shfl_up(incl, o, VCM_WAVE); if (lane >= o) incl += t; }
+    if (lane == VCM_WAVE - 1) sWave[wave] = incl;
+    __syncthreads();
+    int waveOffset = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < VCM_SCAN_BLOCK / VCM_WAVE; w++) { const int t = sWave[w]; if (w < wave) waveOffset += t; total += t; }
+    if (wave == 0) {
+        int exclusive = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&ctl.state[tile], scan_pack(ctl.epoch, SCAN_KIND_AGG, total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int look = tile - 1;
+            /* a predecessor publishes within microseconds (it has run since before this tile took its ticket); the bound
+               only keeps a logic error from hanging the device: the results are then wrong and every test says so */
+            for (int spins = 0; spins < (1 << 20); spins++) {
+                const int t = look - lane;   /* tiles before the first count as a known prefix of zero */
+                const unsigned long long w = (t >= 0) ? __hip_atomic_load(&ctl.state[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                                                      : scan_pack(ctl.epoch, SCAN_KIND_PREFIX, 0);
+                const unsigned kind = (unsigned)(w >> 32) & 3u;
+                const bool ready = ((unsigned)(w >> 34) == ctl.epoch) && kind != 0u;
+                if (__ballot(!ready)) { __builtin_amdgcn_s_sleep(1); continue; }   /* somebody has not published yet */
+                const unsigned long long prefixes = __ballot(kind == SCAN_KIND_PREFIX);
+                const int firstP = prefixes ? __builtin_ctzll(prefixes) : VCM_WAVE;   /* the nearest tile with a known prefix */
+                exclusive += (int)wave_sum_u32((lane <= firstP) ? (uint32_t)w : 0u);
+                if (prefixes) break;
+                look -= VCM_WAVE;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&ctl.state[tile], scan_pack(ctl.epoch, SCAN_KIND_PREFIX, exclusive + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            sPrefix = exclusive;
+        }
+    }
+    __syncthreads();
+    int run = sPrefix + waveOffset + (incl - sum);
 #pragma unroll
     for (int i = 0; i < VCM_SCAN_ITEMS; i++) {
         if (base + i < n) out[base + i] = run;
         run += v[i];
     }
-    if (writeTotalAtN && blockIdx.x == gridDim.x - 1 && threadIdx.x == VCM_SCAN_BLOCK - 1) out[n] = run;
+    /* the thread that holds item n-1 (or, for n a multiple of the tile, the last thread of the last tile) knows the total */
+    if (n > 0 && base <= n - 1 && n - 1 < base + VCM_SCAN_ITEMS) {
+        if (writeTotalAtN) out[n] = run;
+        if (totalOut) *totalOut = run;
+    }
+#endif
 }
 
 /* ---------------- K1b: compaction into merge records --------------------- */
@@ -929,9 +981,27 @@ k_scan_apply(const T *__restrict__ in, int n, const int *__restrict__ tileOffset
  * (vertexcm.hxx:130-169): pos, WorldDirFix, throughput, dVCM, dVM,
  * ContinuationProb, pathLength.  Record order = the reference's
  * mLightVertices order (path-major, then bounce). */
-__global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
-                                  int *slotOfVertex, int writeRecords)
+/* the box K1 left in the header's key words (minimum as ~key), or the plain keys of k_bbox -> floats (hashgrid.hxx:47-61) */
+__device__ __forceinline__ void bbox_finalize_component(GridHeader *hdr, int c, int nRecords, int minInverted)
 {
+    if (nRecords > 0) {
+        hdr->bboxMin[c] = float_from_order_key(minInverted ? ~hdr->bboxMinU[c] : hdr->bboxMinU[c]);
+        hdr->bboxMax[c] = float_from_order_key(hdr->bboxMaxU[c]);
+    } else {   /* :47-48 initial values */
+        hdr->bboxMin[c] = 1e36f;
+        hdr->bboxMax[c] = -1e36f;
+    }
+}
+/* hdr != NULL (single rank): the first block also publishes the vertex counts (what k_set_counts does) and, with
+   finalizeBox, turns the box K1 accumulated into floats -- two one-lane launches less per iteration */
+__global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
+                                  int *slotOfVertex, int writeRecords, GridHeader *hdr, const int *localTotal, int finalizeBox)
+{
+    if (hdr && blockIdx.x == 0 && threadIdx.x < 3) {
+        const int n = *localTotal;
+        if (threadIdx.x == 0) { hdr->nLocalRecords = n; hdr->nRecords = n; }
+        if (finalizeBox) bbox_finalize_component(hdr, (int)threadIdx.x, n, 1);
+    }
     /* one lane per light path: slot reads are coalesced across the wave for every j (slot-major store) */
     for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < P.nLocal; lp += gridDim.x * blockDim.x) {
         const int n = (int)store.count[lp];
@@ -1176,16 +1246,7 @@ __global__ void __launch_bounds__(256) k_bbox(VertexSource src, GridHeader *hdr)
 
 __global__ void k_bbox_finalize(GridHeader *hdr, int minInverted /* the words K1 left: minimum as ~key */)
 {
-    if (threadIdx.x < 3) {
-        const int c = threadIdx.x;
-        if (hdr->nRecords > 0) {
-            hdr->bboxMin[c] = float_from_order_key(minInverted ? ~hdr->bboxMinU[c] : hdr->bboxMinU[c]);
-            hdr->bboxMax[c] = float_from_order_key(hdr->bboxMaxU[c]);
-        } else {   /* :47-48 initial values */
-            hdr->bboxMin[c] = 1e36f;
-            hdr->bboxMax[c] = -1e36f;
-        }
-    }
+    if (threadIdx.x < 3) bbox_finalize_component(hdr, (int)threadIdx.x, hdr->nRecords, minInverted);
 }
 
 __global__ void k_cell_count(IterParams P, VertexSource src, const GridHeader *__restrict__ hdr,
