@@ -27,6 +27,26 @@
 #include <string.h>
 #include <math.h>
 
+/* Two other definitions of the same three functions, for ONE purpose: to state what the deterministic definition
+ * costs against the arithmetic the reference itself is built with (oracle/libm_tolerance.py):
+ *   -DORACLE_LIBM_GLIBC   the host's libm, i.e. what std::sin / std::cos / std::pow of a float resolve to in the
+ *                         reference (utils.hxx:85-117, :173-199, bsdf.hxx:290-318, :414-446);
+ *   -DORACLE_LIBM_CR      round 1's definition: evaluated in binary64 and rounded once (correctly rounded but for
+ *                         double-rounding cases of probability ~2^-29).
+ * liboracle.so (the checker) is always built WITHOUT either. */
+#if defined(ORACLE_LIBM_GLIBC) || defined(ORACLE_LIBM_CR)
+#if defined(ORACLE_LIBM_GLIBC)
+static inline float dmr_sinf(float x) { return sinf(x); }
+static inline float dmr_cosf(float x) { return cosf(x); }
+static inline float dmr_powf(float x, float y) { return powf(x, y); }
+#else
+static inline float dmr_sinf(float x) { return (float)sin((double)x); }
+static inline float dmr_cosf(float x) { return (float)cos((double)x); }
+static inline float dmr_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+#endif
+static inline void dmr_sincosf(float x, float *s, float *c) { *s = dmr_sinf(x); *c = dmr_cosf(x); }
+#else
+
 static inline float dmr_from_bits32(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t dmr_to_bits32(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
@@ -124,4 +144,5 @@ static inline float dmr_powf(float xf, float yf)
     return (float)p;
 }
 
+#endif /* the deterministic definition */
 #endif

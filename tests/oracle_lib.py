@@ -26,10 +26,23 @@ def _bptr(a):
 _oracle = None
 
 
+def load_oracle(path):
+    """a build of oracle/vcm_oracle.cpp with its entry points declared (liboracle.so = the checker; liboracle_glibc.so /
+    liboracle_cr.so = the same restatement over another sin / cos / pow, for oracle/libm_tolerance.py only)"""
+    L = C.CDLL(path)
+    _declare(L)
+    return L
+
+
 def oracle():
     global _oracle
     if _oracle is None:
-        L = C.CDLL(ORACLE_SO)
+        _oracle = load_oracle(ORACLE_SO)
+    return _oracle
+
+
+def _declare(L):
+    if True:
         L.oracle_create.restype = C.c_void_p
         L.oracle_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
         L.oracle_create2.restype = C.c_void_p
@@ -65,15 +78,13 @@ def oracle():
         L.oracle_path_float.argtypes = [C.c_uint32] * 5
         L.oracle_path_float.restype = C.c_float
         L.oracle_max_threads.restype = C.c_int
-        _oracle = L
-    return _oracle
 
 
 class Oracle:
     """CPU restatement of VertexCM (oracle/vcm_oracle.cpp)."""
 
-    def __init__(self, scene, algo, radius_factor=0.003, radius_alpha=0.75, seed=1234, rank=0, world=1, threads=1):
-        self.L = oracle()
+    def __init__(self, scene, algo, radius_factor=0.003, radius_alpha=0.75, seed=1234, rank=0, world=1, threads=1, lib=None):
+        self.L = lib if lib is not None else oracle()
         self.scene = scene
         create = self.L.oracle_create2 if isinstance(scene, SceneDesc2) else self.L.oracle_create
         self.h = create(C.byref(scene), algo, radius_factor, radius_alpha, seed, rank, world)

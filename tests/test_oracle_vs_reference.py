@@ -135,3 +135,37 @@ def test_statistical_agreement_with_stock_reference():
         ref, _ = oracle_lib.ref_render_stock(mask, res, res, algo, iterations=nit, threads=1)
         m1, m2 = mine.mean(axis=(0, 1)), ref.mean(axis=(0, 1))
         assert np.all(np.abs(m1 - m2) < 0.04 * np.maximum(m2, 0.05)), (sid, algo, m1, m2)
+
+
+def test_deterministic_libm_against_the_hosts_libm():
+    """What the deterministic sin / cos / pow cost against the arithmetic the reference is built with (glibc), at the
+    same random numbers: the oracle -- per-path random streams -- built over detmath (the specification), over the
+    host's libm, and over round 1's correctly rounded definition renders the same paths.  Stated tolerance (DESIGN.md
+    section 4, profiles/r05_libm_tolerance.json for C1 / C4): no path takes a different number of random floats
+    (< 1e-4 of the paths allowed), one iteration's framebuffer differs by an RMSE below 3e-3 of the image mean (at 160^2; it falls with the pixel count).  The
+    host's libm is whatever glibc this box has: the bounds are loose on purpose, the JSON holds the measured values."""
+    import os
+    import subprocess
+    import numpy as np
+    from smallvcm_amd.renderer import cornell_scene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "glibc"], check=True, capture_output=True)
+    libs = {k: oracle_lib.load_oracle(os.path.join(root, "oracle", "liboracle%s.so" % s)) for k, s in (("det", ""), ("glibc", "_glibc"), ("cr", "_cr"))}
+    sc = cornell_scene(1, 160, 160)
+    out = {}
+    for k, L in libs.items():
+        o = oracle_lib.Oracle(sc, 4, threads=8, lib=L)
+        o.run_iteration(0, 0, 10)
+        out[k] = (o.framebuffer().astype(np.float64), o.counts())
+    mean = out["glibc"][0].mean()
+    for k in ("det", "cr"):
+        fb, (lc, cc) = out[k]
+        flipped = (lc != out["glibc"][1][0]).sum() + (cc != out["glibc"][1][1]).sum()
+        assert flipped <= 1e-4 * (lc.size + cc.size), (k, flipped)
+        rmse = np.sqrt(((fb - out["glibc"][0]) ** 2).mean())
+        assert rmse < 3e-3 * mean, (k, rmse, mean)
+        assert abs((fb - out["glibc"][0]).mean()) < 1e-4 * mean      # no bias: the differences are rounding noise
+    # the checker itself is the deterministic build: identical to the golden-pinned oracle
+    o = oracle_lib.Oracle(sc, 4, threads=8)
+    o.run_iteration(0, 0, 10)
+    assert np.array_equal(o.framebuffer().astype(np.float64), out["det"][0])
