@@ -85,9 +85,9 @@ KERNEL_SOURCES = ["vcm_api.hip", "vcm_kernels.h", "vcm_core.h", "vcm_math.h", "d
 # iteration-parallel threads, smallvcm.cxx:61-108) taking turns on the one GPU, their iterations overlapping
 OTHER_CONFIGS = [("C1", 1, "vcm", 512, 1), ("C1x4", 1, "vcm", 512, 4), ("C2", 3, "vcm", 1024, 1), ("C2x2", 3, "vcm", 1024, 2),
                  ("C3", 1, "bpm", 2048, 1), ("C4x2", 1, "vcm", 2048, 2),
-                 # not a BASELINE config: SURVEY 8(f) #3, a scene beyond the Cornell boxes through the BVH
-                 # (tests/mesh_scenes.py bumpy_room: a tessellated height-field floor, 10 380 primitives)
-                 ("M1", "mesh:72", "vcm", 1024, 1)]
+                 # not a BASELINE config: SURVEY 8(f) #3, a scene beyond the Cornell boxes: a scene FILE (OBJ + MTL +
+                 # .vcmscene, vcm_scene_load) of 10 380 primitives -- a tessellated height-field floor -- through the BVH
+                 ("M1", "file:tests/scenes/bumpy_room.vcmscene", "vcm", 1024, 1)]
 
 
 def kernel_source_hash():
@@ -313,7 +313,8 @@ def add_counters(roof, dom, counters, note, st, n_local):
 
 def workload_name(scene, algo, res, replicas, first, last):
     if isinstance(scene, str):
-        scene_txt = "tests/mesh_scenes.py bumpy_room(grid=%s), BVH," % scene.split(":")[1]
+        scene_txt = ("scene file %s (vcm_scene_load), BVH," % scene.split(":", 1)[1] if scene.startswith("file:")
+                     else "tests/mesh_scenes.py bumpy_room(grid=%s), BVH," % scene.split(":")[1])
         return ("%s -a %s %dx%d maxPathLength 10 minPathLength 0 radiusFactor 0.003 radiusAlpha 0.75 seed 1234, iterations %d..%d timed"
                 % (scene_txt, algo, res, res, first, last))
     return ("scene %d -a %s %dx%d maxPathLength 10 minPathLength 0 radiusFactor 0.003 radiusAlpha 0.75 seed 1234%s, "
@@ -529,7 +530,10 @@ def main():
         torch.cuda.synchronize()
 
     def make_farm(scene, algo_name, res, shards, inflight):
-        if isinstance(scene, str):   # "mesh:<grid>": a version-2 scene (any number of primitives, BVH)
+        if isinstance(scene, str) and scene.startswith("file:"):   # a scene file: version-2 description, BVH
+            from smallvcm_amd.scene_file import load_scene
+            sc = load_scene(os.path.join(ROOT, scene.split(":", 1)[1]), res, res)
+        elif isinstance(scene, str):   # "mesh:<grid>": the same room built procedurally
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from mesh_scenes import bumpy_room
             sc = bumpy_room(grid=int(scene.split(":")[1]), resx=res, resy=res)

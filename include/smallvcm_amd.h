@@ -353,6 +353,20 @@ int  vcm_make_camera(const float *position, const float *forward, const float *u
                      vcm_camera *out);
 void vcm_make_scene_sphere(const vcm_prim *prims, int nPrims, float *center3, float *radius, float *invRadiusSqr);
 
+/* Scene files.  The reference has no loader ("Scenes are hard-coded", README:210; Scene::LoadCornellBox,
+ * scene.hxx:132-398, is the only way a scene comes into being).  vcm_scene_load reads a `.vcmscene` text file --
+ * directives processed in order: `obj <file>` (Wavefront OBJ triangles with their MTL library: Kd / Ks+Ns / illum /
+ * Ni -> Material, Ke -> one AreaLight per triangle as in scene.hxx:333-361), `sphere`, `camera`, `light
+ * point|directional|background`, `mtllib` -- or a bare `.obj` (default camera), and builds the version-2 description
+ * with the vcm_make_* constructors above; smallvcm_amd/csrc/scene_file.cpp documents the format.  The description
+ * points into the handle: keep it until the renderers are created (vcm_create2 copies).  NULL on failure, with the
+ * reason in vcm_scene_load_error(). */
+typedef struct vcm_scene_file vcm_scene_file;
+vcm_scene_file *vcm_scene_load(const char *path, int resX, int resY);
+const vcm_scene_desc2 *vcm_scene_file_desc(const vcm_scene_file *scene);
+void vcm_scene_file_free(vcm_scene_file *scene);
+const char *vcm_scene_load_error(void);
+
 #ifdef __cplusplus
 }
 #endif

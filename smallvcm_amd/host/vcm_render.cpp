@@ -9,7 +9,7 @@
 //   vcm_render -s <scene 0..3> -a <el|pt|lt|ppm|bpm|bpt|vcm> -i <iterations>
 //              [--res W H] [--seed S] [--minlen A] [--maxlen B]
 //              [--renderers R] [--radius-factor F] [--radius-alpha A]
-//              [--device D] [--strict] [--warmup W] [-o out.pfm] [--json]
+//              [--device D] [--strict] [--warmup W] [-o out.pfm] [--json] [--scene-file f.vcmscene|f.obj]
 //              [--gpus N [--shards S] [--inflight K] [--devices 0,1,..] [--collectives rccl|threads] [--same-window]]
 //
 // --gpus N: the multi-GPU host (vcm_farm.hpp): N ranks = N host threads, one per GPU, cut into N / S groups; a
@@ -68,7 +68,7 @@ int main(int argc, char **argv)
     std::vector<float> rankMs;
     std::vector<int> devices;
     float radiusFactor = 0.003f, radiusAlpha = 0.75f;
-    std::string out, algoName = "vcm";
+    std::string out, algoName = "vcm", sceneFile;
     for (int i = 1; i < argc; i++) {
         const std::string a(argv[i]);
         auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "vcm_render: %s needs %d argument(s)\n", a.c_str(), n); exit(2); } };
@@ -91,6 +91,7 @@ int main(int argc, char **argv)
         else if (a == "--collectives") { need(1); rccl = std::string(argv[++i]) == "threads" ? 0 : 1; }
         else if (a == "--devices") { need(1); for (const char *p = argv[++i]; *p;) { char *e; devices.push_back((int)strtol(p, &e, 10)); p = (*e == ',') ? e + 1 : e; if (e == p && *p) break; } }
         else if (a == "--same-window") sameWindow = 1;   // benchmark schedule: every renderer runs the iteration indices warmup ..
+        else if (a == "--scene-file") { need(1); sceneFile = argv[++i]; }   // instead of -s: OBJ + MTL / .vcmscene (vcm_scene_load)
         else if (a == "--strict") strict = 1;
         else if (a == "--json") json = 1;
         else { fprintf(stderr, "vcm_render: unknown option %s (see the header of vcm_render.cpp)\n", a.c_str()); return 2; }
@@ -102,6 +103,12 @@ int main(int argc, char **argv)
 
     vcm_scene_desc scene;
     if (vcm_scene_cornell(resX, resY, vcm_scene_config_mask(sceneID), &scene)) return die("vcm_scene_cornell");
+    vcm_scene_file *loaded = NULL;   // --scene-file: a version-2 description (any number of primitives, BVH)
+    if (!sceneFile.empty()) {
+        loaded = vcm_scene_load(sceneFile.c_str(), resX, resY);
+        if (!loaded) { fprintf(stderr, "vcm_render: %s\n", vcm_scene_load_error()); return 2; }
+        if (gpus > 0) { fprintf(stderr, "vcm_render: --scene-file with --gpus is not supported (the farm takes the built-in scenes)\n"); return 2; }
+    }
 
     const size_t n3 = (size_t)resX * resY * 3;
     std::vector<float> fb(n3, 0.f), tmp(n3);
@@ -134,13 +141,15 @@ int main(int argc, char **argv)
     // render(): one renderer per "thread", seed base + i (smallvcm.cxx:61-72)
     r.assign((size_t)renderers, (vcm_ctx *)NULL);
     for (int g = 0; g < renderers; g++) {
-        r[g] = vcm_create_sharded(&scene, algorithm, radiusFactor, radiusAlpha, seed + g, device, 0, 1);
+        r[g] = loaded ? vcm_create_sharded2(vcm_scene_file_desc(loaded), algorithm, radiusFactor, radiusAlpha, seed + g, device, 0, 1)
+                      : vcm_create_sharded(&scene, algorithm, radiusFactor, radiusAlpha, seed + g, device, 0, 1);
         if (!r[g]) return die("vcm_create");
         if (strict && vcm_set_strict_order(r[g], 1)) return die("vcm_set_strict_order");
     }
     // untimed warm-up on a throw-away renderer: allocations, first-launch costs
     if (warmup > 0) {
-        vcm_ctx *w = vcm_create_sharded(&scene, algorithm, radiusFactor, radiusAlpha, seed, device, 0, 1);
+        vcm_ctx *w = loaded ? vcm_create_sharded2(vcm_scene_file_desc(loaded), algorithm, radiusFactor, radiusAlpha, seed, device, 0, 1)
+                            : vcm_create_sharded(&scene, algorithm, radiusFactor, radiusAlpha, seed, device, 0, 1);
         if (!w) return die("vcm_create");
         for (int it = 0; it < warmup; it++) if (vcm_run_iteration(w, it, minLen, maxLen)) return die("vcm_run_iteration");
         vcm_synchronize(w);
@@ -225,6 +234,7 @@ int main(int argc, char **argv)
         fclose(f);
     }
     for (size_t g = 0; g < r.size(); g++) vcm_destroy(r[g]);
+    vcm_scene_file_free(loaded);
     double mean[3] = { 0, 0, 0 };
     for (size_t i = 0; i < n3; i++) mean[i % 3] += fb[i];
     const double paths = (algorithm == VCM_ALGO_PATH_TRACE || algorithm == VCM_ALGO_EYE_LIGHT ? 1.0 : 2.0) * resX * resY * iterations;

@@ -88,3 +88,77 @@ def tilted_room(resx=64, resy=64, angle=0.37, sun=False):
         b.emissive_triangle(q[2], q[3], q[0], (25.0, 25.0, 25.0))
     return b.build(rot((-0.0439815, -4.12529, 0.222539)), rot((0.00688625, 0.998505, -0.0542161)), rot((3.73896e-4, 0.0542148, 0.998529)),
                    45.0, resx, resy)
+
+
+def write_bumpy_room_files(directory, grid=24, seed=5, name="bumpy_room"):
+    """bumpy_room(grid, spheres=True) as scene FILES -- <name>.vcmscene, <name>.obj, <name>_light.obj, <name>.mtl (the
+    format of smallvcm_amd/csrc/scene_file.cpp) -- with every number printed to nine significant digits, i.e. exactly.
+    Same primitives in the same order as the procedural scene; -> path of the .vcmscene"""
+    import os
+    rng = np.random.default_rng(seed)
+    lo, hi = -1.25, 1.25
+    xs = np.linspace(lo, hi, grid + 1, dtype=np.float32)
+    h = (0.04 * np.sin(3.1 * xs)[:, None] * np.cos(2.3 * xs)[None, :] + 0.01 * rng.random((grid + 1, grid + 1))).astype(np.float32)
+    z = (np.float32(lo) + h).astype(np.float32)
+
+    def f(v):
+        return "%.9g" % float(np.float32(v))
+    with open(os.path.join(directory, name + ".mtl"), "w") as m:
+        m.write("# materials of the bumpy room (tests/mesh_scenes.py)\n")
+        for nm, kd in (("white", (0.803922, 0.803922, 0.803922)), ("green", (0.156863, 0.803922, 0.172549)), ("red", (0.803922, 0.152941, 0.152941))):
+            m.write("newmtl %s\nKd %s %s %s\n" % ((nm,) + tuple(f(x) for x in kd)))
+        m.write("newmtl glossy\nKd %s %s %s\nKs %s %s %s\nNs 90\nillum 2\n" % (f(0.1), f(0.1), f(0.1), f(0.7), f(0.7), f(0.7)))
+        m.write("newmtl mirror\nKs 1 1 1\nillum 3\n")
+        m.write("newmtl glass\nKs 1 1 1\nNi %s\nillum 7\n" % f(1.6))
+        m.write("newmtl lamp\nKe 25 25 25\n")
+    with open(os.path.join(directory, name + ".obj"), "w") as o:
+        o.write("# floor height field (%d x %d cells), walls, ceiling\nmtllib %s.mtl\n" % (grid, grid, name))
+        for i in range(grid + 1):
+            for j in range(grid + 1):
+                o.write("v %s %s %s\n" % (f(xs[i]), f(xs[j]), f(z[i, j])))
+
+        def vid(i, j):
+            return i * (grid + 1) + j + 1
+        current = None
+        for i in range(grid):
+            for j in range(grid):
+                mat = "glossy" if (i + j) % 3 else "white"
+                if mat != current:
+                    o.write("usemtl %s\n" % mat)
+                    current = mat
+                o.write("f %d %d %d\nf %d %d %d\n" % (vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i + 1, j + 1), vid(i, j + 1), vid(i, j)))
+        c = [(lo, hi, lo), (hi, hi, lo), (hi, hi, hi), (lo, hi, hi), (lo, lo, lo), (hi, lo, lo), (hi, lo, hi), (lo, lo, hi)]
+        for p in c:
+            o.write("v %s %s %s\n" % tuple(f(x) for x in p))
+        n0 = (grid + 1) * (grid + 1) + 1
+
+        def quad(a, b, cc, d, mat):   # two triangles, the order of bumpy_room: (a, b, c), (c, d, a)
+            o.write("usemtl %s\nf %d %d %d\nf %d %d %d\n" % (mat, n0 + a, n0 + b, n0 + cc, n0 + cc, n0 + d, n0 + a))
+        quad(0, 1, 2, 3, "white")
+        o.write("usemtl green\nf %d %d %d\nf %d %d %d\n" % (n0 + 3, n0 + 7, n0 + 4, n0 + 4, n0 + 0, n0 + 3))
+        o.write("usemtl red\nf %d %d %d\nf %d %d %d\n" % (n0 + 1, n0 + 5, n0 + 6, n0 + 6, n0 + 2, n0 + 1))
+        o.write("usemtl white\nf %d %d %d\nf %d %d %d\n" % (n0 + 2, n0 + 6, n0 + 7, n0 + 7, n0 + 3, n0 + 2))
+    with open(os.path.join(directory, name + "_light.obj"), "w") as o:
+        o.write("# the lamp: two emissive triangles under the ceiling (relative indices, a quad given as ONE polygon: fanned)\n")
+        q = [(-0.25, -0.25, 1.2), (0.25, -0.25, 1.2), (0.25, 0.25, 1.2), (-0.25, 0.25, 1.2)]
+        for p in q:
+            o.write("v %s %s %s\n" % tuple(f(x) for x in p))
+        # bumpy_room's second lamp triangle is (q2, q3, q0); a fan around q0 would give (q0, q2, q3): write both faces
+        o.write("usemtl lamp\nf -4 -3 -2\nf -2/1 -1/1/1 -4//1\n")
+    path = os.path.join(directory, name + ".vcmscene")
+    with open(path, "w") as s:
+        s.write("# the bumpy room of tests/mesh_scenes.py as a scene file (format: smallvcm_amd/csrc/scene_file.cpp)\n")
+        s.write("obj %s.obj\n" % name)
+        s.write("sphere %s %s %s %s mirror\n" % (f(-0.5), f(0.3), f(-0.75), f(0.4)))
+        s.write("sphere %s %s %s %s glass\n" % (f(0.55), f(-0.2), f(-0.8), f(0.35)))
+        s.write("obj %s_light.obj\n" % name)
+        s.write("camera %s\n" % " ".join(f(x) for x in (-0.0439815, -4.12529, 0.222539, 0.00688625, 0.998505, -0.0542161,
+                                                        3.73896e-4, 0.0542148, 0.998529, 45.0)))
+    return path
+
+
+if __name__ == "__main__":   # python tests/mesh_scenes.py: regenerate the committed scene file (10 380 primitives)
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes")
+    os.makedirs(d, exist_ok=True)
+    print(write_bumpy_room_files(d, grid=72))

@@ -33,6 +33,8 @@ def test_recorded_traffic_needs_the_same_kernel_sources(tmp_path, monkeypatch):
 def test_workload_names():
     assert "scene 1 -a vcm 2048x2048" in bench.workload_name(1, "vcm", 2048, 1, 2, 9)
     assert "bumpy_room(grid=72)" in bench.workload_name("mesh:72", "vcm", 1024, 1, 2, 9)
+    assert "scene file tests/scenes/bumpy_room.vcmscene" in bench.workload_name("file:tests/scenes/bumpy_room.vcmscene", "vcm", 1024, 1, 2, 9)
+    assert os.path.exists(os.path.join(bench.ROOT, [c[1] for c in bench.OTHER_CONFIGS if c[0] == "M1"][0].split(":", 1)[1]))
 
 
 def _stats(**kw):

@@ -267,3 +267,106 @@ def test_gpu_cornell_scenes_through_a_forced_bvh_equal_brute_force():
         assert r.returncode == 0, r.stderr[-2000:]
         imgs.append(np.load(path))
     assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+
+
+# ---- scene files (include/smallvcm_amd.h: vcm_scene_load; smallvcm_amd/csrc/scene_file.cpp) ------------------------------
+def _desc_arrays(d):
+    import ctypes as C
+    from smallvcm_amd._abi import Light, Material, Prim
+    prims = np.frombuffer(C.string_at(d.prims, d.nPrims * C.sizeof(Prim)), np.uint32).reshape(d.nPrims, -1)
+    mats = np.frombuffer(C.string_at(d.materials, d.nMaterials * C.sizeof(Material)), np.uint32).reshape(d.nMaterials, -1)
+    lights = np.frombuffer(C.string_at(d.lights, d.nLights * C.sizeof(Light)), np.uint32).reshape(d.nLights, -1)
+    m2l = np.array([d.mat2light[i] for i in range(d.nMaterials)])
+    return prims, mats, lights, m2l
+
+
+def test_scene_file_equals_the_procedural_scene(tmp_path):
+    """OBJ + MTL + .vcmscene written from the procedural bumpy room load back as the same scene: every primitive's
+    geometry, the material each primitive refers to, the lights behind the emissive triangles, the scene sphere and the
+    camera, bit for bit (material NUMBERS differ: the loader numbers materials by first use); and the oracle renders the
+    same image from both."""
+    from mesh_scenes import write_bumpy_room_files
+    from smallvcm_amd.scene_file import load_scene
+    path = write_bumpy_room_files(str(tmp_path), grid=6)
+    a, b = load_scene(path, 40, 32), bumpy_room(grid=6, resx=40, resy=32)
+    pa, ma, la, m2la = _desc_arrays(a)
+    pb, mb, lb, m2lb = _desc_arrays(b)
+    assert a.nPrims == b.nPrims == 2 * 36 + 8 + 2 + 2 and a.nLights == b.nLights == 2
+    assert np.array_equal(pa[:, 0], pb[:, 0]) and np.array_equal(pa[:, 2:], pb[:, 2:])      # type, p0, p1, p2, normal
+    assert np.array_equal(ma[pa[:, 1]], mb[pb[:, 1]])                                        # the material OF each primitive
+    assert np.array_equal(m2la[pa[:, 1]], m2lb[pb[:, 1]]) and np.array_equal(la, lb)         # ... and its light
+    assert bytes(a.camera) == bytes(b.camera)
+    assert (a.sceneRadius, list(a.sceneCenter), a.invSceneRadiusSqr) == (b.sceneRadius, list(b.sceneCenter), b.invSceneRadiusSqr)
+    fbs = []
+    for sc in (a, b):
+        o = Oracle(sc, 4, threads=8)
+        o.run_iteration(0, 0, 10)
+        fbs.append(o.framebuffer())
+    assert np.array_equal(fbs[0].view(np.uint32), fbs[1].view(np.uint32)) and fbs[0].max() > 0
+
+
+def test_the_committed_scene_file_is_the_10k_triangle_room():
+    """tests/scenes/bumpy_room.vcmscene (regenerate: python tests/mesh_scenes.py) = bumpy_room(grid=72): what bench.py
+    renders as configuration M1"""
+    import os
+    from smallvcm_amd.scene_file import load_scene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes", "bumpy_room.vcmscene")
+    a, b = load_scene(path, 64, 64), bumpy_room(grid=72, resx=64, resy=64)
+    pa, pb = _desc_arrays(a)[0], _desc_arrays(b)[0]
+    assert a.nPrims == b.nPrims == 10380 and np.array_equal(pa[:, 2:], pb[:, 2:]) and bytes(a.camera) == bytes(b.camera)
+
+
+def test_scene_file_errors_are_reported(tmp_path):
+    from smallvcm_amd.scene_file import load_scene
+    with pytest.raises(ValueError, match="cannot open"):
+        load_scene(str(tmp_path / "nothing.vcmscene"), 8, 8)
+    (tmp_path / "a.mtl").write_text("newmtl m\nKd 0.5 0.5 0.5\nnewmtl lamp\nKe 3 3 3\n")
+    (tmp_path / "bad1.obj").write_text("mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl nope\nf 1 2 3\n")
+    with pytest.raises(ValueError, match="unknown material"):
+        load_scene(str(tmp_path / "bad1.obj"), 8, 8)
+    (tmp_path / "bad2.obj").write_text("mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl m\nf 1 2 4\n")
+    with pytest.raises(ValueError, match="out of range"):
+        load_scene(str(tmp_path / "bad2.obj"), 8, 8)
+    (tmp_path / "dark.obj").write_text("mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl m\nf 1 2 3\n")
+    with pytest.raises(ValueError, match="no light"):
+        load_scene(str(tmp_path / "dark.obj"), 8, 8)
+    # a bare .obj with an emissive material loads with the default camera; a polygon is fanned, relative indices work
+    (tmp_path / "ok.obj").write_text("mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nusemtl m\nf 1 2 3 4\nv 0 0 2\nv 1 0 2\nv 0 1 2\nusemtl lamp\nf -3 -2 -1\n")
+    d = load_scene(str(tmp_path / "ok.obj"), 16, 16)
+    assert d.nPrims == 3 and d.nLights == 1 and d.nMaterials == 2 and d.mat2light[1] == 0
+    (tmp_path / "s.vcmscene").write_text("obj ok.obj\nfrobnicate 1 2 3\n")
+    with pytest.raises(ValueError, match="unknown directive"):
+        load_scene(str(tmp_path / "s.vcmscene"), 8, 8)
+
+
+@pytest.mark.gpu
+def test_gpu_scene_file_through_the_loader_equals_oracle():
+    """the committed 10 380-primitive scene FILE, loaded by the library, traced through the BVH: tape, counters and
+    framebuffer equal to the oracle's brute force over the same description, and the image equal to the procedural
+    scene's (same geometry, other material numbers)"""
+    import os
+    from smallvcm_amd.renderer import VertexCM
+    from smallvcm_amd.scene_file import load_scene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes", "bumpy_room.vcmscene")
+    sc = load_scene(path, 96, 96)
+    o = Oracle(sc, 4, threads=os.cpu_count() or 1)
+    r = VertexCM(sc, 4, 0.003, 0.75, 1234)
+    r.mMaxPathLength = 10
+    for it in range(2):
+        o.run_iteration(it, 0, 10)
+        r.RunIteration(it)
+        lc, cc = r.backend.rng_counts()
+        olc, occ = o.counts()
+        assert np.array_equal(lc, olc) and np.array_equal(cc, occ)
+        so, sg = o.stats(), r.stats()
+        for k in ("lightVertices", "mergeCandidates", "mergeAccepted", "connections", "lightSplats", "shadowRays"):
+            assert so[k] == sg[k], (k, so[k], sg[k])
+    fb = r.framebuffer_sum()
+    r.close()
+    assert np.array_equal(fb.view(np.uint32), o.framebuffer().view(np.uint32)) and fb.max() > 0
+    r2 = VertexCM(bumpy_room(grid=72, resx=96, resy=96), 4, 0.003, 0.75, 1234)
+    r2.mMaxPathLength = 10
+    r2.RunIteration(0)
+    r2.RunIteration(1)
+    assert np.array_equal(fb.view(np.uint32), r2.framebuffer_sum().view(np.uint32))
+    r2.close()
