@@ -54,8 +54,7 @@ struct Scratch {
     LightStore store;                 /* S*nLocal slots (+ count[nLocal]) */
     int *dPathStart;                  /* nLocal+1 */
     int *dLocalTotal;                 /* 1 */
-    unsigned long long *dScanState[3]; /* per-tile words of the single-pass scan: [0] main stream, [1] side stream (grid build), [2] splat stream */
-    unsigned *dScanTicket;            /* [0..2]: tile ticket counters; never reset (Arena::scanTickets is their value) */
+    int *dTileSums[3];                /* scan scratch: [0] main stream, [1] side stream (grid build), [2] splat stream */
     int *dPixCount, *dPixStart;       /* N+2 each: light splats per pixel, and the start of every pixel's list (K1d) */
     int *dSplatArrival;               /* per light vertex: the place of its splat in its pixel's list */
     F4 *dSplatList;                   /* per light vertex: the splats grouped by pixel */
@@ -98,7 +97,6 @@ struct Arena {
     bool allocated;
     hipEvent_t lastUse; bool eventReady, lastValid;
     vcm_ctx *lastUser;                /* whose iteration the buffers still hold (NULL: nobody's) */
-    unsigned scanEpoch[3], scanTickets[3];   /* k_scan_onepass: launches so far / tickets handed out so far, per stream */
 };
 #define VCM_MAX_ARENAS 8
 struct ArenaPool {
@@ -221,7 +219,7 @@ static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
     DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
-    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dScanState[0]); DFREE(s.dScanState[1]); DFREE(s.dScanState[2]); DFREE(s.dScanTicket);
+    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums[0]); DFREE(s.dTileSums[1]); DFREE(s.dTileSums[2]);
     DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
@@ -256,16 +254,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
-    {   /* the scan's tile words and ticket counters start at zero ONCE: epochs and ticket bases take it from there */
-        const size_t tiles = maxScan / VCM_SCAN_TILE + 2;
-        if (dalloc(&s.dScanTicket, 4)) return -1;
-        HIPCHK(hipMemset(s.dScanTicket, 0, 4 * sizeof(unsigned)));
-        for (int w = 0; w < 3; w++) {
-            if (dalloc(&s.dScanState[w], tiles)) return -1;
-            HIPCHK(hipMemset(s.dScanState[w], 0, tiles * sizeof(unsigned long long)));
-            a->scanEpoch[w] = 0u; a->scanTickets[w] = 0u;
-        }
-    }
+    for (int w = 0; w < 3; w++) if (dalloc(&s.dTileSums[w], maxScan / VCM_SCAN_TILE + 2)) return -1;
     if (dalloc(&s.dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dSlotOfVertex, slots) || dalloc(&s.dSplat, slots)) return -1;
     if (dalloc(&s.dPixCount, cn + 2) || dalloc(&s.dPixStart, cn + 2) || dalloc(&s.dSplatArrival, slots) || dalloc(&s.dSplatList, slots)) return -1;
@@ -585,26 +574,18 @@ static int mark_on(vcm_ctx *c, int ev, hipStream_t stream)
 }
 static int mark(vcm_ctx *c, int ev) { return mark_on(c, ev, c->stream); }
 
-/* exclusive scan of n ints/bytes: one launch (k_scan_onepass); `which` = 0 main stream, 1 side stream -- each has its
-   own tile words and ticket counter in the arena, because the two scans may run at the same time */
+/* exclusive scan of n ints/bytes: two launches (vcm_kernels.h); `which` = 0 main stream, 1 side stream, 2 splat stream --
+   each has its own tile sums in the arena, because the scans of different streams may run at the same time */
 template <typename T>
 static int launch_scan_on(vcm_ctx *c, int which, hipStream_t stream, const T *in, int n, int *out, int *totalOut, int writeTotalAtN,
                           StampArgs st)
 {
     if (n <= 0) return fail("launch_scan", "empty scan");
-    Arena *a = c->arena;
     const int nTiles = (n + VCM_SCAN_TILE - 1) / VCM_SCAN_TILE;
-    ScanCtl ctl;
-    ctl.state = c->dScanState[which]; ctl.ticket = c->dScanTicket + which;
-    ctl.ticketBase = a->scanTickets[which];
-    unsigned epoch = (a->scanEpoch[which] + 1u) & 0x3fffffffu;
-    if (epoch == 0u) epoch = 1u;   /* 0 = the freshly zeroed words */
-    ctl.epoch = epoch;
-    hipLaunchKernelGGL((k_scan_onepass<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, out, totalOut, writeTotalAtN, ctl, st);
+    int *tileSums = c->dTileSums[which];
+    hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums, st);
+    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, (const int *)tileSums, out, totalOut, writeTotalAtN);
     HIPCHK(hipGetLastError());
-    /* only a launch that went out moves the device's ticket counter: keep the host's copy in step with it */
-    a->scanEpoch[which] = epoch;
-    a->scanTickets[which] += (unsigned)nTiles;   /* wraps like the device counter */
     return 0;
 }
 template <typename T>

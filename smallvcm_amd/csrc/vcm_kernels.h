@@ -475,32 +475,12 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
         const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
         const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
         const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+        /* (Round 3 tried to leave out the edge / corner probes that cannot hold a photon within the radius -- 21 % of the
+           edge probes, 48 % of the corner probes for evenly spread queries, decided from the query's position in its
+           cell with a 1 % margin and only when no other probe shares the bucket: bit-exact, 14 % fewer candidates, and
+           2 % SLOWER, profiles/r05b_ab_summary.txt: the wave walks until the lane with the MOST candidates is done,
+           and that is a lane near a cell corner, which skips nothing.) */
         int lo[8], hi[8];
-        uint32_t far = 0u;
-#if !defined(VCM_WALK_NOSKIP)
-        /* Edge and corner neighbours that cannot hold a photon within the radius are not scanned.  The cell across an
-           edge (two offset axes) or the corner (three) is at least sqrt(ax^2 + ay^2 (+ az^2)) cells away, a = the
-           query's distance to the face on that axis (<= half a cell = one radius): for a query in the middle of its
-           cell that exceeds the radius -- 21 % of the edge probes, 48 % of the corner probes for evenly spread queries.
-           The test is conservative by 1 % of the squared radius, orders of magnitude more than the rounding of the two
-           cell coordinates (~1e-4 of a cell at a thousand cells per axis) and of the reference's own distance
-           (hashgrid.hxx:162-165), so every skipped entry is one the reference rejects.  A probe is only skipped when no
-           other probe of the query hashes to the same bucket: the reference walks a colliding bucket once per probe
-           (:142-155), and the photons of the OTHER cell in it must still be met twice.  Two probes of one
-           bucket have the same range start; so has, harmlessly, an empty bucket right in front of a full one (then
-           nothing is skipped).  The candidate counter keeps counting the skipped entries: it reports the reference's
-           distance tests.  (One mask register across the range loads: the kernel sits two registers below the
-           128 that cost a wave per SIMD.) */
-        {
-            const float ax = fractCoord.x < 0.5f ? fractCoord.x : 1.f - fractCoord.x;
-            const float ay = fractCoord.y < 0.5f ? fractCoord.y : 1.f - fractCoord.y;
-            const float az = fractCoord.z < 0.5f ? fractCoord.z : 1.f - fractCoord.z;
-            const float lim = (P.radiusSqr * 1.01f) * (P.invCellSize * P.invCellSize);   /* in cells^2 */
-            const float xx = ax * ax, yy = ay * ay, zz = az * az;
-            far = (yy + zz > lim ? 1u << 3 : 0u) | (xx + zz > lim ? 1u << 5 : 0u) | (xx + yy > lim ? 1u << 6 : 0u) |
-                  (xx + yy + zz > lim ? 1u << 7 : 0u);
-        }
-#endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             lo[j] = 0; hi[j] = 0;
@@ -510,18 +490,6 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
                 hi[j] = g.cellStart[cell + 1];
             }
         }
-#if !defined(VCM_WALK_NOSKIP)
-        if (far) {
-#pragma unroll
-            for (int j = 3; j < 8; j++) {
-                if (j == 4) continue;
-                bool alone = true;
-#pragma unroll
-                for (int k = 0; k < 8; k++) alone = alone && (k == j || lo[k] != lo[j]);
-                if (((far >> j) & 1u) && alone) { ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]); hi[j] = lo[j]; }
-            }
-        }
-#endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]);   /* one distance test per entry (:162-165) */
@@ -889,86 +857,77 @@ __global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, const uin
     }
 }
 
-/* ---------------- exclusive scan (ints): ONE launch, decoupled look-back ---------------- */
-/* A tile = 2048 consecutive items, one workgroup each.  A workgroup takes its tile number from a ticket counter
- * (so tile t has started before tile t+1 exists: whoever waits, waits for somebody who runs), reduces its tile,
- * publishes the tile's AGGREGATE, then looks back over its predecessors' words -- 64 at a time, one per lane of wave
- * 0 -- adding aggregates until it meets a tile whose inclusive PREFIX is known, publishes its own prefix and writes
- * its 2048 results.  One pass over the data and one launch, where the first version took three launches (tile sums,
- * one 256-thread block over the tile sums, apply): at 512^2 the four scans of an iteration were 0.31 of 1.54 ms
- * (profiles/r02n_trace512_summary.txt: 12 launches, the single-block kernel 40 us each).
- * A tile's word = [epoch:30 | kind:2 | value:32], written and read whole (64-bit atomics): value and flag cannot be
- * seen apart.  The host passes a fresh epoch per launch (words of earlier launches read as "not there yet") and the
- * ticket counter's value at launch time, so neither array is ever zeroed again after allocation. */
+/* ---------------- exclusive scan (ints), 2 launches ---------------------- */
+/* A tile = 2048 consecutive items, one workgroup each.  (1) k_scan_tile_sums: the sum of every tile.  (2) k_scan_apply:
+ * a workgroup adds up the sums of ALL tiles before its own -- its 256 threads take them in strides, at most 8192 tile
+ * sums = 32 KB out of L2 -- and scans its tile from there.  No workgroup waits for another: the first version put a
+ * single 256-thread block between the two (40 us per scan at 512^2, four scans per iteration: 0.31 of 1.54 ms,
+ * profiles/r02n_trace512_summary.txt), and a single-pass scan with decoupled look-back (one launch; tried in round 3)
+ * is bound by the latency of its look-back chain on this chip -- 64 tiles per ~4 us step: 1.2 ms for the 16.8 M-entry
+ * bucket table of a 2048^2 frame against 70 us here (profiles/r05b_ab_summary.txt).  Wave scans are shuffles
+ * (6 steps), the four wave totals cross LDS once. */
 #define VCM_SCAN_BLOCK 256
 #define VCM_SCAN_ITEMS 8
 #define VCM_SCAN_TILE (VCM_SCAN_BLOCK * VCM_SCAN_ITEMS)
-enum { SCAN_KIND_AGG = 1, SCAN_KIND_PREFIX = 2 };
-__device__ __forceinline__ unsigned long long scan_pack(unsigned epoch, unsigned kind, int value)
+
+/* sum over the block (every thread gets it); one barrier pair */
+__device__ __forceinline__ int block_sum(int v)
 {
-    return ((unsigned long long)epoch << 34) | ((unsigned long long)kind << 32) | (unsigned long long)(unsigned)value;
+    __shared__ int sW[VCM_SCAN_BLOCK / VCM_WAVE];
+    v = (int)wave_sum_u32((uint32_t)v);
+    __syncthreads();   /* the previous use of sW is over */
+    if ((threadIdx.x & (VCM_WAVE - 1)) == 0) sW[threadIdx.x / VCM_WAVE] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < VCM_SCAN_BLOCK / VCM_WAVE; w++) t += sW[w];
+    return t;
 }
-struct ScanCtl { unsigned long long *state; unsigned *ticket; unsigned ticketBase, epoch; };
+
+template <typename T>
+__global__ void __launch_bounds__(VCM_SCAN_BLOCK) k_scan_tile_sums(const T *__restrict__ in, int n, int *tileSums, StampArgs st)
+{
+    stamp_entry(st);
+    const int base = blockIdx.x * VCM_SCAN_TILE + threadIdx.x * VCM_SCAN_ITEMS;
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < VCM_SCAN_ITEMS; i++) if (base + i < n) sum += (int)in[base + i];
+    const int total = block_sum(sum);
+    if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(VCM_SCAN_BLOCK)
-k_scan_onepass(const T *__restrict__ in, int n, int *out, int *totalOut, int writeTotalAtN, ScanCtl ctl, StampArgs st)
+k_scan_apply(const T *__restrict__ in, int n, const int *__restrict__ tileSums, int *out, int *totalOut, int writeTotalAtN)
 {
-    stamp_entry(st);
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ int sTile, sPrefix, sWave[VCM_SCAN_BLOCK / VCM_WAVE];
     const int tid = (int)threadIdx.x, lane = tid & (VCM_WAVE - 1), wave = tid / VCM_WAVE;
-    if (tid == 0) sTile = (int)(atomicAdd(ctl.ticket, 1u) - ctl.ticketBase);
-    __syncthreads();
-    const int tile = sTile;
-    const int base = tile * VCM_SCAN_TILE + tid * VCM_SCAN_ITEMS;
+    const int base = blockIdx.x * VCM_SCAN_TILE + tid * VCM_SCAN_ITEMS;
     int v[VCM_SCAN_ITEMS];
     int sum = 0;
 #pragma unroll
     for (int i = 0; i < VCM_SCAN_ITEMS; i++) { v[i] = (base + i < n) ? (int)in[base + i] : 0; sum += v[i]; }
+    /* everything before this tile */
+    int before = 0;
+    for (int t = tid; t < (int)blockIdx.x; t += VCM_SCAN_BLOCK) before += tileSums[t];
+    const int tileOffset = block_sum(before);
     /* inclusive scan of the thread sums inside the wave, then the four wave totals through LDS */
     int incl = sum;
 #pragma unroll
     for (int o = 1; o < VCM_WAVE; o <<= 1) { const int t = __shfl_up(incl, o, VCM_WAVE); if (lane >= o) incl += t; }
+    __shared__ int sWave[VCM_SCAN_BLOCK / VCM_WAVE];
     if (lane == VCM_WAVE - 1) sWave[wave] = incl;
     __syncthreads();
-    int waveOffset = 0, total = 0;
+    int waveOffset = 0;
 #pragma unroll
-    for (int w = 0; w < VCM_SCAN_BLOCK / VCM_WAVE; w++) { const int t = sWave[w]; if (w < wave) waveOffset += t; total += t; }
-    if (wave == 0) {
-        int exclusive = 0;
-        if (tile > 0) {
-            if (lane == 0) __hip_atomic_store(&ctl.state[tile], scan_pack(ctl.epoch, SCAN_KIND_AGG, total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            int look = tile - 1;
-            /* a predecessor publishes within microseconds (it has run since before this tile took its ticket); the bound
-               only keeps a logic error from hanging the device: the results are then wrong and every test says so */
-            for (int spins = 0; spins < (1 << 20); spins++) {
-                const int t = look - lane;   /* tiles before the first count as a known prefix of zero */
-                const unsigned long long w = (t >= 0) ? __hip_atomic_load(&ctl.state[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
-                                                      : scan_pack(ctl.epoch, SCAN_KIND_PREFIX, 0);
-                const unsigned kind = (unsigned)(w >> 32) & 3u;
-                const bool ready = ((unsigned)(w >> 34) == ctl.epoch) && kind != 0u;
-                if (__ballot(!ready)) { __builtin_amdgcn_s_sleep(1); continue; }   /* somebody has not published yet */
-                const unsigned long long prefixes = __ballot(kind == SCAN_KIND_PREFIX);
-                const int firstP = prefixes ? __builtin_ctzll(prefixes) : VCM_WAVE;   /* the nearest tile with a known prefix */
-                exclusive += (int)wave_sum_u32((lane <= firstP) ? (uint32_t)w : 0u);
-                if (prefixes) break;
-                look -= VCM_WAVE;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(&ctl.state[tile], scan_pack(ctl.epoch, SCAN_KIND_PREFIX, exclusive + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            sPrefix = exclusive;
-        }
-    }
-    __syncthreads();
-    int run = sPrefix + waveOffset + (incl - sum);
+    for (int w = 0; w < VCM_SCAN_BLOCK / VCM_WAVE; w++) if (w < wave) waveOffset += sWave[w];
+    int run = tileOffset + waveOffset + (incl - sum);
 #pragma unroll
     for (int i = 0; i < VCM_SCAN_ITEMS; i++) {
         if (base + i < n) out[base + i] = run;
         run += v[i];
     }
-    /* the thread that holds item n-1 (or, for n a multiple of the tile, the last thread of the last tile) knows the total */
+    /* the thread that holds item n-1 knows the total */
     if (n > 0 && base <= n - 1 && n - 1 < base + VCM_SCAN_ITEMS) {
         if (writeTotalAtN) out[n] = run;
         if (totalOut) *totalOut = run;
