@@ -602,6 +602,10 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPa
     static const char *tw = getenv("SMALLVCM_AMD_TRACE_WAVES");
     /* 4096 = 16 waves per CU: measured best (fewer, longer-lived waves leave fewer partly used queue blocks) */
     int maxWaves = (tw && atoi(tw) > 0) ? atoi(tw) : 256 * 16;
+    /* a 512^2 frame is exactly 4096 waves of one path per lane: every wave then lives as long as its longest path.  With
+       3072 waves a third of the lanes take a second path: K3 0.41 -> 0.36 ms (profiles/r05c_ab_summary.txt; at 1024^2
+       4096 is best) */
+    if (!(tw && atoi(tw) > 0) && nLocal <= (1 << 18)) maxWaves = 256 * 12;
     static const char *lw = getenv("SMALLVCM_AMD_LIGHT_WAVES");   /* K1 needs fewer registers than K3: 5 waves per SIMD fit */
     if (lightPass && lw && atoi(lw) > 0) maxWaves = atoi(lw);
     if (maxWaves > VCM_MAX_TRACE_WAVES) maxWaves = VCM_MAX_TRACE_WAVES;   /* the queue buffers hold one spare block per wave */
@@ -962,13 +966,13 @@ static int flush_light_splats(vcm_ctx *c)
     c->splatsPending = false;
     {
         /* K1c / K1d only read the light-vertex store and add to the framebuffer; nothing of the camera pass touches the
-           framebuffer before K5.  On frames too small to fill the chip (up to 1024^2: one path per lane, latency-bound
-           kernels) they run on a stream of their own next to the grid build and the camera pass and are joined before
-           K5; at 2048^2 every kernel fills the chip by itself and the overlap buys nothing (measured in round 1).
-           SMALLVCM_AMD_SPLAT_STREAM=0 / 1 forces it off / on. */
+           framebuffer before K5.  They run on a stream of their own next to the grid build and the camera pass and are
+           joined before K5: +4.5 % at 512^2, +7 % at 1024^2, +3 % at 2048^2 (profiles/r05c_ab_summary.txt; in round 1,
+           when they still shared their scratch with the grid build, the overlap had bought nothing).
+           SMALLVCM_AMD_SPLAT_STREAM=0 puts them back in line. */
         static int force = -2;
         if (force == -2) { const char *e = getenv("SMALLVCM_AMD_SPLAT_STREAM"); force = e ? (e[0] == '1' ? 1 : 0) : -1; }
-        const bool overlap = (force >= 0 ? force == 1 : c->nLocal < (1 << 21)) && c->world == 1 && !c->strictOrder;
+        const bool overlap = (force != 0) && c->world == 1 && !c->strictOrder;
         hipStream_t q = overlap ? c->splat : c->stream;
         const StampArgs none = { { NULL, NULL, NULL, NULL } };
         if (overlap) {
@@ -1290,6 +1294,20 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
+            /* K3c reads what K3 appended and the light store, and only K5 reads what it writes: on frames too small to
+               fill the chip it runs on the splat stream, next to K3b and K4 (joined before K5).  At 2048^2 the VALU-bound
+               K3c next to K4 cost 5 % (round 1).  SMALLVCM_AMD_VC_STREAM=0 / 1 forces it off / on. */
+            static int vcForce = -2;
+            if (vcForce == -2) { const char *e = getenv("SMALLVCM_AMD_VC_STREAM"); vcForce = e ? (e[0] == '1' ? 1 : 0) : -1; }
+            const bool vcAside = (vcForce >= 0 ? vcForce == 1 : c->nLocal < (1 << 21)) && c->world == 1;
+            if (vcAside) {
+                HIPCHK(hipEventRecord(c->evSplatFork, c->stream));   /* behind K3 */
+                HIPCHK(hipStreamWaitEvent(c->splat, c->evSplatFork, 0));
+                LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->splat, c->dScene, c->P, c->vs,
+                                   c->store, c->dStats);
+                HIPCHK(hipEventRecord(c->evSplatDone, c->splat));   /* also behind the light splats: same stream */
+                c->splatInFlight = true;
+            }
             /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
@@ -1297,8 +1315,9 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             LAUNCH_SC(c, k_connect_di, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
                                c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
-            LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
-                               c->store, c->dStats);
+            if (!vcAside)
+                LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
+                                   c->store, c->dStats);
         }
         if (mark(c, EV_CONNECT_K1)) return -1;
     } else {
