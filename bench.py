@@ -496,6 +496,7 @@ def main():
     ap.add_argument("--res", type=int, default=2048)
     ap.add_argument("--scene", type=int, default=1)
     ap.add_argument("--algo", default="vcm")
+    ap.add_argument("--scene-file", default="", help="a .vcmscene / .obj scene file (relative to the repository) instead of --scene")
     ap.add_argument("--shards", type=int, default=0,
                     help="GPUs that share one iteration (default: 2 when --gpus is even, else all)")
     ap.add_argument("--inflight", type=int, default=0,
@@ -514,6 +515,9 @@ def main():
     args = ap.parse_args()
     if args.no_cpu_baseline:
         args.cpu_baseline = "none"
+    if args.scene_file:   # a scene the reference cannot load: no CPU leg, no per-kernel child runs by scene id
+        args.scene = "file:" + args.scene_file
+        args.cpu_baseline, args.no_traffic = "none", True
     if args.gpus > 1:
         return multi_gpu(args)
 
@@ -563,11 +567,11 @@ def main():
     dom, roof = roofline_block(st, n_local, n_paths)
     headline = (args.scene, args.algo, res) == (1, "vcm", 2048)
     out = {
-        "metric": "Mpaths/sec (light+camera), %s scene %d at %d^2" % (args.algo.upper(), args.scene, res),
+        "metric": "Mpaths/sec (light+camera), %s scene %s at %d^2" % (args.algo.upper(), args.scene, res),
         "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic (reference's built-in Cornell box scene %d)" % args.scene,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (reference's built-in Cornell box scene %s)" % args.scene,
         "config": {"workload": workload_name(args.scene, args.algo, res, replicas, args.warmup * replicas,
                                              (args.warmup + args.steps) * replicas - 1),
                    "baseline_config": "C4 at 1 GPU (BASELINE.json metric)" if headline else "other",

@@ -36,6 +36,7 @@ struct SceneHost {
     std::vector<FastSphere> fastSpheres;  /* and the spheres */
     float fastRw2, fastCenter[3], fastRadius;
     std::vector<BvhNode> nodes;
+    std::vector<BvhWide> wide;            /* one per inner node: both children's boxes (the ordered traversals, vcm_core.h) */
     std::vector<int> leafPrims;
 
     /* the view the device functions take, filled IN PLACE: the arrays are addressed relative to the DScene object
@@ -49,6 +50,7 @@ struct SceneHost {
         d.offOps = (const char *)ops.data() - base; d.offPairs = (const char *)pairs.data() - base;
         d.offNodes = (const char *)nodes.data() - base; d.offLeafPrims = (const char *)leafPrims.data() - base;
         d.offFastPairs = (const char *)fastPairs.data() - base; d.offFastSpheres = (const char *)fastSpheres.data() - base;
+        d.offWide = (const char *)wide.data() - base;
     }
     void fill_scalars(DScene &d) const
     {
@@ -322,12 +324,24 @@ inline void scene_host_build_bvh(SceneHost &s)
     const float pad = 1e-4f * extent + 1e-30f;
     s.nodes.reserve((size_t)n);
     bvh_build_node(s, bp, 0, n, pad);
+    /* the wide view: inner nodes numbered in depth-first order, each holding the boxes of its two children -- the left
+       child is the next node in memory, the right one the left's escape */
+    s.wide.clear();
+    for (size_t i = 0; i < s.nodes.size(); i++) if (s.nodes[i].leaf < 0) { s.nodes[i].leaf = -1 - (int)s.wide.size(); s.wide.push_back(BvhWide()); }
+    for (size_t i = 0; i < s.nodes.size(); i++) {
+        if (s.nodes[i].leaf >= 0) continue;
+        BvhWide &w = s.wide[(size_t)(-1 - s.nodes[i].leaf)];
+        const int l = (int)i + 1, r = s.nodes[(size_t)l].escape;
+        const BvhNode &nl = s.nodes[(size_t)l], &nr = s.nodes[(size_t)r];
+        for (int k = 0; k < 3; k++) { w.lmin[k] = nl.bmin[k]; w.lmax[k] = nl.bmax[k]; w.rmin[k] = nr.bmin[k]; w.rmax[k] = nr.bmax[k]; }
+        w.lnode = l; w.lref = nl.leaf; w.rnode = r; w.rref = nr.leaf;
+    }
 }
 
 /* what the intersection code walks: the packed list for the reference's own scenes, the BVH beyond */
 inline void scene_host_build_accel(SceneHost &s, bool forceBvh)
 {
-    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.leafPrims.clear(); s.fastPairs.clear(); s.fastSpheres.clear();
+    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.wide.clear(); s.leafPrims.clear(); s.fastPairs.clear(); s.fastSpheres.clear();
     s.fastRw2 = s.fastRadius = 0.f; s.fastCenter[0] = s.fastCenter[1] = s.fastCenter[2] = 0.f;
     if ((int)s.prims.size() > VCM_MAX_PRIMS || (forceBvh && !s.prims.empty())) scene_host_build_bvh(s);
     else { scene_host_build_pairs(s); scene_host_build_fast(s); }

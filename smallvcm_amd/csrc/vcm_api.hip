@@ -421,12 +421,13 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
         {   /* the scene in ONE device allocation: the DScene header, then the arrays it addresses by offset */
             const SceneHost &h = *c->scene;
-            struct Part { const void *src; size_t bytes; size_t off; } parts[10] = {
+            struct Part { const void *src; size_t bytes; size_t off; } parts[11] = {
                 { h.prims.data(), h.prims.size() * sizeof(vcm_prim), 0 }, { h.materials.data(), h.materials.size() * sizeof(vcm_material), 0 },
                 { h.mat2light.data(), h.mat2light.size() * sizeof(int), 0 }, { h.lights.data(), h.lights.size() * sizeof(vcm_light), 0 },
                 { h.ops.data(), h.ops.size() * sizeof(PrimOp), 0 }, { h.pairs.data(), h.pairs.size() * sizeof(TriPair), 0 },
                 { h.nodes.data(), h.nodes.size() * sizeof(BvhNode), 0 }, { h.leafPrims.data(), h.leafPrims.size() * sizeof(int), 0 },
-                { h.fastPairs.data(), h.fastPairs.size() * sizeof(FastPair), 0 }, { h.fastSpheres.data(), h.fastSpheres.size() * sizeof(FastSphere), 0 } };
+                { h.fastPairs.data(), h.fastPairs.size() * sizeof(FastPair), 0 }, { h.fastSpheres.data(), h.fastSpheres.size() * sizeof(FastSphere), 0 },
+                { h.wide.data(), h.wide.size() * sizeof(BvhWide), 0 } };
             size_t total = (sizeof(DScene) + 255) & ~(size_t)255;
             for (Part &p : parts) { p.off = total; total += (p.bytes + 255) & ~(size_t)255; }
             if (dalloc(&c->dSceneBlob, total + 256)) return -1;
@@ -440,6 +441,7 @@ static int ensure_device(vcm_ctx *c)
             view.offOps = (long long)parts[4].off; view.offPairs = (long long)parts[5].off;
             view.offNodes = (long long)parts[6].off; view.offLeafPrims = (long long)parts[7].off;
             view.offFastPairs = (long long)parts[8].off; view.offFastSpheres = (long long)parts[9].off;
+            view.offWide = (long long)parts[10].off;
             c->dScene = reinterpret_cast<DScene *>(c->dSceneBlob);
             HIPCHK(hipMemcpy(c->dScene, &view, sizeof(DScene), hipMemcpyHostToDevice));
         }

@@ -231,7 +231,20 @@ struct alignas(16) FastSphere { float c[3], radius; int prim; int pad[3]; };
  * to `escape`, the node after the subtree.  32 bytes, two 16-byte loads. */
 struct alignas(16) BvhNode {
     float bmin[3]; int escape;        /* index of the node after this subtree (nNodes at the end) */
-    float bmax[3]; int leaf;          /* -1: inner node; else (first << 4) | count into leafPrims, count <= 15 */
+    float bmax[3]; int leaf;          /* >= 0: (first << 4) | count into leafPrims, count <= 15; < 0: inner node, -1 - its index
+                                         in the array of wide nodes */
+};
+/* The same hierarchy as the ordered traversals walk it: one 64-byte record per INNER node holding the boxes of BOTH
+ * children and what they are, so a level costs one load (four 16-byte words) and two slab tests -- with BvhNode alone it
+ * was the node, its left child and, dependent on that, the right child: two dependent round trips per level.  A child
+ * is named twice: `node` = its BvhNode (what goes on the closest-hit stack: the box is tested again when it is popped,
+ * against the distance held by then), `ref` = what to do with it: >= 0 a leaf (the descriptor of BvhNode::leaf),
+ * < 0 an inner node, -1 - its wide index. */
+struct alignas(16) BvhWide {
+    float lmin[3]; int lnode;
+    float lmax[3]; int lref;
+    float rmin[3]; int rnode;
+    float rmax[3]; int rref;
 };
 
 /* The scene as the device functions see it.  Scalars are those of vcm_scene_desc (the C-ABI struct the scene arrives
@@ -250,7 +263,7 @@ struct DScene {
     vcm_camera camera;
     /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0); BVH: nNodes > 0 */
     int nOps, nNodes;
-    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFastPairs, offFastSpheres;
+    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFastPairs, offFastSpheres, offWide;
     /* scene constants of the filter's error bounds: max |vertex|^2 over the triangles; a sphere around their vertices */
     float fastRw2, fastCenter[3], fastRadius;
     int nFastPairs, nFastSpheres;
@@ -264,6 +277,7 @@ struct DScene {
     VCM_HD const TriPair *pairs() const { return at<TriPair>(offPairs); }
     VCM_HD const BvhNode *nodes() const { return at<BvhNode>(offNodes); }
     VCM_HD const int *leafPrims() const { return at<int>(offLeafPrims); }
+    VCM_HD const BvhWide *wide() const { return at<BvhWide>(offWide); }
     VCM_HD const FastPair *fastPairs() const { return at<FastPair>(offFastPairs); }
     VCM_HD const FastSphere *fastSpheres() const { return at<FastSphere>(offFastSpheres); }
 };
@@ -557,20 +571,25 @@ VCM_HD bool list_intersect(const DScene &sc, const Ray &ray, Isect &res)
  * within 1e-7 of each other along it: the contact point of a sphere resting on the floor) is re-done by the
  * list walk. */
 VCM_HD bool near_tie(float a, float b) { const int d = (int)f2u(a) - (int)f2u(b); return d >= -2 && d <= 2; }
-/* entry distance of the ray into the node's box (bvh_box_hit's tnear); hit = the box is met within [0, tmax] */
-VCM_HD bool bvh_box_near(const BvhNode &nd, V3 org, V3 invDir, float tmax, float &tnear)
+/* entry distance of the ray into a box (bvh_box_hit's tnear); hit = the box is met within [0, tmax] */
+VCM_HD bool bvh_box_near6(const float *bmin, const float *bmax, V3 org, V3 invDir, float tmax, float &tnear)
 {
-    const float ax = (nd.bmin[0] - org.x) * invDir.x, bx = (nd.bmax[0] - org.x) * invDir.x;
-    const float ay = (nd.bmin[1] - org.y) * invDir.y, by = (nd.bmax[1] - org.y) * invDir.y;
-    const float az = (nd.bmin[2] - org.z) * invDir.z, bz = (nd.bmax[2] - org.z) * invDir.z;
+    const float ax = (bmin[0] - org.x) * invDir.x, bx = (bmax[0] - org.x) * invDir.x;
+    const float ay = (bmin[1] - org.y) * invDir.y, by = (bmax[1] - org.y) * invDir.y;
+    const float az = (bmin[2] - org.z) * invDir.z, bz = (bmax[2] - org.z) * invDir.z;
     tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
     const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     return tnear <= tfar * 1.0000004f;
 }
-/* the primitives of one leaf against the hit held so far: lexicographic on (distance, list index), see below */
-VCM_HD void bvh_leaf(const DScene &sc, const BvhNode &nd, const Ray &ray, Isect &res, bool &any, bool &ambiguous, bool &bestIsSphere)
+VCM_HD bool bvh_box_near(const BvhNode &nd, V3 org, V3 invDir, float tmax, float &tnear)
 {
-    const int first = nd.leaf >> 4, count = nd.leaf & 15;
+    return bvh_box_near6(nd.bmin, nd.bmax, org, invDir, tmax, tnear);
+}
+/* the primitives of one leaf (descriptor (first << 4) | count) against the hit held so far: lexicographic on
+   (distance, list index), see below */
+VCM_HD void bvh_leaf(const DScene &sc, int leaf, const Ray &ray, Isect &res, bool &any, bool &ambiguous, bool &bestIsSphere)
+{
+    const int first = leaf >> 4, count = leaf & 15;
     for (int k = 0; k < count; k++) {
         const int pi = sc.leafPrims()[first + k];
         const vcm_prim &pr = sc.prims()[pi];
@@ -598,72 +617,113 @@ VCM_HD void bvh_leaf(const DScene &sc, const BvhNode &nd, const Ray &ray, Isect 
         }
     }
 }
-/* Closest hit, ORDERED: at an inner node both children's boxes are tested (the left child is the next node in memory,
- * the right one the left's escape), the nearer is descended first and the farther goes on a per-lane stack, to be
- * dropped unvisited if a hit closer than its box has been found by the time it is popped -- the threaded walk
- * (bvh_occluded below, and the first version of this function) visits the subtrees in memory order whatever the ray's
- * direction and prunes only by what it happens to have found: 158 -> ... Mpaths/s on the 10 380-triangle room.
+/* any primitive of the leaf hit within (0, tmax)?  (GeometryList::IntersectP, geometry.hxx:80-91, for a subset) */
+VCM_HD bool bvh_leaf_occluded(const DScene &sc, int leaf, const Ray &ray, float tmaxp)
+{
+    const int first = leaf >> 4, count = leaf & 15;
+    bool occluded = false;
+    for (int k = 0; k < count; k++) {
+        const int pi = sc.leafPrims()[first + k];
+        const vcm_prim &pr = sc.prims()[pi];
+        if (pr.type == VCM_PRIM_TRIANGLE) {
+            float distance;
+            const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
+            if (inside && (distance > 0.f) && (distance < tmaxp)) occluded = true;
+        } else {
+            Isect s; s.dist = tmaxp; s.matID = 0; s.lightID = -1; s.normal = sp3(0.f); s.prim = -1;
+            if (sph_intersect(pr, pi, ray, s)) occluded = true;
+        }
+    }
+    return occluded;
+}
+
+/* The traversal stack: 32 levels per lane, in LDS on the device ([level][thread], no bank conflicts; 32 KB per block of
+ * 256 lanes), ONE array for the closest-hit and the any-hit traversal -- a kernel that runs both (strict mode) never
+ * has both alive.  A deeper tree finishes the ray with the threaded walk. */
+#define VCM_BVH_STACK 32
+#define VCM_BVH_NONE 0x7fffffff
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int *bvh_stack(int &stride)
+{
+    __shared__ int stackNode[VCM_BVH_STACK][256];
+    stride = 256;
+    return &stackNode[0][threadIdx.x];
+}
+#endif
+
+/* Closest hit, ORDERED, one wide node per level: both children's boxes are tested, the nearer is descended first and
+ * the farther goes on the stack, to be dropped unvisited if a hit closer than its box has been found by the time it is
+ * popped (its own BvhNode is loaded then and tested against the distance held NOW) -- the threaded walk (the first
+ * version of this function) visits the subtrees in memory order whatever the ray's direction and prunes only by what
+ * it happens to have found.  The loop is "while-while": a lane keeps descending until it holds a leaf, and the leaves
+ * are intersected when no lane of the wave has an inner node left -- so the slab tests run with the lanes that
+ * descend and the triangle tests with the lanes that hold leaves, instead of every step paying for both.
  * The visiting order cannot change the result: the winner is the minimum of (distance, list index), and a
  * primitive within 2 ulp of the winner is never pruned (the boxes are padded by 1e-4 of the scene, scene_host.h), so
- * the near-tie rule sees the same pairs.  Stack: 32 levels per lane, in LDS on the device ([level][thread], no bank
- * conflicts); a deeper tree finishes the lane with the threaded walk. */
-#define VCM_BVH_STACK 32
+ * the near-tie rule sees the same pairs. */
 VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
 {
     const V3 invDir = mk3(1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z);
     const Isect start = res;
     bool any = false, ambiguous = false, bestIsSphere = false, overflow = false;
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ int stackNode[VCM_BVH_STACK][256];   /* 32 KB per block: four blocks per CU stay resident */
-    int *sn = &stackNode[0][threadIdx.x];
-    const int stride = 256;
+    int stride;
+    int *sn = bvh_stack(stride);
 #else
     int stackNode[VCM_BVH_STACK];
     int *sn = stackNode;
     const int stride = 1;
 #endif
-    int sp = 0, node = -1;
+    int sp = 0, ref = VCM_BVH_NONE;
 #if defined(VCM_BVH_THREADED)   /* measurement switch: the threaded walk only */
     overflow = true;
 #else
     if (sc.nNodes > 0) {
+        const BvhNode root = sc.nodes()[0];
         float t;
-        if (bvh_box_near(sc.nodes()[0], ray.org, invDir, res.dist, t)) node = 0;
+        if (bvh_box_near(root, ray.org, invDir, res.dist, t)) ref = root.leaf;
     }
 #endif
-    while (node >= 0) {
-        const BvhNode nd = sc.nodes()[node];
-        if (nd.leaf >= 0) {
-            bvh_leaf(sc, nd, ray, res, any, ambiguous, bestIsSphere);
-            node = -1;
-        } else {
-            const int l = node + 1;
-            const BvhNode nl = sc.nodes()[l];
-            const int r = nl.escape;
-            const BvhNode nr = sc.nodes()[r];
+    for (;;) {
+        while (ref < 0) {   /* an inner node: one 64-byte record, two slab tests */
+            const BvhWide w = sc.wide()[-1 - ref];
             float tl, tr;
-            const bool hl = bvh_box_near(nl, ray.org, invDir, res.dist, tl), hr = bvh_box_near(nr, ray.org, invDir, res.dist, tr);
+            const bool hl = bvh_box_near6(w.lmin, w.lmax, ray.org, invDir, res.dist, tl);
+            const bool hr = bvh_box_near6(w.rmin, w.rmax, ray.org, invDir, res.dist, tr);
             if (hl && hr) {
                 const bool leftFirst = tl <= tr;
-                if (sp < VCM_BVH_STACK) { sn[sp * stride] = leftFirst ? r : l; sp++; }
+                if (sp < VCM_BVH_STACK) { sn[sp * stride] = leftFirst ? w.rnode : w.lnode; sp++; }
                 else overflow = true;
-                node = leftFirst ? l : r;
-            } else node = hl ? l : (hr ? r : -1);
+                ref = leftFirst ? w.lref : w.rref;
+            } else if (hl) ref = w.lref;
+            else if (hr) ref = w.rref;
+            else {   /* next pending subtree that can still hold a closer (or equal: the tie rule) hit */
+                ref = VCM_BVH_NONE;
+                while (ref == VCM_BVH_NONE && sp > 0) {
+                    sp--;
+                    const BvhNode nd = sc.nodes()[sn[sp * stride]];
+                    float t;
+                    if (bvh_box_near(nd, ray.org, invDir, res.dist, t)) ref = nd.leaf;
+                }
+            }
         }
-        while (node < 0 && sp > 0) {   /* next pending subtree that can still hold a closer (or equal: the tie rule) hit:
-                                          its box is tested again against the distance held NOW */
+        if (ref == VCM_BVH_NONE) break;
+        bvh_leaf(sc, ref, ray, res, any, ambiguous, bestIsSphere);
+        ref = VCM_BVH_NONE;
+        while (ref == VCM_BVH_NONE && sp > 0) {
             sp--;
-            const int cand = sn[sp * stride];
+            const BvhNode nd = sc.nodes()[sn[sp * stride]];
             float t;
-            if (bvh_box_near(sc.nodes()[cand], ray.org, invDir, res.dist, t)) node = cand;
+            if (bvh_box_near(nd, ray.org, invDir, res.dist, t)) ref = nd.leaf;
         }
+        if (ref == VCM_BVH_NONE) break;
     }
     if (overflow) {   /* deeper than the stack: the threaded walk over the whole tree (order-free, same result) */
         int nodeT = 0;
         while (nodeT < sc.nNodes) {
             const BvhNode nd = sc.nodes()[nodeT];
             if (!bvh_box_hit(nd, ray.org, invDir, res.dist)) { nodeT = nd.escape; continue; }
-            if (nd.leaf >= 0) bvh_leaf(sc, nd, ray, res, any, ambiguous, bestIsSphere);
+            if (nd.leaf >= 0) bvh_leaf(sc, nd.leaf, ray, res, any, ambiguous, bestIsSphere);
             nodeT++;
         }
     }
@@ -672,31 +732,60 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
     return any;
 }
 
-/* Scene::Occluded over the BVH: any hit in (0, tmax) (order-free) */
+/* Scene::Occluded over the BVH: any hit in (0, tmax).  The answer does not depend on the order, and tmax does not
+ * shrink: a child whose box is met is simply remembered by its REF and needs no second test when it is popped -- one
+ * 64-byte record per inner node is all the traversal loads above the leaves (the threaded walk of rounds 1-2 loaded a
+ * 32-byte node per visited node, each load dependent on the one before).  While-while as above; the nearer child
+ * first, because an occluder near the origin ends the ray. */
 VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
 {
     const V3 invDir = mk3(1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z);
-    bool occluded = false;
-    int node = 0;
-    while (node < sc.nNodes && !occluded) {
-        const BvhNode nd = sc.nodes()[node];
-        if (!bvh_box_hit(nd, ray.org, invDir, tmaxp)) { node = nd.escape; continue; }
-        if (nd.leaf >= 0) {
-            const int first = nd.leaf >> 4, count = nd.leaf & 15;
-            for (int k = 0; k < count; k++) {
-                const int pi = sc.leafPrims()[first + k];
-                const vcm_prim &pr = sc.prims()[pi];
-                if (pr.type == VCM_PRIM_TRIANGLE) {
-                    float distance;
-                    const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
-                    if (inside && (distance > 0.f) && (distance < tmaxp)) occluded = true;
-                } else {
-                    Isect s; s.dist = tmaxp; s.matID = 0; s.lightID = -1; s.normal = sp3(0.f); s.prim = -1;
-                    if (sph_intersect(pr, pi, ray, s)) occluded = true;
-                }
-            }
+    bool occluded = false, overflow = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int stride;
+    int *sn = bvh_stack(stride);
+#else
+    int stackNode[VCM_BVH_STACK];
+    int *sn = stackNode;
+    const int stride = 1;
+#endif
+    int sp = 0, ref = VCM_BVH_NONE;
+#if defined(VCM_BVH_THREADED)
+    overflow = true;
+#else
+    if (sc.nNodes > 0) {
+        const BvhNode root = sc.nodes()[0];
+        if (bvh_box_hit(root, ray.org, invDir, tmaxp)) ref = root.leaf;
+    }
+#endif
+    while (!overflow) {
+        while (ref < 0) {
+            const BvhWide w = sc.wide()[-1 - ref];
+            float tl, tr;
+            const bool hl = bvh_box_near6(w.lmin, w.lmax, ray.org, invDir, tmaxp, tl);
+            const bool hr = bvh_box_near6(w.rmin, w.rmax, ray.org, invDir, tmaxp, tr);
+            if (hl && hr) {
+                const bool leftFirst = tl <= tr;
+                if (sp < VCM_BVH_STACK) { sn[sp * stride] = leftFirst ? w.rref : w.lref; sp++; ref = leftFirst ? w.lref : w.rref; }
+                else { overflow = true; ref = VCM_BVH_NONE; }
+            } else if (hl) ref = w.lref;
+            else if (hr) ref = w.rref;
+            else if (sp > 0) { sp--; ref = sn[sp * stride]; }
+            else ref = VCM_BVH_NONE;
         }
-        node++;
+        if (ref == VCM_BVH_NONE) break;
+        if (bvh_leaf_occluded(sc, ref, ray, tmaxp)) { occluded = true; break; }
+        if (sp > 0) { sp--; ref = sn[sp * stride]; }
+        else break;
+    }
+    if (overflow && !occluded) {   /* deeper than the stack: the threaded walk over the whole tree */
+        int node = 0;
+        while (node < sc.nNodes && !occluded) {
+            const BvhNode nd = sc.nodes()[node];
+            if (!bvh_box_hit(nd, ray.org, invDir, tmaxp)) { node = nd.escape; continue; }
+            if (nd.leaf >= 0) occluded = bvh_leaf_occluded(sc, nd.leaf, ray, tmaxp);
+            node++;
+        }
     }
     return occluded;
 }
