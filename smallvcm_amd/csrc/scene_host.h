@@ -38,6 +38,7 @@ struct SceneHost {
     std::vector<BvhNode> nodes;
     std::vector<BvhWide> wide;            /* one per inner node: both children's boxes (the ordered traversals, vcm_core.h) */
     std::vector<int> leafPrims;
+    std::vector<LeafPrim> leafData;       /* the leaves' primitives in leaf order (what the traversals read) */
 
     /* the view the device functions take, filled IN PLACE: the arrays are addressed relative to the DScene object
        itself (vcm_core.h), so `d` must stay where it is while it is in use (host emulation) */
@@ -50,7 +51,7 @@ struct SceneHost {
         d.offOps = (const char *)ops.data() - base; d.offPairs = (const char *)pairs.data() - base;
         d.offNodes = (const char *)nodes.data() - base; d.offLeafPrims = (const char *)leafPrims.data() - base;
         d.offFastPairs = (const char *)fastPairs.data() - base; d.offFastSpheres = (const char *)fastSpheres.data() - base;
-        d.offWide = (const char *)wide.data() - base;
+        d.offWide = (const char *)wide.data() - base; d.offLeafData = (const char *)leafData.data() - base;
     }
     void fill_scalars(DScene &d) const
     {
@@ -336,12 +337,14 @@ inline void scene_host_build_bvh(SceneHost &s)
         for (int k = 0; k < 3; k++) { w.lmin[k] = nl.bmin[k]; w.lmax[k] = nl.bmax[k]; w.rmin[k] = nr.bmin[k]; w.rmax[k] = nr.bmax[k]; }
         w.lnode = l; w.lref = nl.leaf; w.rnode = r; w.rref = nr.leaf;
     }
+    s.leafData.resize(s.leafPrims.size());
+    for (size_t i = 0; i < s.leafPrims.size(); i++) { s.leafData[i].prim = s.prims[(size_t)s.leafPrims[i]]; s.leafData[i].index = s.leafPrims[i]; s.leafData[i].pad = 0; }
 }
 
 /* what the intersection code walks: the packed list for the reference's own scenes, the BVH beyond */
 inline void scene_host_build_accel(SceneHost &s, bool forceBvh)
 {
-    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.wide.clear(); s.leafPrims.clear(); s.fastPairs.clear(); s.fastSpheres.clear();
+    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.wide.clear(); s.leafPrims.clear(); s.leafData.clear(); s.fastPairs.clear(); s.fastSpheres.clear();
     s.fastRw2 = s.fastRadius = 0.f; s.fastCenter[0] = s.fastCenter[1] = s.fastCenter[2] = 0.f;
     if ((int)s.prims.size() > VCM_MAX_PRIMS || (forceBvh && !s.prims.empty())) scene_host_build_bvh(s);
     else { scene_host_build_pairs(s); scene_host_build_fast(s); }

@@ -421,13 +421,13 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
         {   /* the scene in ONE device allocation: the DScene header, then the arrays it addresses by offset */
             const SceneHost &h = *c->scene;
-            struct Part { const void *src; size_t bytes; size_t off; } parts[11] = {
+            struct Part { const void *src; size_t bytes; size_t off; } parts[12] = {
                 { h.prims.data(), h.prims.size() * sizeof(vcm_prim), 0 }, { h.materials.data(), h.materials.size() * sizeof(vcm_material), 0 },
                 { h.mat2light.data(), h.mat2light.size() * sizeof(int), 0 }, { h.lights.data(), h.lights.size() * sizeof(vcm_light), 0 },
                 { h.ops.data(), h.ops.size() * sizeof(PrimOp), 0 }, { h.pairs.data(), h.pairs.size() * sizeof(TriPair), 0 },
                 { h.nodes.data(), h.nodes.size() * sizeof(BvhNode), 0 }, { h.leafPrims.data(), h.leafPrims.size() * sizeof(int), 0 },
                 { h.fastPairs.data(), h.fastPairs.size() * sizeof(FastPair), 0 }, { h.fastSpheres.data(), h.fastSpheres.size() * sizeof(FastSphere), 0 },
-                { h.wide.data(), h.wide.size() * sizeof(BvhWide), 0 } };
+                { h.wide.data(), h.wide.size() * sizeof(BvhWide), 0 }, { h.leafData.data(), h.leafData.size() * sizeof(LeafPrim), 0 } };
             size_t total = (sizeof(DScene) + 255) & ~(size_t)255;
             for (Part &p : parts) { p.off = total; total += (p.bytes + 255) & ~(size_t)255; }
             if (dalloc(&c->dSceneBlob, total + 256)) return -1;
@@ -441,7 +441,7 @@ static int ensure_device(vcm_ctx *c)
             view.offOps = (long long)parts[4].off; view.offPairs = (long long)parts[5].off;
             view.offNodes = (long long)parts[6].off; view.offLeafPrims = (long long)parts[7].off;
             view.offFastPairs = (long long)parts[8].off; view.offFastSpheres = (long long)parts[9].off;
-            view.offWide = (long long)parts[10].off;
+            view.offWide = (long long)parts[10].off; view.offLeafData = (long long)parts[11].off;
             c->dScene = reinterpret_cast<DScene *>(c->dSceneBlob);
             HIPCHK(hipMemcpy(c->dScene, &view, sizeof(DScene), hipMemcpyHostToDevice));
         }
@@ -1370,9 +1370,18 @@ static int vcm_merge_impl(vcm_ctx *c)
                profiles/r02c_ab_summary.txt) but slower: the kernel is not bound by the candidate loads, and the
                staging adds instructions and barriers. */
             const int mergeStaged = c->mergeKind;
-            if (mergeStaged == 2)
-                hipLaunchKernelGGL(k_merge_walk, dim3(merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
-                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
+            if (mergeStaged == 2) {
+                /* SMALLVCM_AMD_MERGE_DEAL=slab: one contiguous eighth of the sorted queries per XCD, drawn batch by batch
+                   from eight counters (vs.count[24..31], zeroed with the queue counts), with stealing -- as many
+                   workgroups as are resident (4 per CU); "chunk" (default): the static dealing of rounds 1-2 */
+                static int slab = -1;
+                if (slab < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slab = (e && !strcmp(e, "slab")) ? 1 : 0; }
+                static int slabBlocks = 0;
+                if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
+                hipLaunchKernelGGL(k_merge_walk, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
+                                   slab ? c->vs.count + 24 : (int *)NULL);
+            }
             else if (mergeStaged) {
                 int ch = mergeChunk * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK;
                 if (ch < 1) ch = 1;

@@ -240,6 +240,10 @@ struct alignas(16) BvhNode {
  * is named twice: `node` = its BvhNode (what goes on the closest-hit stack: the box is tested again when it is popped,
  * against the distance held by then), `ref` = what to do with it: >= 0 a leaf (the descriptor of BvhNode::leaf),
  * < 0 an inner node, -1 - its wide index. */
+/* The primitives of the leaves, copied in LEAF order with their list index: a leaf's (at most 15, usually <= 4)
+ * primitives are one contiguous run of 64-byte records -- through leafPrims[] -> prims[] every triangle test began with
+ * two dependent gathers. */
+struct alignas(16) LeafPrim { vcm_prim prim; int index; int pad; };
 struct alignas(16) BvhWide {
     float lmin[3]; int lnode;
     float lmax[3]; int lref;
@@ -263,7 +267,7 @@ struct DScene {
     vcm_camera camera;
     /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0); BVH: nNodes > 0 */
     int nOps, nNodes;
-    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFastPairs, offFastSpheres, offWide;
+    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFastPairs, offFastSpheres, offWide, offLeafData;
     /* scene constants of the filter's error bounds: max |vertex|^2 over the triangles; a sphere around their vertices */
     float fastRw2, fastCenter[3], fastRadius;
     int nFastPairs, nFastSpheres;
@@ -278,6 +282,7 @@ struct DScene {
     VCM_HD const BvhNode *nodes() const { return at<BvhNode>(offNodes); }
     VCM_HD const int *leafPrims() const { return at<int>(offLeafPrims); }
     VCM_HD const BvhWide *wide() const { return at<BvhWide>(offWide); }
+    VCM_HD const LeafPrim *leafData() const { return at<LeafPrim>(offLeafData); }
     VCM_HD const FastPair *fastPairs() const { return at<FastPair>(offFastPairs); }
     VCM_HD const FastSphere *fastSpheres() const { return at<FastSphere>(offFastSpheres); }
 };
@@ -591,8 +596,9 @@ VCM_HD void bvh_leaf(const DScene &sc, int leaf, const Ray &ray, Isect &res, boo
 {
     const int first = leaf >> 4, count = leaf & 15;
     for (int k = 0; k < count; k++) {
-        const int pi = sc.leafPrims()[first + k];
-        const vcm_prim &pr = sc.prims()[pi];
+        const LeafPrim &lp = sc.leafData()[first + k];
+        const vcm_prim &pr = lp.prim;
+        const int pi = lp.index;
         if (pr.type == VCM_PRIM_TRIANGLE) {
             float distance;
             const bool inside = tri_inside(pr, ray.org, ray.dir, distance);
@@ -623,8 +629,9 @@ VCM_HD bool bvh_leaf_occluded(const DScene &sc, int leaf, const Ray &ray, float 
     const int first = leaf >> 4, count = leaf & 15;
     bool occluded = false;
     for (int k = 0; k < count; k++) {
-        const int pi = sc.leafPrims()[first + k];
-        const vcm_prim &pr = sc.prims()[pi];
+        const LeafPrim &lp = sc.leafData()[first + k];
+        const vcm_prim &pr = lp.prim;
+        const int pi = lp.index;
         if (pr.type == VCM_PRIM_TRIANGLE) {
             float distance;
             const bool inside = tri_inside(pr, ray.org, ray.dir, distance);

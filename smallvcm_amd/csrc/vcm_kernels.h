@@ -544,9 +544,19 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
 }
 #endif
 
+/* How the batches (256 consecutive queries of the cell-sorted order) reach the workgroups:
+ *   slabCtr == NULL  static: chunks of `chunk` batches dealt round-robin to the XCDs (k_merge_lane's scheme, rounds 1-2);
+ *   slabCtr != NULL  every XCD owns one contiguous EIGHTH of the sorted queries -- a slab of space -- and its workgroups
+ *                    (blockIdx & 7 = the XCD, round-robin dispatch) draw batch after batch from the slab's counter, so
+ *                    the ~128 workgroups resident on an XCD always work on ~128 consecutive batches and find each
+ *                    other's photons in that XCD's L2; a workgroup whose slab is exhausted STEALS from the next slabs
+ *                    (the contiguous ranges of round 1 had no stealing: the XCDs that owned the dense regions formed a
+ *                    long tail, 6.8 ms).  Which workgroup evaluates a query does not matter: every query has its own
+ *                    output slot. */
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK) VCM_K4_ATTR
 k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
-             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
+             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st,
+             int *slabCtr)
 {
     stamp_entry(st);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -554,15 +564,35 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
     const int nQ = *nSorted;
     __shared__ uint32_t accQ[(VCM_WALK_Q + 1) * VCM_MERGE_BLOCK];
     __shared__ WalkRun runs[8 * VCM_MERGE_BLOCK];
+    __shared__ int sBatch;
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK; ms.cap = VCM_WALK_Q;
     LaneStats ls; lane_stats_zero(ls);
-    /* batches of the cell-sorted queries are dealt to the XCDs in chunks, as in k_merge_lane */
     const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
     const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
+    const int perSlab = (nBatches + 7) / 8;
     for (int t = wgOfXcd;; t += wgPerXcd) {
-        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
-        if ((t / chunk) * 8 * chunk >= nBatches) break;
-        if (b >= nBatches) continue;
+        int b;
+        if (slabCtr) {
+            if (threadIdx.x == 0) {
+                int got = -1;
+                for (int v = 0; v < 8 && got < 0; v++) {   /* own slab first, then the others in turn */
+                    const int s = (xcd + v) & 7;
+                    const int lo = s * perSlab, hi = min(nBatches, lo + perSlab);
+                    if (lo >= hi) continue;
+                    const int k = atomicAdd(&slabCtr[s], 1);
+                    if (lo + k < hi) got = lo + k;
+                }
+                sBatch = got;
+            }
+            __syncthreads();
+            b = sBatch;
+            __syncthreads();   /* everybody has read it before thread 0 draws again */
+            if (b < 0) break;
+        } else {
+            b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
+            if ((t / chunk) * 8 * chunk >= nBatches) break;
+            if (b >= nBatches) continue;
+        }
         const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
         if (q < nQ) {   /* the runs of a lane are private to it: no barrier */
             const int vi = sortedVertex[q];
