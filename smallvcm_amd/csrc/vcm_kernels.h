@@ -359,7 +359,7 @@ k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, Light
 
 /* holes and out-of-bbox vertices are not sorted at all (key -1): they would all
  * land in one bucket, i.e. on one atomic word */
-__global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__restrict__ hdr, int *key, int *arrival,
+__global__ void __launch_bounds__(256) k_query_count(IterParams P, VertexStore vs, const GridHeader *__restrict__ hdr, int *key, int *arrival,
                               int *bucketCount, StampArgs st)
 {
     stamp_entry(st);
@@ -378,7 +378,7 @@ __global__ void k_query_count(IterParams P, VertexStore vs, const GridHeader *__
     }
 }
 
-__global__ void k_query_scatter(VertexStore vs, const int *__restrict__ key, const int *__restrict__ arrival,
+__global__ void __launch_bounds__(256) k_query_scatter(VertexStore vs, const int *__restrict__ key, const int *__restrict__ arrival,
                                 const int *__restrict__ bucketStart, int *sortedVertex)
 {
     const int nQ = vs.count[0];
@@ -863,7 +863,7 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
  * order.  Pixel q can receive from paths q-resX-1, q-resX, q-1, q (ascending
  * = the reference's order); light splats of the iteration are already in.
  * Wavefront mode: a path's colour is rebuilt by replay_path_color. */
-__global__ void k_resolve(IterParams P, const F4 *__restrict__ camOut, const uint32_t *__restrict__ camMask,
+__global__ void __launch_bounds__(256) k_resolve(IterParams P, const F4 *__restrict__ camOut, const uint32_t *__restrict__ camMask,
                           VertexStore vs, float *fb, StampArgs st)
 {
     stamp_entry(st);
@@ -983,7 +983,7 @@ __device__ __forceinline__ void bbox_finalize_component(GridHeader *hdr, int c, 
 }
 /* hdr != NULL (single rank): the first block also publishes the vertex counts (what k_set_counts does) and, with
    finalizeBox, turns the box K1 accumulated into floats -- two one-lane launches less per iteration */
-__global__ void k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
+__global__ void __launch_bounds__(256) k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
                                   int *slotOfVertex, int writeRecords, GridHeader *hdr, const int *localTotal, int finalizeBox)
 {
     if (hdr && blockIdx.x == 0 && threadIdx.x < 3) {
@@ -1046,7 +1046,7 @@ k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
 /* ---------------- K1d: ordered application of the light splats ------------ */
 /* the scatter moves the splat VALUE (rgb | vertex index) into its pixel's segment, so that k_splat_apply reads
  * one contiguous run per pixel instead of gathering 16 bytes per splat from all over the vertex-ordered array */
-__global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restrict__ nVertices,
+__global__ void __launch_bounds__(256) k_splat_scatter(const F4 *__restrict__ splat, const int *__restrict__ nVertices,
                                 const int *__restrict__ pixStart, const int *__restrict__ arrival, F4 *list, int *longCount)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *longCount = 0;   /* k_splat_apply's queue of long lists (the word is dead by now) */
@@ -1068,7 +1068,7 @@ __global__ void k_splat_scatter(const F4 *__restrict__ splat, const int *__restr
  * iteration of the 10 380-triangle room, profiles/r02w.) */
 #define VCM_SPLAT_REG 8
 #define VCM_SPLAT_LONG 48   /* up to here a lane orders its list by selection (k^2 / 2 loads that hit the cache) */
-__global__ void k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb,
+__global__ void __launch_bounds__(256) k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb,
                               int *longPix, int *longCount, int longThreshold /* VCM_SPLAT_LONG; tests lower it */)
 {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
@@ -1238,7 +1238,7 @@ __global__ void k_bbox_finalize(GridHeader *hdr, int minInverted /* the words K1
     if (threadIdx.x < 3) bbox_finalize_component(hdr, (int)threadIdx.x, hdr->nRecords, minInverted);
 }
 
-__global__ void k_cell_count(IterParams P, VertexSource src, const GridHeader *__restrict__ hdr,
+__global__ void __launch_bounds__(256) k_cell_count(IterParams P, VertexSource src, const GridHeader *__restrict__ hdr,
                              int *cellId, int *arrival, int *cellCount, StampArgs st)
 {
     stamp_entry(st);   /* :67-71 */
@@ -1253,7 +1253,7 @@ __global__ void k_cell_count(IterParams P, VertexSource src, const GridHeader *_
 
 /* list entry of a cell: everything k_cell_rank_gather needs about the vertex, in one 16-byte element -- one random
  * write here instead of three dependent random 4-byte reads (cell id, slot, then the data) per vertex there */
-__global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__restrict__ cellId,
+__global__ void __launch_bounds__(256) k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__restrict__ cellId,
                                const int *__restrict__ arrival, const int *__restrict__ cellStart,
                                const int *__restrict__ slotOfVertex /* NULL: records */, I4 *unsorted)
 {   /* :83-88, but in arbitrary order inside a cell; k_cell_rank_gather restores the order */
@@ -1271,7 +1271,7 @@ __global__ void k_cell_scatter(const GridHeader *__restrict__ hdr, const int *__
  * cell with a smaller index; the vertex data is then written to its final
  * position, so the query reads contiguous, cell-sorted memory and needs no
  * mIndices indirection. */
-__global__ void k_cell_rank_gather(const GridHeader *__restrict__ hdr, VertexSource src,
+__global__ void __launch_bounds__(256) k_cell_rank_gather(const GridHeader *__restrict__ hdr, VertexSource src,
                                    const int *__restrict__ cellStart, const I4 *__restrict__ unsorted,
                                    float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3, int *sortedIndex)
 {
