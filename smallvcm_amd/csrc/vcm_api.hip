@@ -1371,13 +1371,16 @@ static int vcm_merge_impl(vcm_ctx *c)
                staging adds instructions and barriers. */
             const int mergeStaged = c->mergeKind;
             if (mergeStaged == 2) {
-                /* One contiguous eighth of the sorted queries per XCD, drawn batch by batch from eight counters
-                   (vs.count[24..31], zeroed with the queue counts), with stealing; as many workgroups as are resident
-                   (4 per CU).  Against the static dealing of rounds 1-2 (SMALLVCM_AMD_MERGE_DEAL=chunk): K4's HBM traffic
-                   6.89 -> 5.58 GB per launch, 3.155 -> 3.11 ms at 2048^2, 0.260 -> 0.229 ms at 512^2
-                   (profiles/r05e_ab_summary.txt; 2048 workgroups: slower) */
+                /* SMALLVCM_AMD_MERGE_DEAL=slab: one contiguous eighth of the sorted queries per XCD, drawn batch by batch
+                   from eight counters (vs.count[24..31], zeroed with the queue counts), with stealing; as many workgroups
+                   as are resident (4 per CU).  Measured against the static dealing (default) on the Cornell scenes: K4's
+                   HBM traffic 6.89 -> 5.58 GB per launch, 3.155 -> 3.11 ms at 2048^2, 0.260 -> 0.229 ms at 512^2
+                   (profiles/r05e_ab_summary.txt) -- and on the 10 380-triangle room, whose caustic puts thousands of
+                   photons into a few cells, 1.06 -> 1.48 ms (profiles/r05f_ab_summary.txt): the queries of the hot cells
+                   are neighbours in the sorted order, i.e. ONE slab, and one XCD's L2 then serves the reads that the
+                   round-robin chunks spread over all eight.  Not the default. */
                 static int slab = -1;
-                if (slab < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slab = (e && !strcmp(e, "chunk")) ? 0 : 1; }
+                if (slab < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slab = (e && !strcmp(e, "slab")) ? 1 : 0; }
                 static int slabBlocks = 0;
                 if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
                 hipLaunchKernelGGL(k_merge_walk, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
