@@ -218,14 +218,14 @@ static ArenaPool *pool_get(int device)
 static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
-    DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
+    DFREE(s.store.v); DFREE(s.store.w); DFREE(s.store.count); DFREE(s.store.lenMask);
     DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums[0]); DFREE(s.dTileSums[1]); DFREE(s.dTileSums[2]);
     DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
     DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
-    DFREE(s.vs.q); DFREE(s.vs.meta); DFREE(s.vs.count);
+    DFREE(s.vs.q); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
     DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
     DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryArrival);
     a->allocated = false;
@@ -250,7 +250,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
-    if (dalloc(&s.store.v, slots * VCM_LV_FIELDS) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
+    if (dalloc(&s.store.v, slots * 4) || dalloc(&s.store.w, slots) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
@@ -277,7 +277,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const size_t vcPerPath = (cL >= 3) ? (size_t)(cL - 1) * (size_t)(cL - 2) / 2 : 1;
     const size_t vcslots = 2 * vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
     s.vs.qcap = vslots;
-    if (dalloc(&s.vs.q, vslots * 5) || dalloc(&s.vs.meta, vslots) ||
+    if (dalloc(&s.vs.q, vslots * 4) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
         dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.diOut, vslots) ||
         dalloc(&s.vs.mergeOut, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
         dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;

@@ -50,25 +50,28 @@ struct GridHeader {
     int   pad[2];
 };
 
-/* Light-vertex store: vertex j of local path lp lives in slot [j * nLocal + lp], a record of five
- * 16-byte fields (80 B).  K1 writes slot-major, so a wave (64 consecutive paths at the same bounce) fills one
- * contiguous 5 KB region; the consumers that GATHER a vertex (vertex connection K3c, the cell-sorted copy
- * of the grid build) find all of it in one or two cache lines.  (Five separate arrays -- SoA -- were
- * measured: the gathers then touch five lines per vertex, k_cell_rank_gather 1.16 ms instead of 0.6.)
- * Replaces the AoS std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
+/* Light-vertex store: vertex j of local path lp lives in slot [j * nLocal + lp].  K1 writes slot-major, so a wave
+ * (64 consecutive paths at the same bounce) fills contiguous memory; the consumers GATHER: a random read moves a whole
+ * 128-byte line whatever it uses of it (profiles/r05a_fetch_calib.json), so what counts is the number of LINES a
+ * vertex occupies for each consumer.  Two arrays (round 3):
+ *     v   four 16-byte fields = 64 bytes, 64-byte aligned: everything the CONNECTIONS read (K1c, K3c) -- one line;
+ *     w   the fifth field, read only when the cell-sorted copy of the grid is made (k_cell_rank_gather).
+ * As one 80-byte record (rounds 1-2) a vertex straddled two lines half of the time: 1.5 lines per gather for every
+ * consumer.  (Five separate arrays were measured in round 1: five lines per gather, k_cell_rank_gather 1.16 ms
+ * instead of 0.6.)  Replaces the AoS std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
 #define VCM_LV_FIELDS 5
 struct LightStore {
-    F4 *v;    /* [slot * 5 + k]:
+    F4 *v;    /* [slot * 4 + k]:
                  k=0 hitpoint.xyz | pathLength (bits 0-7) , matID (bits 8-15)
                  k=1 throughput.xyz | dVCM
                  k=2 isect.normal.xyz | dVC
-                 k=3 localDirFix.xyz | dVM
-                 k=4 WorldDirFix().xyz | ContinuationProb()                  */
+                 k=3 localDirFix.xyz | dVM */
+    F4 *w;    /* [slot]: k=4 WorldDirFix().xyz | ContinuationProb() */
     unsigned char *count;   /* stored vertices per local path (mPathEnds, :395) */
     uint32_t *lenMask;      /* per local path: bit L set <=> a vertex with pathLength L is stored (stored vertices have
                                increasing pathLength, so vertex j is the j-th set bit); valid while maxPathLength <= 31 */
 };
-VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return s.v[slot * VCM_LV_FIELDS + (size_t)k]; }
+VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return k < 4 ? s.v[slot * 4 + (size_t)k] : s.w[slot]; }
 
 /* Hash grid, vertices sorted by cell (replaces mIndices indirection,
  * hashgrid.hxx:83-88): cell c = [cellStart[c], cellStart[c+1]) */
@@ -92,16 +95,18 @@ struct GridStore {
  * every path in the reference's order. */
 struct alignas(16) I4 { int x, y, z, w; };
 struct VertexStore {
-    /* the record of camera vertex i: five 16-byte fields, CONTIGUOUS (80 B): q[i * 5 + k].  As five separate arrays
-       (round 1) a wave's append was five partly written cache lines per step and every consumer's gather touched
-       five lines: K4 3.55 -> 3.39 ms, K3 unchanged (profiles/r02r_ab_summary.txt)
+    /* the record of camera vertex i: four 16-byte fields, contiguous and 64-byte aligned (q[i * 4 + k]) = what the merge
+       (K4, which GATHERS the vertices in cell order: one 128-byte line each) and the connections read, plus a fifth
+       in an array of its own (q4[i]) that only K3b / K3c want.  As one 80-byte record (round 2) a vertex straddled two
+       lines half of the time; as five separate arrays (round 1) a wave's append was five partly written lines per
+       step and every gather touched five (K4 3.55 -> 3.39 ms when they were joined, profiles/r02r_ab_summary.txt)
          k=0 hitpoint.xyz | local path index
          k=1 isect.normal.xyz | pathLength (bits 0-7), matID (8-15)
          k=2 localDirFix.xyz | dVCM
          k=3 throughput.xyz | dVM
          k=4 dVC | the position of the 3 random floats of DirectIllumination (:672-673) in the path's stream */
-    F4 *q;
-    size_t qcap;     /* records allocated (the SoA measurement build indexes q[k * qcap + i]) */
+    F4 *q, *q4;
+    size_t qcap;     /* records allocated */
     I4 *meta;        /* per PATH SLOT: DI task (-1: none) | first VC task | number of VC tasks | 0 */
     int *count;      /* [0] vertices  [1] DI tasks  [2] VC tasks                  */
     int *diTask;     /* DI task -> vertex                                         */
@@ -117,11 +122,7 @@ struct VertexStore {
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
 };
-#if defined(VCM_VS_SOA)   /* measurement switch: five arrays */
-VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return vs.q[(size_t)k * vs.qcap + i]; }
-#else
-VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return vs.q[i * 5 + (size_t)k]; }
-#endif
+VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 4 + (size_t)k] : vs.q4[i]; }
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;

@@ -30,7 +30,7 @@ struct Emul {
     int seed, iterations;
     int resX, resY, N, p0, nLocal;
     IterParams P;
-    std::vector<F4> v0 /* the light store, 5 fields per slot */, g1, g2, camOut;
+    std::vector<F4> v0 /* the light store: 4 fields per slot */, w0 /* and the fifth */, g1, g2, camOut;
     std::vector<F2> g3;
     std::vector<float> gx, gy, gz, fb, records;
     std::vector<unsigned char> count, rngL, rngC;
@@ -150,11 +150,12 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
         return;
     }
     const size_t slots = (size_t)S * e.nLocal;
-    e.v0.assign(slots * VCM_LV_FIELDS, mk4(0, 0, 0, 0));
+    e.v0.assign(slots * 4, mk4(0, 0, 0, 0));
+    e.w0.assign(slots, mk4(0, 0, 0, 0));
     e.count.assign((size_t)e.nLocal, 0); e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
     lane_stats_zero(e.ls);
     std::vector<uint32_t> lenMask((size_t)e.nLocal, 0u);
-    LightStore store; store.v = e.v0.data(); store.count = e.count.data(); store.lenMask = lenMask.data();
+    LightStore store; store.v = e.v0.data(); store.w = e.w0.data(); store.count = e.count.data(); store.lenMask = lenMask.data();
 
     /* K1 */
     for (int lp = 0; lp < e.nLocal; lp++) {
@@ -171,8 +172,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     for (int lp = 0; lp < e.nLocal; lp++)
         for (int j = 0; j < e.count[lp]; j++) {
             const size_t slot = (size_t)j * e.nLocal + lp;
-            const F4 a = e.v0[slot * VCM_LV_FIELDS + 0], b = e.v0[slot * VCM_LV_FIELDS + 1], d = e.v0[slot * VCM_LV_FIELDS + 3],
-                     w = e.v0[slot * VCM_LV_FIELDS + 4];
+            const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), d = lv(store, slot, 3), w = lv(store, slot, 4);
             const float r[13] = { a.x, a.y, a.z, w.x, w.y, w.z, b.x, b.y, b.z, b.w, d.w, w.w, u2f(f2u(a.w) & 0xffu) };
             e.records.insert(e.records.end(), r, r + 13);
         }
