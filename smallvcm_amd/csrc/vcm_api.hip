@@ -225,8 +225,8 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
     DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
-    DFREE(s.vs.q); DFREE(s.vs.q4); DFREE(s.vs.slotRec); DFREE(s.vs.count);
-    DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.vcOut);
+    DFREE(s.vs.q); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
+    DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
     DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryArrival);
     a->allocated = false;
     a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
@@ -277,8 +277,9 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const size_t vcPerPath = (cL >= 3) ? (size_t)(cL - 1) * (size_t)(cL - 2) / 2 : 1;
     const size_t vcslots = 2 * vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
     s.vs.qcap = vslots;
-    if (dalloc(&s.vs.q, vslots * 4) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.slotRec, vslots * 3) ||
-        dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
+    if (dalloc(&s.vs.q, vslots * 4) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
+        dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.diOut, vslots) ||
+        dalloc(&s.vs.mergeOut, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
         dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;
     const size_t qsN = (cn > (size_t)VCM_QSORT_BUCKETS ? cn : (size_t)VCM_QSORT_BUCKETS) + 2;   /* also pixStart of K1d */
     if (dalloc(&s.dQueryStart, qsN) || dalloc(&s.dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||

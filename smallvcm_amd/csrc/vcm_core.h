@@ -107,28 +107,22 @@ struct VertexStore {
          k=4 dVC | the position of the 3 random floats of DirectIllumination (:672-673) in the path's stream */
     F4 *q, *q4;
     size_t qcap;     /* records allocated */
+    I4 *meta;        /* per PATH SLOT: DI task (-1: none) | first VC task | number of VC tasks | 0 */
     int *count;      /* [0] vertices  [1] DI tasks  [2] VC tasks                  */
     int *diTask;     /* DI task -> vertex                                         */
     int *vcTask;     /* VC task -> (vertex, index j of the light vertex)          */
     /* What k_resolve reads per vertex is indexed by the vertex's PATH SLOT (pathLength-1)*nLocal + lp, not by its
        queue position: lanes of k_resolve hold neighbouring paths, so these reads coalesce (the queue order is the
-       order in which waves happened to append).  The three things a path slot holds are ONE 48-byte record
-       (slot_meta / slot_di / slot_merge below), written 16 bytes at a time by K3, K3b and K4: as three arrays
-       (rounds 1-2) a vertex in a sparsely filled plane -- path lengths >= 4, where few of 64 neighbouring paths have a
-       vertex -- cost k_resolve three 128-byte lines. */
-    F4 *slotRec;     /* per path slot: [0] throughput * DirectIllumination() (:491)
-                                       [1] throughput * vmNormalization * contrib (:534)
-                                       [2] as I4: DI task (-1: none) | first VC task | number of VC tasks | 0 */
+       order in which waves happened to append). */
+    F4 *diOut;       /* per path slot: throughput * DirectIllumination()  (:491)   */
     F4 *vcOut;       /* per VC task:   throughput * lvThroughput * ConnectVertices() (:523) */
+    F4 *mergeOut;    /* per path slot: throughput * vmNormalization * contrib (:534) */
     /* K4a folded into K3 when the grid exists before the camera pass (single-rank order light -> grid -> camera):
        the vertex takes its bucket key and its place in the bucket the moment it is appended; NULL otherwise */
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
 };
 VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 4 + (size_t)k] : vs.q4[i]; }
-VCM_HD F4 &slot_di(const VertexStore &vs, size_t ps) { return vs.slotRec[ps * 3]; }
-VCM_HD F4 &slot_merge(const VertexStore &vs, size_t ps) { return vs.slotRec[ps * 3 + 1]; }
-VCM_HD I4 &slot_meta(const VertexStore &vs, size_t ps) { return *reinterpret_cast<I4 *>(&vs.slotRec[ps * 3 + 2]); }
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
@@ -2241,7 +2235,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
             vq(vs, 3, vi) = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVM);
             vq(vs, 4, vi) = mk4(st.dVC, u2f(diK), 0.f, 0.f);
             I4 m; m.x = hasDI ? di : -1; m.y = vc0; m.z = nvc; m.w = 0;
-            slot_meta(vs, path_slot(P, st.pathLength, (uint32_t)cp.lp)) = m;
+            vs.meta[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = m;
 #if defined(__HIP_DEVICE_COMPILE__)
             if (vs.sortKey && P.useVM) {   /* K4a's histogram pass, here (see VertexStore) */
                 const int k = query_sort_key(P, vs.sortHdr, hitPoint);
@@ -2251,7 +2245,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
 #else
                 if (k >= 0) { wqs.pendingVertex = vi; wqs.pendingArrival = atomicAdd(&vs.bucketCount[k], 1); }
 #endif
-                else slot_merge(vs, path_slot(P, st.pathLength, (uint32_t)cp.lp)) = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
+                else vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
             }
 #endif
             if (hasDI) vs.diTask[di] = vi;
@@ -2380,9 +2374,9 @@ VCM_HD V3 replay_path_color(const IterParams &P, const VertexStore &vs, int lp, 
         const int L = __builtin_ctz(mask);
         mask &= mask - 1u;
         const size_t ps = path_slot(P, (uint32_t)L, (uint32_t)lp);
-        const I4 m = slot_meta(vs, ps);
-        const F4 di = slot_di(vs, ps);
-        const F4 mg = P.useVM ? slot_merge(vs, ps) : mk4(0.f, 0.f, 0.f, 0.f);
+        const I4 m = vs.meta[ps];
+        const F4 di = vs.diOut[ps];
+        const F4 mg = P.useVM ? vs.mergeOut[ps] : mk4(0.f, 0.f, 0.f, 0.f);
         if (m.x >= 0) color = color + mk3(di.x, di.y, di.z);
         for (int k0 = 0; k0 < m.z; k0 += 4) {
             F4 t[4];

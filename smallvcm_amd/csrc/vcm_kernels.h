@@ -320,7 +320,7 @@ k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsig
         if (vi < 0) continue;   /* hole */
         size_t ps;
         const V3 v = eval_di_task(sc, P, vs, vi, ls, ps);
-        slot_di(vs, ps) = mk4(v.x, v.y, v.z, 0.f);
+        vs.diOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         if (sortedVertex) {   /* K4a's scatter pass, here: this kernel visits every camera vertex once */
             const int k = vs.sortKey[vi];
             if (k >= 0) sortedVertex[bucketStart[k] + vs.sortArrival[vi]] = vi;
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256) k_query_count(IterParams P, VertexStore v
         if (f2u(r0.w) != 0xffffffffu) {
             k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
             if (k < 0)   /* empty query: contrib = 0 */
-                slot_merge(vs, path_slot(P, f2u(vq(vs, 1, q).w) & 0xffu, f2u(r0.w))) = mk4(0.f, 0.f, 0.f, 0.f);
+                vs.mergeOut[path_slot(P, f2u(vq(vs, 1, q).w) & 0xffu, f2u(r0.w))] = mk4(0.f, 0.f, 0.f, 0.f);
         }
         key[q] = k;
         /* the value the atomic returns is the vertex's place in its bucket: the scatter needs no second atomic */
@@ -428,7 +428,7 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             const int vi = sortedVertex[q];
             size_t ps;
             const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms, ps);
-            slot_merge(vs, ps) = mk4(v.x, v.y, v.z, 0.f);
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -604,7 +604,7 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             sps.pathLength = f2u(bq.w) & 0xffu; sps.dVCM = c.w; sps.dVM = d.w;
             const V3 contrib = merge_query_walk(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
-            slot_merge(vs, ps) = mk4(v.x, v.y, v.z, 0.f);
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -850,7 +850,7 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
             st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
             const V3 contrib = merge_query_staged(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
-            slot_merge(vs, ps) = mk4(v.x, v.y, v.z, 0.f);
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
         __syncthreads();
     }
