@@ -250,7 +250,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
-    if (dalloc(&s.store.v, slots * 4) || dalloc(&s.store.w, slots) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
+    if (dalloc(&s.store.v, slots * 5 /* 4 in use; 5 for the VCM_STORE_80 measurement build */) || dalloc(&s.store.w, slots) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
@@ -277,7 +277,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const size_t vcPerPath = (cL >= 3) ? (size_t)(cL - 1) * (size_t)(cL - 2) / 2 : 1;
     const size_t vcslots = 2 * vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
     s.vs.qcap = vslots;
-    if (dalloc(&s.vs.q, vslots * 4) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
+    if (dalloc(&s.vs.q, vslots * 5 /* 4 in use; 5 for the VCM_VQ_80 measurement build */) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
         dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.diOut, vslots) ||
         dalloc(&s.vs.mergeOut, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
         dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;

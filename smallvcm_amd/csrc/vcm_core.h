@@ -71,7 +71,11 @@ struct LightStore {
     uint32_t *lenMask;      /* per local path: bit L set <=> a vertex with pathLength L is stored (stored vertices have
                                increasing pathLength, so vertex j is the j-th set bit); valid while maxPathLength <= 31 */
 };
+#if defined(VCM_STORE_80)   /* measurement switch: the 80-byte record of rounds 1-2 */
+VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return s.v[slot * 5 + (size_t)k]; }
+#else
 VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return k < 4 ? s.v[slot * 4 + (size_t)k] : s.w[slot]; }
+#endif
 
 /* Hash grid, vertices sorted by cell (replaces mIndices indirection,
  * hashgrid.hxx:83-88): cell c = [cellStart[c], cellStart[c+1]) */
@@ -122,7 +126,11 @@ struct VertexStore {
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
 };
+#if defined(VCM_VQ_80)   /* measurement switch: the 80-byte record of round 2 */
+VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return vs.q[i * 5 + (size_t)k]; }
+#else
 VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 4 + (size_t)k] : vs.q4[i]; }
+#endif
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
