@@ -250,7 +250,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
-    if (dalloc(&s.store.v, slots * 5 /* 4 in use; 5 for the VCM_STORE_80 measurement build */) || dalloc(&s.store.w, slots) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
+    if (dalloc(&s.store.v, slots * VCM_LV_FIELDS) || dalloc(&s.store.w, slots) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;

@@ -50,31 +50,33 @@ struct GridHeader {
     int   pad[2];
 };
 
-/* Light-vertex store: vertex j of local path lp lives in slot [j * nLocal + lp].  K1 writes slot-major, so a wave
- * (64 consecutive paths at the same bounce) fills contiguous memory; the consumers GATHER: a random read moves a whole
- * 128-byte line whatever it uses of it (profiles/r05a_fetch_calib.json), so what counts is the number of LINES a
- * vertex occupies for each consumer.  Two arrays (round 3):
- *     v   four 16-byte fields = 64 bytes, 64-byte aligned: everything the CONNECTIONS read (K1c, K3c) -- one line;
- *     w   the fifth field, read only when the cell-sorted copy of the grid is made (k_cell_rank_gather).
- * As one 80-byte record (rounds 1-2) a vertex straddled two lines half of the time: 1.5 lines per gather for every
- * consumer.  (Five separate arrays were measured in round 1: five lines per gather, k_cell_rank_gather 1.16 ms
- * instead of 0.6.)  Replaces the AoS std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
+/* Light-vertex store: vertex j of local path lp lives in slot [j * nLocal + lp], a record of five
+ * 16-byte fields (80 B).  K1 writes slot-major, so a wave (64 consecutive paths at the same bounce) fills one
+ * contiguous 5 KB region; the consumers GATHER a vertex (vertex connection K3c, the camera connection K1c, the
+ * cell-sorted copy of the grid build) and a gather moves whole 128-byte lines (profiles/r05a_fetch_calib.json): an
+ * 80-byte record lies in 1.5 of them on average.  Round 3 measured the alternative -- the four fields the connections
+ * read as a 64-byte aligned record (one line), the fifth in an array of its own (-DVCM_STORE_SPLIT): the connections
+ * gain, the grid build (which wants fields 0, 1, 3 AND 4: two lines) loses and slows the camera pass it runs next to:
+ * 868 against 875 Mpaths/s (profiles/r05h_ab_summary.txt).  The camera-vertex records, below, ARE split.
+ * (Five separate arrays were measured in round 1: five lines per gather, k_cell_rank_gather 1.16 ms instead of 0.6.)
+ * Replaces the AoS std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
 #define VCM_LV_FIELDS 5
 struct LightStore {
-    F4 *v;    /* [slot * 4 + k]:
+    F4 *v;    /* [slot * 5 + k]:
                  k=0 hitpoint.xyz | pathLength (bits 0-7) , matID (bits 8-15)
                  k=1 throughput.xyz | dVCM
                  k=2 isect.normal.xyz | dVC
-                 k=3 localDirFix.xyz | dVM */
-    F4 *w;    /* [slot]: k=4 WorldDirFix().xyz | ContinuationProb() */
+                 k=3 localDirFix.xyz | dVM
+                 k=4 WorldDirFix().xyz | ContinuationProb()                  */
+    F4 *w;    /* the -DVCM_STORE_SPLIT measurement build keeps field 4 here ([slot]) and four fields per slot in v */
     unsigned char *count;   /* stored vertices per local path (mPathEnds, :395) */
     uint32_t *lenMask;      /* per local path: bit L set <=> a vertex with pathLength L is stored (stored vertices have
                                increasing pathLength, so vertex j is the j-th set bit); valid while maxPathLength <= 31 */
 };
-#if defined(VCM_STORE_80)   /* measurement switch: the 80-byte record of rounds 1-2 */
-VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return s.v[slot * 5 + (size_t)k]; }
-#else
+#if defined(VCM_STORE_SPLIT)
 VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return k < 4 ? s.v[slot * 4 + (size_t)k] : s.w[slot]; }
+#else
+VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return s.v[slot * VCM_LV_FIELDS + (size_t)k]; }
 #endif
 
 /* Hash grid, vertices sorted by cell (replaces mIndices indirection,
@@ -101,9 +103,10 @@ struct alignas(16) I4 { int x, y, z, w; };
 struct VertexStore {
     /* the record of camera vertex i: four 16-byte fields, contiguous and 64-byte aligned (q[i * 4 + k]) = what the merge
        (K4, which GATHERS the vertices in cell order: one 128-byte line each) and the connections read, plus a fifth
-       in an array of its own (q4[i]) that only K3b / K3c want.  As one 80-byte record (round 2) a vertex straddled two
-       lines half of the time; as five separate arrays (round 1) a wave's append was five partly written lines per
-       step and every gather touched five (K4 3.55 -> 3.39 ms when they were joined, profiles/r02r_ab_summary.txt)
+       in an array of its own (q4[i]) that only K3b / K3c want.  As one 80-byte record (round 2; -DVCM_VQ_80) a vertex
+       straddled two lines half of the time: 864 -> 875 Mpaths/s with the split (profiles/r05h_ab_summary.txt); as five
+       separate arrays (round 1) a wave's append was five partly written lines per step and every gather touched five
+       (K4 3.55 -> 3.39 ms when they were joined, profiles/r02r_ab_summary.txt)
          k=0 hitpoint.xyz | local path index
          k=1 isect.normal.xyz | pathLength (bits 0-7), matID (8-15)
          k=2 localDirFix.xyz | dVCM

@@ -30,7 +30,7 @@ struct Emul {
     int seed, iterations;
     int resX, resY, N, p0, nLocal;
     IterParams P;
-    std::vector<F4> v0 /* the light store: 4 fields per slot */, w0 /* and the fifth */, g1, g2, camOut;
+    std::vector<F4> v0 /* the light store: 5 fields per slot */, w0 /* (the split measurement layout's fifth) */, g1, g2, camOut;
     std::vector<F2> g3;
     std::vector<float> gx, gy, gz, fb, records;
     std::vector<unsigned char> count, rngL, rngC;
@@ -150,7 +150,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
         return;
     }
     const size_t slots = (size_t)S * e.nLocal;
-    e.v0.assign(slots * 4, mk4(0, 0, 0, 0));
+    e.v0.assign(slots * VCM_LV_FIELDS, mk4(0, 0, 0, 0));
     e.w0.assign(slots, mk4(0, 0, 0, 0));
     e.count.assign((size_t)e.nLocal, 0); e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
     lane_stats_zero(e.ls);
