@@ -34,6 +34,8 @@ struct SceneHost {
     std::vector<TriPair> pairs;
     std::vector<FastPair> fastPairs;      /* the filter's view of the list (vcm_core.h): triangles two by two, */
     std::vector<FastSphere> fastSpheres;  /* and the spheres */
+    std::vector<FastRect> fastRects;      /* the same pairs as axis-aligned rectangles, grouped by normal axis -- if ALL of them are */
+    int nFastRects[3]; float fastGmax;
     float fastRw2, fastCenter[3], fastRadius;
     std::vector<BvhNode> nodes;
     std::vector<BvhWide> wide;            /* one per inner node: both children's boxes (the ordered traversals, vcm_core.h) */
@@ -52,6 +54,7 @@ struct SceneHost {
         d.offNodes = (const char *)nodes.data() - base; d.offLeafPrims = (const char *)leafPrims.data() - base;
         d.offFastPairs = (const char *)fastPairs.data() - base; d.offFastSpheres = (const char *)fastSpheres.data() - base;
         d.offWide = (const char *)wide.data() - base; d.offLeafData = (const char *)leafData.data() - base;
+        d.offFastRects = (const char *)fastRects.data() - base;
     }
     void fill_scalars(DScene &d) const
     {
@@ -67,6 +70,9 @@ struct SceneHost {
         for (const FastPair &f : fastPairs) if (!(f.flags & 4)) d.fastOnePlane = 0;
         { const char *e = getenv("SMALLVCM_AMD_NO_ONEPLANE"); if (e && e[0] == '1') d.fastOnePlane = 0; }   /* measurement switch */
         for (int k = 0; k < 3; k++) d.fastCenter[k] = fastCenter[k];
+        for (int k = 0; k < 3; k++) d.nFastRects[k] = nFastRects[k];
+        d.fastGmax = fastGmax;
+        { const char *e = getenv("SMALLVCM_AMD_NO_RECTS"); if (e && e[0] == '1') d.nFastRects[0] = d.nFastRects[1] = d.nFastRects[2] = 0; }   /* measurement switch */
     }
 };
 
@@ -140,6 +146,59 @@ inline void scene_host_build_pairs(SceneHost &s)
         s.pairs.push_back(tp);
         i += two ? 2 : 1;
     }
+}
+
+/* ---- the pairs as axis-aligned rectangles (vcm_core.h FastRect), if EVERY pair is one: the reference's own boxes ---- */
+inline bool scene_host_rect_triangle(const vcm_prim &t, int k, const float *(&diag)[2], float c[2], float g[2])
+{   /* the reference's edge functions (geometry.hxx:133-139): V(c, b), V(b, a), V(a, c); one must be the diagonal, one
+       run along u = k+1 (constant v), one along v = k+2 (constant u) */
+    const int u = (k + 1) % 3, v = (k + 2) % 3;
+    const float *e[3][2] = { { t.p2, t.p1 }, { t.p1, t.p0 }, { t.p0, t.p2 } };
+    bool haveU = false, haveV = false, haveD = false;
+    for (int i = 0; i < 3; i++) {
+        const float *P = e[i][0], *Q = e[i][1];
+        const bool sameU = P[u] == Q[u], sameV = P[v] == Q[v];
+        if (sameV && !sameU) { if (haveU) return false; haveU = true; c[0] = P[v]; g[0] = (float)((double)P[u] - (double)Q[u]); }        /* along u: V = d_k (P_u - Q_u)(c - X_v) */
+        else if (sameU && !sameV) { if (haveV) return false; haveV = true; c[1] = P[u]; g[1] = (float)((double)Q[v] - (double)P[v]); }   /* along v: V = d_k (Q_v - P_v)(c - X_u) */
+        else if (!sameU && !sameV) { if (haveD) return false; haveD = true; diag[0] = P; diag[1] = Q; }
+        else return false;   /* a degenerate edge */
+    }
+    return haveU && haveV && haveD;
+}
+inline void scene_host_build_rects(SceneHost &s)
+{
+    s.fastRects.clear();
+    s.nFastRects[0] = s.nFastRects[1] = s.nFastRects[2] = 0; s.fastGmax = 0.f;
+    std::vector<FastRect> byAxis[3];
+    for (const FastPair &f : s.fastPairs) {
+        if ((f.flags & 7) != 7) return;   /* two triangles, shared diagonal, one plane */
+        const vcm_prim &t = s.prims[(size_t)f.prim[0]], &w = s.prims[(size_t)f.prim[1]];
+        int k = -1;
+        for (int a = 0; a < 3; a++) if (std::fabs(t.n[a]) == 1.f && t.n[(a + 1) % 3] == 0.f && t.n[(a + 2) % 3] == 0.f) k = a;
+        if (k < 0) return;
+        const float *vs[6] = { t.p0, t.p1, t.p2, w.p0, w.p1, w.p2 };
+        for (int i = 1; i < 6; i++) if (vs[i][k] != vs[0][k]) return;
+        if (w.n[k] != t.n[k]) return;
+        FastRect r;
+        std::memset(&r, 0, sizeof(r));
+        const float *da[2], *db[2];
+        if (!scene_host_rect_triangle(t, k, da, r.c, r.g) || !scene_host_rect_triangle(w, k, db, r.c + 2, r.g + 2)) return;
+        /* B's diagonal must be A's, reversed: then B's third edge function is exactly minus A's */
+        bool rev = true;
+        for (int a = 0; a < 3; a++) rev = rev && da[0][a] == db[1][a] && da[1][a] == db[0][a];
+        if (!rev) return;
+        {   /* V(P, Q) = Dot(dir, P x Q) + Dot(o x dir, Q - P), binary64, rounded once (as scene_host_build_fast) */
+            const double p[3] = { da[0][0], da[0][1], da[0][2] }, q[3] = { da[1][0], da[1][1], da[1][2] };
+            r.NEd[0] = (float)(p[1] * q[2] - p[2] * q[1]); r.NEd[1] = (float)(p[2] * q[0] - p[0] * q[2]); r.NEd[2] = (float)(p[0] * q[1] - p[1] * q[0]);
+            for (int a = 0; a < 3; a++) r.NEd[3 + a] = (float)(q[a] - p[a]);
+        }
+        r.pk = t.p0[k]; r.nk = t.n[k];
+        r.prim[0] = f.prim[0]; r.prim[1] = f.prim[1];
+        for (int a = 0; a < 4; a++) s.fastGmax = std::max(s.fastGmax, std::fabs(r.g[a]) * 1.000001f);
+        byAxis[k].push_back(r);
+    }
+    if (s.fastPairs.empty()) return;
+    for (int k = 0; k < 3; k++) { s.nFastRects[k] = (int)byAxis[k].size(); s.fastRects.insert(s.fastRects.end(), byAxis[k].begin(), byAxis[k].end()); }
 }
 
 /* ---- the filter's view of the list (vcm_core.h "certified filters"): planes and Pluecker edge data, computed in
@@ -218,6 +277,7 @@ inline void scene_host_build_fast(SceneHost &s)
             r2 = std::max(r2, d2);
         }
     }
+    scene_host_build_rects(s);
     /* rounded up: they enter error BOUNDS */
     s.fastRw2 = (float)(rw2 * 1.0001) + 1e-30f;
     s.fastRadius = (float)(std::sqrt(r2) * 1.0001) + 1e-30f;
@@ -344,7 +404,8 @@ inline void scene_host_build_bvh(SceneHost &s)
 /* what the intersection code walks: the packed list for the reference's own scenes, the BVH beyond */
 inline void scene_host_build_accel(SceneHost &s, bool forceBvh)
 {
-    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.wide.clear(); s.leafPrims.clear(); s.leafData.clear(); s.fastPairs.clear(); s.fastSpheres.clear();
+    s.ops.clear(); s.pairs.clear(); s.nodes.clear(); s.wide.clear(); s.leafPrims.clear(); s.leafData.clear(); s.fastPairs.clear(); s.fastSpheres.clear(); s.fastRects.clear();
+    s.nFastRects[0] = s.nFastRects[1] = s.nFastRects[2] = 0; s.fastGmax = 0.f;
     s.fastRw2 = s.fastRadius = 0.f; s.fastCenter[0] = s.fastCenter[1] = s.fastCenter[2] = 0.f;
     if ((int)s.prims.size() > VCM_MAX_PRIMS || (forceBvh && !s.prims.empty())) scene_host_build_bvh(s);
     else { scene_host_build_pairs(s); scene_host_build_fast(s); }

@@ -114,9 +114,11 @@ static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_t
 
 /* Kernels that cast rays exist once per kind of scene (vcm_core.h SceneList / SceneBvh); the launch picks. */
 #define LAUNCH_SC(c, K, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<SceneBvh>), __VA_ARGS__); \
+                                  else if ((c)->sceneRects) hipLaunchKernelGGL((K<SceneRects>), __VA_ARGS__); \
                                   else if ((c)->sceneQuads) hipLaunchKernelGGL((K<SceneQuads>), __VA_ARGS__); \
                                   else hipLaunchKernelGGL((K<SceneList>), __VA_ARGS__); } while (0)
 #define LAUNCH_SC_MODE(c, K, M, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<M, SceneBvh>), __VA_ARGS__); \
+                                          else if ((c)->sceneRects) hipLaunchKernelGGL((K<M, SceneRects>), __VA_ARGS__); \
                                           else if ((c)->sceneQuads) hipLaunchKernelGGL((K<M, SceneQuads>), __VA_ARGS__); \
                                           else hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); } while (0)
 
@@ -163,6 +165,7 @@ struct vcm_ctx : Scratch {
     bool strictOrder;
     int mergeKind;                    /* VCM_MERGE_* */
     bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
+    bool sceneRects;                  /* ... and is an axis-aligned rectangle: the SceneRects kernels */
     IterParams P;
     bool inIteration;
     hipEvent_t ev[EV_COUNT];
@@ -421,13 +424,14 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
         {   /* the scene in ONE device allocation: the DScene header, then the arrays it addresses by offset */
             const SceneHost &h = *c->scene;
-            struct Part { const void *src; size_t bytes; size_t off; } parts[12] = {
+            struct Part { const void *src; size_t bytes; size_t off; } parts[13] = {
                 { h.prims.data(), h.prims.size() * sizeof(vcm_prim), 0 }, { h.materials.data(), h.materials.size() * sizeof(vcm_material), 0 },
                 { h.mat2light.data(), h.mat2light.size() * sizeof(int), 0 }, { h.lights.data(), h.lights.size() * sizeof(vcm_light), 0 },
                 { h.ops.data(), h.ops.size() * sizeof(PrimOp), 0 }, { h.pairs.data(), h.pairs.size() * sizeof(TriPair), 0 },
                 { h.nodes.data(), h.nodes.size() * sizeof(BvhNode), 0 }, { h.leafPrims.data(), h.leafPrims.size() * sizeof(int), 0 },
                 { h.fastPairs.data(), h.fastPairs.size() * sizeof(FastPair), 0 }, { h.fastSpheres.data(), h.fastSpheres.size() * sizeof(FastSphere), 0 },
-                { h.wide.data(), h.wide.size() * sizeof(BvhWide), 0 }, { h.leafData.data(), h.leafData.size() * sizeof(LeafPrim), 0 } };
+                { h.wide.data(), h.wide.size() * sizeof(BvhWide), 0 }, { h.leafData.data(), h.leafData.size() * sizeof(LeafPrim), 0 },
+                { h.fastRects.data(), h.fastRects.size() * sizeof(FastRect), 0 } };
             size_t total = (sizeof(DScene) + 255) & ~(size_t)255;
             for (Part &p : parts) { p.off = total; total += (p.bytes + 255) & ~(size_t)255; }
             if (dalloc(&c->dSceneBlob, total + 256)) return -1;
@@ -436,12 +440,13 @@ static int ensure_device(vcm_ctx *c)
             DScene view;
             h.fill_scalars(view);
             c->sceneQuads = h.nodes.empty() && view.fastOnePlane != 0;
+            c->sceneRects = c->sceneQuads && (view.nFastRects[0] + view.nFastRects[1] + view.nFastRects[2]) > 0;
             view.offPrims = (long long)parts[0].off; view.offMaterials = (long long)parts[1].off;
             view.offMat2light = (long long)parts[2].off; view.offLights = (long long)parts[3].off;
             view.offOps = (long long)parts[4].off; view.offPairs = (long long)parts[5].off;
             view.offNodes = (long long)parts[6].off; view.offLeafPrims = (long long)parts[7].off;
             view.offFastPairs = (long long)parts[8].off; view.offFastSpheres = (long long)parts[9].off;
-            view.offWide = (long long)parts[10].off; view.offLeafData = (long long)parts[11].off;
+            view.offWide = (long long)parts[10].off; view.offLeafData = (long long)parts[11].off; view.offFastRects = (long long)parts[12].off;
             c->dScene = reinterpret_cast<DScene *>(c->dSceneBlob);
             HIPCHK(hipMemcpy(c->dScene, &view, sizeof(DScene), hipMemcpyHostToDevice));
         }

@@ -235,6 +235,24 @@ struct alignas(16) FastPair {
     int   pad;
 };
 struct alignas(16) FastSphere { float c[3], radius; int prim; int pad[3]; };
+/* An AXIS-ALIGNED RECTANGLE of the list -- two consecutive triangles with a common plane normal to a coordinate axis
+ * k, sharing their diagonal, the other four edges parallel to the axes u = k+1, v = k+2 (cyclic): every quad of the
+ * reference's Cornell boxes (scene.hxx:215-330).  For an edge P -> Q in the plane the reference's edge function is
+ *     V(P, Q) = Dot(dir, Cross(P - o, Q - o)) = dir_k * [ (P_u - X_u)(Q_v - X_v) - (P_v - X_v)(Q_u - X_u) ],
+ * X = the point where the ray meets the plane (the offsets to o differ from those to X by multiples of dir, which drop
+ * out of the triple product).  For an edge along u (P_v = Q_v = c) that is  dir_k * (P_u - Q_u) * (c - X_v),  for one
+ * along v (P_u = Q_u = c)  dir_k * (Q_v - P_v) * (c - X_u):  a coordinate difference of the hit point times two
+ * factors known per rectangle and ray -- against six fused multiply-adds for the same edge in Pluecker form.  Only the
+ * diagonal keeps its Pluecker evaluation.  64 bytes instead of FastPair's 208: the burst of scalar loads per entry,
+ * on which the loop stalls, shrinks with it.  Entries are grouped by the axis k (three loops with compile-time
+ * components; the filter's answer does not depend on the order of the entries). */
+struct alignas(16) FastRect {
+    float pk, nk;        /* the plane: coordinate along k of the vertices; Triangle::mNormal's component along k (+-1) */
+    float c[4];          /* the constant coordinate of: A's edge along u (a v value), A's edge along v (a u value), B's two likewise */
+    float g[4];          /* their signed extents: V = dir_k * g * (c - X_w) */
+    float NEd[6];        /* the diagonal as triangle A's edge function (B's is its negative), Pluecker form */
+    int   prim[2];       /* list indices of A and B */
+};
 
 /* One node of the bounding-volume hierarchy used for scenes with more primitives than the brute-force loop is
  * meant for (the reference has no acceleration structure: README:208-209, Scene::Intersect scene.hxx:53-70).
@@ -279,11 +297,13 @@ struct DScene {
     vcm_camera camera;
     /* brute force: GeometryList order, triangles in pairs (nOps > 0 and nNodes == 0); BVH: nNodes > 0 */
     int nOps, nNodes;
-    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFastPairs, offFastSpheres, offWide, offLeafData;
+    long long offPrims, offMaterials, offMat2light, offLights, offOps, offPairs, offNodes, offLeafPrims, offFastPairs, offFastSpheres, offWide, offLeafData, offFastRects;
     /* scene constants of the filter's error bounds: max |vertex|^2 over the triangles; a sphere around their vertices */
     float fastRw2, fastCenter[3], fastRadius;
     int nFastPairs, nFastSpheres;
     int fastOnePlane;   /* every FastPair has flags bit 2: the loops then contain no per-entry branch (one burst of loads) */
+    int nFastRects[3];  /* every FastPair is an axis-aligned rectangle: their FastRect view, grouped by normal axis (else 0, 0, 0) */
+    float fastGmax;     /* the longest rectangle edge (enters an error bound) */
     template <class T> VCM_HD const T *at(long long off) const { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(this) + off); }
     VCM_HD const vcm_prim *prims() const { return at<vcm_prim>(offPrims); }
     VCM_HD const vcm_material *materials() const { return at<vcm_material>(offMaterials); }
@@ -295,6 +315,7 @@ struct DScene {
     VCM_HD const int *leafPrims() const { return at<int>(offLeafPrims); }
     VCM_HD const BvhWide *wide() const { return at<BvhWide>(offWide); }
     VCM_HD const LeafPrim *leafData() const { return at<LeafPrim>(offLeafData); }
+    VCM_HD const FastRect *fastRects() const { return at<FastRect>(offFastRects); }
     VCM_HD const FastPair *fastPairs() const { return at<FastPair>(offFastPairs); }
     VCM_HD const FastSphere *fastSpheres() const { return at<FastSphere>(offFastSpheres); }
 };
@@ -302,11 +323,13 @@ struct DScene {
  * nNodes), so the brute-force kernels hold no traversal code and the BVH kernels no list loop.  Compiled together the
  * two paths cost the headline kernels 11-27 VGPRs, i.e. a wave per SIMD (K3 122 -> 133 registers: 713 -> 576
  * Mpaths/s on the same box, profiles/r02g_*).  Functions that cast rays take `const SC &`, the rest `const DScene &`. */
-struct SceneList : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = false; };
-struct SceneBvh : DScene { static constexpr bool kBvh = true; static constexpr bool kOnePlane = false; };
+struct SceneList : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = false; static constexpr bool kRects = false; };
+struct SceneBvh : DScene { static constexpr bool kBvh = true; static constexpr bool kOnePlane = false; static constexpr bool kRects = false; };
 /* a list whose triangle pairs all share their plane part (FastPair::flags bit 2: axis-aligned quads, i.e. the reference's
    Cornell boxes): its kernels carry only that loop */
-struct SceneQuads : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; };
+struct SceneQuads : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; static constexpr bool kRects = false; };
+/* a list whose triangle pairs are all axis-aligned rectangles (FastRect): the reference's own boxes */
+struct SceneRects : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; static constexpr bool kRects = true; };
 
 /* ---- utils.hxx ---------------------------------------------------- */
 VCM_HD float luminance(V3 c)
@@ -981,15 +1004,120 @@ VCM_HD void fast_offer(FastBest &fb, bool cand, bool cert, float L, float U, int
     fb.bestU = isBest ? U : fb.bestU;
     fb.bestCertain = isBest ? cert : fb.bestCertain;
 }
+/* ---- the filter for lists of axis-aligned rectangles (FastRect) ----
+ * Per rectangle: the plane distance t from the reference's own operands (for a normal along axis k they are
+ * num = n_k (p_k - o_k), den = n_k dir_k exactly, up to the sign of a zero: the other two products of the reference's
+ * dot are zeros); the hit point's in-plane coordinates X~_u = fma(t, dir_u, o_u), X~_v likewise; then the four axis
+ * edges as  dir_k g (c - X~_w)  and the diagonal in Pluecker form, classified exactly as the general filter does.
+ * Error bound (u = 2^-24): t~ carries a relative error <= 8 u against the exact quotient (one rounded subtraction,
+ * the reciprocal, one product), so |X~_w - X_w| <= e_p = 16 u (|t| + |o|) (|dir| <= 1 up to rounding; generous);
+ * the two products of the proxy add 2 u relative.  The proxy w~ of an axis edge therefore differs from the exact edge
+ * function V by at most |dir_k| |g| e_p (1 + 2 u) + 2 u |w~|, and the reference's computed value from V by at most
+ * 14 u Lo^2 (general filter, above).  With tau = max(tauW, tauRef + 2.5 |dir_k| gmax e_p), tauRef = 32 u Lo^2 -- twice
+ * the reference's bound -- |w~| > tau certifies the sign the reference computes; the diagonal keeps tauW. */
+struct FastRayRect { float tauRef, lw1, gmax; };
+VCM_HD void fast_ray_setup_rect(const DScene &sc, V3 org, V3 dir, FastRay &r, FastRayRect &rr)
+{
+    r.o = org; r.d = dir;
+    r.m = mk3(__builtin_fmaf(org.y, dir.z, -(org.z * dir.y)), __builtin_fmaf(org.z, dir.x, -(org.x * dir.z)),
+              __builtin_fmaf(org.x, dir.y, -(org.y * dir.x)));
+    const float oo = __builtin_fmaf(org.x, org.x, __builtin_fmaf(org.y, org.y, org.z * org.z));
+    const float dd = fmaxf(1.f, __builtin_fmaf(dir.x, dir.x, __builtin_fmaf(dir.y, dir.y, dir.z * dir.z)));
+    const float lw2 = fmaxf(oo, sc.fastRw2);
+    const V3 oc = org - ld3(sc.fastCenter);
+    const float lo = approx_sqrt(__builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, oc.z * oc.z))) * 1.00001f + sc.fastRadius;
+    const float lo2 = lo * lo;
+    r.tauW = (VCM_FILTER_U * dd) * __builtin_fmaf(64.f, lw2, 32.f * lo2);
+    rr.tauRef = (VCM_FILTER_U * 32.f * dd) * lo2;
+    rr.lw1 = approx_sqrt(oo) * 1.00001f;
+    rr.gmax = sc.fastGmax * 2.5f * dd;
+}
+template <int K> VCM_HD float v3c(V3 a) { return K == 0 ? a.x : (K == 1 ? a.y : a.z); }
+/* plane part + the five edge functions of one rectangle: L, U = bounds of the reference's distance; a0, a1, a2 the
+   edge functions of triangle A, b0, b1 (and -a2) those of B, as proxies with a common certainty threshold tau */
+template <int K>
+VCM_HD void fast_rect_plane(const FastRect &p, const FastRay &r, float &num, float &den, float &t, float &L, float &U)
+{
+    num = p.nk * (p.pk - v3c<K>(r.o));
+    den = p.nk * v3c<K>(r.d);
+    t = num * approx_rcp(den);
+    const float at = fabsf(t);
+    const float eps = (VCM_FILTER_U * 8.f) * at;
+    const bool known = at < 1e30f;      /* false for inf / NaN (den = 0 or denormal, overflow) */
+    L = known ? t - eps : -VCM_FILTER_INF;
+    U = known ? t + eps : VCM_FILTER_INF;
+}
+template <int K>
+VCM_HD void fast_rect_edges(const FastRect &p, const FastRay &r, const FastRayRect &rr, float t, FastHit &ha, FastHit &hb)
+{
+    constexpr int KU = (K + 1) % 3, KV = (K + 2) % 3;
+    const float dk = v3c<K>(r.d);
+    const float xu = __builtin_fmaf(t, v3c<KU>(r.d), v3c<KU>(r.o)), xv = __builtin_fmaf(t, v3c<KV>(r.d), v3c<KV>(r.o));
+    const float ep = (VCM_FILTER_U * 16.f) * (fabsf(t) + rr.lw1);
+    /* (an unknown t makes ep and the proxies NaN: fmaxf returns tauW, every comparison is false, nothing is certain) */
+    const float tau = fmaxf(r.tauW, __builtin_fmaf(fabsf(dk) * rr.gmax, ep, rr.tauRef));
+    const float a0 = (dk * p.g[0]) * (p.c[0] - xv);
+    const float a1 = (dk * p.g[1]) * (p.c[1] - xu);
+    const float b0 = (dk * p.g[2]) * (p.c[2] - xv);
+    const float b1 = (dk * p.g[3]) * (p.c[3] - xu);
+    const float a2 = fast_edge(p.NEd, r);
+    fast_classify(a0, a1, a2, tau, ha);
+    fast_classify(b0, b1, -a2, tau, hb);
+}
+template <int K>
+VCM_HD void rects_offer(const FastRect *rects, int n, const FastRay &r, const FastRayRect &rr, float tmin, float resDist, FastBest &fb)
+{
+    for (int i = 0; i < n; i++) {
+        const FastRect &p = rects[i];
+        FastHit ha, hb;
+        float num, den, t;
+        fast_rect_plane<K>(p, r, num, den, t, ha.L, ha.U);
+        fast_rect_edges<K>(p, r, rr, t, ha, hb);
+        /* one plane, two triangles: the same distance bounds for both; at most one of them contains the point */
+        const bool reach = !(ha.U <= tmin) && !(ha.L >= resDist), sure = (ha.L > tmin) && (ha.U < resDist);
+        const bool candA = reach && !ha.certOut, candB = reach && !hb.certOut;
+        const bool certA = sure && ha.certIn && hb.certOut, certB = sure && hb.certIn && ha.certOut;
+        fast_offer(fb, candA || candB, certA || certB, ha.L, ha.U, certB ? p.prim[1] : p.prim[0]);
+    }
+}
+template <int K>
+VCM_HD void rects_occluded(const FastRect *rects, int n, const FastRay &r, const FastRayRect &rr, float tmaxp, bool &occ, bool &unknown)
+{
+    for (int i = 0; i < n; i++) {
+        const FastRect &p = rects[i];
+        FastHit ha, hb;
+        float num, den, t;
+        fast_rect_plane<K>(p, r, num, den, t, ha.L, ha.U);
+        /* can the plane part report a hit in (0, tmax) at all?  (occluded_pairs below has the argument; num and den
+           are the reference's operands up to the sign of a zero, and a zero numerator is a miss for both) */
+        const bool reach = (((f2u(num) ^ f2u(den)) & 0x80000000u) == 0u) && !(fabsf(num) >= 1.000001f * (tmaxp * fabsf(den)));
+        if (!wave_any(reach && !occ)) continue;   /* no lane can report a hit: the wave skips the edges */
+        fast_rect_edges<K>(p, r, rr, t, ha, hb);
+        const bool inRange = (ha.L > 0.f) && (ha.U < tmaxp);
+        const bool hitA = reach && ha.certIn && inRange, missA = !reach || ha.certOut;
+        const bool hitB = reach && hb.certIn && inRange, missB = !reach || hb.certOut;
+        occ = occ || hitA || hitB;
+        unknown = unknown || !(hitA || missA) || !(hitB || missB);
+    }
+}
+
 /* Scene::Intersect over the list with the filter in front.  `certain` = this lane's answer is final. */
-template <bool ONE_PLANE>
+template <bool ONE_PLANE, bool RECTS = false>
 VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res, bool &certain)
 {
     FastRay r;
-    fast_ray_setup(sc, ray.org, ray.dir, r);
     FastBest fb;
     fb.minL1 = fb.minL2 = fb.bestU = VCM_FILTER_INF; fb.best = -1; fb.bestCertain = false;
-    if (ONE_PLANE) {
+    if (RECTS) {
+        FastRayRect rr;
+        fast_ray_setup_rect(sc, ray.org, ray.dir, r, rr);
+        const FastRect *rc = sc.fastRects();
+        rects_offer<0>(rc, sc.nFastRects[0], r, rr, ray.tmin, res.dist, fb);
+        rects_offer<1>(rc + sc.nFastRects[0], sc.nFastRects[1], r, rr, ray.tmin, res.dist, fb);
+        rects_offer<2>(rc + sc.nFastRects[0] + sc.nFastRects[1], sc.nFastRects[2], r, rr, ray.tmin, res.dist, fb);
+    } else fast_ray_setup(sc, ray.org, ray.dir, r);
+    if (RECTS) {
+    } else if (ONE_PLANE) {
         for (int i = 0; i < sc.nFastPairs; i++) {
             const FastPair &p = sc.fastPairs()[i];
             FastHit ha, hb;
@@ -1082,13 +1210,22 @@ VCM_HD void occluded_pairs(const DScene &sc, const FastRay &r, float tmaxp, bool
     }
 }
 /* Scene::Occluded over the list with the filter in front */
-template <bool ONE_PLANE>
+template <bool ONE_PLANE, bool RECTS = false>
 VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp, bool &certain)
 {
     FastRay r;
-    fast_ray_setup(sc, ray.org, ray.dir, r);
     bool occ = false, unknown = false;
-    occluded_pairs<ONE_PLANE>(sc, r, tmaxp, occ, unknown);
+    if (RECTS) {
+        FastRayRect rr;
+        fast_ray_setup_rect(sc, ray.org, ray.dir, r, rr);
+        const FastRect *rc = sc.fastRects();
+        rects_occluded<0>(rc, sc.nFastRects[0], r, rr, tmaxp, occ, unknown);
+        rects_occluded<1>(rc + sc.nFastRects[0], sc.nFastRects[1], r, rr, tmaxp, occ, unknown);
+        rects_occluded<2>(rc + sc.nFastRects[0] + sc.nFastRects[1], sc.nFastRects[2], r, rr, tmaxp, occ, unknown);
+    } else {
+        fast_ray_setup(sc, ray.org, ray.dir, r);
+        occluded_pairs<ONE_PLANE>(sc, r, tmaxp, occ, unknown);
+    }
     for (int i = 0; i < sc.nFastSpheres; i++) {
         const FastSphere &p = sc.fastSpheres()[i];
         FastRoots fr;
@@ -1114,7 +1251,7 @@ VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
 #if !defined(VCM_NO_FILTER)
     bool certain;
     Isect fast = res;
-    const bool hit = list_intersect_filtered<SC::kOnePlane>(sc, ray, fast, certain);
+    const bool hit = list_intersect_filtered<SC::kOnePlane, SC::kRects>(sc, ray, fast, certain);
 #if !defined(__HIP_DEVICE_COMPILE__)
     g_filterStats.isect++; if (!certain) g_filterStats.isectExact++;
 #endif
@@ -1143,7 +1280,7 @@ VCM_HD bool scene_occluded(const SC &sc, V3 point, V3 dir, float tmax)
     if constexpr (SC::kBvh) return bvh_occluded(sc, ray, tmaxp);
 #if !defined(VCM_NO_FILTER)
     bool certain;
-    const bool occ = list_occluded_filtered<SC::kOnePlane>(sc, ray, tmaxp, certain);
+    const bool occ = list_occluded_filtered<SC::kOnePlane, SC::kRects>(sc, ray, tmaxp, certain);
 #if !defined(__HIP_DEVICE_COMPILE__)
     g_filterStats.occl++; if (!certain) g_filterStats.occlExact++;
 #endif

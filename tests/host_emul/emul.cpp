@@ -17,6 +17,7 @@ using namespace vcm;
 template <class F> static void with_scene(const DScene &sc, F &&f)
 {
     if (sc.nNodes > 0) f(static_cast<const SceneBvh &>(sc));
+    else if (sc.fastOnePlane && sc.nFastRects[0] + sc.nFastRects[1] + sc.nFastRects[2] > 0) f(static_cast<const SceneRects &>(sc));
     else if (sc.fastOnePlane) f(static_cast<const SceneQuads &>(sc));
     else f(static_cast<const SceneList &>(sc));
 }
