@@ -385,47 +385,18 @@ inline void scene_host_build_bvh(SceneHost &s)
     const float pad = 1e-4f * extent + 1e-30f;
     s.nodes.reserve((size_t)n);
     bvh_build_node(s, bp, 0, n, pad);
-    /* the wide view (vcm_core.h BvhWide): the binary tree collapsed two levels at a time.  A wide node belongs to the
-       root and to every inner node that is a CHILD of a wide node; its (up to four) children are the binary node's
-       grandchildren, or a child itself where that is a leaf.  The left child is the next node in memory, the right one
-       the left's escape.  Inner nodes that were collapsed away are never referred to. */
+    /* the wide view: inner nodes numbered in depth-first order, each holding the boxes of its two children -- the left
+       child is the next node in memory, the right one the left's escape */
     s.wide.clear();
-    std::vector<int> todo;
-    std::vector<int> wideOf(s.nodes.size(), VCM_BVH_NONE);
-    if (!s.nodes.empty() && s.nodes[0].leaf < 0) { wideOf[0] = 0; s.wide.push_back(BvhWide()); todo.push_back(0); }
-    for (size_t q = 0; q < todo.size(); q++) {
-        const int i = todo[q];
-        int kids[4], nk = 0;
-        const int l = i + 1, r = s.nodes[(size_t)l].escape;
-        const int two[2] = { l, r };
-        for (int h = 0; h < 2; h++) {
-            const int c = two[h];
-            if (s.nodes[(size_t)c].leaf >= 0) kids[nk++] = c;                       /* a leaf stays a child */
-            else { kids[nk++] = c + 1; kids[nk++] = s.nodes[(size_t)c + 1].escape; }   /* an inner child gives way to its children */
-        }
-        BvhWide w;
-        std::memset(&w, 0, sizeof(w));
-        for (int c = 0; c < 4; c++) {
-            if (c < nk) {
-                const BvhNode &kd = s.nodes[(size_t)kids[c]];
-                for (int a = 0; a < 3; a++) { w.bmin[a][c] = kd.bmin[a]; w.bmax[a][c] = kd.bmax[a]; }
-                w.node[c] = kids[c];
-                if (kd.leaf >= 0) w.ref[c] = kd.leaf;
-                else {
-                    if (wideOf[(size_t)kids[c]] == VCM_BVH_NONE) { wideOf[(size_t)kids[c]] = (int)s.wide.size(); s.wide.push_back(BvhWide()); todo.push_back(kids[c]); }
-                    w.ref[c] = -1 - wideOf[(size_t)kids[c]];
-                }
-            } else {
-                for (int a = 0; a < 3; a++) { w.bmin[a][c] = 3.0e37f; w.bmax[a][c] = 3.0e37f; }
-                w.node[c] = 0; w.ref[c] = VCM_BVH_NONE;
-            }
-        }
-        s.wide[(size_t)wideOf[(size_t)i]] = w;
+    for (size_t i = 0; i < s.nodes.size(); i++) if (s.nodes[i].leaf < 0) { s.nodes[i].leaf = -1 - (int)s.wide.size(); s.wide.push_back(BvhWide()); }
+    for (size_t i = 0; i < s.nodes.size(); i++) {
+        if (s.nodes[i].leaf >= 0) continue;
+        BvhWide &w = s.wide[(size_t)(-1 - s.nodes[i].leaf)];
+        const int l = (int)i + 1, r = s.nodes[(size_t)l].escape;
+        const BvhNode &nl = s.nodes[(size_t)l], &nr = s.nodes[(size_t)r];
+        for (int k = 0; k < 3; k++) { w.lmin[k] = nl.bmin[k]; w.lmax[k] = nl.bmax[k]; w.rmin[k] = nr.bmin[k]; w.rmax[k] = nr.bmax[k]; }
+        w.lnode = l; w.lref = nl.leaf; w.rnode = r; w.rref = nr.leaf;
     }
-    /* BvhNode::leaf of an inner node: -1 - its wide index (what a popped stack entry turns into), VCM_BVH_NONE... never
-       for a node the traversal can hold: the root and the children of wide nodes all have one */
-    for (size_t i = 0; i < s.nodes.size(); i++)
-        if (s.nodes[i].leaf < 0) s.nodes[i].leaf = (wideOf[i] == VCM_BVH_NONE) ? -1 - 0x3fffffff : -1 - wideOf[i];
     s.leafData.resize(s.leafPrims.size());
     for (size_t i = 0; i < s.leafPrims.size(); i++) { s.leafData[i].prim = s.prims[(size_t)s.leafPrims[i]]; s.leafData[i].index = s.leafPrims[i]; s.leafData[i].pad = 0; }
 }

@@ -262,26 +262,25 @@ struct alignas(16) FastRect {
 struct alignas(16) BvhNode {
     float bmin[3]; int escape;        /* index of the node after this subtree (nNodes at the end) */
     float bmax[3]; int leaf;          /* >= 0: (first << 4) | count into leafPrims, count <= 15; < 0: inner node, -1 - its index
-                                         in the array of wide nodes (VCM_BVH_NONE for an inner node that was collapsed into its
-                                         parent's wide node: nothing ever refers to it) */
+                                         in the array of wide nodes */
 };
-/* The same hierarchy as the ordered traversals walk it, FOUR children wide: the binary tree collapsed two levels at a
- * time -- a wide node holds the boxes of an inner node's grandchildren (or of a child that is a leaf), 128 bytes = eight
- * 16-byte loads that go out together.  The traversals are bound by the latency of their dependent loads, not by slab
- * tests: with BvhNode alone a level of the BINARY tree cost two dependent round trips (the node, then its right child,
- * found through the left one); one wide node per binary level (the first version of round 3) made it one; this makes
- * it one per TWO binary levels.  A child is named twice: `node` = its BvhNode (what goes on the closest-hit stack: the
- * box is tested again when it is popped, against the distance held by then), `ref` = what to do with it: >= 0 a leaf
- * (the descriptor of BvhNode::leaf), < 0 an inner node, -1 - its wide index; VCM_BVH_NONE = no such child. */
-#define VCM_BVH_NONE 0x7fffffff
+/* The same hierarchy as the ordered traversals walk it: one 64-byte record per INNER node holding the boxes of BOTH
+ * children and what they are, so a level costs one load (four 16-byte words) and two slab tests -- with BvhNode alone it
+ * was the node, its left child and, dependent on that, the right child: two dependent round trips per level.  A child
+ * is named twice: `node` = its BvhNode (what goes on the closest-hit stack: the box is tested again when it is popped,
+ * against the distance held by then), `ref` = what to do with it: >= 0 a leaf (the descriptor of BvhNode::leaf),
+ * < 0 an inner node, -1 - its wide index. */
 /* The primitives of the leaves, copied in LEAF order with their list index: a leaf's (at most 15, usually <= 4)
  * primitives are one contiguous run of 64-byte records -- through leafPrims[] -> prims[] every triangle test began with
  * two dependent gathers. */
 struct alignas(16) LeafPrim { vcm_prim prim; int index; int pad; };
 struct alignas(16) BvhWide {
-    float bmin[3][4], bmax[3][4];   /* [axis][child] */
-    int node[4], ref[4];
+    float lmin[3]; int lnode;
+    float lmax[3]; int lref;
+    float rmin[3]; int rnode;
+    float rmax[3]; int rref;
 };
+
 /* The scene as the device functions see it.  Scalars are those of vcm_scene_desc (the C-ABI struct the scene arrives
  * in); primitives, materials, lights and the structure the intersection code walks are arrays of any length, so the
  * same code serves the reference's built-in boxes (<= 32 primitives, brute force in list order over packed triangle
@@ -680,10 +679,11 @@ VCM_HD bool bvh_leaf_occluded(const DScene &sc, int leaf, const Ray &ray, float 
     return occluded;
 }
 
-/* The traversal stack: 32 entries per lane, in LDS on the device ([level][thread], no bank conflicts; 32 KB per block of
+/* The traversal stack: 32 levels per lane, in LDS on the device ([level][thread], no bank conflicts; 32 KB per block of
  * 256 lanes), ONE array for the closest-hit and the any-hit traversal -- a kernel that runs both (strict mode) never
- * has both alive.  A wide node pushes at most three entries, a ray that overflows finishes with the threaded walk. */
+ * has both alive.  A deeper tree finishes the ray with the threaded walk. */
 #define VCM_BVH_STACK 32
+#define VCM_BVH_NONE 0x7fffffff
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ int *bvh_stack(int &stride)
 {
@@ -692,37 +692,14 @@ __device__ __forceinline__ int *bvh_stack(int &stride)
     return &stackNode[0][threadIdx.x];
 }
 #endif
-/* the four slab tests of a wide node: entry distances (3e38 for a child whose box is not met within [0, tmax]) */
-VCM_HD void bvh_wide_test(const BvhWide &w, V3 org, V3 invDir, float tmax, float tn[4])
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int c = 0; c < 4; c++) {
-        const float ax = (w.bmin[0][c] - org.x) * invDir.x, bx = (w.bmax[0][c] - org.x) * invDir.x;
-        const float ay = (w.bmin[1][c] - org.y) * invDir.y, by = (w.bmax[1][c] - org.y) * invDir.y;
-        const float az = (w.bmin[2][c] - org.z) * invDir.z, bz = (w.bmax[2][c] - org.z) * invDir.z;
-        /* fminf / fmaxf return the other operand for a NaN (0 * inf on a slab plane): the slab then does not constrain */
-        const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-        const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-        tn[c] = (w.ref[c] != VCM_BVH_NONE && tnear <= tfar * 1.0000004f) ? tnear : 3.0e38f;
-    }
-}
-/* order (distance, payload) pairs by distance: five compare-exchanges */
-VCM_HD void bvh_cswap(float &ta, int &pa, int &qa, float &tb, int &pb, int &qb)
-{
-    const bool sw = tb < ta;
-    const float t0 = sw ? tb : ta, t1 = sw ? ta : tb;
-    const int p0 = sw ? pb : pa, p1 = sw ? pa : pb, q0 = sw ? qb : qa, q1 = sw ? qa : qb;
-    ta = t0; tb = t1; pa = p0; pb = p1; qa = q0; qb = q1;
-}
 
-/* Closest hit, ORDERED: the (up to four) children whose boxes are met are visited nearest first -- the nearest now, the
- * others pushed farthest first, each to be dropped unvisited if a hit closer than its box has been found by the time it
- * is popped (its own BvhNode is loaded then and tested against the distance held NOW).  The loop is "while-while": a
- * lane keeps descending until it holds a leaf, and the leaves are intersected when no lane of the wave has an inner
- * node left -- so the slab tests run with the lanes that descend and the triangle tests with the lanes that hold
- * leaves, instead of every step paying for both.
+/* Closest hit, ORDERED, one wide node per level: both children's boxes are tested, the nearer is descended first and
+ * the farther goes on the stack, to be dropped unvisited if a hit closer than its box has been found by the time it is
+ * popped (its own BvhNode is loaded then and tested against the distance held NOW) -- the threaded walk (the first
+ * version of this function) visits the subtrees in memory order whatever the ray's direction and prunes only by what
+ * it happens to have found.  The loop is "while-while": a lane keeps descending until it holds a leaf, and the leaves
+ * are intersected when no lane of the wave has an inner node left -- so the slab tests run with the lanes that
+ * descend and the triangle tests with the lanes that hold leaves, instead of every step paying for both.
  * The visiting order cannot change the result: the winner is the minimum of (distance, list index), and a
  * primitive within 2 ulp of the winner is never pruned (the boxes are padded by 1e-4 of the scene, scene_host.h), so
  * the near-tie rule sees the same pairs. */
@@ -750,30 +727,26 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
     }
 #endif
     for (;;) {
-        while (ref < 0) {   /* an inner node: one 128-byte record, four slab tests */
+        while (ref < 0) {   /* an inner node: one 64-byte record, two slab tests */
             const BvhWide w = sc.wide()[-1 - ref];
-            float t[4];
-            bvh_wide_test(w, ray.org, invDir, res.dist, t);
-            int nd[4] = { w.node[0], w.node[1], w.node[2], w.node[3] }, rf[4] = { w.ref[0], w.ref[1], w.ref[2], w.ref[3] };
-            bvh_cswap(t[0], nd[0], rf[0], t[1], nd[1], rf[1]); bvh_cswap(t[2], nd[2], rf[2], t[3], nd[3], rf[3]);
-            bvh_cswap(t[0], nd[0], rf[0], t[2], nd[2], rf[2]); bvh_cswap(t[1], nd[1], rf[1], t[3], nd[3], rf[3]);
-            bvh_cswap(t[1], nd[1], rf[1], t[2], nd[2], rf[2]);
-            /* t[0] <= t[1] <= t[2] <= t[3]; the met ones come first.  Farthest first onto the stack */
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int c = 3; c >= 1; c--) {
-                if (t[c] < 3.0e38f) {
-                    if (sp < VCM_BVH_STACK) { sn[sp * stride] = nd[c]; sp++; }
-                    else overflow = true;
+            float tl, tr;
+            const bool hl = bvh_box_near6(w.lmin, w.lmax, ray.org, invDir, res.dist, tl);
+            const bool hr = bvh_box_near6(w.rmin, w.rmax, ray.org, invDir, res.dist, tr);
+            if (hl && hr) {
+                const bool leftFirst = tl <= tr;
+                if (sp < VCM_BVH_STACK) { sn[sp * stride] = leftFirst ? w.rnode : w.lnode; sp++; }
+                else overflow = true;
+                ref = leftFirst ? w.lref : w.rref;
+            } else if (hl) ref = w.lref;
+            else if (hr) ref = w.rref;
+            else {   /* next pending subtree that can still hold a closer (or equal: the tie rule) hit */
+                ref = VCM_BVH_NONE;
+                while (ref == VCM_BVH_NONE && sp > 0) {
+                    sp--;
+                    const BvhNode nd = sc.nodes()[sn[sp * stride]];
+                    float t;
+                    if (bvh_box_near(nd, ray.org, invDir, res.dist, t)) ref = nd.leaf;
                 }
-            }
-            ref = (t[0] < 3.0e38f) ? rf[0] : VCM_BVH_NONE;
-            while (ref == VCM_BVH_NONE && sp > 0) {   /* next pending subtree that can still hold a closer (or equal: the tie rule) hit */
-                sp--;
-                const BvhNode pn = sc.nodes()[sn[sp * stride]];
-                float tt;
-                if (bvh_box_near(pn, ray.org, invDir, res.dist, tt)) ref = pn.leaf;
             }
         }
         if (ref == VCM_BVH_NONE) break;
@@ -781,13 +754,13 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
         ref = VCM_BVH_NONE;
         while (ref == VCM_BVH_NONE && sp > 0) {
             sp--;
-            const BvhNode pn = sc.nodes()[sn[sp * stride]];
-            float tt;
-            if (bvh_box_near(pn, ray.org, invDir, res.dist, tt)) ref = pn.leaf;
+            const BvhNode nd = sc.nodes()[sn[sp * stride]];
+            float t;
+            if (bvh_box_near(nd, ray.org, invDir, res.dist, t)) ref = nd.leaf;
         }
         if (ref == VCM_BVH_NONE) break;
     }
-    if (overflow) {   /* more pending subtrees than the stack holds: the threaded walk over the whole tree (order-free, same result) */
+    if (overflow) {   /* deeper than the stack: the threaded walk over the whole tree (order-free, same result) */
         int nodeT = 0;
         while (nodeT < sc.nNodes) {
             const BvhNode nd = sc.nodes()[nodeT];
@@ -803,8 +776,8 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
 
 /* Scene::Occluded over the BVH: any hit in (0, tmax).  The answer does not depend on the order, and tmax does not
  * shrink: a child whose box is met is simply remembered by its REF and needs no second test when it is popped -- one
- * 128-byte record per wide node is all the traversal loads above the leaves (the threaded walk of rounds 1-2 loaded a
- * 32-byte node per visited node, each load dependent on the one before).  While-while as above; the nearest child
+ * 64-byte record per inner node is all the traversal loads above the leaves (the threaded walk of rounds 1-2 loaded a
+ * 32-byte node per visited node, each load dependent on the one before).  While-while as above; the nearer child
  * first, because an occluder near the origin ends the ray. */
 VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
 {
@@ -828,37 +801,26 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
     }
 #endif
     while (!overflow) {
-        while (ref < 0 && !overflow) {
+        while (ref < 0) {
             const BvhWide w = sc.wide()[-1 - ref];
-            float t[4];
-            bvh_wide_test(w, ray.org, invDir, tmaxp, t);
-            /* the nearest met child next, the other met ones remembered (any order) */
-            int best = 0;
-            float tb = t[0];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int c = 1; c < 4; c++) if (t[c] < tb) { tb = t[c]; best = c; }
-            int next = VCM_BVH_NONE;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int c = 0; c < 4; c++) {
-                if (t[c] < 3.0e38f) {
-                    if (c == best) next = w.ref[c];
-                    else if (sp < VCM_BVH_STACK) { sn[sp * stride] = w.ref[c]; sp++; }
-                    else overflow = true;
-                }
-            }
-            ref = next;
-            if (ref == VCM_BVH_NONE && sp > 0) { sp--; ref = sn[sp * stride]; }
+            float tl, tr;
+            const bool hl = bvh_box_near6(w.lmin, w.lmax, ray.org, invDir, tmaxp, tl);
+            const bool hr = bvh_box_near6(w.rmin, w.rmax, ray.org, invDir, tmaxp, tr);
+            if (hl && hr) {
+                const bool leftFirst = tl <= tr;
+                if (sp < VCM_BVH_STACK) { sn[sp * stride] = leftFirst ? w.rref : w.lref; sp++; ref = leftFirst ? w.lref : w.rref; }
+                else { overflow = true; ref = VCM_BVH_NONE; }
+            } else if (hl) ref = w.lref;
+            else if (hr) ref = w.rref;
+            else if (sp > 0) { sp--; ref = sn[sp * stride]; }
+            else ref = VCM_BVH_NONE;
         }
-        if (overflow || ref == VCM_BVH_NONE) break;
+        if (ref == VCM_BVH_NONE) break;
         if (bvh_leaf_occluded(sc, ref, ray, tmaxp)) { occluded = true; break; }
         if (sp > 0) { sp--; ref = sn[sp * stride]; }
         else break;
     }
-    if (overflow && !occluded) {   /* more pending subtrees than the stack holds: the threaded walk over the whole tree */
+    if (overflow && !occluded) {   /* deeper than the stack: the threaded walk over the whole tree */
         int node = 0;
         while (node < sc.nNodes && !occluded) {
             const BvhNode nd = sc.nodes()[node];
