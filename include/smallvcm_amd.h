@@ -156,11 +156,13 @@ typedef struct vcm_stats {
     long long mergeAccepted;   /* A: RangeQuery::Process calls                */
     long long connections;     /* K: ConnectVertices calls                    */
     long long lightSplats;     /* S: Framebuffer::AddColor from light paths   */
-    float msLight, msGrid, msCamera, msTotal; /* phases: light(+compaction), grid build, camera(+resolve) */
+    float msLight, msGrid, msCamera, msTotal; /* phases: light(+compaction; the light splats run on a stream of their own
+                                                 and end inside msCamera), grid build, camera(+resolve) */
     float msLightKernel, msCameraKernel;      /* k_light_trace / k_camera_trace alone        */
     float msMergeKernel;                      /* k_merge_lane (0 in strict-order mode)       */
     float msQuerySort;                        /* camera-vertex counting sort (0 in strict mode) */
-    float msConnectKernels;                   /* k_connect_di + k_connect_vc (0 in strict mode) */
+    float msConnectKernels;                   /* k_connect_di + k_connect_vc (0 in strict mode); on frames below 2048^2
+                                                 k_connect_vc runs on another stream and is not in this span */
     float radius;              /* merge radius of the iteration               */
 } vcm_stats;
 
