@@ -415,8 +415,22 @@ static int ensure_device(vcm_ctx *c)
     if (!c->deviceReady) {
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
+        {   /* the two helper streams at the lowest priority: the grid build and the light splats fill what the main
+               stream's kernels leave free instead of sharing the chip evenly with them -- 885.6 -> 893.3 Mpaths/s, same
+               box, two runs each (profiles/r05k_prio.txt; in round 2, with one helper stream, it moved nothing).
+               SMALLVCM_AMD_STREAM_PRIO=0: equal priorities */
+            static int prio = -1;
+            if (prio < 0) { const char *e = getenv("SMALLVCM_AMD_STREAM_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
+            int lo = 0, hi = 0;
+            if (prio) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   /* lo = the numerically largest = least urgent */
+            if (prio) {
+                HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo));
+                HIPCHK(hipStreamCreateWithPriority(&c->splat, hipStreamNonBlocking, lo));
+            } else {
+                HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+                HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
+            }
+        }
         HIPCHK(hipEventCreateWithFlags(&c->evSplatFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSplatDone, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
