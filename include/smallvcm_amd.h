@@ -161,8 +161,8 @@ typedef struct vcm_stats {
     float msLightKernel, msCameraKernel;      /* k_light_trace / k_camera_trace alone        */
     float msMergeKernel;                      /* k_merge_lane (0 in strict-order mode)       */
     float msQuerySort;                        /* camera-vertex counting sort (0 in strict mode) */
-    float msConnectKernels;                   /* k_connect_di + k_connect_vc (0 in strict mode); on frames below 2048^2
-                                                 k_connect_vc runs on another stream and is not in this span */
+    float msConnectKernels;                   /* k_connect_di (0 in strict mode); k_connect_vc runs on another stream and is
+                                                 not in this span */
     float radius;              /* merge radius of the iteration               */
 } vcm_stats;
 

@@ -1315,12 +1315,13 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
-            /* K3c reads what K3 appended and the light store, and only K5 reads what it writes: on frames too small to
-               fill the chip it runs on the splat stream, next to K3b and K4 (joined before K5).  At 2048^2 the VALU-bound
-               K3c next to K4 cost 5 % (round 1).  SMALLVCM_AMD_VC_STREAM=0 / 1 forces it off / on. */
+            /* K3c reads what K3 appended and the light store, and only K5 reads what it writes: it runs on the splat
+               stream, next to K3b and K4, joined before K5: +2 % at 512^2, +6 % at 1024^2 (profiles/r05d_ab_summary.txt)
+               and, since the helper streams have the lowest priority, +1.4 % at 2048^2 (profiles/r05l_prio2.txt; with
+               equal priorities the VALU-bound K3c next to K4 bought nothing there).  SMALLVCM_AMD_VC_STREAM=0: in line. */
             static int vcForce = -2;
             if (vcForce == -2) { const char *e = getenv("SMALLVCM_AMD_VC_STREAM"); vcForce = e ? (e[0] == '1' ? 1 : 0) : -1; }
-            const bool vcAside = (vcForce >= 0 ? vcForce == 1 : c->nLocal < (1 << 21)) && c->world == 1;
+            const bool vcAside = (vcForce != 0) && c->world == 1;
             if (vcAside) {
                 HIPCHK(hipEventRecord(c->evSplatFork, c->stream));   /* behind K3 */
                 HIPCHK(hipStreamWaitEvent(c->splat, c->evSplatFork, 0));
