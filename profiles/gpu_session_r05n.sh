@@ -1,0 +1,23 @@
+#!/bin/bash
+# r05n: rectangle loop read one entry ahead, one reciprocal per axis, scalar primitive indices -- against the previous build
+set -u
+export TMPDIR=/tmp
+tag=${1:-r05n}
+mkdir -p gpurun_out
+out=gpurun_out/${tag}_ab.txt
+: > $out
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3 | tee -a $out
+B="python bench.py --no-cpu-baseline --no-configs --no-traffic --steps 12 --warmup 3"
+p() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']['per_kernel']; print(d['value'], d['ms_per_step'], r['k_light_trace']['ms'], r['k_camera_trace']['ms'], r['k_connect_di+vc']['ms'], r['k_merge']['ms'])"; }
+PREV=$PWD/smallvcm_amd/csrc/libsmallvcm_amd_prev.so
+for rep in 1 2; do
+  echo "== prev-$rep" | tee -a $out; SMALLVCM_AMD_LIB=$PREV $B 2>/dev/null | grep '^{' | p | tee -a $out
+  echo "== new-$rep" | tee -a $out; $B 2>/dev/null | grep '^{' | p | tee -a $out
+done
+echo "== prev-512" | tee -a $out; SMALLVCM_AMD_LIB=$PREV $B --res 512 2>/dev/null | grep '^{' | p | tee -a $out
+echo "== new-512" | tee -a $out; $B --res 512 2>/dev/null | grep '^{' | p | tee -a $out
+echo "== prev-s3" | tee -a $out; SMALLVCM_AMD_LIB=$PREV $B --scene 3 --res 1024 2>/dev/null | grep '^{' | p | tee -a $out
+echo "== new-s3" | tee -a $out; $B --scene 3 --res 1024 2>/dev/null | grep '^{' | p | tee -a $out
+export SMALLVCM_AMD_LIB=$PWD/smallvcm_amd/csrc/libsmallvcm_amd_rc.so
+timeout 120 python profiles/tools/region_clock.py 1 2048 vcm > gpurun_out/${tag}_region_clock.txt 2>&1
+cat gpurun_out/${tag}_region_clock.txt | head -32

@@ -149,6 +149,35 @@ VCM_HD void lane_stats_zero(LaneStats &s)
     s.mergeAccepted = s.connections = s.lightSplats = s.stored = 0;
 }
 
+/* Measurement build only (make variant NAME=rc EXTRA=-DVCM_REGION_CLOCK, profiles/tools/region_clock.py): where
+ * the shader-clock time of a wave goes inside the big kernels.  RC_MARK(id) charges the cycles since the previous
+ * mark of this wave to region `id` (first active lane: one atomic per wave and mark).  Compiles to nothing otherwise. */
+#if defined(VCM_REGION_CLOCK) && defined(__HIPCC__)
+#define VCM_RC_SLOTS 2048   /* one row per (wave mod SLOTS): the marks of a launch would otherwise queue on a dozen words */
+__device__ unsigned long long g_regionClock[VCM_RC_SLOTS * 64];   /* row: [id] cycles, [32 + id] marks */
+#endif
+#if defined(VCM_REGION_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
+struct RegionClock { unsigned long long t; };
+__device__ __forceinline__ void rc_mark(RegionClock &r, int id)
+{
+    const unsigned long long n = clock64();
+    const unsigned long long m = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)m) - 1) {
+        unsigned long long *row = g_regionClock + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (VCM_RC_SLOTS - 1)) * 64;
+        atomicAdd(&row[id], n - r.t);
+        atomicAdd(&row[32 + id], 1ull);
+    }
+    r.t = clock64();
+}
+#define RC_DECL RegionClock rc_; rc_.t = clock64()
+#define RC_MARK(id) rc_mark(rc_, id)
+#define RC_RESET rc_.t = clock64()
+#else
+#define RC_DECL
+#define RC_MARK(id)
+#define RC_RESET
+#endif
+
 /* float atomic add to the framebuffer (light splats land on arbitrary
  * pixels: vertexcm.hxx:931).  Order of concurrent adds is not defined, which
  * is the one place results are not bit-reproducible (DESIGN.md "Parity"). */
@@ -908,6 +937,15 @@ VCM_HD float approx_sqrt(float x) { return sqrtf(x); }
 struct FilterStats { unsigned long long isect, isectExact, occl, occlExact; };
 inline FilterStats g_filterStats = { 0, 0, 0, 0 };
 #endif
+/* v_min_f32 / v_max_f32 as they are (minNum / maxNum: a NaN operand loses, which the filter relies on); fminf / fmaxf
+   compile to the same instruction behind a canonicalising v_max_f32 x, x of every operand that might be a signalling NaN */
+#if defined(__HIP_DEVICE_COMPILE__)
+VCM_HD float filter_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+VCM_HD float filter_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+VCM_HD float filter_min(float a, float b) { return fminf(a, b); }
+VCM_HD float filter_max(float a, float b) { return fmaxf(a, b); }
+#endif
 #define VCM_FILTER_U 5.9604645e-8f          /* 2^-24 */
 #define VCM_FILTER_INF 3.0e38f
 struct FastRay { V3 o, d, m; float tauW; };
@@ -943,10 +981,14 @@ VCM_HD float fast_edge(const float *NE, const FastRay &r)
 }
 VCM_HD void fast_classify(float w0, float w1, float w2, float tau, FastHit &h)
 {
-    const bool n0 = w0 < -tau, n1 = w1 < -tau, n2 = w2 < -tau;
-    const bool p0 = w0 > tau, p1 = w1 > tau, p2 = w2 > tau;
-    h.certIn = (n0 && n1 && n2) || (p0 && p1 && p2);     /* geometry.hxx:141-142, signs certain */
-    h.certOut = (n0 || n1 || n2) && (p0 || p1 || p2);
+    /* geometry.hxx:141-142 with certain signs: all three below -tau or all three above tau = certainly inside; one below
+       -tau and one above tau = certainly outside.  Taken on the smallest and the largest of the three (v_min3 / v_max3,
+       four comparisons, two mask operations -- six comparisons and ten mask operations when written per edge, and the
+       scalar unit issues no faster than a SIMD: profiles/r05o_ab.txt, +1.3 %).  min / max skip a NaN operand, so a
+       caller whose operands can be NaN makes tau infinite instead (fast_rect_edges; Pluecker edges are finite). */
+    const float lo = fminf(fminf(w0, w1), w2), hi = fmaxf(fmaxf(w0, w1), w2);
+    h.certIn = (bool)((int)(hi < -tau) | (int)(lo > tau));
+    h.certOut = (bool)((int)(lo < -tau) & (int)(hi > tau));
 }
 /* the edge functions of both triangles of an entry */
 VCM_HD void fast_pair_edges(const FastPair &p, const FastRay &r, FastHit &ha, FastHit &hb)
@@ -998,11 +1040,11 @@ VCM_HD void fast_offer(FastBest &fb, bool cand, bool cert, float L, float U, int
 {
     const float Lc = cand ? L : VCM_FILTER_INF;
     const bool isBest = Lc < fb.minL1;
-    fb.minL2 = fminf(fb.minL2, isBest ? fb.minL1 : Lc);
+    fb.minL2 = filter_min(fb.minL2, isBest ? fb.minL1 : Lc);
     fb.minL1 = isBest ? Lc : fb.minL1;
     fb.best = isBest ? prim : fb.best;
     fb.bestU = isBest ? U : fb.bestU;
-    fb.bestCertain = isBest ? cert : fb.bestCertain;
+    fb.bestCertain = (bool)(((int)isBest & (int)cert) | ((int)!isBest & (int)fb.bestCertain));   /* mask logic (scalar unit): no select of 0 / 1, no branch */
 }
 /* ---- the filter for lists of axis-aligned rectangles (FastRect) ----
  * Per rectangle: the plane distance t from the reference's own operands (for a normal along axis k they are
@@ -1035,12 +1077,14 @@ VCM_HD void fast_ray_setup_rect(const DScene &sc, V3 org, V3 dir, FastRay &r, Fa
 template <int K> VCM_HD float v3c(V3 a) { return K == 0 ? a.x : (K == 1 ? a.y : a.z); }
 /* plane part + the five edge functions of one rectangle: L, U = bounds of the reference's distance; a0, a1, a2 the
    edge functions of triangle A, b0, b1 (and -a2) those of B, as proxies with a common certainty threshold tau */
+/* (n_k = +-1 exactly -- scene_host_build_rects admits nothing else -- so the reference's operands are
+   num = +-(p_k - o_k), den = +-dir_k with the SAME sign, and num * rcp(den) = (p_k - o_k) * rcp(dir_k) bit for bit:
+   one reciprocal per axis group instead of one per rectangle; `inv` = rcp(dir_k).) */
 template <int K>
-VCM_HD void fast_rect_plane(const FastRect &p, const FastRay &r, float &num, float &den, float &t, float &L, float &U)
+VCM_HD void fast_rect_plane(const FastRect &p, const FastRay &r, float inv, float &num, float &t, float &L, float &U)
 {
-    num = p.nk * (p.pk - v3c<K>(r.o));
-    den = p.nk * v3c<K>(r.d);
-    t = num * approx_rcp(den);
+    num = p.pk - v3c<K>(r.o);
+    t = num * inv;
     const float at = fabsf(t);
     const float eps = (VCM_FILTER_U * 8.f) * at;
     const bool known = at < 1e30f;      /* false for inf / NaN (den = 0 or denormal, overflow) */
@@ -1054,8 +1098,9 @@ VCM_HD void fast_rect_edges(const FastRect &p, const FastRay &r, const FastRayRe
     const float dk = v3c<K>(r.d);
     const float xu = __builtin_fmaf(t, v3c<KU>(r.d), v3c<KU>(r.o)), xv = __builtin_fmaf(t, v3c<KV>(r.d), v3c<KV>(r.o));
     const float ep = (VCM_FILTER_U * 16.f) * (fabsf(t) + rr.lw1);
-    /* (an unknown t makes ep and the proxies NaN: fmaxf returns tauW, every comparison is false, nothing is certain) */
-    const float tau = fmaxf(r.tauW, __builtin_fmaf(fabsf(dk) * rr.gmax, ep, rr.tauRef));
+    /* an unknown t (inf / NaN) makes ep and the proxies NaN: nothing may be certain then */
+    const float tauKnown = filter_max(r.tauW, __builtin_fmaf(fabsf(dk) * rr.gmax, ep, rr.tauRef));
+    const float tau = (fabsf(t) < 1e30f) ? tauKnown : VCM_FILTER_INF;
     const float a0 = (dk * p.g[0]) * (p.c[0] - xv);
     const float a1 = (dk * p.g[1]) * (p.c[1] - xu);
     const float b0 = (dk * p.g[2]) * (p.c[2] - xv);
@@ -1064,41 +1109,106 @@ VCM_HD void fast_rect_edges(const FastRect &p, const FastRay &r, const FastRayRe
     fast_classify(a0, a1, a2, tau, ha);
     fast_classify(b0, b1, -a2, tau, hb);
 }
+/* a value every lane holds alike, kept in a scalar register (the compiler otherwise selects between the ADDRESSES of
+   prim[0] and prim[1] per lane and fetches the index with a vector load the loop then waits for, once per entry) */
+/* nothing is scheduled across this point (the read-ahead below must be ISSUED before the arithmetic it overlaps) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VCM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+/* first use of a scalar that a load in flight delivers: the s_waitcnt lands HERE.  Scalar loads return out of order,
+   so the only wait there is is lgkmcnt(0), for all of them: the entry being waited for must be the only one in flight,
+   i.e. the next entry's loads are issued after this point, not before */
+#define VCM_AWAIT_SCALAR(x) asm volatile("; await" :: "s"(x))
+#else
+#define VCM_SCHED_FENCE()
+#define VCM_AWAIT_SCALAR(x)
+#endif
+VCM_HD int wave_uniform(int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+/* The entries are read one AHEAD (scalar loads: the next entry's burst is in flight while this one is evaluated;
+   issued and awaited in the same trip, the loads were what the loop waited for, four waves of a SIMD together), in a
+   loop unrolled by two with two register sets: with one set the compiler copies the 17 prefetched words into place
+   with 34 s_mov per entry, and the scalar unit issues no faster than a SIMD does (one instruction per four cycles
+   each): the loop then ran at the pace of its ~60 scalar instructions instead of its 58 vector ones. */
+template <int K>
+VCM_HD void rect_offer_one(const FastRect &p, const FastRay &r, const FastRayRect &rr, float inv, float tmin, float resDist, FastBest &fb)
+{
+    FastHit ha, hb;
+    float num, t;
+    fast_rect_plane<K>(p, r, inv, num, t, ha.L, ha.U);
+    fast_rect_edges<K>(p, r, rr, t, ha, hb);
+    /* one plane, two triangles: the same distance bounds for both; at most one of them contains the point */
+    const bool reach = !(ha.U <= tmin) && !(ha.L >= resDist), sure = (ha.L > tmin) && (ha.U < resDist);
+    const bool candA = reach && !ha.certOut, candB = reach && !hb.certOut;
+    const bool certA = sure && ha.certIn && hb.certOut, certB = sure && hb.certIn && ha.certOut;
+    const int primA = wave_uniform(p.prim[0]), primB = wave_uniform(p.prim[1]);
+    fast_offer(fb, candA || candB, certA || certB, ha.L, ha.U, certB ? primB : primA);
+}
 template <int K>
 VCM_HD void rects_offer(const FastRect *rects, int n, const FastRay &r, const FastRayRect &rr, float tmin, float resDist, FastBest &fb)
 {
-    for (int i = 0; i < n; i++) {
-        const FastRect &p = rects[i];
-        FastHit ha, hb;
-        float num, den, t;
-        fast_rect_plane<K>(p, r, num, den, t, ha.L, ha.U);
-        fast_rect_edges<K>(p, r, rr, t, ha, hb);
-        /* one plane, two triangles: the same distance bounds for both; at most one of them contains the point */
-        const bool reach = !(ha.U <= tmin) && !(ha.L >= resDist), sure = (ha.L > tmin) && (ha.U < resDist);
-        const bool candA = reach && !ha.certOut, candB = reach && !hb.certOut;
-        const bool certA = sure && ha.certIn && hb.certOut, certB = sure && hb.certIn && ha.certOut;
-        fast_offer(fb, candA || candB, certA || certB, ha.L, ha.U, certB ? p.prim[1] : p.prim[0]);
+    if (n <= 0) return;
+    const float inv = approx_rcp(v3c<K>(r.d));
+    FastRect a = rects[0];
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        VCM_AWAIT_SCALAR(a.pk);
+        VCM_SCHED_FENCE();
+        const FastRect b = rects[i + 1];
+        VCM_SCHED_FENCE();
+        rect_offer_one<K>(a, r, rr, inv, tmin, resDist, fb);
+        VCM_AWAIT_SCALAR(b.pk);
+        VCM_SCHED_FENCE();
+        if (i + 2 < n) a = rects[i + 2];
+        VCM_SCHED_FENCE();
+        rect_offer_one<K>(b, r, rr, inv, tmin, resDist, fb);
     }
+    if (i < n) rect_offer_one<K>(a, r, rr, inv, tmin, resDist, fb);
+}
+template <int K>
+VCM_HD void rect_occluded_one(const FastRect &p, const FastRay &r, const FastRayRect &rr, float inv, float reachDen, float tmaxp,
+                              bool &occ, bool &unknown)
+{
+    FastHit ha, hb;
+    float num, t;
+    fast_rect_plane<K>(p, r, inv, num, t, ha.L, ha.U);
+    /* can the plane part report a hit in (0, tmax) at all?  (occluded_pairs below has the argument; num and dir_k
+       are the reference's operands up to their common sign n_k, and a zero numerator is a miss for both) */
+    const bool reach = (((f2u(num) ^ f2u(v3c<K>(r.d))) & 0x80000000u) == 0u) && !(fabsf(num) >= reachDen);
+    if (!wave_any(reach && !occ)) return;   /* no lane can report a hit: the wave skips the edges */
+    fast_rect_edges<K>(p, r, rr, t, ha, hb);
+    const bool inRange = (ha.L > 0.f) && (ha.U < tmaxp);
+    const bool hitA = reach && ha.certIn && inRange, missA = !reach || ha.certOut;
+    const bool hitB = reach && hb.certIn && inRange, missB = !reach || hb.certOut;
+    occ = occ || hitA || hitB;
+    unknown = unknown || !(hitA || missA) || !(hitB || missB);
 }
 template <int K>
 VCM_HD void rects_occluded(const FastRect *rects, int n, const FastRay &r, const FastRayRect &rr, float tmaxp, bool &occ, bool &unknown)
 {
-    for (int i = 0; i < n; i++) {
-        const FastRect &p = rects[i];
-        FastHit ha, hb;
-        float num, den, t;
-        fast_rect_plane<K>(p, r, num, den, t, ha.L, ha.U);
-        /* can the plane part report a hit in (0, tmax) at all?  (occluded_pairs below has the argument; num and den
-           are the reference's operands up to the sign of a zero, and a zero numerator is a miss for both) */
-        const bool reach = (((f2u(num) ^ f2u(den)) & 0x80000000u) == 0u) && !(fabsf(num) >= 1.000001f * (tmaxp * fabsf(den)));
-        if (!wave_any(reach && !occ)) continue;   /* no lane can report a hit: the wave skips the edges */
-        fast_rect_edges<K>(p, r, rr, t, ha, hb);
-        const bool inRange = (ha.L > 0.f) && (ha.U < tmaxp);
-        const bool hitA = reach && ha.certIn && inRange, missA = !reach || ha.certOut;
-        const bool hitB = reach && hb.certIn && inRange, missB = !reach || hb.certOut;
-        occ = occ || hitA || hitB;
-        unknown = unknown || !(hitA || missA) || !(hitB || missB);
+    if (n <= 0) return;
+    const float dk = v3c<K>(r.d), inv = approx_rcp(dk);
+    const float reachDen = 1.000001f * (tmaxp * fabsf(dk));
+    FastRect a = rects[0];
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        VCM_AWAIT_SCALAR(a.pk);
+        VCM_SCHED_FENCE();
+        const FastRect b = rects[i + 1];
+        VCM_SCHED_FENCE();
+        rect_occluded_one<K>(a, r, rr, inv, reachDen, tmaxp, occ, unknown);
+        VCM_AWAIT_SCALAR(b.pk);
+        VCM_SCHED_FENCE();
+        if (i + 2 < n) a = rects[i + 2];
+        VCM_SCHED_FENCE();
+        rect_occluded_one<K>(b, r, rr, inv, reachDen, tmaxp, occ, unknown);
     }
+    if (i < n) rect_occluded_one<K>(a, r, rr, inv, reachDen, tmaxp, occ, unknown);
 }
 
 /* Scene::Intersect over the list with the filter in front.  `certain` = this lane's answer is final. */
@@ -1146,8 +1256,11 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
                        hb.certIn && (hb.L > ray.tmin) && (hb.U < res.dist), hb.L, hb.U, p.prim[1]);
         }
     }
+    FastSphere nextSphere;
+    if (sc.nFastSpheres > 0) nextSphere = sc.fastSpheres()[0];
     for (int i = 0; i < sc.nFastSpheres; i++) {
-        const FastSphere &p = sc.fastSpheres()[i];
+        const FastSphere p = nextSphere;   /* read one ahead, as the rectangles are */
+        if (i + 1 < sc.nFastSpheres) nextSphere = sc.fastSpheres()[i + 1];
         FastRoots fr;
         fast_sphere(p, ray.org, ray.dir, fr);
         /* Sphere::Intersect offers the first root beyond tmin (:226-234) */
@@ -1156,7 +1269,7 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
         const float L = fr.ok ? t - e : -VCM_FILTER_INF, U = fr.ok ? t + e : VCM_FILTER_INF;
         const bool cand = !fr.noRoot && !(fr.ok && loInvalid && (fr.hi + fr.eHi <= ray.tmin)) && !(L >= res.dist);
         const bool cert = !fr.noRoot && fr.ok && (loValid || (loInvalid && (fr.hi - fr.eHi > ray.tmin))) && (U < res.dist);
-        fast_offer(fb, cand, cert, L, U, p.prim);
+        fast_offer(fb, cand, cert, L, U, wave_uniform(p.prim));
     }
     if (fb.best < 0) { certain = true; return false; }   /* every primitive certainly missed */
     certain = fb.bestCertain && (fb.minL2 > fb.bestU);
@@ -1226,8 +1339,11 @@ VCM_HD bool list_occluded_filtered(const DScene &sc, const Ray &ray, float tmaxp
         fast_ray_setup(sc, ray.org, ray.dir, r);
         occluded_pairs<ONE_PLANE>(sc, r, tmaxp, occ, unknown);
     }
+    FastSphere nextSphere;
+    if (sc.nFastSpheres > 0) nextSphere = sc.fastSpheres()[0];
     for (int i = 0; i < sc.nFastSpheres; i++) {
-        const FastSphere &p = sc.fastSpheres()[i];
+        const FastSphere p = nextSphere;
+        if (i + 1 < sc.nFastSpheres) nextSphere = sc.fastSpheres()[i + 1];
         FastRoots fr;
         fast_sphere(p, ray.org, ray.dir, fr);
         /* geometry.hxx:226-234 with res.dist = tmax: a hit iff one of the roots lies in (0, tmax) */
@@ -1704,6 +1820,7 @@ VCM_HD void connect_to_camera(const SC &sc, const IterParams &P, const SubPathSt
                               const Bsdf &bsdf, float *fb, LaneStats &ls, F4 *splatOut = 0)
 {
     if (splatOut) *splatOut = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
+    RC_DECL;
     const vcm_camera &cam = sc.camera;
     V3 directionToCamera = ld3(cam.position) - hitpoint;
     if (dot(ld3(cam.forward), -directionToCamera) <= 0.f) return;
@@ -1726,9 +1843,12 @@ VCM_HD void connect_to_camera(const SC &sc, const IterParams &P, const SubPathSt
     const float misWeight = P.lightTraceOnly ? 1.f : (1.f / (wLight + 1.f));
     const float surfaceToImageFactor = 1.f / imageToSurfaceFactor;
     const V3 contrib = misWeight * st.throughput * bsdfFactor / (P.lightSubPathCount * surfaceToImageFactor);
+    RC_MARK(17);
     if (!iszero(contrib)) {
         ls.shadowRays++;
-        if (scene_occluded(sc, hitpoint, directionToCamera, distance)) return;
+        const bool occluded = scene_occluded(sc, hitpoint, directionToCamera, distance);
+        RC_MARK(18);
+        if (occluded) return;
         const int x = int(ip.x), y = int(ip.y);
         if (splatOut) {
             *splatOut = mk4(contrib.x, contrib.y, contrib.z, u2f((uint32_t)(x + y * P.resX)));
@@ -1775,7 +1895,10 @@ VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, co
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
     Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
     ls.lightRays++;
-    if (!scene_intersect(sc, ray, isect)) return false;
+    RC_DECL;
+    const bool hitSomething = scene_intersect(sc, ray, isect);
+    RC_MARK(0);
+    if (!hitSomething) return false;
     const V3 hitPoint = ray.org + ray.dir * isect.dist;
     isect.dist += VCM_EPS_RAY;
     Bsdf bsdf;
@@ -1787,6 +1910,7 @@ VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, co
         st.dVC  /= mis(fabsf(bsdf.localDirFix.z));
         st.dVM  /= mis(fabsf(bsdf.localDirFix.z));
     }
+    RC_MARK(1);
     if (!bsdf.isDelta && (P.useVC || P.useVM || (MODE == 1 && P.lightTraceOnly))) {   /* :364-377 */
         const size_t slot = (size_t)lp.nStored * (size_t)P.nLocal + (size_t)lp.lp;
         const V3 wdir = to_world(bsdf.frame, bsdf.localDirFix);   /* WorldDirFix bsdf.hxx:264 */
@@ -1804,8 +1928,11 @@ VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, co
     if (MODE == 0 && !bsdf.isDelta && (P.useVC || P.lightTraceOnly)) {   /* :380-384 */
         if (st.pathLength + 1 >= P.minLen) connect_to_camera(sc, P, st, hitPoint, bsdf, fb, ls);
     }
+    RC_MARK(2);
     if (st.pathLength + 2 > P.maxLen) return false;   /* :387 */
-    if (!sample_scattering(sc, P, true, lp.rng, bsdf, hitPoint, st)) return false;
+    const bool goesOn = sample_scattering(sc, P, true, lp.rng, bsdf, hitPoint, st);
+    RC_MARK(3);
+    if (!goesOn) return false;
     ++st.pathLength;
     return true;
 }
@@ -1852,6 +1979,7 @@ template <class SC>
 VCM_HD V3 direct_illumination(const SC &sc, const IterParams &P, float rPick, float rx, float ry,
                               const SubPathState &st, V3 hitpoint, const Bsdf &bsdf, LaneStats &ls)
 {   /* rPick, rx, ry: the three floats drawn at :672-673 */
+    RC_DECL;
     const int lightCount = sc.nLights;
     const float lightPickProb = 1.f / lightCount;
     const int lightID = int(rPick * lightCount);
@@ -1872,9 +2000,12 @@ VCM_HD V3 direct_illumination(const SC &sc, const IterParams &P, float rPick, fl
                           (P.misVmWeightFactor + st.dVCM + st.dVC * mis(bsdfRevPdfW));
     const float misWeight = 1.f / (wLight + 1.f + wCamera);
     const V3 contrib = (misWeight * cosToLight / (lightPickProb * directPdfW)) * (radiance * bsdfFactor);
+    RC_MARK(9);
     if (iszero(contrib)) return sp3(0.f);
     ls.shadowRays++;
-    if (scene_occluded(sc, hitpoint, directionToLight, distance)) return sp3(0.f);
+    const bool occluded = scene_occluded(sc, hitpoint, directionToLight, distance);
+    RC_MARK(10);
+    if (occluded) return sp3(0.f);
     return contrib;
 }
 
@@ -1885,6 +2016,7 @@ VCM_HD V3 connect_vertices(const SC &sc, const IterParams &P, V3 lvHitpoint, con
                            const SubPathState &st, LaneStats &ls)
 {
     ls.connections++;
+    RC_DECL;
     V3 direction = lvHitpoint - cameraHitpoint;
     const float dist2 = lensqr(direction);
     const float distance = sqrtf(dist2);
@@ -1909,9 +2041,12 @@ VCM_HD V3 connect_vertices(const SC &sc, const IterParams &P, V3 lvHitpoint, con
     const float wCamera = mis(lightBsdfDirPdfA) * (P.misVmWeightFactor + st.dVCM + st.dVC * mis(cameraBsdfRevPdfW));
     const float misWeight = 1.f / (wLight + 1.f + wCamera);
     const V3 contrib = (misWeight * geometryTerm) * cameraBsdfFactor * lightBsdfFactor;
+    RC_MARK(12);
     if (iszero(contrib)) return sp3(0.f);
     ls.shadowRays++;
-    if (scene_occluded(sc, cameraHitpoint, direction, distance)) return sp3(0.f);
+    const bool occluded = scene_occluded(sc, cameraHitpoint, direction, distance);
+    RC_MARK(13);
+    if (occluded) return sp3(0.f);
     return contrib;
 }
 
@@ -2313,7 +2448,10 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
     Isect isect; isect.dist = 1e36f; isect.matID = 0; isect.lightID = -1; isect.normal = sp3(0.f); isect.prim = -1;
     ls.cameraRays++;
-    if (!scene_intersect(sc, ray, isect)) {   /* :434-447 */
+    RC_DECL;
+    const bool hitSomething = scene_intersect(sc, ray, isect);
+    RC_MARK(4);
+    if (!hitSomething) {   /* :434-447 */
         if (sc.backgroundLight >= 0) {
             if (st.pathLength >= P.minLen)
                 cp.color = cp.color + st.throughput * get_light_radiance(sc, P, sc.lights()[sc.backgroundLight], st, ray.dir);
@@ -2338,6 +2476,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
         return false;
     }
     if (st.pathLength >= P.maxLen) return false;   /* :482 */
+    RC_MARK(5);
 
     if (MODE == 1) {
         if (!bsdf.isDelta && (P.useVC || P.useVM)) {
@@ -2444,7 +2583,10 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
             if (P.ppm) return false;
         }
     }
-    if (!sample_scattering(sc, P, false, cp.rng, bsdf, hitPoint, st)) return false;
+    RC_MARK(6);
+    const bool goesOn = sample_scattering(sc, P, false, cp.rng, bsdf, hitPoint, st);
+    RC_MARK(7);
+    if (!goesOn) return false;
     ++st.pathLength;
     return true;
 }

@@ -142,6 +142,7 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
     LaneBox box; lane_box_init(box);
     LightPath path;
     bool alive = false;
+    RC_DECL;
     for (;;) {
         /* refill dead lanes: ballot + prefix popcount over the wave */
         const unsigned long long need = __ballot(!alive);
@@ -149,15 +150,18 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
             const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
             if (!alive && idx >= 0) { light_path_begin(sc, P, path, idx); alive = true; }
         }
+        RC_MARK(19);
         if (!__any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = light_path_step<MODE>(sc, P, path, store, fb, ls, box);
+            RC_RESET;
             if (!alive) {
                 store.count[path.lp] = (unsigned char)path.nStored;   /* mPathEnds :395 */
                 store.lenMask[path.lp] = path.lenMask;
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
         }
+        RC_MARK(21);
     }
     {   /* the box of the vertices this block stored -> the grid header, both ends as order keys under atomicMax (the
            minimum inverted): the words start at zero, which the iteration's zeroing kernel provides */
@@ -211,15 +215,18 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
     wqs.pendingVertex = -1; wqs.pendingArrival = 0;
     CameraPath path;
     bool alive = false;
+    RC_DECL;
     for (;;) {
         const unsigned long long need = __ballot(!alive);
         if (need) {
             const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
             if (!alive && idx >= 0) { camera_path_begin(sc, P, path, idx); alive = true; }
         }
+        RC_MARK(20);
         if (!__any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs);
+            RC_RESET;
 #if !defined(VCM_NO_DEFER)
             if (MODE == 1 && wqs.pendingVertex >= 0) { vs.sortArrival[wqs.pendingVertex] = wqs.pendingArrival; wqs.pendingVertex = -1; }
 #endif
@@ -230,6 +237,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
         }
+        RC_MARK(22);
     }
     if (MODE == 1) {   /* mark the unused tails of this wave's last blocks as holes */
         const int vb = wqs.v.p[0], vl = wqs.v.p[1], db = wqs.di.p[0], dl = wqs.di.p[1], cb = wqs.vc.p[0], cl = wqs.vc.p[1];
@@ -463,6 +471,7 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     V3 contrib = sp3(0.f);
     int n = 0;
+    RC_DECL;
     {   /* hashgrid.hxx:116-155: bbox test, the 8 cells toward the nearer faces */
         const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
         const V3 distMin = queryPos - bmin, distMax = bmax - queryPos;
@@ -498,6 +507,7 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
     }
     MergeEval ev;
     merge_eval_setup(ev, sc, P, cameraBsdf, st);
+    RC_MARK(14);
     const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
     int qn = 0, k = 0;
     WalkRun cur, nxt;
@@ -534,12 +544,16 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
         } else cur.lo = stepEnd;
         if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
             ls.mergeAccepted += (uint32_t)qn;
+            RC_MARK(15);
             merge_drain(P, g, ev, ms, qn, contrib);
+            RC_MARK(16);
             qn = 0;
         }
     }
     ls.mergeAccepted += (uint32_t)qn;
+    RC_MARK(15);
     merge_drain(P, g, ev, ms, qn, contrib);
+    RC_MARK(16);
     return contrib;
 }
 #endif
