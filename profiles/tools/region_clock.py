@@ -24,6 +24,10 @@ NAMES = {
     17: ("K1c", "connect_to_camera: evaluation"), 18: ("K1c", "connect_to_camera: scene_occluded"),
     9: ("K3b", "direct_illumination: evaluation"), 10: ("K3b", "direct_illumination: scene_occluded"),
     12: ("K3c", "connect_vertices: evaluation"), 13: ("K3c", "connect_vertices: scene_occluded"),
+    23: ("K1 sample_scattering", "rng_peek (Philox)"), 24: ("K1 sample_scattering", "bsdf_sample"), 25: ("K1 sample_scattering", "bsdf_pdf (reverse)"),
+    26: ("K1 sample_scattering", "Russian roulette + MIS update"),
+    27: ("K3 sample_scattering", "rng_peek (Philox)"), 28: ("K3 sample_scattering", "bsdf_sample"), 29: ("K3 sample_scattering", "bsdf_pdf (reverse)"),
+    30: ("K3 sample_scattering", "Russian roulette + MIS update"),
     14: ("K4", "cells + set-up"), 15: ("K4", "scan"), 16: ("K4", "drain (RangeQuery::Process)"),
 }
 

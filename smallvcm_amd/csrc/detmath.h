@@ -136,7 +136,7 @@ VCM_HD float dm_powf_wave(float xf, float yf)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yf)));
-    if (y0 >= 1.0f && y0 <= 65536.0f && y0 == floorf(y0) && __all(yf == y0)) {   /* wave-uniform */
+    if (y0 >= 1.0f && y0 <= 65536.0f && y0 == floorf(y0) && __builtin_amdgcn_ballot_w64(!(yf == y0)) == 0ull) {   /* wave-uniform */
         unsigned n = (unsigned)y0;
         double b = (double)xf, r = 1.0;
         for (;;) {

@@ -161,7 +161,7 @@ struct RegionClock { unsigned long long t; };
 __device__ __forceinline__ void rc_mark(RegionClock &r, int id)
 {
     const unsigned long long n = clock64();
-    const unsigned long long m = __ballot(1);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
     if ((int)__lane_id() == __ffsll((long long)m) - 1) {
         unsigned long long *row = g_regionClock + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (VCM_RC_SLOTS - 1)) * 64;
         atomicAdd(&row[id], n - r.t);
@@ -199,7 +199,17 @@ struct Isect { float dist; int matID; int lightID; V3 normal; int prim; /* index
 VCM_HD bool wave_any(bool x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __any(x);
+    /* the ballot of a condition IS its lane mask (s_and with exec, s_cmp); __any() turns the condition into 0 / 1 per
+       lane and compares that again (v_cndmask + v_cmp, per call -- three per step of K4's scan) */
+    return __builtin_amdgcn_ballot_w64(x) != 0ull;
+#else
+    return x;
+#endif
+}
+VCM_HD bool wave_all(bool x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(!x) == 0ull;
 #else
     return x;
 #endif
@@ -1035,13 +1045,21 @@ VCM_HD void fast_sphere(const FastSphere &p, V3 org, V3 dir, FastRoots &fr)
 }
 
 /* running choice of the closest-hit filter: the candidate with the smallest lower bound, and the second smallest */
-struct FastBest { float minL1, minL2, bestU; int best; bool bestCertain; };
+struct FastBest { float minL1, minL2, bestU; int best; bool bestCertain, poison /* some entry's bounds are unknown: nothing is certain */; };
+VCM_HD float filter_med3(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#endif
+}
 VCM_HD void fast_offer(FastBest &fb, bool cand, bool cert, float L, float U, int prim)
 {
     const float Lc = cand ? L : VCM_FILTER_INF;
     const bool isBest = Lc < fb.minL1;
-    fb.minL2 = filter_min(fb.minL2, isBest ? fb.minL1 : Lc);
-    fb.minL1 = isBest ? Lc : fb.minL1;
+    fb.minL2 = filter_med3(fb.minL1, fb.minL2, Lc);   /* minL1 <= minL2: the second smallest of the three */
+    fb.minL1 = filter_min(fb.minL1, Lc);
     fb.best = isBest ? prim : fb.best;
     fb.bestU = isBest ? U : fb.bestU;
     fb.bestCertain = (bool)(((int)isBest & (int)cert) | ((int)!isBest & (int)fb.bestCertain));   /* mask logic (scalar unit): no select of 0 / 1, no branch */
@@ -1085,11 +1103,11 @@ VCM_HD void fast_rect_plane(const FastRect &p, const FastRay &r, float inv, floa
 {
     num = p.pk - v3c<K>(r.o);
     t = num * inv;
-    const float at = fabsf(t);
-    const float eps = (VCM_FILTER_U * 8.f) * at;
-    const bool known = at < 1e30f;      /* false for inf / NaN (den = 0 or denormal, overflow) */
-    L = known ? t - eps : -VCM_FILTER_INF;
-    U = known ? t + eps : VCM_FILTER_INF;
+    /* an unknown t (inf / NaN: den = 0 or denormal, overflow) leaves L and U inf / NaN: no comparison with them holds,
+       fast_rect_edges certifies nothing for it, and the closest-hit side poisons its choice (rect_offer_one) */
+    const float eps = (VCM_FILTER_U * 8.f) * fabsf(t);
+    L = t - eps;
+    U = t + eps;
 }
 template <int K>
 VCM_HD void fast_rect_edges(const FastRect &p, const FastRay &r, const FastRayRect &rr, float t, FastHit &ha, FastHit &hb)
@@ -1147,6 +1165,7 @@ VCM_HD void rect_offer_one(const FastRect &p, const FastRay &r, const FastRayRec
     const bool candA = reach && !ha.certOut, candB = reach && !hb.certOut;
     const bool certA = sure && ha.certIn && hb.certOut, certB = sure && hb.certIn && ha.certOut;
     const int primA = wave_uniform(p.prim[0]), primB = wave_uniform(p.prim[1]);
+    fb.poison = fb.poison || !(fabsf(t) < 1e30f);
     fast_offer(fb, candA || candB, certA || certB, ha.L, ha.U, certB ? primB : primA);
 }
 template <int K>
@@ -1170,17 +1189,23 @@ VCM_HD void rects_offer(const FastRect *rects, int n, const FastRay &r, const Fa
     }
     if (i < n) rect_offer_one<K>(a, r, rr, inv, tmin, resDist, fb);
 }
+/* Can the plane part report a hit in (0, tmax) at all?  fl(num / den) > 0 needs equal signs, < tmax needs
+   |num| < tmax |den| up to the rounding of this test's own products (occluded_pairs below has the argument; num and
+   dir_k are the reference's operands up to their common sign n_k).  Both in ONE unsigned comparison of bit patterns:
+   with the sign of dir_k folded into num, "sign clear and below the bound" is "pattern below the bound's pattern"
+   (patterns of non-negative floats order as the floats do, every pattern with the sign set lies above them; a NaN
+   numerator reaches nothing, which is the reference's answer for it: no comparison with a NaN distance holds).  One
+   comparison is also what lets the wave's "any lane?" be the comparison's own lane mask: of a combination of
+   conditions the compiler first makes a 0 / 1 per lane and compares that again. */
 template <int K>
-VCM_HD void rect_occluded_one(const FastRect &p, const FastRay &r, const FastRayRect &rr, float inv, float reachDen, float tmaxp,
-                              bool &occ, bool &unknown)
+VCM_HD void rect_occluded_one(const FastRect &p, const FastRay &r, const FastRayRect &rr, float inv, uint32_t dkSign, uint32_t reachBits,
+                              float tmaxp, bool &occ, bool &unknown)
 {
     FastHit ha, hb;
     float num, t;
     fast_rect_plane<K>(p, r, inv, num, t, ha.L, ha.U);
-    /* can the plane part report a hit in (0, tmax) at all?  (occluded_pairs below has the argument; num and dir_k
-       are the reference's operands up to their common sign n_k, and a zero numerator is a miss for both) */
-    const bool reach = (((f2u(num) ^ f2u(v3c<K>(r.d))) & 0x80000000u) == 0u) && !(fabsf(num) >= reachDen);
-    if (!wave_any(reach && !occ)) return;   /* no lane can report a hit: the wave skips the edges */
+    const bool reach = (f2u(num) ^ dkSign) < reachBits;
+    if (!wave_any(reach)) return;   /* no lane can report a hit: the wave skips the edges */
     fast_rect_edges<K>(p, r, rr, t, ha, hb);
     const bool inRange = (ha.L > 0.f) && (ha.U < tmaxp);
     const bool hitA = reach && ha.certIn && inRange, missA = !reach || ha.certOut;
@@ -1194,6 +1219,8 @@ VCM_HD void rects_occluded(const FastRect *rects, int n, const FastRay &r, const
     if (n <= 0) return;
     const float dk = v3c<K>(r.d), inv = approx_rcp(dk);
     const float reachDen = 1.000001f * (tmaxp * fabsf(dk));
+    const uint32_t dkSign = f2u(dk) & 0x80000000u;
+    const uint32_t reachBits = (reachDen > 0.f) ? f2u(reachDen) : ((reachDen <= 0.f) ? 0u : 0x7fc00000u);   /* NaN bound: everything reaches */
     FastRect a = rects[0];
     int i = 0;
     for (; i + 1 < n; i += 2) {
@@ -1201,14 +1228,14 @@ VCM_HD void rects_occluded(const FastRect *rects, int n, const FastRay &r, const
         VCM_SCHED_FENCE();
         const FastRect b = rects[i + 1];
         VCM_SCHED_FENCE();
-        rect_occluded_one<K>(a, r, rr, inv, reachDen, tmaxp, occ, unknown);
+        rect_occluded_one<K>(a, r, rr, inv, dkSign, reachBits, tmaxp, occ, unknown);
         VCM_AWAIT_SCALAR(b.pk);
         VCM_SCHED_FENCE();
         if (i + 2 < n) a = rects[i + 2];
         VCM_SCHED_FENCE();
-        rect_occluded_one<K>(b, r, rr, inv, reachDen, tmaxp, occ, unknown);
+        rect_occluded_one<K>(b, r, rr, inv, dkSign, reachBits, tmaxp, occ, unknown);
     }
-    if (i < n) rect_occluded_one<K>(a, r, rr, inv, reachDen, tmaxp, occ, unknown);
+    if (i < n) rect_occluded_one<K>(a, r, rr, inv, dkSign, reachBits, tmaxp, occ, unknown);
 }
 
 /* Scene::Intersect over the list with the filter in front.  `certain` = this lane's answer is final. */
@@ -1217,7 +1244,7 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
 {
     FastRay r;
     FastBest fb;
-    fb.minL1 = fb.minL2 = fb.bestU = VCM_FILTER_INF; fb.best = -1; fb.bestCertain = false;
+    fb.minL1 = fb.minL2 = fb.bestU = VCM_FILTER_INF; fb.best = -1; fb.bestCertain = false; fb.poison = false;
     if (RECTS) {
         FastRayRect rr;
         fast_ray_setup_rect(sc, ray.org, ray.dir, r, rr);
@@ -1271,6 +1298,7 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
         const bool cert = !fr.noRoot && fr.ok && (loValid || (loInvalid && (fr.hi - fr.eHi > ray.tmin))) && (U < res.dist);
         fast_offer(fb, cand, cert, L, U, wave_uniform(p.prim));
     }
+    if (fb.poison) { certain = false; return false; }
     if (fb.best < 0) { certain = true; return false; }   /* every primitive certainly missed */
     certain = fb.bestCertain && (fb.minL2 > fb.bestU);
     if (!certain) return false;
@@ -1745,16 +1773,20 @@ VCM_HD bool sample_scattering(const DScene &sc, const IterParams &P, bool lightS
     /* the 3 floats of BSDF::Sample (:944) and the Russian-roulette float (:964), which only counts as drawn if
        the sample is non-zero: 4 consecutive floats, generated at one site */
     float rnd[4];
+    RC_DECL;
     rng_peek(rng, rng.k, rnd, 4);
+    RC_MARK(lightSample ? 23 : 27);
     rng.k += 3u;
     const float r0 = rnd[0], r1 = rnd[1], r2 = rnd[2];
     float bsdfDirPdfW, cosThetaOut;
     uint32_t sampledEvent;
     const V3 bsdfFactor = bsdf_sample(bsdf, sc, lightSample, r0, r1, r2, st.direction, bsdfDirPdfW, cosThetaOut,
                                       sampledEvent);
+    RC_MARK(lightSample ? 24 : 28);
     if (iszero(bsdfFactor)) return false;
     float bsdfRevPdfW = bsdfDirPdfW;
     if ((sampledEvent & kSpecular) == 0) bsdfRevPdfW = bsdf_pdf(bsdf, sc, st.direction, true);
+    RC_MARK(lightSample ? 25 : 29);
     const float contProb = bsdf.contProb;
     rng.k += 1u;
     if (rnd[3] > contProb) return false;
@@ -1773,6 +1805,7 @@ VCM_HD bool sample_scattering(const DScene &sc, const IterParams &P, bool lightS
     }
     st.origin = hitPoint;
     st.throughput = st.throughput * (bsdfFactor * (cosThetaOut / bsdfDirPdfW));
+    RC_MARK(lightSample ? 26 : 30);
     return true;
 }
 
@@ -2326,6 +2359,8 @@ struct CameraPath {
     int lp;
     float sx, sy;    /* the jittered screen sample (:576) */
     uint32_t queryMask;   /* wavefront mode: bit L set = a vertex record was appended at path length L */
+    uint32_t lightLenMask;   /* wavefront mode: LightStore::lenMask of the light path of the same index, fetched when the
+                             path starts (it was a dependent gather in front of every vertex's VC tasks) */
 };
 
 /* ---- wave-level block allocator for the device queues --------------------
@@ -2362,12 +2397,12 @@ template <typename HoleFill>
 VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, int n, HoleFill holeFill)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long act = __ballot(1);
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
     const int rank = (int)lanes_below_mask_popc(act);
     int prefix = 0, total = 0;
 #pragma unroll
     for (int bit = 0; bit < 5; bit++) {
-        const unsigned long long m = __ballot((n >> bit) & 1);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(((n >> bit) & 1) != 0);
         prefix += (int)lanes_below_mask_popc(m) << bit;
         total += __popcll(m) << bit;
     }
@@ -2387,15 +2422,50 @@ VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, in
     const int r = *counter; *counter += n; return r;
 #endif
 }
+/* The same on a copy of the queue's two words that the caller has read (and writes back): K3 appends to three queues
+ * per vertex, and three read - modify - write round trips through LDS, one after the other, were a fifth of its step.
+ * BITS = how many bits of n can be set (0: n is 1 in every active lane -- rank and count of the active lanes are the
+ * prefix and the total). */
+template <int BITS, typename HoleFill>
+VCM_HD int wave_queue_take(int &base, int &left, int *counter, int blockSize, int n, unsigned long long act, int rank, HoleFill holeFill)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int prefix = rank, total = (int)__popcll(act);
+    if (BITS > 0) {
+        prefix = 0; total = 0;
+#pragma unroll
+        for (int bit = 0; bit < BITS; bit++) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(((n >> bit) & 1) != 0);
+            prefix += (int)lanes_below_mask_popc(m) << bit;
+            total += __popcll(m) << bit;
+        }
+    }
+    if (total > left) {   /* wave-uniform */
+        holeFill(base, left, rank, (int)__popcll(act));
+        const int take = ((total + blockSize - 1) / blockSize) * blockSize;
+        int nb = 0;
+        if (rank == 0) nb = atomicAdd(counter, take);
+        base = __shfl(nb, __ffsll((long long)act) - 1, 64);
+        left = take;
+    }
+    const int mine = base + prefix;
+    base += total; left -= total;
+    return mine;
+#else
+    (void)base; (void)left; (void)blockSize; (void)holeFill; (void)act; (void)rank;
+    const int r = *counter; *counter += n; return r;
+#endif
+}
 
 /* GenerateCameraSample :564-606 (+ Camera::GenerateRay camera.hxx:108-117) */
-VCM_HD void camera_path_begin(const DScene &sc, const IterParams &P, CameraPath &cp, int localPath)
+VCM_HD void camera_path_begin(const DScene &sc, const IterParams &P, CameraPath &cp, int localPath, const uint32_t *lightLenMask = 0)
 {
     const vcm_camera &cam = sc.camera;
     const int pathIdx = P.p0 + localPath;
     cp.lp = localPath;
     cp.color = sp3(0.f);
     cp.queryMask = 0u;
+    cp.lightLenMask = (lightLenMask && P.useVC) ? lightLenMask[localPath] : 0u;
     rng_init(cp.rng, P.seed, P.localIter, (uint32_t)pathIdx, 1u);
     const int x = pathIdx % P.resX;
     const int y = pathIdx / P.resX;
@@ -2495,7 +2565,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
                arithmetic on the path's length mask instead of one dependent 16-byte gather per light vertex */
             uint32_t jmask = 0u;
             if (P.useVC) {
-                const uint32_t M = store.lenMask[cp.lp];
+                const uint32_t M = cp.lightLenMask;
                 const int loLen = (int)P.minLen - 1 - (int)st.pathLength;    /* lvLen >= loLen */
                 const int hiLen = (int)P.maxLen - 1 - (int)st.pathLength;    /* lvLen <= hiLen */
                 if (hiLen >= 0) {
@@ -2506,16 +2576,27 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
                 }
             }
             const int nvc = __builtin_popcount(jmask);
-            const int vi = wave_queue_alloc(wqs.v, &vs.count[0], P.qblockVertex, 1,
-                [&](int first, int cnt, int rank, int na) {
-                    for (int i = rank; i < cnt; i += na) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            /* the three queues' words: read together, written back together by the first active lane */
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            const int rank = (int)lanes_below_mask_popc(act);
+            int vb = wqs.v.p[0], vl = wqs.v.p[1], db = wqs.di.p[0], dl = wqs.di.p[1], cb = wqs.vc.p[0], cl = wqs.vc.p[1];
+            const int vi = wave_queue_take<0>(vb, vl, &vs.count[0], P.qblockVertex, 1, act, rank,
+                [&](int first, int cnt, int rk, int na) {
+                    for (int i = rk; i < cnt; i += na) {
                         vq(vs, 0, first + i) = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
                         if (vs.sortKey) vs.sortKey[first + i] = -1;
                     } });
-            const int di = wave_queue_alloc(wqs.di, &vs.count[1], P.qblockDI, hasDI,
-                [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.diTask[first + i] = -1; });
-            const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], P.qblockVC, nvc,
-                [&](int first, int cnt, int rank, int na) { for (int i = rank; i < cnt; i += na) vs.vcTask[2 * (first + i)] = -1; });
+            const int di = wave_queue_take<1>(db, dl, &vs.count[1], P.qblockDI, hasDI, act, rank,
+                [&](int first, int cnt, int rk, int na) { for (int i = rk; i < cnt; i += na) vs.diTask[first + i] = -1; });
+            const int vc0 = wave_queue_take<5>(cb, cl, &vs.count[2], P.qblockVC, nvc, act, rank,
+                [&](int first, int cnt, int rk, int na) { for (int i = rk; i < cnt; i += na) vs.vcTask[2 * (first + i)] = -1; });
+            if (rank == 0) { wqs.v.p[0] = vb; wqs.v.p[1] = vl; wqs.di.p[0] = db; wqs.di.p[1] = dl; wqs.vc.p[0] = cb; wqs.vc.p[1] = cl; }
+#else
+            const int vi = wave_queue_alloc(wqs.v, &vs.count[0], P.qblockVertex, 1, [](int, int, int, int) {});
+            const int di = wave_queue_alloc(wqs.di, &vs.count[1], P.qblockDI, hasDI, [](int, int, int, int) {});
+            const int vc0 = wave_queue_alloc(wqs.vc, &vs.count[2], P.qblockVC, nvc, [](int, int, int, int) {});
+#endif
             vq(vs, 0, vi) = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f((uint32_t)cp.lp));
             vq(vs, 1, vi) = mk4(isect.normal.x, isect.normal.y, isect.normal.z, u2f(st.pathLength | (shade_code(bsdf.matID, isect.prim) << 8)));
             vq(vs, 2, vi) = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVCM);

@@ -145,13 +145,13 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
     RC_DECL;
     for (;;) {
         /* refill dead lanes: ballot + prefix popcount over the wave */
-        const unsigned long long need = __ballot(!alive);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(!alive);
         if (need) {
             const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
             if (!alive && idx >= 0) { light_path_begin(sc, P, path, idx); alive = true; }
         }
         RC_MARK(19);
-        if (!__any(alive)) { if (ww.exhausted) break; else continue; }
+        if (!wave_any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = light_path_step<MODE>(sc, P, path, store, fb, ls, box);
             RC_RESET;
@@ -217,13 +217,13 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
     bool alive = false;
     RC_DECL;
     for (;;) {
-        const unsigned long long need = __ballot(!alive);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(!alive);
         if (need) {
             const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
-            if (!alive && idx >= 0) { camera_path_begin(sc, P, path, idx); alive = true; }
+            if (!alive && idx >= 0) { camera_path_begin(sc, P, path, idx, MODE == 1 ? store.lenMask : (const uint32_t *)0); alive = true; }
         }
         RC_MARK(20);
-        if (!__any(alive)) { if (ww.exhausted) break; else continue; }
+        if (!wave_any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs);
             RC_RESET;
@@ -267,12 +267,12 @@ k_path_trace(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned 
     PtPath path;
     bool alive = false;
     for (;;) {
-        const unsigned long long need = __ballot(!alive);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(!alive);
         if (need) {
             const int idx = wave_work_take(ww, work, chunk, P.nLocal, need, lane);
             if (!alive && idx >= 0) { pt_path_begin(sc, P, path, idx); alive = true; }
         }
-        if (!__any(alive)) { if (ww.exhausted) break; else continue; }
+        if (!wave_any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
             alive = pt_path_step(sc, P, path, ls);
             if (!alive) {
