@@ -33,12 +33,16 @@ NAMES = {
 
 
 def main():
-    scene_id = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    scene_id = sys.argv[1] if len(sys.argv) > 1 else "1"   # a built-in configuration, or the path of a .vcmscene file
     res = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     algo = {"vcm": R.VertexCM.kVcm, "bpm": R.VertexCM.kBpm, "bpt": R.VertexCM.kBpt}[sys.argv[3] if len(sys.argv) > 3 else "vcm"]
     L = R.load_library()
     L.region_clock_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    sc = R.cornell_scene(scene_id, res, res)
+    if scene_id.isdigit():
+        sc = R.cornell_scene(int(scene_id), res, res)
+    else:
+        from smallvcm_amd.scene_file import load_scene
+        sc = load_scene(scene_id, res, res)
     r = R.VertexCM(sc, algo, 0.003, 0.75, 1234)
     r.mMaxPathLength = 10
     for it in range(5):
@@ -54,7 +58,7 @@ def main():
     per = {}
     for rid, (k, name) in NAMES.items():
         per.setdefault(k, []).append((rid, name, buf[rid] / n, buf[32 + rid] / n))
-    print("scene %d %dx%d, mean of %d iterations; cycles are wave-residence shader clocks summed over waves" % (scene_id, res, res, n))
+    print("scene %s %dx%d, mean of %d iterations; cycles are wave-residence shader clocks summed over waves" % (scene_id, res, res, n))
     for k, rows in per.items():
         tot = sum(x[2] for x in rows) or 1.0
         print("%s: %.1f M wave-cycles per iteration" % (k, tot / 1e6))

@@ -391,13 +391,12 @@ VCM_HD float fresnel_dielectric(float cosInc, float ior)
 }
 VCM_HD V3 reflect_local(V3 v) { return mk3(-v.x, -v.y, v.z); }   /* :77-80 */
 
-VCM_HD V3 sample_power_cos_hemisphere(float sx, float sy, float power)
+/* (sin, cos of term1 = 2 pi sx come from the caller: BSDF::Sample's diffuse and Phong branches both start from them,
+   same argument, and a wave that holds lanes of both kinds would evaluate dm_sincosf once per branch) */
+VCM_HD V3 sample_power_cos_hemisphere(float s, float c, float sy, float power)
 {   /* :85-103, oPdfW == NULL at its only call site (bsdf.hxx:296) */
-    const float term1 = 2.f * VCM_PI_F * sx;
     const float term2 = dm_powf(sy, 1.f / (power + 1.f));
     const float term3 = sqrtf(1.f - term2 * term2);
-    float s, c;
-    dm_sincosf(term1, s, c);
     return mk3(c * term3, s * term3, term2);
 }
 VCM_HD float power_cos_hemisphere_pdf(V3 n, V3 d, float power)
@@ -427,15 +426,19 @@ VCM_HD void sample_concentric_disc(float sx, float sy, float &ox, float &oy)
     oy = r * s;
 }
 VCM_HD float concentric_disc_pdf_a() { return VCM_INV_PI_F; }   /* :162-165 */
-VCM_HD V3 sample_cos_hemisphere(float sx, float sy, float &pdfW)
-{   /* :173-190 */
-    const float term1 = 2.f * VCM_PI_F * sx;
+VCM_HD V3 sample_cos_hemisphere_sc(float s, float c, float sy, float &pdfW)
+{   /* :173-190 with sin, cos of term1 = 2 pi sx given */
     const float term2 = sqrtf(1.f - sy);
-    float s, c;
-    dm_sincosf(term1, s, c);
     const V3 ret = mk3(c * term2, s * term2, sqrtf(sy));
     pdfW = ret.z * VCM_INV_PI_F;
     return ret;
+}
+VCM_HD V3 sample_cos_hemisphere(float sx, float sy, float &pdfW)
+{   /* :173-190 */
+    const float term1 = 2.f * VCM_PI_F * sx;
+    float s, c;
+    dm_sincosf(term1, s, c);
+    return sample_cos_hemisphere_sc(s, c, sy, pdfW);
 }
 VCM_HD float cos_hemisphere_pdf(V3 n, V3 d) { return smax(0.f, dot(n, d)) * VCM_INV_PI_F; }   /* :192-197 */
 VCM_HD void sample_uniform_triangle(float sx, float sy, float &u, float &v)
@@ -1576,17 +1579,19 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0
     pdfW = 0.f;
     V3 result = sp3(0.f);
     V3 gen = sp3(0.f);
+    float sinPhi = 0.f, cosPhi = 0.f;   /* of term1 = 2 pi r0 (utils.hxx:91, :177), for the two branches that sample a lobe */
+    if (sampledEvent == kDiffuse || sampledEvent == kPhong) dm_sincosf(2.f * VCM_PI_F * r0, sinPhi, cosPhi);
 
     if (sampledEvent == kDiffuse) {
         if (b.localDirFix.z < VCM_EPS_COSINE) return sp3(0.f);
         float unweightedPdfW;
-        gen = sample_cos_hemisphere(r0, r1, unweightedPdfW);
+        gen = sample_cos_hemisphere_sc(sinPhi, cosPhi, r1, unweightedPdfW);
         pdfW += unweightedPdfW * b.diffProb;
         result = result + ld3(m.diffuse) * VCM_INV_PI_F;
         if (iszero(result)) return sp3(0.f);
         result = result + bsdf_eval_phong(b, m, gen, &pdfW, (float *)0);
     } else if (sampledEvent == kPhong) {
-        gen = sample_power_cos_hemisphere(r0, r1, m.phongExp);
+        gen = sample_power_cos_hemisphere(sinPhi, cosPhi, r1, m.phongExp);
         const V3 refl = reflect_local(b.localDirFix);
         {
             Frame fr;
