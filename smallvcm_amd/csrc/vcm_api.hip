@@ -415,15 +415,19 @@ static int ensure_device(vcm_ctx *c)
     if (!c->deviceReady) {
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-        {   /* the two helper streams at the lowest priority: the grid build and the light splats fill what the main
-               stream's kernels leave free instead of sharing the chip evenly with them -- 885.6 -> 893.3 Mpaths/s, same
-               box, two runs each (profiles/r05k_prio.txt; in round 2, with one helper stream, it moved nothing).
-               SMALLVCM_AMD_STREAM_PRIO=0: equal priorities */
-            static int prio = -1;
-            if (prio < 0) { const char *e = getenv("SMALLVCM_AMD_STREAM_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
+        {   /* the two helper streams at the lowest priority -- on LARGE frames only.  There the grid build and the light
+               splats fill what the main stream's long kernels leave free instead of sharing the chip evenly with them:
+               885.6 -> 893.3 Mpaths/s at 2048^2 (profiles/r05k_prio.txt), 918 -> 962 on a faster box (r05r_configs.txt).
+               On small frames the camera pass is one wave-round that holds the whole chip, a low-priority grid build
+               starts when it ends, and the merge waits for the build: 512^2 407 -> 295 Mpaths/s, the BVH room at 1024^2
+               403 -> 379, two renderers in flight at 1024^2 1379 -> 810 (r05r).  SMALLVCM_AMD_STREAM_PRIO=0 / 1 forces. */
+            static int prio = -2;
+            if (prio == -2) { const char *e = getenv("SMALLVCM_AMD_STREAM_PRIO"); prio = e ? (e[0] == '0' ? 0 : 1) : -1; }
+            const long long pixels = (long long)c->scene->camera.resolution[0] * (long long)c->scene->camera.resolution[1];
+            const bool low = prio >= 0 ? prio == 1 : pixels >= (1ll << 22);
             int lo = 0, hi = 0;
-            if (prio) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   /* lo = the numerically largest = least urgent */
-            if (prio) {
+            if (low) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   /* lo = the numerically largest = least urgent */
+            if (low) {
                 HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo));
                 HIPCHK(hipStreamCreateWithPriority(&c->splat, hipStreamNonBlocking, lo));
             } else {
@@ -1700,6 +1704,7 @@ __global__ void k_numeric_spec(int op, int n, const float *a, const float *b, fl
 template <class SC>
 __global__ void k_kat(const DScene *__restrict__ scp, int op, int n, const float *in, float *out)
 {
+    stage_scene_tables(*scp);   /* before any thread leaves: it holds a barrier */
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float a[VCM_KAT_FLOATS], r[VCM_KAT_FLOATS];

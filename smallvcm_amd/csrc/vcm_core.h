@@ -370,6 +370,114 @@ struct SceneQuads : DScene { static constexpr bool kBvh = false; static constexp
 /* a list whose triangle pairs are all axis-aligned rectangles (FastRect): the reference's own boxes */
 struct SceneRects : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; static constexpr bool kRects = true; };
 
+/* ---- the scene's small tables in LDS ----
+ * A lane's material, the primitive its ray ends on, the light it samples are GATHERS (the index is per lane): as global
+ * loads, one dependent trip through the vector memory path in front of the component probabilities, one inside every
+ * branch of BSDF::Sample, one per Evaluate / Pdf, one for the winner of Scene::Intersect, one per light sample -- in
+ * kernels that wait for latency, not bandwidth.  Every kernel that traces or shades copies the tables (materials,
+ * primitives, material -> light, lights: the reference's scenes have at most 10 / 26 / 10 / 2 entries) into LDS when it
+ * starts (stage_scene_tables: all threads of the block, one barrier) and scene_material() / scene_prim() /
+ * scene_mat2light() / scene_light() read them from there; a table with more entries than its room keeps the global path
+ * (a scalar branch on the count).  Materials alone: 887 / 893 -> 924 / 917 Mpaths/s, same box (profiles/r05s_ab.txt).
+ * RULE: a kernel that can reach one of the accessors calls stage_scene_tables() first -- nothing else initialises the
+ * copy (the merge kernels do not, and pass lds = false where they read a material). */
+#define VCM_LDS_MATERIALS 32
+#define VCM_LDS_PRIMS 32
+#define VCM_LDS_LIGHTS 4
+#define VCM_LDS_MAT_WORDS 11
+#define VCM_LDS_PRIM_WORDS 14
+#define VCM_LDS_LIGHT_WORDS 24
+#define VCM_LDS_OFF_PRIMS (VCM_LDS_MATERIALS * VCM_LDS_MAT_WORDS)
+#define VCM_LDS_OFF_M2L (VCM_LDS_OFF_PRIMS + VCM_LDS_PRIMS * VCM_LDS_PRIM_WORDS)
+#define VCM_LDS_OFF_LIGHTS (VCM_LDS_OFF_M2L + VCM_LDS_MATERIALS)
+#define VCM_LDS_SCENE_WORDS (VCM_LDS_OFF_LIGHTS + VCM_LDS_LIGHTS * VCM_LDS_LIGHT_WORDS)
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ uint32_t g_ldsScene[VCM_LDS_SCENE_WORDS];
+typedef const __attribute__((address_space(3))) uint32_t *LdsWords;
+__device__ __forceinline__ LdsWords lds_scene(int offset) { return (LdsWords)g_ldsScene + offset; }
+#endif
+VCM_HD void stage_scene_tables(const DScene &sc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(vcm_material) == VCM_LDS_MAT_WORDS * 4 && sizeof(vcm_prim) == VCM_LDS_PRIM_WORDS * 4 &&
+                  sizeof(vcm_light) == VCM_LDS_LIGHT_WORDS * 4, "table entries are whole words");
+    const int t = (int)threadIdx.x, nt = (int)blockDim.x;
+    if (sc.nMaterials <= VCM_LDS_MATERIALS) {
+        const uint32_t *src = (const uint32_t *)sc.materials();
+        for (int i = t; i < sc.nMaterials * VCM_LDS_MAT_WORDS; i += nt) g_ldsScene[i] = src[i];
+        const uint32_t *m2l = (const uint32_t *)sc.mat2light();
+        for (int i = t; i < sc.nMaterials; i += nt) g_ldsScene[VCM_LDS_OFF_M2L + i] = m2l[i];
+    }
+    if (sc.nPrims <= VCM_LDS_PRIMS) {
+        const uint32_t *src = (const uint32_t *)sc.prims();
+        for (int i = t; i < sc.nPrims * VCM_LDS_PRIM_WORDS; i += nt) g_ldsScene[VCM_LDS_OFF_PRIMS + i] = src[i];
+    }
+    if (sc.nLights <= VCM_LDS_LIGHTS) {
+        const uint32_t *src = (const uint32_t *)sc.lights();
+        for (int i = t; i < sc.nLights * VCM_LDS_LIGHT_WORDS; i += nt) g_ldsScene[VCM_LDS_OFF_LIGHTS + i] = src[i];
+    }
+    __syncthreads();
+#else
+    (void)sc;
+#endif
+}
+/* lds = false: the caller's kernel does not stage the tables (the merge kernels: two material reads per QUERY are
+   nothing next to its candidates, and the copy's registers cost k_merge_walk its fourth wave per SIMD) */
+VCM_HD vcm_material scene_material(const DScene &sc, int matID, bool lds = true)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lds && sc.nMaterials <= VCM_LDS_MATERIALS) {   /* wave-uniform */
+        LdsWords p = lds_scene(matID * VCM_LDS_MAT_WORDS);
+        vcm_material m;
+        m.diffuse[0] = u2f(p[0]); m.diffuse[1] = u2f(p[1]); m.diffuse[2] = u2f(p[2]);
+        m.phong[0] = u2f(p[3]); m.phong[1] = u2f(p[4]); m.phong[2] = u2f(p[5]);
+        m.phongExp = u2f(p[6]);
+        m.mirror[0] = u2f(p[7]); m.mirror[1] = u2f(p[8]); m.mirror[2] = u2f(p[9]);
+        m.ior = u2f(p[10]);
+        return m;
+    }
+#endif
+    return sc.materials()[matID];
+}
+VCM_HD vcm_prim scene_prim(const DScene &sc, int index)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (sc.nPrims <= VCM_LDS_PRIMS) {
+        LdsWords p = lds_scene(VCM_LDS_OFF_PRIMS + index * VCM_LDS_PRIM_WORDS);
+        vcm_prim r;
+        r.type = (int)p[0]; r.matID = (int)p[1];
+        for (int k = 0; k < 3; k++) { r.p0[k] = u2f(p[2 + k]); r.p1[k] = u2f(p[5 + k]); r.p2[k] = u2f(p[8 + k]); r.n[k] = u2f(p[11 + k]); }
+        return r;
+    }
+#endif
+    return sc.prims()[index];
+}
+VCM_HD int scene_mat2light(const DScene &sc, int matID)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (sc.nMaterials <= VCM_LDS_MATERIALS) return (int)lds_scene(VCM_LDS_OFF_M2L)[matID];
+#endif
+    return sc.mat2light()[matID];
+}
+VCM_HD vcm_light scene_light(const DScene &sc, int index)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (sc.nLights <= VCM_LDS_LIGHTS) {
+        LdsWords p = lds_scene(VCM_LDS_OFF_LIGHTS + index * VCM_LDS_LIGHT_WORDS);
+        vcm_light l;
+        l.type = (int)p[0];
+        for (int k = 0; k < 3; k++) {
+            l.p0[k] = u2f(p[1 + k]); l.e1[k] = u2f(p[4 + k]); l.e2[k] = u2f(p[7 + k]);
+            l.frameX[k] = u2f(p[10 + k]); l.frameY[k] = u2f(p[13 + k]); l.frameZ[k] = u2f(p[16 + k]); l.intensity[k] = u2f(p[19 + k]);
+        }
+        l.invArea = u2f(p[22]); l.scale = u2f(p[23]);
+        return l;
+    }
+#endif
+    return sc.lights()[index];
+}
+
+
 /* ---- utils.hxx ---------------------------------------------------- */
 VCM_HD float luminance(V3 c)
 {   /* :36-41 */
@@ -1305,8 +1413,9 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
     if (fb.best < 0) { certain = true; return false; }   /* every primitive certainly missed */
     certain = fb.bestCertain && (fb.minL2 > fb.bestU);
     if (!certain) return false;
-    /* the reference's arithmetic for the winner alone (per-lane index: vector loads, once per ray) */
-    const vcm_prim &pr = sc.prims()[fb.best];
+    /* the reference's arithmetic for the winner alone (per-lane index: a gather, once per ray -- out of LDS for the
+       reference's scenes) */
+    const vcm_prim pr = scene_prim(sc, fb.best);
     bool hit;
     if (pr.type == VCM_PRIM_TRIANGLE) {
         const V3 n = ld3(pr.n);
@@ -1319,7 +1428,7 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
         hit = sph_intersect(pr, fb.best, ray, res);
         if (!hit) certain = false;
     }
-    if (hit) res.lightID = sc.mat2light()[res.matID];
+    if (hit) res.lightID = scene_mat2light(sc, res.matID);
     return hit;
 }
 /* the triangle entries of Scene::Occluded; ONE_PLANE: every entry's two triangles share the plane part (no branch
@@ -1482,7 +1591,7 @@ VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, int prim, const
     frame_from_z(b.frame, normal);
     b.localDirFix = to_local(b.frame, -rayDir);
     if (fabsf(b.localDirFix.z) < VCM_EPS_COSINE) return;
-    bsdf_component_probabilities(b, sc.materials()[matID]);
+    bsdf_component_probabilities(b, scene_material(sc, matID));
     b.isDelta = (b.diffProb == 0.f) && (b.phongProb == 0.f);
     b.matID = matID;
 }
@@ -1490,12 +1599,12 @@ VCM_HD void bsdf_setup(Bsdf &b, V3 rayDir, V3 normal, int matID, int prim, const
 VCM_HD uint32_t shade_code(int matID, int /*prim*/) { return (uint32_t)matID & 0xffffffu; }
 /* Rebuild the BSDF of a STORED vertex from (isect.normal, mLocalDirFix, matID): the same operations Setup ran,
  * hence the same bits. */
-VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, uint32_t code, const DScene &sc)
+VCM_HD void bsdf_restore(Bsdf &b, V3 normal, V3 localDirFix, uint32_t code, const DScene &sc, bool ldsMaterials = true)
 {
     const int matID = (int)(code & 0xffffffu);
     frame_from_z(b.frame, normal);
     b.localDirFix = localDirFix;
-    bsdf_component_probabilities(b, sc.materials()[matID]);
+    bsdf_component_probabilities(b, scene_material(sc, matID, ldsMaterials));
     b.isDelta = false;
     b.matID = matID;
 }
@@ -1550,7 +1659,7 @@ VCM_HD V3 bsdf_evaluate(const Bsdf &b, const DScene &sc, V3 worldDirGen, float &
     const V3 gen = to_local(b.frame, worldDirGen);
     if (gen.z * b.localDirFix.z < 0.f) return result;
     cosThetaGen = fabsf(gen.z);
-    const vcm_material &m = sc.materials()[b.matID];
+    const vcm_material m = scene_material(sc, b.matID);
     result = result + bsdf_eval_diffuse(b, m, gen, dirPdf, revPdf);
     result = result + bsdf_eval_phong(b, m, gen, dirPdf, revPdf);
     return result;
@@ -1559,7 +1668,7 @@ VCM_HD float bsdf_pdf(const Bsdf &b, const DScene &sc, V3 worldDirGen, bool eval
 {   /* Pdf :161-180 */
     const V3 gen = to_local(b.frame, worldDirGen);
     if (gen.z * b.localDirFix.z < 0.f) return 0.f;
-    const vcm_material &m = sc.materials()[b.matID];
+    const vcm_material m = scene_material(sc, b.matID);
     float directPdfW = 0.f, reversePdfW = 0.f;
     bsdf_pdf_diffuse(b, gen, &directPdfW, &reversePdfW);
     bsdf_pdf_phong(b, m, gen, &directPdfW, &reversePdfW);
@@ -1575,7 +1684,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0
     else if (r2 < b.diffProb + b.phongProb + b.reflProb) sampledEvent = kReflect;
     else sampledEvent = kRefract;
 
-    const vcm_material &m = sc.materials()[b.matID];
+    const vcm_material m = scene_material(sc, b.matID);
     pdfW = 0.f;
     V3 result = sp3(0.f);
     V3 gen = sp3(0.f);
@@ -1643,10 +1752,10 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0
 /* ---- lights.hxx ---------------------------------------------------- */
 VCM_HD bool light_is_finite(const vcm_light &l) { return l.type == VCM_LIGHT_AREA || l.type == VCM_LIGHT_POINT; }
 VCM_HD bool light_is_delta(const vcm_light &l) { return l.type == VCM_LIGHT_DIRECTIONAL || l.type == VCM_LIGHT_POINT; }
-VCM_HD const vcm_light &get_light(const DScene &sc, int idx)
+VCM_HD vcm_light get_light(const DScene &sc, int idx)
 {   /* Scene::GetLightPtr scene.hxx:98-102 */
     idx = (sc.nLights - 1 < idx) ? sc.nLights - 1 : idx;
-    return sc.lights()[idx];
+    return scene_light(sc, idx);
 }
 
 VCM_HD V3 light_illuminate(const vcm_light &l, const DScene &sc, V3 recvPos, float rx, float ry,
@@ -2135,9 +2244,9 @@ struct MergeEval {
     bool cosOk;           /* !(mLocalDirFix.z < EPS_COSINE) */
 };
 VCM_HD void merge_eval_setup(MergeEval &e, const DScene &sc, const IterParams &P, const Bsdf &b,
-                             const SubPathState &st)
+                             const SubPathState &st, bool ldsMaterials = true)
 {
-    const vcm_material &m = sc.materials()[b.matID];
+    const vcm_material m = scene_material(sc, b.matID, ldsMaterials);
     e.frame = b.frame;
     e.refl = reflect_local(b.localDirFix);
     e.diffuseVal = ld3(m.diffuse) * VCM_INV_PI_F;
@@ -2230,7 +2339,7 @@ VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval
  * lane still processes ITS photons in the reference's order, so the sum
  * (:168) is bit-identical. */
 VCM_HD V3 merge_query(const DScene &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
-                      const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms)
+                      const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms, bool ldsMaterials = true)
 {
     V3 contrib = sp3(0.f);
     const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
@@ -2246,7 +2355,7 @@ VCM_HD V3 merge_query(const DScene &sc, const IterParams &P, const GridStore &g,
     const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
     const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
     MergeEval ev;
-    merge_eval_setup(ev, sc, P, cameraBsdf, st);
+    merge_eval_setup(ev, sc, P, cameraBsdf, st, ldsMaterials);
     int qn = 0;
     /* the range of cell j+1 is fetched while cell j is scanned: one dependent memory round trip per cell less */
     int nlo = 0, nhi = 0;
@@ -2727,15 +2836,15 @@ VCM_HD V3 eval_vc_task(const SC &sc, const IterParams &P, const VertexStore &vs,
 }
 /* the addend of :534  (color += throughput * mVmNormalization * query.GetContrib()) */
 VCM_HD V3 eval_merge_task(const DScene &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
-                          int vi, LaneStats &ls, const MergeScratch &ms, size_t &pathSlot)
+                          int vi, LaneStats &ls, const MergeScratch &ms, size_t &pathSlot, bool ldsMaterials = true)
 {
     const F4 a = vq(vs, 0, vi), b = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
     pathSlot = path_slot(P, f2u(b.w) & 0xffu, f2u(a.w));
     Bsdf bsdf;
-    bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(b.w) >> 8, sc);
+    bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(b.w) >> 8, sc, ldsMaterials);
     SubPathState st;
     st.pathLength = f2u(b.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
-    const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms);
+    const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms, ldsMaterials);
     return mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
 }
 /* Replays vertexcm.hxx:417-544 for one camera path: colour starts at 0, every

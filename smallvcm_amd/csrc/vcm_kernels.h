@@ -136,6 +136,7 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
+    stage_scene_tables(sc);
     const unsigned lane = lane_id();
     WaveWork ww; wave_work_init(ww, chunk, P.nLocal);
     LaneStats ls; lane_stats_zero(ls);
@@ -191,7 +192,9 @@ k_light_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, fl
  * MODE 0 ("strict"): everything inside the path. */
 #if defined(VCM_K3_WAVES)   /* experiment: cap K3's registers for more waves per SIMD (spills go to scratch) */
 #define VCM_K3_ATTR __attribute__((amdgpu_waves_per_eu(VCM_K3_WAVES, VCM_K3_WAVES)))
-#else
+#else   /* (amdgpu_waves_per_eu(4) here would hold the wavefront instantiations, which sit at 126-129 registers, to four
+           waves per SIMD -- and the strict ones, which share the template, to 128 registers with spills: not set; the
+           SceneQuads instantiation, the fallback for quads that are not axis-aligned rectangles, is the one at 129) */
 #define VCM_K3_ATTR
 #endif
 template <int MODE, class SC>
@@ -201,6 +204,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
+    stage_scene_tables(sc);
     const unsigned lane = lane_id();
     WaveWork ww; wave_work_init(ww, chunk, P.nLocal);
     int *work = vs.count + 8;   /* the chunk counter of this launch (zeroed with the queue counts) */
@@ -261,6 +265,7 @@ k_path_trace(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned 
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
+    stage_scene_tables(sc);
     const unsigned lane = lane_id();
     WaveWork ww; wave_work_init(ww, chunk, P.nLocal);
     LaneStats ls; lane_stats_zero(ls);
@@ -291,6 +296,7 @@ k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned c
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
+    stage_scene_tables(sc);
     LaneStats ls; lane_stats_zero(ls);
     for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < P.nLocal; lp += gridDim.x * blockDim.x) {
         V3 color = sp3(0.f);
@@ -321,6 +327,7 @@ k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsig
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
+    stage_scene_tables(sc);
     const int n = vs.count[1];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
@@ -343,6 +350,7 @@ k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, Light
              unsigned long long *gstats)
 {
     const SC &sc = *static_cast<const SC *>(scp);
+    stage_scene_tables(sc);
     const int n = vs.count[2];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
@@ -435,7 +443,7 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
         if (q < nQ) {
             const int vi = sortedVertex[q];
             size_t ps;
-            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms, ps);
+            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms, ps, false);   /* this kernel stages no material table */
             vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
@@ -506,7 +514,7 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
         }
     }
     MergeEval ev;
-    merge_eval_setup(ev, sc, P, cameraBsdf, st);
+    merge_eval_setup(ev, sc, P, cameraBsdf, st, false);
     RC_MARK(14);
     const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
     int qn = 0, k = 0;
@@ -613,7 +621,7 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
             const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
             Bsdf bsdf;
-            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
+            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
             SubPathState sps;
             sps.pathLength = f2u(bq.w) & 0xffu; sps.dVCM = c.w; sps.dVM = d.w;
             const V3 contrib = merge_query_walk(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK);
@@ -706,7 +714,7 @@ __device__ __forceinline__ V3 merge_query_staged(const DScene &sc, const IterPar
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     V3 contrib = sp3(0.f);
     MergeEval ev;
-    merge_eval_setup(ev, sc, P, cameraBsdf, st);
+    merge_eval_setup(ev, sc, P, cameraBsdf, st, false);
     const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
     int qn = 0;
     for (int j = 0; j < 8; j++) {
@@ -859,7 +867,7 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
             const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
             const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
             Bsdf bsdf;
-            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
+            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
             SubPathState st;
             st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
             const V3 contrib = merge_query_staged(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
@@ -1040,6 +1048,7 @@ k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
                  int *pixCount, int *arrival, unsigned long long *gstats)
 {
     const SC &sc = *static_cast<const SC *>(scp);
+    stage_scene_tables(sc);
     const int n = *nVertices;
     LaneStats ls; lane_stats_zero(ls);
     /* the place of a splat in its pixel's list comes back from a returning atomic: it is stored one task later, so
