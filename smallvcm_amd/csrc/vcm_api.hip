@@ -415,16 +415,17 @@ static int ensure_device(vcm_ctx *c)
     if (!c->deviceReady) {
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-        {   /* the two helper streams at the lowest priority -- on LARGE frames only.  There the grid build and the light
-               splats fill what the main stream's long kernels leave free instead of sharing the chip evenly with them:
-               885.6 -> 893.3 Mpaths/s at 2048^2 (profiles/r05k_prio.txt), 918 -> 962 on a faster box (r05r_configs.txt).
-               On small frames the camera pass is one wave-round that holds the whole chip, a low-priority grid build
-               starts when it ends, and the merge waits for the build: 512^2 407 -> 295 Mpaths/s, the BVH room at 1024^2
-               403 -> 379, two renderers in flight at 1024^2 1379 -> 810 (r05r).  SMALLVCM_AMD_STREAM_PRIO=0 / 1 forces. */
-            static int prio = -2;
-            if (prio == -2) { const char *e = getenv("SMALLVCM_AMD_STREAM_PRIO"); prio = e ? (e[0] == '0' ? 0 : 1) : -1; }
-            const long long pixels = (long long)c->scene->camera.resolution[0] * (long long)c->scene->camera.resolution[1];
-            const bool low = prio >= 0 ? prio == 1 : pixels >= (1ll << 22);
+        {   /* The helper streams at the lowest priority (SMALLVCM_AMD_STREAM_PRIO=1; default: equal priorities).  On a
+               2048^2 frame the grid build and the light splats then fill what the main stream's long kernels leave free
+               instead of sharing the chip evenly with them: +0.5 to +0.9 % (profiles/r05k_prio.txt, r05s_ab.txt).  On small
+               frames the camera pass is one wave-round that holds the whole chip, a low-priority grid build starts when it
+               ends, and the merge waits for the build: 512^2 407 -> 295 Mpaths/s, the BVH room at 1024^2 403 -> 379, two
+               renderers in flight at 1024^2 1379 -> 810 (r05r_configs.txt) -- and contexts created LATER in the same
+               process with equal priorities were slowed too (r05s: the runtime seems to hand their streams the hardware
+               queues of the low-priority ones).  Half a percent does not pay for that: off. */
+            static int prio = -1;
+            if (prio < 0) { const char *e = getenv("SMALLVCM_AMD_STREAM_PRIO"); prio = (e && e[0] == '1') ? 1 : 0; }
+            const bool low = prio == 1;
             int lo = 0, hi = 0;
             if (low) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   /* lo = the numerically largest = least urgent */
             if (low) {
@@ -1320,9 +1321,9 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
             /* K3c reads what K3 appended and the light store, and only K5 reads what it writes: it runs on the splat
-               stream, next to K3b and K4, joined before K5: +2 % at 512^2, +6 % at 1024^2 (profiles/r05d_ab_summary.txt)
-               and, since the helper streams have the lowest priority, +1.4 % at 2048^2 (profiles/r05l_prio2.txt; with
-               equal priorities the VALU-bound K3c next to K4 bought nothing there).  SMALLVCM_AMD_VC_STREAM=0: in line. */
+               stream, next to K3b and K4, joined before K5: +2 % at 512^2, +6 % at 1024^2 (profiles/r05d_ab_summary.txt);
+               at 2048^2, where K4 is issue-bound, it neither gains nor loses with equal stream priorities (r05f) and gained
+               1.4 % with the helper streams at low priority (r05l).  SMALLVCM_AMD_VC_STREAM=0: in line. */
             static int vcForce = -2;
             if (vcForce == -2) { const char *e = getenv("SMALLVCM_AMD_VC_STREAM"); vcForce = e ? (e[0] == '1' ? 1 : 0) : -1; }
             const bool vcAside = (vcForce != 0) && c->world == 1;
