@@ -2490,7 +2490,33 @@ struct CameraPath {
 /* allocator state of ONE wave: {next free slot, slots left in the block}.  It
  * lives in LDS (one pair per wave and queue): the allocation runs in divergent
  * code, so a register copy would go stale in the lanes that sit a call out. */
-struct WaveQueue { volatile int *p; };
+/* The two words of a queue live in LDS and are reached through an LDS pointer with relaxed atomic loads and stores:
+ * ds_read / ds_write that the compiler neither caches in a register nor hoists out of the loop.  (They were a
+ * `volatile int *` first: a GENERIC pointer, so every access was a flat_load / flat_store with system scope followed
+ * by s_waitcnt vmcnt(0) -- twelve of them per vertex K3 appended, each also waiting for every record store in flight:
+ * 28 % of K3's wave time, profiles/r05z_region_clock.txt.) */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) int *WaveQueueWords;
+#else
+typedef int *WaveQueueWords;
+#endif
+VCM_HD int wq_load(WaveQueueWords p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+#else
+    return *p;
+#endif
+}
+VCM_HD void wq_store(WaveQueueWords p, int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __atomic_store_n(p, v, __ATOMIC_RELAXED);
+#else
+    *p = v;
+#endif
+}
+struct WaveQueue { WaveQueueWords p; };
 
 VCM_HD uint32_t lanes_below_mask_popc(unsigned long long m)
 {
@@ -2520,7 +2546,7 @@ VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, in
         prefix += (int)lanes_below_mask_popc(m) << bit;
         total += __popcll(m) << bit;
     }
-    int base = wq.p[0], left = wq.p[1];   /* same values in every active lane */
+    int base = wq_load(wq.p), left = wq_load(wq.p + 1);   /* same values in every active lane */
     if (total > left) {   /* wave-uniform */
         holeFill(base, left, rank, (int)__popcll(act));
         const int take = ((total + blockSize - 1) / blockSize) * blockSize;
@@ -2529,7 +2555,7 @@ VCM_HD int wave_queue_alloc(const WaveQueue &wq, int *counter, int blockSize, in
         base = __shfl(nb, __ffsll((long long)act) - 1, 64);
         left = take;
     }
-    if (rank == 0) { wq.p[0] = base + total; wq.p[1] = left - total; }
+    if (rank == 0) { wq_store(wq.p, base + total); wq_store(wq.p + 1, left - total); }
     return base + prefix;
 #else
     (void)wq; (void)blockSize; (void)holeFill;
@@ -2694,7 +2720,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
             /* the three queues' words: read together, written back together by the first active lane */
             const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
             const int rank = (int)lanes_below_mask_popc(act);
-            int vb = wqs.v.p[0], vl = wqs.v.p[1], db = wqs.di.p[0], dl = wqs.di.p[1], cb = wqs.vc.p[0], cl = wqs.vc.p[1];
+            int vb = wq_load(wqs.v.p), vl = wq_load(wqs.v.p + 1), db = wq_load(wqs.di.p), dl = wq_load(wqs.di.p + 1), cb = wq_load(wqs.vc.p), cl = wq_load(wqs.vc.p + 1);
             const int vi = wave_queue_take<0>(vb, vl, &vs.count[0], P.qblockVertex, 1, act, rank,
                 [&](int first, int cnt, int rk, int na) {
                     for (int i = rk; i < cnt; i += na) {
@@ -2705,7 +2731,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
                 [&](int first, int cnt, int rk, int na) { for (int i = rk; i < cnt; i += na) vs.diTask[first + i] = -1; });
             const int vc0 = wave_queue_take<5>(cb, cl, &vs.count[2], P.qblockVC, nvc, act, rank,
                 [&](int first, int cnt, int rk, int na) { for (int i = rk; i < cnt; i += na) vs.vcTask[2 * (first + i)] = -1; });
-            if (rank == 0) { wqs.v.p[0] = vb; wqs.v.p[1] = vl; wqs.di.p[0] = db; wqs.di.p[1] = dl; wqs.vc.p[0] = cb; wqs.vc.p[1] = cl; }
+            if (rank == 0) { wq_store(wqs.v.p, vb); wq_store(wqs.v.p + 1, vl); wq_store(wqs.di.p, db); wq_store(wqs.di.p + 1, dl); wq_store(wqs.vc.p, cb); wq_store(wqs.vc.p + 1, cl); }
 #else
             const int vi = wave_queue_alloc(wqs.v, &vs.count[0], P.qblockVertex, 1, [](int, int, int, int) {});
             const int di = wave_queue_alloc(wqs.di, &vs.count[1], P.qblockDI, hasDI, [](int, int, int, int) {});

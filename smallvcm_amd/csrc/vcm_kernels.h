@@ -215,7 +215,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
     int *myState = wqState + (threadIdx.x / VCM_WAVE) * 6;
     if (lane < 6) myState[lane] = 0;
     CameraWaveQueues wqs;
-    wqs.v.p = myState; wqs.di.p = myState + 2; wqs.vc.p = myState + 4;
+    wqs.v.p = (WaveQueueWords)myState; wqs.di.p = (WaveQueueWords)(myState + 2); wqs.vc.p = (WaveQueueWords)(myState + 4);
     wqs.pendingVertex = -1; wqs.pendingArrival = 0;
     CameraPath path;
     bool alive = false;
@@ -244,7 +244,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
         RC_MARK(22);
     }
     if (MODE == 1) {   /* mark the unused tails of this wave's last blocks as holes */
-        const int vb = wqs.v.p[0], vl = wqs.v.p[1], db = wqs.di.p[0], dl = wqs.di.p[1], cb = wqs.vc.p[0], cl = wqs.vc.p[1];
+        const int vb = wq_load(wqs.v.p), vl = wq_load(wqs.v.p + 1), db = wq_load(wqs.di.p), dl = wq_load(wqs.di.p + 1), cb = wq_load(wqs.vc.p), cl = wq_load(wqs.vc.p + 1);
         for (int i = (int)lane; i < vl; i += VCM_WAVE) {
             vq(vs, 0, vb + i) = mk4(0.f, 0.f, 0.f, u2f(0xffffffffu));
             if (vs.sortKey) vs.sortKey[vb + i] = -1;
