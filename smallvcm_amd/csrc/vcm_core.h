@@ -2451,18 +2451,43 @@ VCM_HD QueryBuckets query_buckets(const IterParams &P, const GridHeader *hdr)
     return b;
 }
 
-VCM_HD int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
+/* what the key needs of the grid header, read ONCE per kernel into wave-uniform (scalar) registers: the photon bbox is
+ * final before the camera pass starts.  Read where the key is formed -- once per appended camera vertex -- the header
+ * came through two VECTOR loads (the compiler issues no scalar load for memory other kernels write), and the wait for
+ * them was a wait for every record store the vertex had just issued; the bucket geometry was recomputed as well. */
+struct QueryKey { float bminx, bminy, bminz, bmaxx, bmaxy, bmaxz; uint32_t nx, ny; int sx, sy, sz; };   /* scalars: an array member would live in scratch */
+VCM_HD float wave_uniform_f(float v)
 {
-    const V3 bmin = ld3(hdr->bboxMin), bmax = ld3(hdr->bboxMax);
-    const V3 distMin = queryPos - bmin;
-    const V3 distMax = bmax - queryPos;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+#else
+    return v;
+#endif
+}
+VCM_HD QueryKey query_key_load(const IterParams &P, const GridHeader *hdr)
+{
+    QueryKey k;
+    const QueryBuckets b = query_buckets(P, hdr);
+    k.bminx = wave_uniform_f(hdr->bboxMin[0]); k.bminy = wave_uniform_f(hdr->bboxMin[1]); k.bminz = wave_uniform_f(hdr->bboxMin[2]);
+    k.bmaxx = wave_uniform_f(hdr->bboxMax[0]); k.bmaxy = wave_uniform_f(hdr->bboxMax[1]); k.bmaxz = wave_uniform_f(hdr->bboxMax[2]);
+    k.nx = (uint32_t)wave_uniform((int)b.nx); k.ny = (uint32_t)wave_uniform((int)b.ny);
+    k.sx = wave_uniform(b.sx); k.sy = wave_uniform(b.sy); k.sz = wave_uniform(b.sz);
+    return k;
+}
+VCM_HD int query_sort_key(const IterParams &P, const QueryKey &k, V3 queryPos)
+{
+    const V3 distMin = queryPos - mk3(k.bminx, k.bminy, k.bminz);
+    const V3 distMax = mk3(k.bmaxx, k.bmaxy, k.bmaxz) - queryPos;
     if (distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f || distMin.z < 0.f || distMax.z < 0.f)
         return -1;   /* outside the photon bbox: HashGrid::Process returns at once (:116-122) */
-    const QueryBuckets b = query_buckets(P, hdr);
     const V3 cellPt = P.invCellSize * distMin;
-    const uint32_t cx = (uint32_t)floorf(cellPt.x) >> b.sx, cy = (uint32_t)floorf(cellPt.y) >> b.sy,
-                   cz = (uint32_t)floorf(cellPt.z) >> b.sz;
-    return (int)((cz * b.ny + cy) * b.nx + cx);
+    const uint32_t cx = (uint32_t)floorf(cellPt.x) >> k.sx, cy = (uint32_t)floorf(cellPt.y) >> k.sy,
+                   cz = (uint32_t)floorf(cellPt.z) >> k.sz;
+    return (int)((cz * k.ny + cy) * k.nx + cx);
+}
+VCM_HD int query_sort_key(const IterParams &P, const GridHeader *hdr, V3 queryPos)
+{
+    return query_sort_key(P, query_key_load(P, hdr), queryPos);
 }
 
 
@@ -2652,7 +2677,7 @@ struct CameraWaveQueues {   /* wave-uniform allocator state of K3 */
 template <int MODE, class SC>
 VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, const LightStore &store,
                              const GridStore &grid, LaneStats &ls, const MergeScratch &ms, const VertexStore &vs,
-                             CameraWaveQueues &wqs)
+                             CameraWaveQueues &wqs, const QueryKey &qk /* wavefront mode with the query sort: query_key_load, once per kernel */)
 {
     SubPathState &st = cp.st;
     Ray ray; ray.org = st.origin + st.direction * VCM_EPS_RAY; ray.dir = st.direction; ray.tmin = 0;
@@ -2746,7 +2771,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
             vs.meta[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = m;
 #if defined(__HIP_DEVICE_COMPILE__)
             if (vs.sortKey && P.useVM) {   /* K4a's histogram pass, here (see VertexStore) */
-                const int k = query_sort_key(P, vs.sortHdr, hitPoint);
+                const int k = query_sort_key(P, qk, hitPoint);
                 vs.sortKey[vi] = k;
 #if defined(VCM_NO_DEFER)   /* measurement switch: store on the spot */
                 if (k >= 0) vs.sortArrival[vi] = atomicAdd(&vs.bucketCount[k], 1);

@@ -217,6 +217,8 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
     CameraWaveQueues wqs;
     wqs.v.p = (WaveQueueWords)myState; wqs.di.p = (WaveQueueWords)(myState + 2); wqs.vc.p = (WaveQueueWords)(myState + 4);
     wqs.pendingVertex = -1; wqs.pendingArrival = 0;
+    QueryKey qk = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1u, 1u, 0, 0, 0 };
+    if (MODE == 1 && vs.sortKey && P.useVM) qk = query_key_load(P, vs.sortHdr);
     CameraPath path;
     bool alive = false;
     RC_DECL;
@@ -229,7 +231,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
         RC_MARK(20);
         if (!wave_any(alive)) { if (ww.exhausted) break; else continue; }
         if (alive) {
-            alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs);
+            alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs, qk);
             RC_RESET;
 #if !defined(VCM_NO_DEFER)
             if (MODE == 1 && wqs.pendingVertex >= 0) { vs.sortArrival[wqs.pendingVertex] = wqs.pendingArrival; wqs.pendingVertex = -1; }

@@ -221,7 +221,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             VertexStore vs; memset(&vs, 0, sizeof(vs));
             int wqState[6] = {0, 0, 0, 0, 0, 0};
             CameraWaveQueues wqs; wqs.v.p = wqState; wqs.di.p = wqState + 2; wqs.vc.p = wqState + 4; wqs.pendingVertex = -1; wqs.pendingArrival = 0;
-            with_scene(e.sc, [&](const auto &sc) { while (camera_path_step<0>(sc, P, path, store, grid, e.ls, ms, vs, wqs)) {} });
+            QueryKey qk = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1u, 1u, 0, 0, 0 };
+            with_scene(e.sc, [&](const auto &sc) { while (camera_path_step<0>(sc, P, path, store, grid, e.ls, ms, vs, wqs, qk)) {} });
             e.camOut[lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)camera_path_target(P, path)));
             e.rngC[lp] = (unsigned char)path.rng.k;
         }
