@@ -1,6 +1,7 @@
 """The product's device functions (smallvcm_amd/csrc/vcm_core.h), compiled for
 the host and driven serially (tests/host_emul), must equal the oracle bit for
 bit: framebuffer, random-number tape, merge records and workload counters."""
+import os
 import numpy as np
 import pytest
 
@@ -27,3 +28,20 @@ def test_device_functions_equal_oracle(sid, algo, res, nit, mn, mx):
     so, se = o.stats(), e.stats()
     for k in se:
         assert so[k] == se[k], k
+
+
+def test_certified_filters_against_the_reference_loop_on_every_ray():
+    """tests/filter_check.py at a small size: the host build with -DVCM_FILTER_CHECK runs the filter AND the reference's
+    brute-force loop on every ray (rectangles, Pluecker quads, the general list) and prints a line for every certified
+    answer the loop does not give.  (The full-size run is profiles/r05w_filter_check.txt.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "filter_check.py"), "48", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stdout
+    assert "total:" in text
+    assert not [l for l in text.splitlines() if "FILTER MISMATCH" in l and not l.startswith("total:")], text[-2000:]
+    rays = [l for l in text.splitlines() if "closest-hit rays" in l]
+    assert len(rays) == 18   # 4 scenes x 2 filter forms x 2 path lengths + the tilted room x 2
