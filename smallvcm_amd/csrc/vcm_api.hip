@@ -1408,6 +1408,14 @@ static int vcm_merge_impl(vcm_ctx *c)
                 if (slab < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slab = (e && !strcmp(e, "slab")) ? 1 : 0; }
                 static int slabBlocks = 0;
                 if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
+                /* SMALLVCM_AMD_MERGE_DRAIN=transposed: k_merge_walk_t, EXPERIMENTAL and not yet validated on a GPU (see its
+                   comment); 768 workgroups are resident (three per CU) */
+                static int transposed = -1;
+                if (transposed < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DRAIN"); transposed = (e && !strcmp(e, "transposed")) ? 1 : 0; }
+                if (transposed)
+                    hipLaunchKernelGGL(k_merge_walk_t, dim3(768), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
+                else
                 hipLaunchKernelGGL(k_merge_walk, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
                                    c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
                                    slab ? c->vs.count + 24 : (int *)NULL);

@@ -635,6 +635,224 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #endif
 }
 
+/* ---------------- K4, EXPERIMENTAL (SMALLVCM_AMD_MERGE_DRAIN=transposed): the drain transposed ---------------- */
+/* k_merge_walk drains when ONE lane's queue is full, and every lane then evaluates ITS accepted photons: the loop runs
+ * to the fullest lane's ~17 entries while the average lane holds 6.4 (215 M accepted photons in 524 K drains at 2048^2):
+ * RangeQuery::Process, 61 % of the kernel, at ~38 % lane utilisation.  Here the wave's
+ * (query, photon) pairs are flattened -- exclusive prefix sum of the queue lengths -- and lane l evaluates pair
+ * 64 j + l of chunk j, whoever owns it: the owner's per-query state comes out of LDS (written once per query:
+ * frame, local direction, five scalars, path length and material), the material out of the LDS scene tables, and the
+ * pair's TERM  misWeight * f * throughput  (merge_eval_photon on a zero accumulator: 0 + x = x exactly, x >= +0) goes to
+ * LDS.  Every owner then adds the terms of its pairs in the chunk IN QUEUE ORDER (cells in the reference's order, vertices in
+ * index order): the same values added in the same order as k_merge_walk and the reference, hence the same bits (a pair
+ * the reference skips contributes +0 to a sum that is never -0).
+ * NOT VALIDATED ON A GPU YET (written at the end of round 3, after the GPU budget was spent): not selected by default, not
+ * part of the test suite.  Costs per workgroup: 18 words of state per query + prefix + terms + the scene tables = 26 KB of
+ * LDS on top of a 10-entry queue and the runs: three workgroups per CU instead of four. */
+#define VCM_WT_Q 10        /* with 18 words of state per query: 53.9 KB per workgroup, three per CU */
+#define VCM_WT_STATE 18   /* words per query */
+#if defined(__HIP_DEVICE_COMPILE__)
+struct WalkTLds {
+    uint32_t accQ[(VCM_WT_Q + 1) * VCM_MERGE_BLOCK];
+    WalkRun runs[8 * VCM_MERGE_BLOCK];
+    float state[VCM_WT_STATE * VCM_MERGE_BLOCK];   /* [thread][VCM_WT_STATE] */
+    int prefix[VCM_MERGE_BLOCK];                  /* exclusive prefix of the queue lengths, per wave */
+    float term[3 * VCM_MERGE_BLOCK];              /* [component][thread] */
+};
+/* all 64 lanes of the wave call this together; qn = this lane's queue length (0 for a lane without a query) */
+__device__ __forceinline__ void merge_drain_transposed(const DScene &sc, const IterParams &P, const GridStore &g, WalkTLds &L,
+                                                       int qn, V3 &contrib)
+{
+    const int tid = (int)threadIdx.x, lane = tid & (VCM_WAVE - 1), waveBase = tid & ~(VCM_WAVE - 1);
+    int incl = qn;
+#pragma unroll
+    for (int o = 1; o < VCM_WAVE; o <<= 1) { const int v = __shfl_up(incl, o, VCM_WAVE); if (lane >= o) incl += v; }
+    const int start = incl - qn;
+    const int total = __shfl(incl, VCM_WAVE - 1, VCM_WAVE);   /* wave-uniform */
+    if (total == 0) return;
+    L.prefix[tid] = start;
+    for (int base = 0; base < total; base += VCM_WAVE) {
+        const int p = base + lane;
+        const bool valid = p < total;
+        /* the owner of pair p: the LAST lane whose start is <= p (lanes with an empty queue share their start with the
+           next lane, so the last one of a run of equal starts is the one that owns pairs) */
+        int o = 0;
+#pragma unroll
+        for (int step = VCM_WAVE / 2; step > 0; step >>= 1) {
+            const int c = o + step;
+            if (L.prefix[waveBase + c] <= p) o = c;
+        }
+        const int otid = waveBase + o;
+        const int k = p - L.prefix[otid];
+        const uint32_t idx = valid ? L.accQ[k * VCM_MERGE_BLOCK + otid] : 0u;   /* photon 0 is always allocated */
+        const F2 t3 = g.g3[idx];
+        const F4 pb = g.g1[idx], pc = g.g2[idx];
+        /* the owner's state (merge_eval_setup's inputs, written by k_merge_walk_t when the query started) */
+        const float *S = L.state + otid * VCM_WT_STATE;
+        MergeEval e;
+        e.frame.mX = mk3(S[0], S[1], S[2]); e.frame.mY = mk3(S[3], S[4], S[5]); e.frame.mZ = mk3(S[6], S[7], S[8]);
+        const V3 ldf = mk3(S[9], S[10], S[11]);
+        e.diffProb = S[12]; e.phongProb = S[13]; e.camContProb = S[14]; e.camTerm = S[15]; e.camdVM = S[16];
+        const uint32_t packed = f2u(S[17]);
+        e.pathLength = packed & 0xffu;
+        const vcm_material m = scene_material(sc, valid ? (int)(packed >> 8) : 0);   /* the LDS table (the kernel stages it); a lane without a pair may look at a record nobody wrote */
+        /* exactly merge_eval_setup's expressions */
+        e.refl = reflect_local(ldf);
+        e.diffuseVal = ld3(m.diffuse) * VCM_INV_PI_F;
+        e.rho = ld3(m.phong) * (m.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;
+        e.ldfz = ldf.z;
+        e.phongExp = m.phongExp;
+        e.revPdfDiffuse = e.diffProb * smax(0.f, ldf.z * VCM_INV_PI_F);
+        e.cosOk = !(ldf.z < VCM_EPS_COSINE);
+        V3 t = sp3(0.f);
+        if (valid) merge_eval_photon(e, P, f2u(t3.y), mk3(pb.x, pb.y, pb.z), pb.w, mk3(pc.x, pc.y, pc.z), pc.w, t3.x, t);
+        L.term[0 * VCM_MERGE_BLOCK + tid] = t.x; L.term[1 * VCM_MERGE_BLOCK + tid] = t.y; L.term[2 * VCM_MERGE_BLOCK + tid] = t.z;
+        /* the owners add the terms of their pairs in this chunk, in queue order */
+        const int lo = max(start, base), hi = min(start + qn, base + VCM_WAVE);
+        for (int q = lo; wave_any(q < hi); q++) {
+            if (q < hi) {
+                const int src = waveBase + (q - base);
+                contrib = contrib + mk3(L.term[0 * VCM_MERGE_BLOCK + src], L.term[1 * VCM_MERGE_BLOCK + src], L.term[2 * VCM_MERGE_BLOCK + src]);
+            }
+        }
+    }
+}
+
+/* merge_query_walk with the transposed drain; every lane of the wave calls it (hasQuery = false: no runs, no state) */
+__device__ __forceinline__ V3 merge_query_walk_t(const DScene &sc, const IterParams &P, const GridStore &g, bool hasQuery,
+                                                 V3 queryPos, LaneStats &ls, WalkTLds &L)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int tid = (int)threadIdx.x;
+    const int stride = VCM_MERGE_BLOCK;
+    WalkRun *runs = L.runs + tid;
+    uint32_t *q = L.accQ + tid;
+    V3 contrib = sp3(0.f);
+    int n = 0;
+    if (hasQuery) {   /* hashgrid.hxx:116-155, as merge_query_walk */
+        const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
+        const V3 distMin = queryPos - bmin, distMax = bmax - queryPos;
+        const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
+                              distMin.z < 0.f || distMax.z < 0.f);
+        const V3 cellPt = P.invCellSize * distMin;
+        const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+        const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
+        const V3 fractCoord = cellPt - coordF;
+        const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+        const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+        const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+        int lo[8], hi[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            lo[j] = 0; hi[j] = 0;
+            if (inside) {
+                const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
+                lo[j] = g.cellStart[cell];
+                hi[j] = g.cellStart[cell + 1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]);
+            if (hi[j] > lo[j]) { WalkRun r; r.lo = lo[j]; r.hi = hi[j]; runs[n * stride] = r; n++; }
+        }
+    }
+    const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
+    int qn = 0, k = 0;
+    WalkRun cur, nxt;
+    cur.lo = 0; cur.hi = 0; nxt = cur;
+    if (n > 0) cur = runs[0];
+    if (n > 1) nxt = runs[stride];
+    f4u X = *(const f4u *)(g.gx + cur.lo), Y = *(const f4u *)(g.gy + cur.lo), Z = *(const f4u *)(g.gz + cur.lo);
+    while (wave_any(cur.lo < cur.hi)) {
+        const int stepEnd = cur.lo + VCM_MERGE_UNROLL;
+        const bool last = stepEnd >= cur.hi;
+        const int aNext = last ? nxt.lo : stepEnd;
+        const f4u Xn = *(const f4u *)(g.gx + aNext), Yn = *(const f4u *)(g.gy + aNext), Zn = *(const f4u *)(g.gz + aNext);
+        float distSqr[VCM_MERGE_UNROLL];
+        {
+            const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
+            const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
+            const f2 da = dxa * dxa + dya * dya + dza * dza;
+            const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
+            distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
+        }
+        X = Xn; Y = Yn; Z = Zn;
+#pragma unroll
+        for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
+            const int idx = cur.lo + u;
+            const bool acc = (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);
+            q[qn * stride] = (uint32_t)idx;
+            qn += acc ? 1 : 0;
+        }
+        if (last) {
+            cur = nxt;
+            k++;
+            nxt.lo = 0; nxt.hi = 0;
+            if (k + 1 < n) nxt = runs[(k + 1) * stride];
+        } else cur.lo = stepEnd;
+        if (wave_any(qn > VCM_WT_Q - VCM_MERGE_UNROLL)) {
+            ls.mergeAccepted += (uint32_t)qn;
+            merge_drain_transposed(sc, P, g, L, qn, contrib);
+            qn = 0;
+        }
+    }
+    ls.mergeAccepted += (uint32_t)qn;
+    merge_drain_transposed(sc, P, g, L, qn, contrib);
+    return contrib;
+}
+#endif
+
+__global__ void __launch_bounds__(VCM_MERGE_BLOCK)
+k_merge_walk_t(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
+               const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
+{
+    stamp_entry(st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const DScene &sc = *scp;
+    stage_scene_tables(sc);
+    const int nQ = *nSorted;
+    __shared__ WalkTLds L;
+    LaneStats ls; lane_stats_zero(ls);
+    const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
+    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
+    for (int t = wgOfXcd;; t += wgPerXcd) {
+        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
+        if ((t / chunk) * 8 * chunk >= nBatches) break;
+        if (b >= nBatches) continue;
+        const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
+        const bool hasQuery = q < nQ;
+        V3 pos = sp3(0.f), thr = sp3(0.f);
+        size_t ps = 0;
+        if (hasQuery) {
+            const int vi = sortedVertex[q];
+            const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
+            ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
+            Bsdf bsdf;
+            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
+            pos = mk3(a.x, a.y, a.z); thr = mk3(d.x, d.y, d.z);
+            float *S = L.state + threadIdx.x * VCM_WT_STATE;   /* what merge_eval_setup reads of the query */
+            S[0] = bsdf.frame.mX.x; S[1] = bsdf.frame.mX.y; S[2] = bsdf.frame.mX.z;
+            S[3] = bsdf.frame.mY.x; S[4] = bsdf.frame.mY.y; S[5] = bsdf.frame.mY.z;
+            S[6] = bsdf.frame.mZ.x; S[7] = bsdf.frame.mZ.y; S[8] = bsdf.frame.mZ.z;
+            S[9] = bsdf.localDirFix.x; S[10] = bsdf.localDirFix.y; S[11] = bsdf.localDirFix.z;
+            S[12] = bsdf.diffProb; S[13] = bsdf.phongProb; S[14] = bsdf.contProb;
+            S[15] = c.w * P.misVcWeightFactor;   /* camTerm = dVCM * mMisVcWeightFactor */
+            S[16] = d.w;                         /* camdVM */
+            S[17] = u2f((f2u(bq.w) & 0xffu) | ((uint32_t)bsdf.matID << 8));
+        }
+        /* (a wave's lanes read only their own wave's state, prefix and terms: LDS operations of a wave execute in order,
+           so no barrier is needed between the writes above and the reads of the drain) */
+        const V3 contrib = merge_query_walk_t(sc, P, g, hasQuery, pos, ls, L);
+        if (hasQuery) {
+            const V3 v = thr * P.vmNormalization * contrib;
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+        }
+    }
+    flush_stats(ls, gstats);
+#endif
+}
+
 /* ---------------- K4 (default): range-merge with the cell lists staged through LDS ---------------- */
 /* HashGrid::Process walks 8 hashed cells per query (hashgrid.hxx:142-167).  k_merge_lane reads the candidates of
  * those cells with per-lane global loads: three 16-byte loads per lane and step, each touching as many cache lines
