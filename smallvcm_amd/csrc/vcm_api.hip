@@ -1408,7 +1408,7 @@ static int vcm_merge_impl(vcm_ctx *c)
                 if (slab < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slab = (e && !strcmp(e, "slab")) ? 1 : 0; }
                 static int slabBlocks = 0;
                 if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
-                /* SMALLVCM_AMD_MERGE_DRAIN=transposed: k_merge_walk_t, EXPERIMENTAL and not yet validated on a GPU (see its
+                /* SMALLVCM_AMD_MERGE_DRAIN=transposed: k_merge_walk_t, EXPERIMENTAL: same bits, 2.4 x slower as it stands (see its
                    comment); 768 workgroups are resident (three per CU) */
                 static int transposed = -1;
                 if (transposed < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DRAIN"); transposed = (e && !strcmp(e, "transposed")) ? 1 : 0; }

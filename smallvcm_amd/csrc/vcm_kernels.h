@@ -646,8 +646,10 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
  * LDS.  Every owner then adds the terms of its pairs in the chunk IN QUEUE ORDER (cells in the reference's order, vertices in
  * index order): the same values added in the same order as k_merge_walk and the reference, hence the same bits (a pair
  * the reference skips contributes +0 to a sum that is never -0).
- * NOT VALIDATED ON A GPU YET (written at the end of round 3, after the GPU budget was spent): not selected by default, not
- * part of the test suite.  Costs per workgroup: 18 words of state per query + prefix + terms + the scene tables = 26 KB of
+ * MEASURED ONCE (profiles/r05x_transposed.txt, r05y_transposed.txt, the last seconds of round 3's GPU budget): the frames
+ * are k_merge_walk's bit for bit (VCM, BPM at 512^2, VCM at 2048^2) -- and the kernel takes ~8 ms against 3.4: it is chains of
+ * LDS latency (the owner search, the state words, one term per trip of the addition loop), see DESIGN.md section 8 for what
+ * a second version needs.  Not selected by default, not part of the test suite.  Costs per workgroup: 18 words of state per query + prefix + terms + the scene tables = 26 KB of
  * LDS on top of a 10-entry queue and the runs: three workgroups per CU instead of four. */
 #define VCM_WT_Q 10        /* with 18 words of state per query: 53.9 KB per workgroup, three per CU */
 #define VCM_WT_STATE 18   /* words per query */
