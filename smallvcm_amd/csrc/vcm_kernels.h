@@ -646,11 +646,11 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
  * LDS.  Every owner then adds the terms of its pairs in the chunk IN QUEUE ORDER (cells in the reference's order, vertices in
  * index order): the same values added in the same order as k_merge_walk and the reference, hence the same bits (a pair
  * the reference skips contributes +0 to a sum that is never -0).
- * MEASURED ONCE (profiles/r05x_transposed.txt, r05y_transposed.txt, the last seconds of round 3's GPU budget): the frames
- * are k_merge_walk's bit for bit (VCM, BPM at 512^2, VCM at 2048^2) -- and the kernel takes ~8 ms against 3.4: it is chains of
- * LDS latency (the owner search, the state words, one term per trip of the addition loop), see DESIGN.md section 8 for what
- * a second version needs.  Not selected by default, not part of the test suite.  Costs per workgroup: 18 words of state per query + prefix + terms + the scene tables = 26 KB of
- * LDS on top of a 10-entry queue and the runs: three workgroups per CU instead of four. */
+ * MEASURED (profiles/r05x_transposed.txt, r05y*_transposed.txt, the last seconds of round 3's GPU budget): the frames are
+ * k_merge_walk's bit for bit (VCM, BPM at 512^2, VCM at 2048^2) -- and the kernel takes ~8 ms against 3.4, in both
+ * versions (the second: owner by head flags + max-scan, next chunk prefetched, terms read four at a time): every chunk is
+ * a chain of dependent LDS round trips around a global gather, at three workgroups per CU.  DESIGN.md section 8.  Not
+ * selected by default, not part of the test suite. */
 #define VCM_WT_Q 10        /* with 18 words of state per query: 53.9 KB per workgroup, three per CU */
 #define VCM_WT_STATE 18   /* words per query */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -661,7 +661,34 @@ struct WalkTLds {
     int prefix[VCM_MERGE_BLOCK];                  /* exclusive prefix of the queue lengths, per wave */
     float term[3 * VCM_MERGE_BLOCK];              /* [component][thread] */
 };
-/* all 64 lanes of the wave call this together; qn = this lane's queue length (0 for a lane without a query) */
+/* all 64 lanes of the wave call this together; qn = this lane's queue length (0 for a lane without a query).
+ * Second version: the owner of a pair by head flags + an inclusive max-scan over the chunk (the first searched the
+ * prefix array in LDS, six dependent reads), the next chunk's photon in flight while this one is evaluated, the owner's
+ * terms read four at a time. */
+struct WtPair { int owner, k; uint32_t idx; bool valid; F2 t3; F4 pb, pc; };
+__device__ __forceinline__ void wt_pair_fetch(const GridStore &g, WalkTLds &L, int base, int total, int start, int qn, WtPair &w)
+{
+    const int tid = (int)threadIdx.x, lane = tid & (VCM_WAVE - 1), waveBase = tid & ~(VCM_WAVE - 1);
+    const int p = base + lane;
+    w.valid = p < total;
+    /* head flags: a lane whose pairs reach into [base, base + 64) marks the first position it owns there */
+    /* (relaxed atomics: the flag a lane reads is one ANOTHER lane wrote; with plain accesses the compiler forwards this
+       lane's own -1 to the load -- a memory fault on the first try, profiles/r05y2_transposed.txt) */
+    __atomic_store_n(&L.prefix[tid], -1, __ATOMIC_RELAXED);
+    if (qn > 0 && start < base + VCM_WAVE && start + qn > base)
+        __atomic_store_n(&L.prefix[waveBase + max(start, base) - base], lane, __ATOMIC_RELAXED);
+    int o = __atomic_load_n(&L.prefix[tid], __ATOMIC_RELAXED);
+#pragma unroll
+    for (int d = 1; d < VCM_WAVE; d <<= 1) { const int v = __shfl_up(o, d, VCM_WAVE); if (lane >= d) o = max(o, v); }
+    o = max(o, 0);                                  /* (a lane beyond the last pair) */
+    const int ostart = __shfl(start, o, VCM_WAVE);
+    w.owner = waveBase + o;
+    w.k = p - ostart;
+    w.idx = w.valid ? L.accQ[w.k * VCM_MERGE_BLOCK + w.owner] : 0u;   /* photon 0 is always allocated */
+    w.t3 = g.g3[w.idx];
+    w.pb = g.g1[w.idx];
+    w.pc = g.g2[w.idx];
+}
 __device__ __forceinline__ void merge_drain_transposed(const DScene &sc, const IterParams &P, const GridStore &g, WalkTLds &L,
                                                        int qn, V3 &contrib)
 {
@@ -672,32 +699,20 @@ __device__ __forceinline__ void merge_drain_transposed(const DScene &sc, const I
     const int start = incl - qn;
     const int total = __shfl(incl, VCM_WAVE - 1, VCM_WAVE);   /* wave-uniform */
     if (total == 0) return;
-    L.prefix[tid] = start;
+    WtPair cur, nxt;
+    wt_pair_fetch(g, L, 0, total, start, qn, cur);
     for (int base = 0; base < total; base += VCM_WAVE) {
-        const int p = base + lane;
-        const bool valid = p < total;
-        /* the owner of pair p: the LAST lane whose start is <= p (lanes with an empty queue share their start with the
-           next lane, so the last one of a run of equal starts is the one that owns pairs) */
-        int o = 0;
-#pragma unroll
-        for (int step = VCM_WAVE / 2; step > 0; step >>= 1) {
-            const int c = o + step;
-            if (L.prefix[waveBase + c] <= p) o = c;
-        }
-        const int otid = waveBase + o;
-        const int k = p - L.prefix[otid];
-        const uint32_t idx = valid ? L.accQ[k * VCM_MERGE_BLOCK + otid] : 0u;   /* photon 0 is always allocated */
-        const F2 t3 = g.g3[idx];
-        const F4 pb = g.g1[idx], pc = g.g2[idx];
+        const bool more = base + VCM_WAVE < total;             /* wave-uniform */
+        if (more) wt_pair_fetch(g, L, base + VCM_WAVE, total, start, qn, nxt);
         /* the owner's state (merge_eval_setup's inputs, written by k_merge_walk_t when the query started) */
-        const float *S = L.state + otid * VCM_WT_STATE;
+        const float *S = L.state + cur.owner * VCM_WT_STATE;
         MergeEval e;
         e.frame.mX = mk3(S[0], S[1], S[2]); e.frame.mY = mk3(S[3], S[4], S[5]); e.frame.mZ = mk3(S[6], S[7], S[8]);
         const V3 ldf = mk3(S[9], S[10], S[11]);
         e.diffProb = S[12]; e.phongProb = S[13]; e.camContProb = S[14]; e.camTerm = S[15]; e.camdVM = S[16];
         const uint32_t packed = f2u(S[17]);
         e.pathLength = packed & 0xffu;
-        const vcm_material m = scene_material(sc, valid ? (int)(packed >> 8) : 0);   /* the LDS table (the kernel stages it); a lane without a pair may look at a record nobody wrote */
+        const vcm_material m = scene_material(sc, cur.valid ? (int)(packed >> 8) : 0);   /* the LDS table (the kernel stages it); a lane without a pair may look at a record nobody wrote */
         /* exactly merge_eval_setup's expressions */
         e.refl = reflect_local(ldf);
         e.diffuseVal = ld3(m.diffuse) * VCM_INV_PI_F;
@@ -707,16 +722,21 @@ __device__ __forceinline__ void merge_drain_transposed(const DScene &sc, const I
         e.revPdfDiffuse = e.diffProb * smax(0.f, ldf.z * VCM_INV_PI_F);
         e.cosOk = !(ldf.z < VCM_EPS_COSINE);
         V3 t = sp3(0.f);
-        if (valid) merge_eval_photon(e, P, f2u(t3.y), mk3(pb.x, pb.y, pb.z), pb.w, mk3(pc.x, pc.y, pc.z), pc.w, t3.x, t);
+        if (cur.valid) merge_eval_photon(e, P, f2u(cur.t3.y), mk3(cur.pb.x, cur.pb.y, cur.pb.z), cur.pb.w, mk3(cur.pc.x, cur.pc.y, cur.pc.z), cur.pc.w, cur.t3.x, t);
         L.term[0 * VCM_MERGE_BLOCK + tid] = t.x; L.term[1 * VCM_MERGE_BLOCK + tid] = t.y; L.term[2 * VCM_MERGE_BLOCK + tid] = t.z;
-        /* the owners add the terms of their pairs in this chunk, in queue order */
+        /* the owners add the terms of their pairs in this chunk, in queue order, four reads in flight at a time */
         const int lo = max(start, base), hi = min(start + qn, base + VCM_WAVE);
-        for (int q = lo; wave_any(q < hi); q++) {
-            if (q < hi) {
-                const int src = waveBase + (q - base);
-                contrib = contrib + mk3(L.term[0 * VCM_MERGE_BLOCK + src], L.term[1 * VCM_MERGE_BLOCK + src], L.term[2 * VCM_MERGE_BLOCK + src]);
+        for (int q = lo; wave_any(q < hi); q += 4) {
+            V3 tt[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int src = waveBase + min(max(q + u - base, 0), VCM_WAVE - 1);
+                tt[u] = mk3(L.term[0 * VCM_MERGE_BLOCK + src], L.term[1 * VCM_MERGE_BLOCK + src], L.term[2 * VCM_MERGE_BLOCK + src]);
             }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (q + u < hi) contrib = contrib + tt[u];
         }
+        cur = nxt;
     }
 }
 
