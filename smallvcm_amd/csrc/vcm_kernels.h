@@ -468,6 +468,9 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #else
 #define VCM_K4_ATTR
 #endif
+#ifndef VCM_K4_FULL
+#define VCM_K4_FULL 1   /* lanes with a full queue before the wave drains (1: as soon as one is; see merge_query_walk) */
+#endif
 #ifndef VCM_WALK_Q
 #define VCM_WALK_Q 20   /* accepted-index queue per lane: 21 rows + 8 run rows of 8 bytes = 37 KB per block, four blocks per CU
                            (12 / 16 / 20 entries: 3.51 / 3.40 / 3.35 ms, profiles/r03a_ab_summary.txt) */
@@ -526,9 +529,16 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
     if (n > 1) nxt = runs[stride];
     f4u X = *(const f4u *)(g.gx + cur.lo), Y = *(const f4u *)(g.gy + cur.lo), Z = *(const f4u *)(g.gz + cur.lo);
     while (wave_any(cur.lo < cur.hi)) {
+#if VCM_K4_FULL > 1
+        /* experiment: a lane whose queue has no room for a step sits the step out, and the wave drains only when
+           VCM_K4_FULL lanes are full (or nobody can go on) -- fuller queues per drain, at the price of idle scan lanes */
+        const bool go = qn <= ms.cap - VCM_MERGE_UNROLL;
+#else
+        const bool go = true;
+#endif
         const int stepEnd = cur.lo + VCM_MERGE_UNROLL;
         const bool last = stepEnd >= cur.hi;            /* this step finishes the lane's run (or the lane has none left) */
-        const int aNext = last ? nxt.lo : stepEnd;      /* software-pipelined: the candidates of the NEXT step */
+        const int aNext = go ? (last ? nxt.lo : stepEnd) : cur.lo;      /* software-pipelined: the candidates of the NEXT step */
         const f4u Xn = *(const f4u *)(g.gx + aNext), Yn = *(const f4u *)(g.gy + aNext), Zn = *(const f4u *)(g.gz + aNext);
         float distSqr[VCM_MERGE_UNROLL];
         {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */
@@ -542,17 +552,26 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
 #pragma unroll
         for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
             const int idx = cur.lo + u;
-            const bool acc = (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
+            const bool acc = go & (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
             ms.q[qn * ms.stride] = (uint32_t)idx;
             qn += acc ? 1 : 0;
         }
-        if (last) {   /* on to this lane's next run; the one after it comes out of LDS while this one is scanned */
-            cur = nxt;
-            k++;
-            nxt.lo = 0; nxt.hi = 0;
-            if (k + 1 < n) nxt = runs[(k + 1) * stride];
-        } else cur.lo = stepEnd;
-        if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
+        if (go) {
+            if (last) {   /* on to this lane's next run; the one after it comes out of LDS while this one is scanned */
+                cur = nxt;
+                k++;
+                nxt.lo = 0; nxt.hi = 0;
+                if (k + 1 < n) nxt = runs[(k + 1) * stride];
+            } else cur.lo = stepEnd;
+        }
+#if VCM_K4_FULL > 1
+        const unsigned long long fullMask = __builtin_amdgcn_ballot_w64(qn > ms.cap - VCM_MERGE_UNROLL);
+        const bool drainNow = (__popcll(fullMask) >= VCM_K4_FULL) ||
+                              (fullMask != 0ull && !wave_any((qn <= ms.cap - VCM_MERGE_UNROLL) && (cur.lo < cur.hi)));
+#else
+        const bool drainNow = wave_any(qn > ms.cap - VCM_MERGE_UNROLL);
+#endif
+        if (drainNow) {
             ls.mergeAccepted += (uint32_t)qn;
             RC_MARK(15);
             merge_drain(P, g, ev, ms, qn, contrib);
