@@ -20,6 +20,12 @@
  *           -Bsymbolic), see that header for why.
  *       Output: the raw fp32 framebuffer SUM (renderer.hxx:68).
  *
+ *   libsmallvcm_ref_tape_libm.so  (-DREF_TAPE -DREF_TAPE_LIBM)
+ *       (a) without (b): the taped random numbers, and the image's OWN libm (glibc 2.35) for sinf / cosf / powf --
+ *       the reference as shipped but for the random numbers.  Since round 4 detmath restates that libm (one
+ *       deviation: integer exponents), so this build measures what is left between the product and the reference's
+ *       own arithmetic (tests/test_oracle_vs_reference.py, oracle/libm_tolerance.py).
+ *
  *   libsmallvcm_ref_stock.so  (-DREF_STOCK)
  *       the reference exactly as its Makefile builds it (mt19937_64 Rng,
  *       glibc libm), driven by a restatement of render()
@@ -54,7 +60,9 @@
 #include "philox_ref.h"
 #include "detmath_ref.h"
 
-#ifdef REF_TAPE
+#if defined(REF_TAPE) && defined(REF_TAPE_LIBM)
+static long long g_detmath_calls = -1;   /* nothing is interposed: the reference calls the image's libm */
+#elif defined(REF_TAPE)
 /* ---- (b) libm interposition ------------------------------------------- */
 static long long g_detmath_calls = 0;
 extern "C" {

@@ -113,11 +113,15 @@ static thread_local unsigned long long g_threadId = 0;
 static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_threadCounter; return g_threadId; }
 
 /* Kernels that cast rays exist once per kind of scene (vcm_core.h SceneList / SceneBvh); the launch picks. */
-#define LAUNCH_SC(c, K, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<SceneBvh>), __VA_ARGS__); \
+#define LAUNCH_SC(c, K, ...) do { if (!(c)->scene->nodes.empty()) { if ((c)->intPhong) hipLaunchKernelGGL((K<SceneBvh>), __VA_ARGS__); \
+                                                                     else hipLaunchKernelGGL((K<SceneBvhG>), __VA_ARGS__); } \
+                                  else if (!(c)->intPhong) hipLaunchKernelGGL((K<SceneList>), __VA_ARGS__); \
                                   else if ((c)->sceneRects) hipLaunchKernelGGL((K<SceneRects>), __VA_ARGS__); \
                                   else if ((c)->sceneQuads) hipLaunchKernelGGL((K<SceneQuads>), __VA_ARGS__); \
                                   else hipLaunchKernelGGL((K<SceneList>), __VA_ARGS__); } while (0)
-#define LAUNCH_SC_MODE(c, K, M, ...) do { if (!(c)->scene->nodes.empty()) hipLaunchKernelGGL((K<M, SceneBvh>), __VA_ARGS__); \
+#define LAUNCH_SC_MODE(c, K, M, ...) do { if (!(c)->scene->nodes.empty()) { if ((c)->intPhong) hipLaunchKernelGGL((K<M, SceneBvh>), __VA_ARGS__); \
+                                                                             else hipLaunchKernelGGL((K<M, SceneBvhG>), __VA_ARGS__); } \
+                                          else if (!(c)->intPhong) hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); \
                                           else if ((c)->sceneRects) hipLaunchKernelGGL((K<M, SceneRects>), __VA_ARGS__); \
                                           else if ((c)->sceneQuads) hipLaunchKernelGGL((K<M, SceneQuads>), __VA_ARGS__); \
                                           else hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); } while (0)
@@ -166,6 +170,8 @@ struct vcm_ctx : Scratch {
     int mergeKind;                    /* VCM_MERGE_* */
     bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
     bool sceneRects;                  /* ... and is an axis-aligned rectangle: the SceneRects kernels */
+    bool intPhong;                    /* every Phong exponent in use is an integer in [1, 65536]: the kernels whose pow is the binary
+                                         exponentiation alone (detmath.h); otherwise the SceneList / SceneBvhG kernels and the general merge */
     IterParams P;
     bool inIteration;
     hipEvent_t ev[EV_COUNT];
@@ -221,7 +227,7 @@ static ArenaPool *pool_get(int device)
 static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
-    DFREE(s.store.v); DFREE(s.store.w); DFREE(s.store.count); DFREE(s.store.lenMask);
+    DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
     DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums[0]); DFREE(s.dTileSums[1]); DFREE(s.dTileSums[2]);
     DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
@@ -253,7 +259,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     Scratch &s = a->s;
     const size_t slots = (size_t)cs * cl;
     const size_t allRecs = (size_t)cs * cn;
-    if (dalloc(&s.store.v, slots * VCM_LV_FIELDS) || dalloc(&s.store.w, slots) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
+    if (dalloc(&s.store.v, slots * VCM_LV_FIELDS) || dalloc(&s.store.count, cl) || dalloc(&s.store.lenMask, cl)) return -1;
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
@@ -280,7 +286,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const size_t vcPerPath = (cL >= 3) ? (size_t)(cL - 1) * (size_t)(cL - 2) / 2 : 1;
     const size_t vcslots = 2 * vcPerPath * cl + maxWaves * VCM_QBLOCK_VC;
     s.vs.qcap = vslots;
-    if (dalloc(&s.vs.q, vslots * 5 /* 4 in use; 5 for the VCM_VQ_80 measurement build */) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
+    if (dalloc(&s.vs.q, vslots * 4) || dalloc(&s.vs.q4, vslots) || dalloc(&s.vs.meta, vslots) ||
         dalloc(&s.vs.diTask, vslots) || dalloc(&s.vs.diOut, vslots) ||
         dalloc(&s.vs.mergeOut, vslots) || dalloc(&s.vs.vcTask, 2 * vcslots) || dalloc(&s.vs.vcOut, vcslots) ||
         dalloc(&s.dQueryKey, vslots) || dalloc(&s.dSortedVertex, vslots)) return -1;
@@ -460,6 +466,10 @@ static int ensure_device(vcm_ctx *c)
             h.fill_scalars(view);
             c->sceneQuads = h.nodes.empty() && view.fastOnePlane != 0;
             c->sceneRects = c->sceneQuads && (view.nFastRects[0] + view.nFastRects[1] + view.nFastRects[2]) > 0;
+            c->intPhong = true;
+            for (const vcm_material &m : h.materials)
+                if ((m.phong[0] != 0.f || m.phong[1] != 0.f || m.phong[2] != 0.f) && !dm_pow_is_int_case(m.phongExp)) c->intPhong = false;
+            { const char *e = getenv("SMALLVCM_AMD_GENERAL_POW"); if (e && e[0] == '1') c->intPhong = false; }   /* tests: the general kernels on the reference's scenes */
             view.offPrims = (long long)parts[0].off; view.offMaterials = (long long)parts[1].off;
             view.offMat2light = (long long)parts[2].off; view.offLights = (long long)parts[3].off;
             view.offOps = (long long)parts[4].off; view.offPairs = (long long)parts[5].off;
@@ -1408,26 +1418,31 @@ static int vcm_merge_impl(vcm_ctx *c)
                 if (slab < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slab = (e && !strcmp(e, "slab")) ? 1 : 0; }
                 static int slabBlocks = 0;
                 if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
-                /* SMALLVCM_AMD_MERGE_DRAIN=transposed: k_merge_walk_t, EXPERIMENTAL: same bits, 2.4 x slower as it stands (see its
-                   comment); 768 workgroups are resident (three per CU) */
-                static int transposed = -1;
-                if (transposed < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DRAIN"); transposed = (e && !strcmp(e, "transposed")) ? 1 : 0; }
-                if (transposed)
-                    hipLaunchKernelGGL(k_merge_walk_t, dim3(768), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
-                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
+                if (c->intPhong)
+                    hipLaunchKernelGGL(k_merge_walk<true>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
+                                       slab ? c->vs.count + 24 : (int *)NULL);
                 else
-                hipLaunchKernelGGL(k_merge_walk, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
-                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
-                                   slab ? c->vs.count + 24 : (int *)NULL);
+                    hipLaunchKernelGGL(k_merge_walk<false>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
+                                       slab ? c->vs.count + 24 : (int *)NULL);
             }
             else if (mergeStaged) {
                 int ch = mergeChunk * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK;
                 if (ch < 1) ch = 1;
-                hipLaunchKernelGGL(k_merge_staged, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
-                                   c->stream, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
-                                   (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
-            } else
-                hipLaunchKernelGGL(k_merge_lane, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                if (c->intPhong)
+                    hipLaunchKernelGGL(k_merge_staged<true>, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
+                                       c->stream, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
+                                       (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
+                else
+                    hipLaunchKernelGGL(k_merge_staged<false>, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
+                                       c->stream, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
+                                       (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
+            } else if (c->intPhong)
+                hipLaunchKernelGGL(k_merge_lane<true>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
+            else
+                hipLaunchKernelGGL(k_merge_lane<false>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
                                    c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
         } else {
             if (mark(c, EV_SORT_K1)) return -1;
@@ -1691,16 +1706,22 @@ int vcm_debug_read_records(vcm_ctx *c, float *out, long long count)
 }
 
 /* element-wise device evaluation of the numeric spec (detmath / philox):
- * op 0 sinf(a), 1 cosf(a), 2 powf(a,b), 3 a/b, 4 sqrtf(a), 5 dot-style a*b+c via mul,add */
+ * op 0 sinf(a), 1 cosf(a), 2 powf(a,b), 3 a/b, 4 sqrtf(a), 5 dot-style a*b+c via mul,add,
+ * 6 powf(a,b) with its tables read from LDS (the path of the kernels that sample Phong lobes), 7 the Phong lobe's pow
+ * (dm_powf_wave) as the integer-exponent kernels evaluate it, 8 sinf(a) through the call of the cold sites */
 } // extern "C"
 
 namespace vcm {
 __global__ void k_numeric_spec(int op, int n, const float *a, const float *b, float *out)
 {
+    if (op == 6) { dm_stage_tables(); __syncthreads(); }   /* before any thread leaves */
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float r;
     switch (op) {
+    case 6: r = dm_powf(a[i], b[i], true); break;
+    case 7: r = dm_powf_wave(a[i], b[i], false, true); break;
+    case 8: { float cc; dm_sincosf_cold(a[i], r, cc); (void)cc; } break;
     case 0: r = dm_sinf(a[i]); break;
     case 1: r = dm_cosf(a[i]); break;
     case 2: r = dm_powf(a[i], b[i]); break;

@@ -55,7 +55,7 @@ struct GridHeader {
  * contiguous 5 KB region; the consumers GATHER a vertex (vertex connection K3c, the camera connection K1c, the
  * cell-sorted copy of the grid build) and a gather moves whole 128-byte lines (profiles/r05a_fetch_calib.json): an
  * 80-byte record lies in 1.5 of them on average.  Round 3 measured the alternative -- the four fields the connections
- * read as a 64-byte aligned record (one line), the fifth in an array of its own (-DVCM_STORE_SPLIT): the connections
+ * read as a 64-byte aligned record (one line), the fifth in an array of its own: the connections
  * gain, the grid build (which wants fields 0, 1, 3 AND 4: two lines) loses and slows the camera pass it runs next to:
  * 868 against 875 Mpaths/s (profiles/r05h_ab_summary.txt).  The camera-vertex records, below, ARE split.
  * (Five separate arrays were measured in round 1: five lines per gather, k_cell_rank_gather 1.16 ms instead of 0.6.)
@@ -68,16 +68,11 @@ struct LightStore {
                  k=2 isect.normal.xyz | dVC
                  k=3 localDirFix.xyz | dVM
                  k=4 WorldDirFix().xyz | ContinuationProb()                  */
-    F4 *w;    /* the -DVCM_STORE_SPLIT measurement build keeps field 4 here ([slot]) and four fields per slot in v */
     unsigned char *count;   /* stored vertices per local path (mPathEnds, :395) */
     uint32_t *lenMask;      /* per local path: bit L set <=> a vertex with pathLength L is stored (stored vertices have
                                increasing pathLength, so vertex j is the j-th set bit); valid while maxPathLength <= 31 */
 };
-#if defined(VCM_STORE_SPLIT)
-VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return k < 4 ? s.v[slot * 4 + (size_t)k] : s.w[slot]; }
-#else
 VCM_HD F4 &lv(const LightStore &s, size_t slot, int k) { return s.v[slot * VCM_LV_FIELDS + (size_t)k]; }
-#endif
 
 /* Hash grid, vertices sorted by cell (replaces mIndices indirection,
  * hashgrid.hxx:83-88): cell c = [cellStart[c], cellStart[c+1]) */
@@ -103,7 +98,7 @@ struct alignas(16) I4 { int x, y, z, w; };
 struct VertexStore {
     /* the record of camera vertex i: four 16-byte fields, contiguous and 64-byte aligned (q[i * 4 + k]) = what the merge
        (K4, which GATHERS the vertices in cell order: one 128-byte line each) and the connections read, plus a fifth
-       in an array of its own (q4[i]) that only K3b / K3c want.  As one 80-byte record (round 2; -DVCM_VQ_80) a vertex
+       in an array of its own (q4[i]) that only K3b / K3c want.  As one 80-byte record (round 2) a vertex
        straddled two lines half of the time: 864 -> 875 Mpaths/s with the split (profiles/r05h_ab_summary.txt); as five
        separate arrays (round 1) a wave's append was five partly written lines per step and every gather touched five
        (K4 3.55 -> 3.39 ms when they were joined, profiles/r02r_ab_summary.txt)
@@ -129,11 +124,7 @@ struct VertexStore {
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
 };
-#if defined(VCM_VQ_80)   /* measurement switch: the 80-byte record of round 2 */
-VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return vs.q[i * 5 + (size_t)k]; }
-#else
 VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 4 + (size_t)k] : vs.q4[i]; }
-#endif
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
@@ -331,6 +322,8 @@ struct alignas(16) BvhWide {
  * re-reads it with per-lane VECTOR loads into VGPRs instead of scalar loads into SGPRs (the list index is
  * wave-uniform): K3 122 -> 133 registers, 4 -> 3 waves per SIMD, 713 -> 576 Mpaths/s on the same box (r02g). */
 struct DScene {
+    /* (as a type, see the kinds below: may the kernels assume that every Phong exponent is an integer in [1, 65536]?) */
+    static constexpr bool kIntPhong = false;
     int nPrims, nMaterials, nLights, backgroundLight;
     float sceneCenter[3], sceneRadius, invSceneRadiusSqr;
     vcm_camera camera;
@@ -362,13 +355,18 @@ struct DScene {
  * nNodes), so the brute-force kernels hold no traversal code and the BVH kernels no list loop.  Compiled together the
  * two paths cost the headline kernels 11-27 VGPRs, i.e. a wave per SIMD (K3 122 -> 133 registers: 713 -> 576
  * Mpaths/s on the same box, profiles/r02g_*).  Functions that cast rays take `const SC &`, the rest `const DScene &`. */
-struct SceneList : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = false; static constexpr bool kRects = false; };
-struct SceneBvh : DScene { static constexpr bool kBvh = true; static constexpr bool kOnePlane = false; static constexpr bool kRects = false; };
+/* kIntPhong: the host found every Phong exponent in use to be an integer in [1, 65536] (the reference's scenes: 90), so
+ * pow(x, n) of the lobe is detmath.h's binary exponentiation and nothing else -- the kernels of such a kind hold no call
+ * of the general powf where a lobe is only EVALUATED (the call's register constraints cost k_merge_walk its fourth wave
+ * per SIMD: 135 registers against 120).  Scenes with other exponents take SceneList / SceneBvhG. */
+struct SceneList : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = false; static constexpr bool kRects = false; static constexpr bool kIntPhong = false; };
+struct SceneBvh : DScene { static constexpr bool kBvh = true; static constexpr bool kOnePlane = false; static constexpr bool kRects = false; static constexpr bool kIntPhong = true; };
+struct SceneBvhG : DScene { static constexpr bool kBvh = true; static constexpr bool kOnePlane = false; static constexpr bool kRects = false; static constexpr bool kIntPhong = false; };
 /* a list whose triangle pairs all share their plane part (FastPair::flags bit 2: axis-aligned quads, i.e. the reference's
    Cornell boxes): its kernels carry only that loop */
-struct SceneQuads : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; static constexpr bool kRects = false; };
+struct SceneQuads : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; static constexpr bool kRects = false; static constexpr bool kIntPhong = true; };
 /* a list whose triangle pairs are all axis-aligned rectangles (FastRect): the reference's own boxes */
-struct SceneRects : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; static constexpr bool kRects = true; };
+struct SceneRects : DScene { static constexpr bool kBvh = false; static constexpr bool kOnePlane = true; static constexpr bool kRects = true; static constexpr bool kIntPhong = true; };
 
 /* ---- the scene's small tables in LDS ----
  * A lane's material, the primitive its ray ends on, the light it samples are GATHERS (the index is per lane): as global
@@ -416,6 +414,7 @@ VCM_HD void stage_scene_tables(const DScene &sc)
         const uint32_t *src = (const uint32_t *)sc.lights();
         for (int i = t; i < sc.nLights * VCM_LDS_LIGHT_WORDS; i += nt) g_ldsScene[VCM_LDS_OFF_LIGHTS + i] = src[i];
     }
+    dm_stage_tables();   /* powf's two tables (detmath.h), 512 bytes */
     __syncthreads();
 #else
     (void)sc;
@@ -503,14 +502,14 @@ VCM_HD V3 reflect_local(V3 v) { return mk3(-v.x, -v.y, v.z); }   /* :77-80 */
    same argument, and a wave that holds lanes of both kinds would evaluate dm_sincosf once per branch) */
 VCM_HD V3 sample_power_cos_hemisphere(float s, float c, float sy, float power)
 {   /* :85-103, oPdfW == NULL at its only call site (bsdf.hxx:296) */
-    const float term2 = dm_powf(sy, 1.f / (power + 1.f));
+    const float term2 = dm_powf(sy, 1.f / (power + 1.f), true);   /* the kernels that sample stage detmath's tables */
     const float term3 = sqrtf(1.f - term2 * term2);
     return mk3(c * term3, s * term3, term2);
 }
-VCM_HD float power_cos_hemisphere_pdf(V3 n, V3 d, float power)
+VCM_HD float power_cos_hemisphere_pdf(V3 n, V3 d, float power, bool intPhong = false)
 {   /* :105-113 */
     const float cosTheta = smax(0.f, dot(n, d));
-    return (power + 1.f) * dm_powf_wave(cosTheta, power) * (VCM_INV_PI_F * 0.5f);
+    return (power + 1.f) * dm_powf_wave(cosTheta, power, true, intPhong) * (VCM_INV_PI_F * 0.5f);
 }
 VCM_HD void sample_concentric_disc(float sx, float sy, float &ox, float &oy)
 {   /* :119-160 */
@@ -529,7 +528,7 @@ VCM_HD void sample_concentric_disc(float sx, float sy, float &ox, float &oy)
         }
     }
     float s, c;
-    dm_sincosf(phi, s, c);
+    dm_sincosf_cold(phi, s, c);
     ox = r * c;
     oy = r * s;
 }
@@ -560,7 +559,7 @@ VCM_HD V3 sample_uniform_sphere(float sx, float sy, float &pdf)
     const float term1 = 2.f * VCM_PI_F * sx;
     const float term2 = 2.f * sqrtf(sy - sy * sy);
     float s, c;
-    dm_sincosf(term1, s, c);
+    dm_sincosf_cold(term1, s, c);
     const V3 ret = mk3(c * term2, s * term2, 1.f - 2.f * sy);
     pdf = VCM_INV_PI_F * 0.25f;
     return ret;
@@ -1616,7 +1615,7 @@ VCM_HD V3 bsdf_eval_diffuse(const Bsdf &b, const vcm_material &m, V3 gen, float 
     if (revPdf) *revPdf += b.diffProb * smax(0.f, b.localDirFix.z * VCM_INV_PI_F);
     return ld3(m.diffuse) * VCM_INV_PI_F;
 }
-VCM_HD V3 bsdf_eval_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf)
+VCM_HD V3 bsdf_eval_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf, bool intPhong = false)
 {   /* EvaluatePhong :414-446 */
     if (b.phongProb == 0.f) return sp3(0.f);
     if (b.localDirFix.z < VCM_EPS_COSINE || gen.z < VCM_EPS_COSINE) return sp3(0.f);
@@ -1625,7 +1624,7 @@ VCM_HD V3 bsdf_eval_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *d
     if (dot_R_Wi <= VCM_EPS_PHONG) return sp3(0.f);
     /* pow(dot_R_Wi, n) is needed by the pdf (PowerCosHemispherePdfW, whose
        cosTheta = max(0, dot) == dot here) and by the value: evaluate once */
-    const float pw = dm_powf_wave(dot_R_Wi, m.phongExp);
+    const float pw = dm_powf_wave(dot_R_Wi, m.phongExp, true, intPhong);
     if (dirPdf || revPdf) {
         const float pdfW = b.phongProb * ((m.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
         if (dirPdf) *dirPdf += pdfW;
@@ -1640,17 +1639,19 @@ VCM_HD void bsdf_pdf_diffuse(const Bsdf &b, V3 gen, float *dirPdf, float *revPdf
     if (dirPdf) *dirPdf += b.diffProb * smax(0.f, gen.z * VCM_INV_PI_F);
     if (revPdf) *revPdf += b.diffProb * smax(0.f, b.localDirFix.z * VCM_INV_PI_F);
 }
-VCM_HD void bsdf_pdf_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf)
+VCM_HD void bsdf_pdf_phong(const Bsdf &b, const vcm_material &m, V3 gen, float *dirPdf, float *revPdf, bool intPhong = false)
 {   /* PdfPhong :474-503 */
     if (b.phongProb == 0.f) return;
     const V3 refl = reflect_local(b.localDirFix);
     const float dot_R_Wi = dot(refl, gen);
     if (dot_R_Wi <= VCM_EPS_PHONG) return;
-    const float pdfW = power_cos_hemisphere_pdf(refl, gen, m.phongExp) * b.phongProb;
+    const float pdfW = power_cos_hemisphere_pdf(refl, gen, m.phongExp, intPhong) * b.phongProb;
     if (dirPdf) *dirPdf += pdfW;
     if (revPdf) *revPdf += pdfW;
 }
-VCM_HD V3 bsdf_evaluate(const Bsdf &b, const DScene &sc, V3 worldDirGen, float &cosThetaGen,
+/* (S = the scene as the CALLER holds it -- a kind, or plain DScene on the host: S::kIntPhong picks the pow) */
+template <class S>
+VCM_HD V3 bsdf_evaluate(const Bsdf &b, const S &sc, V3 worldDirGen, float &cosThetaGen,
                         float *dirPdf, float *revPdf)
 {   /* Evaluate :128-153 */
     V3 result = sp3(0.f);
@@ -1661,22 +1662,24 @@ VCM_HD V3 bsdf_evaluate(const Bsdf &b, const DScene &sc, V3 worldDirGen, float &
     cosThetaGen = fabsf(gen.z);
     const vcm_material m = scene_material(sc, b.matID);
     result = result + bsdf_eval_diffuse(b, m, gen, dirPdf, revPdf);
-    result = result + bsdf_eval_phong(b, m, gen, dirPdf, revPdf);
+    result = result + bsdf_eval_phong(b, m, gen, dirPdf, revPdf, S::kIntPhong);
     return result;
 }
-VCM_HD float bsdf_pdf(const Bsdf &b, const DScene &sc, V3 worldDirGen, bool evalRev)
+template <class S>
+VCM_HD float bsdf_pdf(const Bsdf &b, const S &sc, V3 worldDirGen, bool evalRev)
 {   /* Pdf :161-180 */
     const V3 gen = to_local(b.frame, worldDirGen);
     if (gen.z * b.localDirFix.z < 0.f) return 0.f;
     const vcm_material m = scene_material(sc, b.matID);
     float directPdfW = 0.f, reversePdfW = 0.f;
     bsdf_pdf_diffuse(b, gen, &directPdfW, &reversePdfW);
-    bsdf_pdf_phong(b, m, gen, &directPdfW, &reversePdfW);
+    bsdf_pdf_phong(b, m, gen, &directPdfW, &reversePdfW, S::kIntPhong);
     return evalRev ? reversePdfW : directPdfW;
 }
 /* Sample :191-257 with SampleDiffuse :274, SamplePhong :290, SampleReflect :320,
  * SampleRefract :335.  fixIsLight is the reference's template argument. */
-VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0, float r1, float r2,
+template <class S>
+VCM_HD V3 bsdf_sample(const Bsdf &b, const S &sc, bool fixIsLight, float r0, float r1, float r2,
                       V3 &worldDirGen, float &pdfW, float &cosThetaGen, uint32_t &sampledEvent)
 {
     if (r2 < b.diffProb) sampledEvent = kDiffuse;
@@ -1698,7 +1701,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0
         pdfW += unweightedPdfW * b.diffProb;
         result = result + ld3(m.diffuse) * VCM_INV_PI_F;
         if (iszero(result)) return sp3(0.f);
-        result = result + bsdf_eval_phong(b, m, gen, &pdfW, (float *)0);
+        result = result + bsdf_eval_phong(b, m, gen, &pdfW, (float *)0, S::kIntPhong);
     } else if (sampledEvent == kPhong) {
         gen = sample_power_cos_hemisphere(sinPhi, cosPhi, r1, m.phongExp);
         const V3 refl = reflect_local(b.localDirFix);
@@ -1710,7 +1713,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const DScene &sc, bool fixIsLight, float r0
         const float dot_R_Wi = dot(refl, gen);
         if (dot_R_Wi <= VCM_EPS_PHONG) return sp3(0.f);
         /* PdfPhong(:309) and the value (:317) use the same pow */
-        const float pw = dm_powf_wave(dot_R_Wi, m.phongExp);
+        const float pw = dm_powf_wave(dot_R_Wi, m.phongExp, true, S::kIntPhong);
         if (b.phongProb != 0.f)
             pdfW += ((m.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f)) * b.phongProb;
         const V3 rho = ld3(m.phong) * (m.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;
@@ -1881,7 +1884,8 @@ struct SubPathState {
 VCM_HD float mis(float pdf) { return pdf; }   /* :553-557 (balance heuristic) */
 
 /* SampleScattering<tLightSample> :938-1006 */
-VCM_HD bool sample_scattering(const DScene &sc, const IterParams &P, bool lightSample, PathRng &rng,
+template <class S>
+VCM_HD bool sample_scattering(const S &sc, const IterParams &P, bool lightSample, PathRng &rng,
                               const Bsdf &bsdf, V3 hitPoint, SubPathState &st)
 {
     /* the 3 floats of BSDF::Sample (:944) and the Russian-roulette float (:964), which only counts as drawn if
@@ -2260,6 +2264,7 @@ VCM_HD void merge_eval_setup(MergeEval &e, const DScene &sc, const IterParams &P
     e.pathLength = st.pathLength;
     e.cosOk = !(b.localDirFix.z < VCM_EPS_COSINE);
 }
+template <bool IP /* the scene's Phong exponents are integers (DScene::kIntPhong) */>
 VCM_HD void merge_eval_photon(const MergeEval &e, const IterParams &P, uint32_t lvLen, V3 lightDirection,
                               float lvContProb, V3 lvThroughput, float lvdVCM, float lvdVM, V3 &contrib)
 {
@@ -2279,7 +2284,7 @@ VCM_HD void merge_eval_photon(const MergeEval &e, const IterParams &P, uint32_t 
     const float dot_R_Wi = dot(e.refl, gen);
     V3 ph = sp3(0.f);
     if (valid && ok && (e.phongProb != 0.f) && !(dot_R_Wi <= VCM_EPS_PHONG)) {
-        const float pw = dm_powf_wave(dot_R_Wi, e.phongExp);
+        const float pw = dm_powf_wave(dot_R_Wi, e.phongExp, false, IP);   /* the merge kernels stage no tables */
         const float pdfW = e.phongProb * ((e.phongExp + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
         dirPdf += pdfW;
         revPdf += pdfW;
@@ -2307,6 +2312,7 @@ VCM_HD void merge_photon_load(const GridStore &g, const MergeScratch &ms, int k,
     p.c = g.g2[idx];
     p.dVM = t.x;
 }
+template <bool IP>
 VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval &e, const MergeScratch &ms, int qn,
                         V3 &contrib)
 {
@@ -2318,8 +2324,8 @@ VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval
         const bool more = wave_any(k + 1 < qn);
         if (more) merge_photon_load(g, ms, k + 1, qn, nxt);
         if (k < qn)
-            merge_eval_photon(e, P, f2u(cur.lenBits), mk3(cur.b.x, cur.b.y, cur.b.z), cur.b.w,
-                              mk3(cur.c.x, cur.c.y, cur.c.z), cur.c.w, cur.dVM, contrib);
+            merge_eval_photon<IP>(e, P, f2u(cur.lenBits), mk3(cur.b.x, cur.b.y, cur.b.z), cur.b.w,
+                                  mk3(cur.c.x, cur.c.y, cur.c.z), cur.c.w, cur.dVM, contrib);
         if (!more) break;
         cur = nxt;
     }
@@ -2338,6 +2344,7 @@ VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval
  * lanes active instead of the ~18 % that accept at any one candidate.  Each
  * lane still processes ITS photons in the reference's order, so the sum
  * (:168) is bit-identical. */
+template <bool IP>
 VCM_HD V3 merge_query(const DScene &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
                       const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms, bool ldsMaterials = true)
 {
@@ -2416,13 +2423,13 @@ VCM_HD V3 merge_query(const DScene &sc, const IterParams &P, const GridStore &g,
             lo = nextLo;
             if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
                 ls.mergeAccepted += (uint32_t)qn;
-                merge_drain(P, g, ev, ms, qn, contrib);
+                merge_drain<IP>(P, g, ev, ms, qn, contrib);
                 qn = 0;
             }
         }
     }
     ls.mergeAccepted += (uint32_t)qn;
-    merge_drain(P, g, ev, ms, qn, contrib);
+    merge_drain<IP>(P, g, ev, ms, qn, contrib);
     return contrib;
 }
 
@@ -2824,7 +2831,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
         }
         if (!bsdf.isDelta && P.useVM) {   /* :530-538 */
             ls.mergeQueries++;
-            const V3 contrib = merge_query(sc, P, grid, bsdf, st, hitPoint, ls, ms);
+            const V3 contrib = merge_query<SC::kIntPhong>(sc, P, grid, bsdf, st, hitPoint, ls, ms);
             cp.color = cp.color + st.throughput * P.vmNormalization * contrib;
             if (P.ppm) return false;
         }
@@ -2886,6 +2893,7 @@ VCM_HD V3 eval_vc_task(const SC &sc, const IterParams &P, const VertexStore &vs,
            connect_vertices(sc, P, mk3(a.x, a.y, a.z), lvBsdf, b.w, c.w, v.bsdf, v.hit, v.st, ls);
 }
 /* the addend of :534  (color += throughput * mVmNormalization * query.GetContrib()) */
+template <bool IP>
 VCM_HD V3 eval_merge_task(const DScene &sc, const IterParams &P, const VertexStore &vs, const GridStore &g,
                           int vi, LaneStats &ls, const MergeScratch &ms, size_t &pathSlot, bool ldsMaterials = true)
 {
@@ -2895,7 +2903,7 @@ VCM_HD V3 eval_merge_task(const DScene &sc, const IterParams &P, const VertexSto
     bsdf_restore(bsdf, mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(b.w) >> 8, sc, ldsMaterials);
     SubPathState st;
     st.pathLength = f2u(b.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
-    const V3 contrib = merge_query(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms, ldsMaterials);
+    const V3 contrib = merge_query<IP>(sc, P, g, bsdf, st, mk3(a.x, a.y, a.z), ls, ms, ldsMaterials);
     return mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
 }
 /* Replays vertexcm.hxx:417-544 for one camera path: colour starts at 0, every

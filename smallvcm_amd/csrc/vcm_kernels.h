@@ -418,6 +418,7 @@ __global__ void __launch_bounds__(256) k_query_scatter(VertexStore vs, const int
 #define VCM_MERGE_BLOCK 256
 /* 104 VGPRs = 4 waves/SIMD.  Forcing 5 / 6 / 8 waves (amdgpu_waves_per_eu) was measured: 5.66 / 6.9 / 10.8 ms
  * against 5.4 ms on the same box -- the spills cost more than the occupancy buys. */
+template <bool IP>
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK)
 k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
              const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
@@ -445,7 +446,7 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
         if (q < nQ) {
             const int vi = sortedVertex[q];
             size_t ps;
-            const V3 v = eval_merge_task(sc, P, vs, g, vi, ls, ms, ps, false);   /* this kernel stages no material table */
+            const V3 v = eval_merge_task<IP>(sc, P, vs, g, vi, ls, ms, ps, false);   /* this kernel stages no material table */
             vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
@@ -468,15 +469,13 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #else
 #define VCM_K4_ATTR
 #endif
-#ifndef VCM_K4_FULL
-#define VCM_K4_FULL 1   /* lanes with a full queue before the wave drains (1: as soon as one is; see merge_query_walk) */
-#endif
 #ifndef VCM_WALK_Q
 #define VCM_WALK_Q 20   /* accepted-index queue per lane: 21 rows + 8 run rows of 8 bytes = 37 KB per block, four blocks per CU
                            (12 / 16 / 20 entries: 3.51 / 3.40 / 3.35 ms, profiles/r03a_ab_summary.txt) */
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 struct alignas(8) WalkRun { int lo, hi; };
+template <bool IP>
 __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
                                                const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms,
                                                WalkRun *runs /* [k * stride + thread] */, int stride)
@@ -529,16 +528,9 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
     if (n > 1) nxt = runs[stride];
     f4u X = *(const f4u *)(g.gx + cur.lo), Y = *(const f4u *)(g.gy + cur.lo), Z = *(const f4u *)(g.gz + cur.lo);
     while (wave_any(cur.lo < cur.hi)) {
-#if VCM_K4_FULL > 1
-        /* experiment: a lane whose queue has no room for a step sits the step out, and the wave drains only when
-           VCM_K4_FULL lanes are full (or nobody can go on) -- fuller queues per drain, at the price of idle scan lanes */
-        const bool go = qn <= ms.cap - VCM_MERGE_UNROLL;
-#else
-        const bool go = true;
-#endif
         const int stepEnd = cur.lo + VCM_MERGE_UNROLL;
         const bool last = stepEnd >= cur.hi;            /* this step finishes the lane's run (or the lane has none left) */
-        const int aNext = go ? (last ? nxt.lo : stepEnd) : cur.lo;      /* software-pipelined: the candidates of the NEXT step */
+        const int aNext = last ? nxt.lo : stepEnd;      /* software-pipelined: the candidates of the NEXT step */
         const f4u Xn = *(const f4u *)(g.gx + aNext), Yn = *(const f4u *)(g.gy + aNext), Zn = *(const f4u *)(g.gz + aNext);
         float distSqr[VCM_MERGE_UNROLL];
         {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */
@@ -552,36 +544,28 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
 #pragma unroll
         for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
             const int idx = cur.lo + u;
-            const bool acc = go & (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
+            const bool acc = (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
             ms.q[qn * ms.stride] = (uint32_t)idx;
             qn += acc ? 1 : 0;
         }
-        if (go) {
-            if (last) {   /* on to this lane's next run; the one after it comes out of LDS while this one is scanned */
-                cur = nxt;
-                k++;
-                nxt.lo = 0; nxt.hi = 0;
-                if (k + 1 < n) nxt = runs[(k + 1) * stride];
-            } else cur.lo = stepEnd;
-        }
-#if VCM_K4_FULL > 1
-        const unsigned long long fullMask = __builtin_amdgcn_ballot_w64(qn > ms.cap - VCM_MERGE_UNROLL);
-        const bool drainNow = (__popcll(fullMask) >= VCM_K4_FULL) ||
-                              (fullMask != 0ull && !wave_any((qn <= ms.cap - VCM_MERGE_UNROLL) && (cur.lo < cur.hi)));
-#else
-        const bool drainNow = wave_any(qn > ms.cap - VCM_MERGE_UNROLL);
-#endif
-        if (drainNow) {
+        if (last) {   /* on to this lane's next run; the one after it comes out of LDS while this one is scanned */
+            cur = nxt;
+            k++;
+            nxt.lo = 0; nxt.hi = 0;
+            if (k + 1 < n) nxt = runs[(k + 1) * stride];
+        } else cur.lo = stepEnd;
+        /* (draining only when K lanes are full was measured in round 3, K = 4 .. 24: no gain, profiles/r05zz_k4full_*.txt) */
+        if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
             ls.mergeAccepted += (uint32_t)qn;
             RC_MARK(15);
-            merge_drain(P, g, ev, ms, qn, contrib);
+            merge_drain<IP>(P, g, ev, ms, qn, contrib);
             RC_MARK(16);
             qn = 0;
         }
     }
     ls.mergeAccepted += (uint32_t)qn;
     RC_MARK(15);
-    merge_drain(P, g, ev, ms, qn, contrib);
+    merge_drain<IP>(P, g, ev, ms, qn, contrib);
     RC_MARK(16);
     return contrib;
 }
@@ -596,6 +580,7 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
  *                    (the contiguous ranges of round 1 had no stealing: the XCDs that owned the dense regions formed a
  *                    long tail, 6.8 ms).  Which workgroup evaluates a query does not matter: every query has its own
  *                    output slot. */
+template <bool IP>
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK) VCM_K4_ATTR
 k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
              const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st,
@@ -645,7 +630,7 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
             SubPathState sps;
             sps.pathLength = f2u(bq.w) & 0xffu; sps.dVCM = c.w; sps.dVM = d.w;
-            const V3 contrib = merge_query_walk(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK);
+            const V3 contrib = merge_query_walk<IP>(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
             vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
@@ -654,247 +639,7 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #endif
 }
 
-/* ---------------- K4, EXPERIMENTAL (SMALLVCM_AMD_MERGE_DRAIN=transposed): the drain transposed ---------------- */
-/* k_merge_walk drains when ONE lane's queue is full, and every lane then evaluates ITS accepted photons: the loop runs
- * to the fullest lane's ~17 entries while the average lane holds 6.4 (215 M accepted photons in 524 K drains at 2048^2):
- * RangeQuery::Process, 61 % of the kernel, at ~38 % lane utilisation.  Here the wave's
- * (query, photon) pairs are flattened -- exclusive prefix sum of the queue lengths -- and lane l evaluates pair
- * 64 j + l of chunk j, whoever owns it: the owner's per-query state comes out of LDS (written once per query:
- * frame, local direction, five scalars, path length and material), the material out of the LDS scene tables, and the
- * pair's TERM  misWeight * f * throughput  (merge_eval_photon on a zero accumulator: 0 + x = x exactly, x >= +0) goes to
- * LDS.  Every owner then adds the terms of its pairs in the chunk IN QUEUE ORDER (cells in the reference's order, vertices in
- * index order): the same values added in the same order as k_merge_walk and the reference, hence the same bits (a pair
- * the reference skips contributes +0 to a sum that is never -0).
- * MEASURED (profiles/r05x_transposed.txt, r05y*_transposed.txt, the last seconds of round 3's GPU budget): the frames are
- * k_merge_walk's bit for bit (VCM, BPM at 512^2, VCM at 2048^2) -- and the kernel takes ~8 ms against 3.4, in both
- * versions (the second: owner by head flags + max-scan, next chunk prefetched, terms read four at a time): every chunk is
- * a chain of dependent LDS round trips around a global gather, at three workgroups per CU.  DESIGN.md section 8.  Not
- * selected by default, not part of the test suite. */
-#define VCM_WT_Q 10        /* with 18 words of state per query: 53.9 KB per workgroup, three per CU */
-#define VCM_WT_STATE 18   /* words per query */
-#if defined(__HIP_DEVICE_COMPILE__)
-struct WalkTLds {
-    uint32_t accQ[(VCM_WT_Q + 1) * VCM_MERGE_BLOCK];
-    WalkRun runs[8 * VCM_MERGE_BLOCK];
-    float state[VCM_WT_STATE * VCM_MERGE_BLOCK];   /* [thread][VCM_WT_STATE] */
-    int prefix[VCM_MERGE_BLOCK];                  /* exclusive prefix of the queue lengths, per wave */
-    float term[3 * VCM_MERGE_BLOCK];              /* [component][thread] */
-};
-/* all 64 lanes of the wave call this together; qn = this lane's queue length (0 for a lane without a query).
- * Second version: the owner of a pair by head flags + an inclusive max-scan over the chunk (the first searched the
- * prefix array in LDS, six dependent reads), the next chunk's photon in flight while this one is evaluated, the owner's
- * terms read four at a time. */
-struct WtPair { int owner, k; uint32_t idx; bool valid; F2 t3; F4 pb, pc; };
-__device__ __forceinline__ void wt_pair_fetch(const GridStore &g, WalkTLds &L, int base, int total, int start, int qn, WtPair &w)
-{
-    const int tid = (int)threadIdx.x, lane = tid & (VCM_WAVE - 1), waveBase = tid & ~(VCM_WAVE - 1);
-    const int p = base + lane;
-    w.valid = p < total;
-    /* head flags: a lane whose pairs reach into [base, base + 64) marks the first position it owns there */
-    /* (relaxed atomics: the flag a lane reads is one ANOTHER lane wrote; with plain accesses the compiler forwards this
-       lane's own -1 to the load -- a memory fault on the first try, profiles/r05y2_transposed.txt) */
-    __atomic_store_n(&L.prefix[tid], -1, __ATOMIC_RELAXED);
-    if (qn > 0 && start < base + VCM_WAVE && start + qn > base)
-        __atomic_store_n(&L.prefix[waveBase + max(start, base) - base], lane, __ATOMIC_RELAXED);
-    int o = __atomic_load_n(&L.prefix[tid], __ATOMIC_RELAXED);
-#pragma unroll
-    for (int d = 1; d < VCM_WAVE; d <<= 1) { const int v = __shfl_up(o, d, VCM_WAVE); if (lane >= d) o = max(o, v); }
-    o = max(o, 0);                                  /* (a lane beyond the last pair) */
-    const int ostart = __shfl(start, o, VCM_WAVE);
-    w.owner = waveBase + o;
-    w.k = p - ostart;
-    w.idx = w.valid ? L.accQ[w.k * VCM_MERGE_BLOCK + w.owner] : 0u;   /* photon 0 is always allocated */
-    w.t3 = g.g3[w.idx];
-    w.pb = g.g1[w.idx];
-    w.pc = g.g2[w.idx];
-}
-__device__ __forceinline__ void merge_drain_transposed(const DScene &sc, const IterParams &P, const GridStore &g, WalkTLds &L,
-                                                       int qn, V3 &contrib)
-{
-    const int tid = (int)threadIdx.x, lane = tid & (VCM_WAVE - 1), waveBase = tid & ~(VCM_WAVE - 1);
-    int incl = qn;
-#pragma unroll
-    for (int o = 1; o < VCM_WAVE; o <<= 1) { const int v = __shfl_up(incl, o, VCM_WAVE); if (lane >= o) incl += v; }
-    const int start = incl - qn;
-    const int total = __shfl(incl, VCM_WAVE - 1, VCM_WAVE);   /* wave-uniform */
-    if (total == 0) return;
-    WtPair cur, nxt;
-    wt_pair_fetch(g, L, 0, total, start, qn, cur);
-    for (int base = 0; base < total; base += VCM_WAVE) {
-        const bool more = base + VCM_WAVE < total;             /* wave-uniform */
-        if (more) wt_pair_fetch(g, L, base + VCM_WAVE, total, start, qn, nxt);
-        /* the owner's state (merge_eval_setup's inputs, written by k_merge_walk_t when the query started) */
-        const float *S = L.state + cur.owner * VCM_WT_STATE;
-        MergeEval e;
-        e.frame.mX = mk3(S[0], S[1], S[2]); e.frame.mY = mk3(S[3], S[4], S[5]); e.frame.mZ = mk3(S[6], S[7], S[8]);
-        const V3 ldf = mk3(S[9], S[10], S[11]);
-        e.diffProb = S[12]; e.phongProb = S[13]; e.camContProb = S[14]; e.camTerm = S[15]; e.camdVM = S[16];
-        const uint32_t packed = f2u(S[17]);
-        e.pathLength = packed & 0xffu;
-        const vcm_material m = scene_material(sc, cur.valid ? (int)(packed >> 8) : 0);   /* the LDS table (the kernel stages it); a lane without a pair may look at a record nobody wrote */
-        /* exactly merge_eval_setup's expressions */
-        e.refl = reflect_local(ldf);
-        e.diffuseVal = ld3(m.diffuse) * VCM_INV_PI_F;
-        e.rho = ld3(m.phong) * (m.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;
-        e.ldfz = ldf.z;
-        e.phongExp = m.phongExp;
-        e.revPdfDiffuse = e.diffProb * smax(0.f, ldf.z * VCM_INV_PI_F);
-        e.cosOk = !(ldf.z < VCM_EPS_COSINE);
-        V3 t = sp3(0.f);
-        if (cur.valid) merge_eval_photon(e, P, f2u(cur.t3.y), mk3(cur.pb.x, cur.pb.y, cur.pb.z), cur.pb.w, mk3(cur.pc.x, cur.pc.y, cur.pc.z), cur.pc.w, cur.t3.x, t);
-        L.term[0 * VCM_MERGE_BLOCK + tid] = t.x; L.term[1 * VCM_MERGE_BLOCK + tid] = t.y; L.term[2 * VCM_MERGE_BLOCK + tid] = t.z;
-        /* the owners add the terms of their pairs in this chunk, in queue order, four reads in flight at a time */
-        const int lo = max(start, base), hi = min(start + qn, base + VCM_WAVE);
-        for (int q = lo; wave_any(q < hi); q += 4) {
-            V3 tt[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int src = waveBase + min(max(q + u - base, 0), VCM_WAVE - 1);
-                tt[u] = mk3(L.term[0 * VCM_MERGE_BLOCK + src], L.term[1 * VCM_MERGE_BLOCK + src], L.term[2 * VCM_MERGE_BLOCK + src]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (q + u < hi) contrib = contrib + tt[u];
-        }
-        cur = nxt;
-    }
-}
-
-/* merge_query_walk with the transposed drain; every lane of the wave calls it (hasQuery = false: no runs, no state) */
-__device__ __forceinline__ V3 merge_query_walk_t(const DScene &sc, const IterParams &P, const GridStore &g, bool hasQuery,
-                                                 V3 queryPos, LaneStats &ls, WalkTLds &L)
-{
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    const int tid = (int)threadIdx.x;
-    const int stride = VCM_MERGE_BLOCK;
-    WalkRun *runs = L.runs + tid;
-    uint32_t *q = L.accQ + tid;
-    V3 contrib = sp3(0.f);
-    int n = 0;
-    if (hasQuery) {   /* hashgrid.hxx:116-155, as merge_query_walk */
-        const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
-        const V3 distMin = queryPos - bmin, distMax = bmax - queryPos;
-        const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
-                              distMin.z < 0.f || distMax.z < 0.f);
-        const V3 cellPt = P.invCellSize * distMin;
-        const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
-        const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
-        const V3 fractCoord = cellPt - coordF;
-        const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
-        const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
-        const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
-        int lo[8], hi[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            lo[j] = 0; hi[j] = 0;
-            if (inside) {
-                const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
-                lo[j] = g.cellStart[cell];
-                hi[j] = g.cellStart[cell + 1];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]);
-            if (hi[j] > lo[j]) { WalkRun r; r.lo = lo[j]; r.hi = hi[j]; runs[n * stride] = r; n++; }
-        }
-    }
-    const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
-    int qn = 0, k = 0;
-    WalkRun cur, nxt;
-    cur.lo = 0; cur.hi = 0; nxt = cur;
-    if (n > 0) cur = runs[0];
-    if (n > 1) nxt = runs[stride];
-    f4u X = *(const f4u *)(g.gx + cur.lo), Y = *(const f4u *)(g.gy + cur.lo), Z = *(const f4u *)(g.gz + cur.lo);
-    while (wave_any(cur.lo < cur.hi)) {
-        const int stepEnd = cur.lo + VCM_MERGE_UNROLL;
-        const bool last = stepEnd >= cur.hi;
-        const int aNext = last ? nxt.lo : stepEnd;
-        const f4u Xn = *(const f4u *)(g.gx + aNext), Yn = *(const f4u *)(g.gy + aNext), Zn = *(const f4u *)(g.gz + aNext);
-        float distSqr[VCM_MERGE_UNROLL];
-        {
-            const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
-            const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
-            const f2 da = dxa * dxa + dya * dya + dza * dza;
-            const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
-            distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
-        }
-        X = Xn; Y = Yn; Z = Zn;
-#pragma unroll
-        for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
-            const int idx = cur.lo + u;
-            const bool acc = (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);
-            q[qn * stride] = (uint32_t)idx;
-            qn += acc ? 1 : 0;
-        }
-        if (last) {
-            cur = nxt;
-            k++;
-            nxt.lo = 0; nxt.hi = 0;
-            if (k + 1 < n) nxt = runs[(k + 1) * stride];
-        } else cur.lo = stepEnd;
-        if (wave_any(qn > VCM_WT_Q - VCM_MERGE_UNROLL)) {
-            ls.mergeAccepted += (uint32_t)qn;
-            merge_drain_transposed(sc, P, g, L, qn, contrib);
-            qn = 0;
-        }
-    }
-    ls.mergeAccepted += (uint32_t)qn;
-    merge_drain_transposed(sc, P, g, L, qn, contrib);
-    return contrib;
-}
-#endif
-
-__global__ void __launch_bounds__(VCM_MERGE_BLOCK)
-k_merge_walk_t(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
-               const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
-{
-    stamp_entry(st);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const DScene &sc = *scp;
-    stage_scene_tables(sc);
-    const int nQ = *nSorted;
-    __shared__ WalkTLds L;
-    LaneStats ls; lane_stats_zero(ls);
-    const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
-    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
-    for (int t = wgOfXcd;; t += wgPerXcd) {
-        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
-        if ((t / chunk) * 8 * chunk >= nBatches) break;
-        if (b >= nBatches) continue;
-        const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
-        const bool hasQuery = q < nQ;
-        V3 pos = sp3(0.f), thr = sp3(0.f);
-        size_t ps = 0;
-        if (hasQuery) {
-            const int vi = sortedVertex[q];
-            const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
-            ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
-            Bsdf bsdf;
-            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc);
-            pos = mk3(a.x, a.y, a.z); thr = mk3(d.x, d.y, d.z);
-            float *S = L.state + threadIdx.x * VCM_WT_STATE;   /* what merge_eval_setup reads of the query */
-            S[0] = bsdf.frame.mX.x; S[1] = bsdf.frame.mX.y; S[2] = bsdf.frame.mX.z;
-            S[3] = bsdf.frame.mY.x; S[4] = bsdf.frame.mY.y; S[5] = bsdf.frame.mY.z;
-            S[6] = bsdf.frame.mZ.x; S[7] = bsdf.frame.mZ.y; S[8] = bsdf.frame.mZ.z;
-            S[9] = bsdf.localDirFix.x; S[10] = bsdf.localDirFix.y; S[11] = bsdf.localDirFix.z;
-            S[12] = bsdf.diffProb; S[13] = bsdf.phongProb; S[14] = bsdf.contProb;
-            S[15] = c.w * P.misVcWeightFactor;   /* camTerm = dVCM * mMisVcWeightFactor */
-            S[16] = d.w;                         /* camdVM */
-            S[17] = u2f((f2u(bq.w) & 0xffu) | ((uint32_t)bsdf.matID << 8));
-        }
-        /* (a wave's lanes read only their own wave's state, prefix and terms: LDS operations of a wave execute in order,
-           so no barrier is needed between the writes above and the reads of the drain) */
-        const V3 contrib = merge_query_walk_t(sc, P, g, hasQuery, pos, ls, L);
-        if (hasQuery) {
-            const V3 v = thr * P.vmNormalization * contrib;
-            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
-        }
-    }
-    flush_stats(ls, gstats);
-#endif
-}
-
-/* ---------------- K4 (default): range-merge with the cell lists staged through LDS ---------------- */
+/* ---------------- K4 (selectable): range-merge with the cell lists staged through LDS ---------------- */
 /* HashGrid::Process walks 8 hashed cells per query (hashgrid.hxx:142-167).  k_merge_lane reads the candidates of
  * those cells with per-lane global loads: three 16-byte loads per lane and step, each touching as many cache lines
  * as the wave has distinct cells (~13) -- the L1/TA path, not HBM and not the VALU, bounds its scan half (2.1 of
@@ -966,6 +711,7 @@ __device__ __forceinline__ uint32_t stage_insert(StageLds &L, int cell, int lo, 
 
 /* HashGrid::Process + RangeQuery::Process for one camera vertex, candidates out of LDS where staged.
  * Mirrors merge_query (vcm_core.h) statement by statement; `slots` = the 8 table slots of step A, 10 bits each. */
+template <bool IP>
 __device__ __forceinline__ V3 merge_query_staged(const DScene &sc, const IterParams &P, const GridStore &g,
                                                  const Bsdf &cameraBsdf, const SubPathState &st, V3 queryPos, bool inside,
                                                  int px, int py, int pz, int pxo, int pyo, int pzo,
@@ -1028,19 +774,20 @@ __device__ __forceinline__ V3 merge_query_staged(const DScene &sc, const IterPar
             i = (ni < len) ? ni : len;
             if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
                 ls.mergeAccepted += (uint32_t)qn;
-                merge_drain(P, g, ev, ms, qn, contrib);
+                merge_drain<IP>(P, g, ev, ms, qn, contrib);
                 qn = 0;
             }
         }
     }
     ls.mergeAccepted += (uint32_t)qn;
-    merge_drain(P, g, ev, ms, qn, contrib);
+    merge_drain<IP>(P, g, ev, ms, qn, contrib);
     return contrib;
 }
 #endif
 
 /* 4 waves per SIMD = two 512-thread workgroups per CU: at 129 registers (one too many) only ONE fitted, 6.4 instead of
  * 4.2 ms (r02j-r03o) */
+template <bool IP>
 __global__ void __launch_bounds__(VCM_STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
                const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
@@ -1131,7 +878,7 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
             bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
             SubPathState st;
             st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
-            const V3 contrib = merge_query_staged(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
+            const V3 contrib = merge_query_staged<IP>(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
             vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }

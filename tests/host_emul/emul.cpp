@@ -31,7 +31,7 @@ struct Emul {
     int seed, iterations;
     int resX, resY, N, p0, nLocal;
     IterParams P;
-    std::vector<F4> v0 /* the light store: 5 fields per slot */, w0 /* (the split measurement layout's fifth) */, g1, g2, camOut;
+    std::vector<F4> v0 /* the light store: 5 fields per slot */, g1, g2, camOut;
     std::vector<F2> g3;
     std::vector<float> gx, gy, gz, fb, records;
     std::vector<unsigned char> count, rngL, rngC;
@@ -152,11 +152,10 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     }
     const size_t slots = (size_t)S * e.nLocal;
     e.v0.assign(slots * VCM_LV_FIELDS, mk4(0, 0, 0, 0));
-    e.w0.assign(slots, mk4(0, 0, 0, 0));
     e.count.assign((size_t)e.nLocal, 0); e.rngL.assign((size_t)e.nLocal, 0); e.rngC.assign((size_t)e.nLocal, 0);
     lane_stats_zero(e.ls);
     std::vector<uint32_t> lenMask((size_t)e.nLocal, 0u);
-    LightStore store; store.v = e.v0.data(); store.w = e.w0.data(); store.count = e.count.data(); store.lenMask = lenMask.data();
+    LightStore store; store.v = e.v0.data(); store.count = e.count.data(); store.lenMask = lenMask.data();
 
     /* K1 */
     for (int lp = 0; lp < e.nLocal; lp++) {

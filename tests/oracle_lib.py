@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_TAPE_SO = os.path.join(ROOT, "oracle", "_ref", "libsmallvcm_ref_tape.so")
 REF_STOCK_SO = os.path.join(ROOT, "oracle", "_ref", "libsmallvcm_ref_stock.so")
+REF_TAPE_LIBM_SO = os.path.join(ROOT, "oracle", "_ref", "libsmallvcm_ref_tape_libm.so")   # tape replay, the image's own libm
 
 _u8p = C.POINTER(C.c_ubyte)
 _fp = C.POINTER(C.c_float)
@@ -163,11 +164,30 @@ class Oracle:
 
 
 _ref_tape = None
+_ref_tape_libm = None
 _ref_stock = None
 
 
 def have_ref():
     return os.path.exists(REF_TAPE_SO) and os.path.exists(REF_STOCK_SO)
+
+
+def _declare_tape(L):
+    L.ref_flatten_scene.argtypes = [C.c_uint, C.c_int, C.c_int, C.POINTER(SceneDesc)]
+    L.ref_detmath_calls.restype = C.c_longlong
+    L.ref_run_tape.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                               C.c_int, C.c_int, C.c_uint, C.c_uint, _u8p, _u8p, _fp,
+                               C.POINTER(C.c_longlong)]
+    return L
+
+
+def ref_tape_libm():
+    """the tape-replay reference linked against the image's OWN libm (no interposition): what is left between the product's
+    definition of sinf / cosf / powf and the reference as shipped"""
+    global _ref_tape_libm
+    if _ref_tape_libm is None:
+        _ref_tape_libm = _declare_tape(C.CDLL(REF_TAPE_LIBM_SO))
+    return _ref_tape_libm
 
 
 def ref_tape():
@@ -207,16 +227,18 @@ def ref_scene(mask, resx, resy):
 
 
 def ref_run_tape(mask, resx, resy, algo, light_counts, cam_counts, radius_factor=0.003, radius_alpha=0.75,
-                 seed=1234, first_iteration=0, n_iter=1, min_len=0, max_len=10):
+                 seed=1234, first_iteration=0, n_iter=1, min_len=0, max_len=10, own_libm=False):
     """Unmodified reference VertexCM, replaying the taped random numbers.
-    Returns (framebuffer sum, floats consumed, desync flag)."""
+    Returns (framebuffer sum, floats consumed, desync flag).  own_libm: the build whose sinf / cosf / powf are the
+    image's libm instead of detmath_ref.h."""
     lc = np.ascontiguousarray(light_counts, np.uint8)
     cc = np.ascontiguousarray(cam_counts, np.uint8)
     assert lc.size == n_iter * resx * resy and cc.size == lc.size
     fb = np.zeros((resy, resx, 3), np.float32)
     consumed = C.c_longlong()
-    bad = ref_tape().ref_run_tape(mask, resx, resy, algo, radius_factor, radius_alpha, seed, first_iteration, n_iter,
-                                  min_len, max_len, _bptr(lc), _bptr(cc), _fptr(fb), C.byref(consumed))
+    L = ref_tape_libm() if own_libm else ref_tape()
+    bad = L.ref_run_tape(mask, resx, resy, algo, radius_factor, radius_alpha, seed, first_iteration, n_iter,
+                         min_len, max_len, _bptr(lc), _bptr(cc), _fptr(fb), C.byref(consumed))
     return fb, consumed.value, bad
 
 

@@ -52,11 +52,48 @@ def test_numeric_spec_on_device():
         return out
     a = (rng.random(n) * 7 - 0.5).astype(np.float32)
     b = (rng.random(n) * 100 + 1e-3).astype(np.float32)
-    assert np.array_equal(dev(0, a, b), np.array([O.oracle_sinf(float(x)) for x in a], np.float32))
-    assert np.array_equal(dev(1, a, b), np.array([O.oracle_cosf(float(x)) for x in a], np.float32))
+
+    def same(x, y):   # bit for bit, any NaN = any NaN
+        x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
+        nan = np.isnan(x)
+        return np.array_equal(nan, np.isnan(y)) and np.array_equal(x[~nan].view(np.uint32), y[~nan].view(np.uint32))
+    M = C.CDLL("libm.so.6")   # the libm of the reference's image: detmath restates it (tests/test_rng_detmath.py)
+    M.sinf.restype = M.cosf.restype = M.powf.restype = C.c_float
+    M.sinf.argtypes = M.cosf.argtypes = [C.c_float]
+    M.powf.argtypes = [C.c_float, C.c_float]
+    # sinf / cosf: the path's range, the large reduction, every kind of bit pattern
+    wide = np.concatenate([a[: n // 4], (rng.standard_normal(n // 4) * 60).astype(np.float32),
+                           np.exp(rng.random(n // 4) * 80 - 40).astype(np.float32),
+                           rng.integers(0, 1 << 32, n // 4, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    wide[:12] = np.array([0.0, -0.0, 2.0 ** -12, 1e-30, 0.75, np.pi / 4, 119.99999, 120.0, 3e38, np.inf, -np.inf, np.nan], np.float32)
+    for op, of, mf in ((0, O.oracle_sinf, M.sinf), (1, O.oracle_cosf, M.cosf)):
+        d = dev(op, wide, b)
+        assert same(d, np.array([of(float(x)) for x in wide], np.float32))
+        assert same(d, np.array([mf(float(x)) for x in wide], np.float32))
     u = rng.random(n).astype(np.float32)
     y = np.where(rng.random(n) < 0.5, 90.0, 1.0 / 91.0).astype(np.float32)
     assert np.array_equal(dev(2, u, y), np.array([O.oracle_powf(float(p), float(q)) for p, q in zip(u, y)], np.float32))
+    # powf, the general path (table walk, subnormals, overflow / underflow, special cases) against oracle and host libm
+    px = np.concatenate([np.exp(rng.random(n // 2) * 170 - 85).astype(np.float32),
+                         rng.integers(0, 1 << 32, n // 2, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    py = np.concatenate([(rng.random(n // 2) * 8 - 4).astype(np.float32),
+                         rng.integers(0, 1 << 32, n // 2, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    sp = [(0.0, 0.5), (-0.0, 0.5), (0.0, -0.5), (-2.0, 0.5), (-2.0, 3.0), (1e-45, 0.5), (1.0, 3.3), (5.0, 0.0), (np.inf, 0.5), (np.inf, -0.5),
+          (0.5, np.inf), (2.0, np.inf), (2.0, -np.inf), (np.nan, 0.5), (2.0, np.nan), (3e38, 1.5), (1e-30, 1.5), (0.5, 149.5), (0.5, 150.5),
+          (0.5, 140.25), (1e-40, 0.3), (0.999, 90.5), (0.3, 70000.0)]
+    px[: len(sp)] = np.array([q[0] for q in sp], np.float32)
+    py[: len(sp)] = np.array([q[1] for q in sp], np.float32)
+    d = dev(2, px, py)
+    assert same(d, np.array([O.oracle_powf(float(p), float(q)) for p, q in zip(px, py)], np.float32))
+    with np.errstate(invalid="ignore"):
+        general = ~((py >= 1) & (py <= 65536) & (py == np.floor(py)))   # integer exponents are the correctly rounded power instead
+    assert same(d[general], np.array([M.powf(float(p), float(q)) for p, q in zip(px[general], py[general])], np.float32))
+    assert same(dev(6, px, py), d)                                   # the same with the tables in LDS
+    yi = rng.integers(1, 300, n).astype(np.float32)                  # lanes with different integer exponents
+    yi[: n // 2] = 90.0                                              # ... and waves whose exponent is uniform
+    assert same(dev(7, u, yi), np.array([O.oracle_powf(float(p), float(q)) for p, q in zip(u, yi)], np.float32))
+    fin = np.isfinite(wide)
+    assert same(dev(8, wide, b)[fin], np.array([O.oracle_sinf(float(x)) for x in wide], np.float32)[fin])
     assert np.array_equal(dev(3, a, b), a / b)                       # correctly rounded fp32 division
     assert np.array_equal(dev(4, np.abs(a), b), np.sqrt(np.abs(a)))   # correctly rounded fp32 sqrt
     assert np.array_equal(dev(5, a, b), a * b + a)                   # mul then add, no FMA

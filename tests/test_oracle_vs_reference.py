@@ -138,34 +138,37 @@ def test_statistical_agreement_with_stock_reference():
 
 
 def test_deterministic_libm_against_the_hosts_libm():
-    """What the deterministic sin / cos / pow cost against the arithmetic the reference is built with (glibc), at the
-    same random numbers: the oracle -- per-path random streams -- built over detmath (the specification), over the
-    host's libm, and over round 1's correctly rounded definition renders the same paths.  Stated tolerance (DESIGN.md
-    section 4, profiles/r05_libm_tolerance.json for C1 / C4): no path takes a different number of random floats
-    (< 1e-4 of the paths allowed), one iteration's framebuffer differs by an RMSE below 3e-3 of the image mean (at 160^2; it falls with the pixel count).  The
-    host's libm is whatever glibc this box has: the bounds are loose on purpose, the JSON holds the measured values."""
+    """north_star: "per-pixel RMSE < 1e-4 vs reference at fixed seed" -- against the reference AS SHIPPED, i.e. with its
+    own libm.  Since round 4 detmath restates that libm (glibc 2.35; one deviation: integer exponents are the correctly
+    rounded power), so the bound is asserted directly, at BASELINE's 512^2 (C1) and on the three other scenes:
+      (1) the UNMODIFIED reference, its own libm (oracle/_ref/libsmallvcm_ref_tape_libm.so: nothing interposed), replays
+          the oracle's tape: no desynchronisation -- every path draws the same number of random floats -- and one
+          iteration's framebuffer within RMSE 1e-6 (measured: 1e-10 .. 2e-9, profiles/r06_libm_tolerance.json);
+      (2) the oracle built over the host's libm calls (liboracle_glibc.so) against the checker: the same bound, no path
+          with a different float count."""
     import os
     import subprocess
     import numpy as np
-    from smallvcm_amd.renderer import cornell_scene
+    from smallvcm_amd._abi import SCENE_CONFIGS
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["make", "-C", os.path.join(root, "oracle"), "glibc"], check=True, capture_output=True)
-    libs = {k: oracle_lib.load_oracle(os.path.join(root, "oracle", "liboracle%s.so" % s)) for k, s in (("det", ""), ("glibc", "_glibc"), ("cr", "_cr"))}
-    sc = cornell_scene(1, 160, 160)
-    out = {}
-    for k, L in libs.items():
-        o = oracle_lib.Oracle(sc, 4, threads=8, lib=L)
+    glibc = oracle_lib.load_oracle(os.path.join(root, "oracle", "liboracle_glibc.so"))
+    for sid, algo, res in ((1, 4, 512), (3, 4, 192), (0, 2, 160), (2, 3, 160), (1, 1, 128)):
+        sc = oracle_lib.ref_scene(SCENE_CONFIGS[sid], res, res)
+        o = oracle_lib.Oracle(sc, algo, threads=8)
         o.run_iteration(0, 0, 10)
-        out[k] = (o.framebuffer().astype(np.float64), o.counts())
-    mean = out["glibc"][0].mean()
-    for k in ("det", "cr"):
-        fb, (lc, cc) = out[k]
-        flipped = (lc != out["glibc"][1][0]).sum() + (cc != out["glibc"][1][1]).sum()
-        assert flipped <= 1e-4 * (lc.size + cc.size), (k, flipped)
-        rmse = np.sqrt(((fb - out["glibc"][0]) ** 2).mean())
-        assert rmse < 3e-3 * mean, (k, rmse, mean)
-        assert abs((fb - out["glibc"][0]).mean()) < 1e-4 * mean      # no bias: the differences are rounding noise
-    # the checker itself is the deterministic build: identical to the golden-pinned oracle
-    o = oracle_lib.Oracle(sc, 4, threads=8)
-    o.run_iteration(0, 0, 10)
-    assert np.array_equal(o.framebuffer().astype(np.float64), out["det"][0])
+        lc, cc = o.counts()
+        fb = o.framebuffer().astype(np.float64)
+        ref, consumed, bad = oracle_lib.ref_run_tape(SCENE_CONFIGS[sid], res, res, algo, lc, cc, own_libm=True)
+        assert bad == 0 and consumed == int(lc.sum()) + int(cc.sum()), (sid, algo, res)
+        rmse = np.sqrt(((fb - ref) ** 2).mean())
+        assert rmse < 1e-6, (sid, algo, res, rmse)          # north_star's bound is 1e-4
+        assert (np.abs(fb - ref).max(axis=2) > 0).mean() < 0.01    # and almost every pixel is the reference's bit for bit
+        g = oracle_lib.Oracle(sc, algo, threads=8, lib=glibc)
+        g.run_iteration(0, 0, 10)
+        glc, gcc = g.counts()
+        assert np.array_equal(glc, lc) and np.array_equal(gcc, cc)
+        assert np.sqrt(((g.framebuffer().astype(np.float64) - fb) ** 2).mean()) < 1e-6
+        # the interposed build (what every bit-exact test replays into) is the checker bit for bit
+        ref2, _, bad2 = oracle_lib.ref_run_tape(SCENE_CONFIGS[sid], res, res, algo, lc, cc)
+        assert bad2 == 0 and np.array_equal(ref2, o.framebuffer())

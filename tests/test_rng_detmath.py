@@ -49,54 +49,95 @@ def _ulp_diff(a, b):
 def _ulp_err(approx, exact):
     """error of the binary32 values `approx` in units of the last place of the exact (binary64) result"""
     exact = np.asarray(exact, np.float64)
-    return np.abs(np.asarray(approx, np.float64) - exact) / np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
+    with np.errstate(over="ignore"):
+        return np.abs(np.asarray(approx, np.float64) - exact) / np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
 
 
 def _vec(fn, *cols):
     return np.array([fn(*[float(v) for v in row]) for row in zip(*cols)], np.float32)
 
 
-def test_detmath_accuracy_and_product_equality():
-    """The definition's stated bounds (detmath.h): sinf/cosf <= 1.6 ulp on the domain the path uses, powf <= 1.9 ulp for
-    0 < y < 1 and correctly rounded for integer exponents; product (host build of smallvcm_amd/csrc/detmath.h) ==
-    oracle (oracle/detmath_ref.h) bit for bit."""
-    L, E = oracle(), emul()
+_libm = None
+
+
+def _host_libm():
+    """the libm the reference is linked with in this image (glibc 2.35), called directly"""
+    global _libm
+    if _libm is None:
+        L = C.CDLL("libm.so.6")
+        for f in (L.sinf, L.cosf):
+            f.argtypes = [C.c_float]
+            f.restype = C.c_float
+        L.powf.argtypes = [C.c_float, C.c_float]
+        L.powf.restype = C.c_float
+        _libm = L
+    return _libm
+
+
+def _bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def _same(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.array_equal(_bits(a)[~np.isnan(a)], _bits(b)[~np.isnan(a)]) and np.array_equal(np.isnan(a), np.isnan(b))
+
+
+def test_detmath_is_the_hosts_libm_and_product_equals_oracle():
+    """detmath (round 4) RESTATES the libm of the reference's image: glibc 2.35's sinf / cosf / powf, FMA variants
+    (smallvcm_amd/csrc/detmath.h, oracle/detmath_ref.h).  oracle/libm_check.c compares them over all 2^32 arguments
+    (profiles/r06_libm_check.txt: no difference); this is the sampled version that stays under test -- oracle == the host's
+    libm bit for bit, and product (host build of detmath.h) == oracle bit for bit.  The one deviation: integer exponents
+    1..65536 are the correctly rounded power."""
+    L, E, M = oracle(), emul(), _host_libm()
     rng = np.random.default_rng(7)
-    xs = np.concatenate([(rng.random(40000) * 2 * np.pi).astype(np.float32),
-                         (rng.random(8000) * 9 - 1.5).astype(np.float32),
-                         np.array([0.0, 1e-8, np.pi / 4, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi, 6.2831855, -0.7853982], np.float32)])
+    xs = np.concatenate([(rng.random(60000) * 2 * np.pi).astype(np.float32),            # 2 pi u: utils.hxx:91, :177, :216
+                         (rng.random(20000) * 2.5 * np.pi - np.pi / 4).astype(np.float32),   # the concentric disc's angle, :119-160
+                         (rng.standard_normal(20000) * 50).astype(np.float32),           # beyond 120: the large reduction
+                         np.exp(rng.random(20000) * 80 - 40).astype(np.float32),
+                         rng.integers(0, 1 << 32, 40000, dtype=np.uint64).astype(np.uint32).view(np.float32),   # any bit pattern
+                         np.array([0.0, -0.0, 1e-8, 2.0 ** -12, np.pi / 4, 0.75, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi, 6.2831855,
+                                   -0.7853982, 119.99999, 120.0, 1e30, np.inf, -np.inf, np.nan], np.float32)])
     s, c = _vec(L.oracle_sinf, xs), _vec(L.oracle_cosf, xs)
-    x64 = xs.astype(np.float64)
-    assert _ulp_err(s, np.sin(x64)).max() <= 1.6 and _ulp_err(c, np.cos(x64)).max() <= 1.6
-    assert np.abs(s.astype(np.float64) - np.sin(x64)).max() < 1.2e-7 and np.abs(c.astype(np.float64) - np.cos(x64)).max() < 1.2e-7
-    assert (_ulp_err(s, np.sin(x64)) > 1).mean() < 0.02       # a percent of the arguments is off by more than one ulp
-    assert np.array_equal(_vec(E.emul_sinf, xs[:6000]), s[:6000]) and np.array_equal(_vec(E.emul_cosf, xs[:6000]), c[:6000])
-    assert np.all(np.abs(s.astype(np.float64) ** 2 + c.astype(np.float64) ** 2 - 1) < 4e-7)
-    # powf, fractional exponents: the stream's floats (2k+1) 2^-24, anything in (0, 200), and the whole binary32 range
+    assert _same(s, _vec(M.sinf, xs)) and _same(c, _vec(M.cosf, xs))
+    assert _same(_vec(E.emul_sinf, xs), s) and _same(_vec(E.emul_cosf, xs), c)
+    fin = np.isfinite(xs) & (np.abs(xs) < 1e6)
+    x64 = xs[fin].astype(np.float64)
+    assert _ulp_err(s[fin], np.sin(x64)).max() <= 0.56 and _ulp_err(c[fin], np.cos(x64)).max() <= 0.56   # glibc's own bound
+    # powf, the general path: the stream's floats (2k+1) 2^-24, the whole binary32 range, special cases
     us = ((2 * rng.integers(0, 1 << 23, 30000) + 1).astype(np.float64) * 2.0 ** -24).astype(np.float32)
     wide = np.exp(rng.random(30000) * 170 - 85).astype(np.float32)
-    for y in (float(np.float32(1.0 / 91.0)), 0.0625, 0.125, float(np.float32(1 / 2.2)), 0.5, 0.99):
+    for y in (float(np.float32(1.0 / 91.0)), 0.0625, 0.125, float(np.float32(1 / 2.2)), 0.5, 0.99, 90.5, 2.25, -0.5, -3.0, 1e-3, 70000.0):
         for x in (us, wide):
             p = _vec(lambda a: L.oracle_powf(a, y), x)
-            assert _ulp_err(p, np.power(x.astype(np.float64), float(np.float32(y)))).max() <= 1.9, y
-    ys = rng.random(30000).astype(np.float32)
+            assert _same(p, _vec(lambda a: M.powf(a, y), x)), y
+            assert _same(_vec(lambda a: E.emul_powf(a, y), x[:4000]), p[:4000]), y
+    ys = (rng.random(30000) * 8 - 4).astype(np.float32)
     p = _vec(L.oracle_powf, wide, ys)
-    assert _ulp_err(p, np.power(wide.astype(np.float64), ys.astype(np.float64))).max() <= 1.9
-    assert np.array_equal(_vec(E.emul_powf, wide[:6000], ys[:6000]), p[:6000])
-    # integer exponents: one rounding of the binary64 product chain, i.e. the correctly rounded result
-    u01 = np.concatenate([rng.random(20000).astype(np.float32), np.array([0.0, 1.0, 1e-3, 1.0000001, 1e-30], np.float32)])
-    for y in (90.0, 1.0, 2.0, 3.0, 17.0, 256.0, 1000.0):
+    assert _same(p, _vec(M.powf, wide, ys)) and _same(_vec(E.emul_powf, wide[:6000], ys[:6000]), p[:6000])
+    anyx = rng.integers(0, 1 << 32, 30000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    anyy = rng.integers(0, 1 << 32, 30000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    with np.errstate(invalid="ignore"):
+        nonint = ~((anyy >= 1) & (anyy <= 65536) & (anyy == np.floor(anyy)))
+    p = _vec(L.oracle_powf, anyx, anyy)
+    assert _same(p[nonint], _vec(M.powf, anyx, anyy)[nonint]) and _same(_vec(E.emul_powf, anyx, anyy), p)
+    special = [(0.0, 0.5), (-0.0, 0.5), (0.0, -0.5), (-2.0, 0.5), (-2.0, -0.5), (1e-45, 0.5), (1.0, 3.3), (5.0, 0.0), (np.inf, 0.5),
+               (np.inf, -0.5), (0.5, np.inf), (2.0, np.inf), (2.0, -np.inf), (np.nan, 0.5), (2.0, np.nan), (1.0, np.nan),
+               (3e38, 1.5), (1e-30, 1.5), (0.5, 149.5), (0.5, 150.5)]
+    for x, y in special:
+        a, b, e = L.oracle_powf(x, y), M.powf(x, y), E.emul_powf(x, y)
+        assert _same([a], [b]) and _same([e], [a]), (x, y, a, b, e)
+    # integer exponents (the Phong lobe: 90): one rounding of the binary64 product chain = the correctly rounded power;
+    # the host's own powf agrees with it except for ~0.2 % of the arguments, by one unit in the last place
+    u01 = np.concatenate([rng.random(20000).astype(np.float32), np.array([0.0, 1.0, 1e-3, 1.0000001, 1e-30, -0.5, -1.5], np.float32)])
+    for y in (90.0, 1.0, 2.0, 3.0, 17.0, 256.0, 1000.0, 65536.0):
         p = _vec(lambda a: L.oracle_powf(a, y), u01)
-        assert _ulp_err(p[p > 1e-37], np.power(u01[p > 1e-37].astype(np.float64), y)).max() <= 0.5001, y
-        assert np.array_equal(_vec(lambda a: E.emul_powf(a, y), u01[:3000]), p[:3000])
-    # mixed and negative exponents, special cases
-    for y in (90.5, 2.25, -0.5, -3.0):
-        x = (rng.random(5000) + 0.6).astype(np.float32) if y > 10 else (rng.random(5000) * 3 + 0.01).astype(np.float32)
-        p = _vec(lambda a: L.oracle_powf(a, y), x)
-        assert _ulp_err(p, np.power(x.astype(np.float64), y)).max() <= 3.0, y
-        assert np.array_equal(_vec(lambda a: E.emul_powf(a, y), x[:2000]), p[:2000])
-    assert L.oracle_powf(0.0, 90.0) == 0.0 and L.oracle_powf(5.0, 0.0) == 1.0 and L.oracle_powf(1.0, 3.3) == 1.0
-    assert L.oracle_powf(-2.0, 0.5) == 0.0 and L.oracle_powf(1e-45, 0.5) > 0.0
-    # the radius schedule (vertexcm.hxx:296): (i + 1)^0.125
+        ok = (np.abs(p) > 1e-37) & np.isfinite(p)
+        assert _ulp_err(p[ok], np.power(u01[ok].astype(np.float64), y)).max() <= 0.5001, y
+        assert _same(_vec(lambda a: E.emul_powf(a, y), u01), p)
+        host = _vec(lambda a: M.powf(a, y), u01)
+        d = _ulp_diff(p[ok], host[ok])   # (the error of the host's log2 grows with the exponent)
+        assert d.max() <= (1 if y <= 256 else 8) and (d > 0).mean() < (0.01 if y <= 256 else 0.3), y
+    # the radius schedule (vertexcm.hxx:296): (i + 1)^0.125 -- the reference's own values now
     it = np.arange(1, 20001).astype(np.float32)
-    assert _ulp_err(_vec(lambda a: L.oracle_powf(a, 0.125), it), np.power(it.astype(np.float64), 0.125)).max() <= 1.9
+    assert _same(_vec(lambda a: L.oracle_powf(a, 0.125), it), _vec(lambda a: M.powf(a, 0.125), it))
