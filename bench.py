@@ -25,7 +25,8 @@ Mpaths/s = 2*N*steps / seconds / 1e6.  One JSON line on stdout:
                 resolution and the same iteration (= radius) window as the GPU; `port` = the oracle restatement,
                 path-parallel over all cores, on a bounded sample.  Baseline only.
 
-N > 1 runs the reference's render() decomposition (smallvcm.cxx:61-72, :99-108, :116-142) on the C++ host
+N = 1 and N > 1 are timed by the SAME host: the C++ farm (one rank thread at N = 1; `host_cross_check` repeats the headline
+through the Python / ctypes loop).  N > 1 runs the reference's render() decomposition (smallvcm.cxx:61-72, :99-108, :116-142) on the C++ host
 (smallvcm_amd/host/vcm_farm.cpp behind include/smallvcm_amd_farm.h: one host thread per GPU, RCCL between them) with a
 GROUP of --shards GPUs as one "thread": inside a group the paths of an iteration are sharded by index and the
 light-vertex merge records are all-gathered (RCCL) every iteration; two renderers take turns on every group
@@ -158,7 +159,7 @@ def live_counters(args):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not found"
-    warm, steps = 2, 6
+    warm, steps = args.warmup, args.steps   # the SAME iteration window as the timed run: traffic, VALU counters and kernel_ms agree
     groups = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
               "valu": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]}
     merged = {}
@@ -169,7 +170,7 @@ def live_counters(args):
                "--steps", str(steps), "--warmup", str(warm)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.PIPE, timeout=300)
+                               stderr=subprocess.PIPE, timeout=600)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %d)" % (" ".join(counters), r.returncode)
@@ -181,8 +182,8 @@ def live_counters(args):
             return None, "rocprofv3 --pmc %s: %r" % (counters[0], e)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return merged, ("live: rocprofv3 --pmc child runs of this workload (FETCH_SIZE | WRITE_SIZE | SQ VALU group, %d launches each "
-                    "after %d warm-up)" % (steps, warm))
+    return merged, ("live: rocprofv3 --pmc child runs of this workload (FETCH_SIZE | WRITE_SIZE | SQ VALU group), iterations %d..%d "
+                    "= the timed window" % (warm, warm + steps - 1))
 
 
 def _sum_over(counters, prefixes, name):
@@ -309,6 +310,45 @@ def add_counters(roof, dom, counters, note, st, n_local):
     if tot:
         roof["iteration_traffic"] = int(tot)
         roof["iteration_traffic_over_design"] = round(tot / float(max(roof["iteration_design_bytes"], 1)), 3)
+
+
+VALU_PEAK_GINST = VALU_SIMDS * VALU_CLK_HZ / VALU_CYCLES_PER_INST / 1e9   # 614.4 G wave-instructions/s
+
+
+def finalize_roofline(roof):
+    """The line's `frac` must be the fraction of the roofline that BINDS the dominant kernel.  SURVEY 8(d)'s gather model
+    prices every merge candidate as an HBM read; the cell-sorted, query-sorted merge serves most of them from cache, so the
+    model exceeds the peak (> 1) and bounds nothing.  Then: frac = max(measured HBM traffic / time / 8 TB/s, VALU issue
+    fraction), `bound` says which, achieved / peak / unit belong to it, and the model's figure stays as frac_algorithmic.
+    Without counters (no rocprofv3) the algorithmic figure is all there is.  Returns the block with the figures a reader
+    needs first."""
+    alg = {"frac_algorithmic": roof["frac"], "achieved_algorithmic_GBs": roof["achieved"]}
+    ft = roof.get("frac_traffic")
+    vf = (roof.get("valu") or {}).get("frac")
+    head = {"bound": "hbm", "kernel": roof["kernel"], "achieved": roof["achieved"], "peak": roof["peak"], "unit": roof["unit"],
+            "frac": roof["frac"]}
+    if roof.get("frac_model_invalid") and (ft is not None or vf is not None):
+        if vf is not None and vf >= (ft or 0.0):
+            insts = roof["valu"]["insts"]
+            head.update({"bound": "valu", "achieved": round(insts / (roof["kernel_ms"] / 1e3) / 1e9, 2), "peak": round(VALU_PEAK_GINST, 1),
+                         "unit": "G wave-instructions/s (1024 SIMDs x 2.4 GHz / 4 cycles)", "frac": vf})
+        else:
+            head.update({"bound": "hbm", "achieved": roof["achieved_traffic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (measured HBM traffic)",
+                         "frac": ft})
+    elif roof.get("frac_model_invalid"):
+        head["frac_note"] = "SURVEY's gather model exceeds the peak and no counters were collected: frac bounds nothing here"
+    head["limiter"] = roof.get("limiter")
+    if roof.get("valu"):
+        head["valu_frac"] = roof["valu"]["frac"]
+        head["valu_lane_util"] = roof["valu"]["lane_util"]
+    head["traffic"] = roof.get("traffic")
+    head["frac_traffic"] = ft
+    head.update(alg)
+    head["frac_model_invalid"] = roof.get("frac_model_invalid")
+    for k, v in roof.items():
+        if k not in head and k not in ("frac", "achieved", "peak", "unit", "bound"):
+            head[k] = v
+    return head
 
 
 def workload_name(scene, algo, res, replicas, first, last):
@@ -475,6 +515,7 @@ def multi_gpu(args):
             "image_mean": [round(float(x), 5) for x in main_run["image"].mean(axis=(0, 1))],
         }
         roof["scope"] = "world rank 0 (1 of %d shards of renderer 0), mean over its timed iterations" % shards
+        out["roofline"] = finalize_roofline(roof)
         if strong is not None:
             out["strong_decomposition"] = {
                 "value": round(strong["value"], 3), "unit": "Mpaths/s", "scaling": "strong",
@@ -511,6 +552,7 @@ def main():
                                                                "it saturates the host's memory system there)")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's other single-GPU configs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 child runs (HBM traffic, VALU counters)")
+    ap.add_argument("--no-cross-check", action="store_true", help="skip the second timing of the headline through the Python host")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # inner run under rocprofv3: GPU loop only
     args = ap.parse_args()
     if args.no_cpu_baseline:
@@ -552,16 +594,45 @@ def main():
         return farm
 
     res, n_paths = args.res, args.res * args.res
-    farm = make_farm(args.scene, args.algo, res, 1, args.inflight if args.inflight > 0 else None)
-    replicas = farm.replicas
-    elapsed, st = timed_run(farm, args.steps, args.warmup, sync)
-    if args.child:
+    from smallvcm_amd import farm as F
+
+    def farm_run(scene_id, algo_name, r, nfl, steps, warmup):
+        """one GPU, the C++ host (vcm_farm.cpp, the same loop `--gpus N` times): `nfl` renderers (seeds 1234 ..) taking
+        turns on the GPU, every one the iteration window warmup .. warmup + steps - 1.  -> (seconds, mean statistics of
+        renderer 0's timed iterations, image, per-rank device ms of an iteration)"""
+        rr = F.farm_render(cornell_scene(scene_id, r, r), ALGO_BY_NAME[algo_name], iterations=steps * nfl, ranks=1, shards=1,
+                           inflight=nfl, devices=[local_rank], warmup=warmup, same_window=True, collectives="threads")
+        return rr["wall_s"], rr["stats"], rr["image"], rr["rank_iteration_ms"]
+
+    builtin = not isinstance(args.scene, str)
+    cross = None
+    if builtin:
+        nfl0 = args.inflight if args.inflight > 0 else 1
+        elapsed, st, fb, _ = farm_run(args.scene, args.algo, res, nfl0, args.steps, args.warmup)
+        if args.child:
+            return
+        replicas, inflight_used, n_local = nfl0, nfl0, n_paths
+        host = ("C++ (smallvcm_amd/host/vcm_farm.cpp via include/smallvcm_amd_farm.h): one rank thread, the loop `--gpus N` runs; "
+                "no collective exists at one rank")
+        if not args.no_cross_check:   # the Python / ctypes loop over the same C-ABI, as a cross-check of the host
+            pf = make_farm(args.scene, args.algo, res, 1, args.inflight if args.inflight > 0 else None)
+            e2, _ = timed_run(pf, args.steps, args.warmup, sync)
+            cross = {"host": "Python (smallvcm_amd.renderer.RenderFarm over ctypes, torch.cuda.synchronize around the timed region)",
+                     "value": round(2.0 * n_paths * args.steps * pf.replicas / e2 / 1e6, 3), "unit": "Mpaths/s",
+                     "ms_per_step": round(e2 / args.steps * 1e3, 3)}
+            pf.close()
+    else:   # a scene file: the farm takes the built-in scenes only
+        farm = make_farm(args.scene, args.algo, res, 1, args.inflight if args.inflight > 0 else None)
+        replicas = farm.replicas
+        elapsed, st = timed_run(farm, args.steps, args.warmup, sync)
+        if args.child:
+            farm.close()
+            return
+        fb = farm.framebuffer()
+        n_local = farm.backend.count
+        inflight_used = farm.inflight
         farm.close()
-        return
-    fb = farm.framebuffer()
-    n_local = farm.backend.count
-    inflight_used = farm.inflight
-    farm.close()
+        host = "Python (smallvcm_amd.renderer.RenderFarm over ctypes): scene files are not wired into the C++ farm"
 
     value = 2.0 * n_paths * args.steps * replicas / elapsed / 1e6
     dom, roof = roofline_block(st, n_local, n_paths)
@@ -572,12 +643,13 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (reference's built-in Cornell box scene %s)" % args.scene,
-        "config": {"workload": workload_name(args.scene, args.algo, res, replicas, args.warmup * replicas,
-                                             (args.warmup + args.steps) * replicas - 1),
+        "config": {"workload": workload_name(args.scene, args.algo, res, replicas, args.warmup, args.warmup + args.steps - 1)
+                               + (" by every renderer" if replicas > 1 else ""),
                    "baseline_config": "C4 at 1 GPU (BASELINE.json metric)" if headline else "other",
                    "paths_per_step": 2 * n_paths * replicas,
                    "parallelism": "%d renderer(s) (iteration-parallel, smallvcm.cxx:61-108) on one GPU, %d in flight"
                                   % (replicas, inflight_used),
+                   "host": host,
                    "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "walk")},
         "roofline": roof,
         "counters": {k: int(st[k]) for k in ("lightVertices", "gridVertices", "mergeQueries", "mergeCandidates",
@@ -585,6 +657,8 @@ def main():
                                              "shadowRays")},
         "image_mean": [round(float(x), 5) for x in fb.mean(axis=(0, 1))],
     }
+    if cross is not None:
+        out["host_cross_check"] = cross
     counters, src = (None, "disabled (--no-traffic)") if args.no_traffic else live_counters(args)
     if counters is not None:
         add_counters(roof, dom, counters, src, st, n_local)
@@ -599,25 +673,31 @@ def main():
             roof["traffic_over_algorithmic"] = round(rec / max(roof["algorithmic_bytes_per_launch"], 1), 4)
         else:
             roof["traffic_source"] = "null: %s; no profiles/*_traffic.json for kernel sources %s" % (src, kernel_source_hash())
+    out["roofline"] = finalize_roofline(roof)
     if headline and not args.no_configs:
         cfgs = []
         for name, scene, algo_name, r, nfl in OTHER_CONFIGS:
             try:
-                f2 = make_farm(scene, algo_name, r, 1, nfl)
-                e2, s2 = timed_run(f2, args.steps, args.warmup, sync)
-                nl = f2.backend.count
-                f2.close()
+                if isinstance(scene, str):   # a scene file: Python host (the farm takes the built-in scenes)
+                    f2 = make_farm(scene, algo_name, r, 1, nfl)
+                    e2, s2 = timed_run(f2, args.steps, args.warmup, sync)
+                    nl = f2.backend.count
+                    f2.close()
+                else:
+                    e2, s2, _, _ = farm_run(scene, algo_name, r, nfl, args.steps, args.warmup)
+                    nl = r * r
                 _, roof2 = roofline_block(s2, nl, r * r)
                 if nfl > 1:
                     roof2["scope"] = "first of the %d renderers; its kernels share the GPU with the others', so per-kernel " \
                                      "times are longer than alone" % nfl
-                cfgs.append({"name": name, "workload": workload_name(scene, algo_name, r, nfl, args.warmup * nfl,
-                                                                     (args.warmup + args.steps) * nfl - 1),
+                cfgs.append({"name": name, "workload": workload_name(scene, algo_name, r, nfl, args.warmup, args.warmup + args.steps - 1)
+                                                 + (" by every renderer" if nfl > 1 else ""),
+                             "host": "Python" if isinstance(scene, str) else "C++ farm",
                              "renderers_in_flight": nfl,
                              "value": round(2.0 * r * r * args.steps * nfl / e2 / 1e6, 3), "unit": "Mpaths/s",
                              "ms_per_step": round(e2 / args.steps * 1e3, 3), "steps": args.steps, "warmup": args.warmup,
                              "paths_per_step": 2 * r * r * nfl,
-                             "roofline": roof2,
+                             "roofline": finalize_roofline(roof2),
                              "counters": {k: int(s2[k]) for k in ("lightVertices", "mergeQueries", "mergeCandidates",
                                                                   "mergeAccepted", "connections", "lightSplats")}})
             except Exception as e:

@@ -99,11 +99,26 @@ struct Loader {
         return it->second.index;
     }
 
+    /* one whole line of any length (a polygon with a thousand vertices is one `f` line: a fixed buffer would cut it in
+       the middle of an index and read the tail as an unknown key) */
+    static bool read_line(FILE *f, std::string &line)
+    {
+        line.clear();
+        char buf[1024];
+        bool any = false;
+        while (fgets(buf, sizeof(buf), f)) {
+            any = true;
+            line += buf;
+            if (!line.empty() && line[line.size() - 1] == '\n') break;
+        }
+        return any;
+    }
+
     bool load_mtl(const std::string &path)
     {
         FILE *f = fopen(path.c_str(), "r");
         if (!f) return fail("cannot open " + path);
-        char line[1024];
+        std::string lineBuf;
         MtlEntry *cur = NULL;
         int illum = 2;
         float ks[3] = { 0, 0, 0 }, ni = 1.f;
@@ -118,13 +133,14 @@ struct Loader {
                 for (int k = 0; k < 3; k++) cur->m.phong[k] = ks[k];
             }
         };
-        while (fgets(line, sizeof(line), f)) {
-            const char *p = line;
+        while (read_line(f, lineBuf)) {
+            const char *p = lineBuf.c_str();
             const std::string key = word(p);
             if (key.empty() || key[0] == '#') continue;
             if (key == "newmtl") {
                 finish();
                 const std::string name = word(p);
+                if (mtl.count(name)) { fclose(f); return fail(path + ": material '" + name + "' is defined twice"); }
                 MtlEntry e;
                 vcm_make_material(&e.m);
                 e.ke[0] = e.ke[1] = e.ke[2] = 0.f; e.emissive = false; e.index = -1;
@@ -174,11 +190,11 @@ struct Loader {
         std::vector<float> v;
         std::string current;
         const MtlEntry *cur = NULL;
-        char line[4096];
+        std::string lineBuf;
         long lineNo = 0;
-        while (fgets(line, sizeof(line), f)) {
+        while (read_line(f, lineBuf)) {
             lineNo++;
-            const char *p = line;
+            const char *p = lineBuf.c_str();
             const std::string key = word(p);
             if (key == "v") {
                 float x[3];
@@ -217,12 +233,12 @@ struct Loader {
         FILE *f = fopen(path.c_str(), "r");
         if (!f) return fail("cannot open " + path);
         const std::string base = dir_of(path);
-        char line[2048];
+        std::string lineBuf;
         long lineNo = 0;
         bool ok = true;
-        while (ok && fgets(line, sizeof(line), f)) {
+        while (ok && read_line(f, lineBuf)) {
             lineNo++;
-            const char *p = line;
+            const char *p = lineBuf.c_str();
             const std::string key = word(p);
             const std::string at = path + " line " + std::to_string(lineNo);
             if (key.empty() || key[0] == '#') continue;
@@ -290,10 +306,18 @@ vcm_scene_file *vcm_scene_load(const char *path, int resX, int resY)
     if (!path || resX < 1 || resY < 1) { g_sceneError = "vcm_scene_load: bad argument"; return NULL; }
     vcm_scene_file *s = new (std::nothrow) vcm_scene_file();
     if (!s) { g_sceneError = "out of memory"; return NULL; }
-    Loader ld;
-    ld.out = s;
-    const std::string p(path);
-    const bool ok = (Loader::ends_with(p, ".obj") ? ld.load_obj(p) : ld.load_scene(p)) && ld.finish(resX, resY);
+    bool ok = false;
+    try {   /* nothing may be thrown through the C-ABI (std::string / std::vector / std::map allocate) */
+        Loader ld;
+        ld.out = s;
+        const std::string p(path);
+        ok = (Loader::ends_with(p, ".obj") ? ld.load_obj(p) : ld.load_scene(p)) && ld.finish(resX, resY);
+    } catch (const std::exception &e) {
+        try { g_sceneError = std::string("vcm_scene_load: ") + e.what(); } catch (...) {}
+        ok = false;
+    } catch (...) {
+        ok = false;
+    }
     if (!ok) { delete s; return NULL; }
     return s;
 }

@@ -616,8 +616,16 @@ template <typename T>
 static int launch_scan_on(vcm_ctx *c, int which, hipStream_t stream, const T *in, int n, int *out, int *totalOut, int writeTotalAtN,
                           StampArgs st)
 {
-    if (n <= 0) return fail("launch_scan", "empty scan");
+    if (n <= 0) {   /* nothing to scan: the total is zero (not a failure of the iteration) */
+        if (totalOut) HIPCHK(hipMemsetAsync(totalOut, 0, sizeof(int), stream));
+        if (writeTotalAtN) HIPCHK(hipMemsetAsync(out, 0, sizeof(int), stream));
+        return 0;
+    }
     const int nTiles = (n + VCM_SCAN_TILE - 1) / VCM_SCAN_TILE;
+    /* k_scan_apply: every tile adds up the tile sums before it -- nTiles^2 / 2 reads out of L2, 134 MB at the 8192 tiles
+       of the largest table in use (the 16.8 M-entry bucket table of the query sort).  Quadratic: refuse what the
+       scratch was not sized for instead of crawling */
+    if (nTiles > 16384) return fail("launch_scan", "more than 16384 tiles: use a three-level scan");
     int *tileSums = c->dTileSums[which];
     hipLaunchKernelGGL((k_scan_tile_sums<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, tileSums, st);
     hipLaunchKernelGGL((k_scan_apply<T>), dim3(nTiles), dim3(VCM_SCAN_BLOCK), 0, stream, in, n, (const int *)tileSums, out, totalOut, writeTotalAtN);
@@ -1185,6 +1193,7 @@ int vcm_export_framebuffer_scaled(vcm_ctx *c, void *dstDev, float scale)
 {
     if (!c || !dstDev) return fail("vcm_export_framebuffer_scaled", "bad argument");
     if (ensure_device(c)) return -1;
+    if (join_splats(c)) return -1;   /* the light splats of an open iteration run on a stream of their own */
     hipLaunchKernelGGL(k_scale_copy, dim3(1024), dim3(256), 0, c->stream, (const float *)c->dFb, (float *)dstDev, (size_t)c->N * 3, scale);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1194,6 +1203,7 @@ int vcm_export_framebuffer(vcm_ctx *c, void *dstDev)
 {
     if (!c || !dstDev) return fail("vcm_export_framebuffer", "bad argument");
     if (ensure_device(c)) return -1;
+    if (join_splats(c)) return -1;
     HIPCHK(hipMemcpyAsync(dstDev, c->dFb, (size_t)c->N * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
@@ -1511,7 +1521,6 @@ int vcm_merge(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_m
 
 static int vcm_end_iteration_impl(vcm_ctx *c)
 {
-    if (!c->merged) return fail("vcm_end_iteration", "vcm_merge has not run");
     if (use_device(c)) return -1;
     if (join_grid(c) || join_splats(c)) return -1;   /* (a merge-free algorithm never waited) */
     if (flush_stamps(c, c->stream) || (c->deviceReady && flush_stamps(c, c->side))) return -1;
@@ -1524,8 +1533,11 @@ static int vcm_end_iteration_impl(vcm_ctx *c)
 int vcm_end_iteration(vcm_ctx *c)
 {
     if (!c || !c->inIteration) return fail("vcm_end_iteration", "no iteration in progress");
+    /* a mis-ordered call is refused and the iteration stays open (the host can still call vcm_merge): tearing it down
+       here would leave the light splats in the framebuffer without counting the iteration */
+    if (!c->merged) return fail("vcm_end_iteration", "vcm_merge has not run");
     g_hipFailed = false;
-    return abort_iteration(c, vcm_end_iteration_impl(c));   /* a failure ends the iteration like every other phase call */
+    return abort_iteration(c, vcm_end_iteration_impl(c));   /* a HIP failure ends the iteration like every other phase call */
 }
 
 int vcm_run_iteration(vcm_ctx *c, int iteration, unsigned minLen, unsigned maxLen)
@@ -1555,6 +1567,7 @@ int vcm_read_framebuffer(vcm_ctx *c, float *rgbHost)
     if (!c || !rgbHost) return fail("vcm_read_framebuffer", "NULL argument");
     if (!c->deviceReady) { memset(rgbHost, 0, (size_t)c->N * 3 * sizeof(float)); return 0; }
     if (use_device(c)) return -1;
+    if (join_splats(c)) return -1;   /* K1c / K1d of an open iteration add to dFb on the splat stream */
     HIPCHK(hipMemcpyAsync(rgbHost, c->dFb, (size_t)c->N * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -1569,6 +1582,7 @@ int vcm_read_image(vcm_ctx *c, int format, float scale, float gamma, unsigned ch
     const size_t bytes = (size_t)c->N * (format == VCM_IMAGE_BGR8 ? 3 : 4);
     unsigned char *d = NULL;
     if (dalloc(&d, bytes)) return -1;
+    if (join_splats(c)) { (void)hipFree(d); return -1; }
     hipLaunchKernelGGL(k_encode_image, dim3(1024), dim3(256), 0, c->stream, (const float *)c->dFb, c->resX, c->resY, format,
                        scale, 1.f / gamma, d);
     hipError_t e = hipGetLastError();
@@ -1583,6 +1597,7 @@ int vcm_framebuffer_device(vcm_ctx *c, void **devPtr)
 {
     if (!c || !devPtr) return fail("vcm_framebuffer_device", "NULL argument");
     if (ensure_device(c)) return -1;
+    if (join_splats(c)) return -1;   /* whoever uses the pointer orders against the context's stream */
     *devPtr = c->dFb;
     return 0;
 }
@@ -1592,6 +1607,7 @@ int vcm_clear_framebuffer(vcm_ctx *c)
     if (!c) return fail("vcm_clear_framebuffer", "ctx is NULL");
     if (!c->deviceReady) return 0;
     if (use_device(c)) return -1;
+    if (join_splats(c)) return -1;
     HIPCHK(hipMemsetAsync(c->dFb, 0, (size_t)c->N * 3 * sizeof(float), c->stream));
     return 0;
 }

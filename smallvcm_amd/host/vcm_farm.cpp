@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -112,10 +113,37 @@ public:
         }
         const ncclResult_t e = ncclGroupEnd();
         if (r == ncclSuccess) r = e;
-        if (r != ncclSuccess) { sh.fail(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); mComms.clear(); }
+        if (r != ncclSuccess) { sh.fail(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); mComms.clear(); return; }
+        { const char *f = getenv("SMALLVCM_AMD_FARM_RCCL_EXCHANGE"); if (f && f[0] == '1') mAllLocal = false; }   // tests: the cross-process exchange with one process
+        if (!mAllLocal) {
+            // A second communicator over the same ranks for the 32-byte exchanges and barriers, with a stream of its own
+            // per member: a rank's communication stream may still hold another in-flight renderer's all-gather (58 - 464 MB)
+            // when the next step's 7 numbers are due, and the host WAITS for those.  Collectives of one communicator run in
+            // issue order whatever stream they are given; two communicators progress independently.  Every rank issues the
+            // small ones in the same order among themselves (pass 2 of a step) and the large ones likewise (pass 3).
+            mSmallComms.assign(localDevices.size(), (ncclComm_t)NULL);
+            mSmallStreams.assign(localDevices.size(), (hipStream_t)NULL);
+            r = ncclGroupStart();
+            for (size_t i = 0; i < localDevices.size() && r == ncclSuccess; i++)
+                r = ncclCommSplit(mComms[i], 0, firstLocal + (int)i, &mSmallComms[i], NULL);
+            const ncclResult_t e2 = ncclGroupEnd();
+            if (r == ncclSuccess) r = e2;
+            if (r != ncclSuccess) {   // not fatal: the small collectives then share the main communicator (round 3's behaviour)
+                fprintf(stderr, "vcm_farm: ncclCommSplit: %s -- the exchanges share the main communicator\n", ncclGetErrorString(r));
+                mSmallComms.clear();
+            } else {
+                for (size_t i = 0; i < localDevices.size(); i++) {
+                    if (hipSetDevice(localDevices[i]) != hipSuccess || hipStreamCreateWithFlags(&mSmallStreams[i], hipStreamNonBlocking) != hipSuccess) {
+                        sh.fail("RcclCollectives: cannot create the exchange stream"); mComms.clear(); return;
+                    }
+                }
+            }
+        }
     }
     ~RcclCollectives()
     {
+        for (size_t i = 0; i < mSmallComms.size(); i++) if (mSmallComms[i]) ncclCommDestroy(mSmallComms[i]);
+        for (size_t i = 0; i < mSmallStreams.size(); i++) if (mSmallStreams[i]) { (void)hipSetDevice(mDevices[i]); (void)hipStreamDestroy(mSmallStreams[i]); }
         for (size_t i = 0; i < mComms.size(); i++) if (mComms[i]) ncclCommDestroy(mComms[i]);
         for (size_t i = 0; i < mScratch.size(); i++) {
             if (mScratch[i]) { (void)hipSetDevice(mDevices[i]); (void)hipFree(mScratch[i]); }
@@ -144,8 +172,10 @@ public:
         uint32_t *host = mPinned[i], *dev = mScratch[i];
         host[0] = (uint32_t)((unsigned long long)mine.n & 0xffffffffu); host[7] = (uint32_t)((unsigned long long)mine.n >> 32);
         memcpy(host + 1, mine.mn, 12); memcpy(host + 4, mine.mx, 12);
+        ncclComm_t comm = mComms[i];
+        if (!mSmallComms.empty()) { comm = mSmallComms[i]; s = mSmallStreams[i]; }   // never behind an all-gather of records
         HIPOK(hipMemcpyAsync(dev, host, 32, hipMemcpyHostToDevice, s));
-        NCCLOK(ncclAllGather(dev, dev + 8, 8, ncclUint32, mComms[i], s));
+        NCCLOK(ncclAllGather(dev, dev + 8, 8, ncclUint32, comm, s));
         HIPOK(hipMemcpyAsync(host + 8, dev + 8, 32 * (size_t)mRanks, hipMemcpyDeviceToHost, s));
         HIPOK(hipStreamSynchronize(s));
         for (int r = 0; r < mRanks; r++) {
@@ -160,7 +190,10 @@ public:
         if (mAllLocal) return mBar.wait();
         if (mComms.empty() || !scratch(sh, rank)) return false;
         const size_t i = (size_t)(rank - mFirst);
-        NCCLOK(ncclAllReduce(mScratch[i], mScratch[i], 1, ncclUint32, ncclSum, mComms[i], s));
+        HIPOK(hipStreamSynchronize(s));   // "its stream s has drained up to here"
+        ncclComm_t comm = mComms[i];
+        if (!mSmallComms.empty()) { comm = mSmallComms[i]; s = mSmallStreams[i]; }
+        NCCLOK(ncclAllReduce(mScratch[i], mScratch[i], 1, ncclUint32, ncclSum, comm, s));
         HIPOK(hipStreamSynchronize(s));
         return true;
     }
@@ -179,6 +212,8 @@ private:
     int mFirst;
     bool mAllLocal;
     std::vector<ncclComm_t> mComms;
+    std::vector<ncclComm_t> mSmallComms;      // empty: the small collectives use mComms (all members local, or the split failed)
+    std::vector<hipStream_t> mSmallStreams;
     std::vector<int> mDevices;
     std::vector<uint32_t *> mScratch, mPinned;
 };

@@ -244,9 +244,13 @@ int main(int argc, char **argv)
         ms += "]";
         printf("{\"scene\": %d, \"algorithm\": \"%s\", \"res\": [%d, %d], \"iterations\": %d, \"renderers\": %d, \"seed\": %d, "
                "\"gpus\": %d, \"rccl_ranks\": %d, \"wall_s\": %.6f, \"Mpaths_s\": %.3f, \"image_mean\": [%.6f, %.6f, %.6f], "
-               "\"last_iteration_ms\": %.3f, \"rank_iteration_ms\": %s}\n",
+               "\"last_iteration_ms\": %.3f, \"rank_iteration_ms\": %s, "
+               "\"last_iteration_counters\": {\"lightVertices\": %lld, \"lightRays\": %lld, \"cameraRays\": %lld, \"shadowRays\": %lld, "
+               "\"mergeQueries\": %lld, \"mergeCandidates\": %lld, \"mergeAccepted\": %lld, \"connections\": %lld, \"lightSplats\": %lld}}\n",
                sceneID, algoName.c_str(), resX, resY, iterations, renderers, seed, gpus > 0 ? gpus : 1, rcclRanks, wall, paths / wall / 1e6,
-               mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal, ms.c_str());
+               mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal, ms.c_str(),
+               st.lightVertices, st.lightRays, st.cameraRays, st.shadowRays, st.mergeQueries, st.mergeCandidates, st.mergeAccepted,
+               st.connections, st.lightSplats);
     }
     else
         printf("scene %d, %s, %dx%d, %d iteration(s) on %d renderer(s): %.3f s wall clock, %.2f Mpaths/s\n", sceneID,

@@ -79,3 +79,23 @@ def test_valu_roofline_and_traffic_from_profiler_rows(tmp_path):
     assert bench.valu_block(t, ["vcm::k_resolve"], 1.0) is None
     fac, src = bench.fetch_factor("k_merge")
     assert fac > 0 and "runs" in src
+
+
+def test_the_lines_frac_is_the_binding_figure():
+    """when SURVEY's gather model exceeds the peak, `frac` is max(measured HBM fraction, VALU issue fraction) <= 1, the
+    model's figure stays as frac_algorithmic, and the figures a reader needs come first"""
+    st = _stats(lightVertices=9_000_000, gridVertices=9_000_000, mergeQueries=10_000_000, mergeCandidates=1_250_000_000,
+                mergeAccepted=210_000_000, connections=19_000_000, lightSplats=7_000_000, msLightKernel=1.0, msCameraKernel=2.0,
+                msConnectKernels=1.8, msMergeKernel=3.0, msTotal=9.8)
+    dom, roof = bench.roofline_block(st, 2048 * 2048, 2048 * 2048)
+    plain = bench.finalize_roofline(dict(roof))
+    assert plain["bound"] == "hbm" and plain["frac"] == plain["frac_algorithmic"] > 1 and "frac_note" in plain   # no counters
+    counters = {"vcm::k_merge_walk": {"FETCH_SIZE": 2.5e6, "WRITE_SIZE": 1.0e5, "SQ_INSTS_VALU": 1.3e9, "SQ_ACTIVE_INST_VALU": 4.0e9,
+                                      "SQ_THREAD_CYCLES_VALU": 4.0e9 * 64 * 0.7, "SQ_WAVE_CYCLES": 1e10, "SQ_WAIT_ANY": 5e9, "_us_valu": 3000.0}}
+    bench.add_counters(roof, dom, counters, "test", st, 2048 * 2048)
+    fin = bench.finalize_roofline(roof)
+    assert list(fin)[:6] == ["bound", "kernel", "achieved", "peak", "unit", "frac"]
+    assert fin["bound"] == "valu" and fin["frac"] == fin["valu_frac"] and 0 < fin["frac"] <= 1.0
+    assert abs(fin["achieved"] / fin["peak"] - fin["frac"]) < 2e-3
+    assert fin["frac_algorithmic"] > 1 and fin["frac_model_invalid"] is True and 0 < fin["frac_traffic"] < fin["frac"]
+    assert abs(fin["valu_lane_util"] - 0.7) < 1e-3 and fin["traffic"] == int(2 * 1024 * 2.5e6 + 1024 * 1.0e5)

@@ -496,8 +496,10 @@ def test_single_rank_local_bbox_before_build_grid():
     r.close()
 
 
-def test_end_iteration_failure_returns_the_arena():
-    """A failing vcm_end_iteration ends the iteration like every other phase call (the scratch arena goes back)."""
+def test_misordered_end_iteration_is_refused_and_the_iteration_stays_open():
+    """vcm_end_iteration before vcm_merge is a host error, not a device failure: it returns -1 and leaves the iteration as
+    it is -- the light splats already applied belong to an iteration that can still be finished and counted (ADVICE r3:
+    tearing it down left them in the framebuffer with the iteration uncounted)."""
     L = load_library()
     sc = cornell_scene(1, 32, 32)
     r = VertexCM(sc, 4, 0.003, 0.75, 1234)
@@ -506,9 +508,47 @@ def test_end_iteration_failure_returns_the_arena():
     b.trace_light()
     assert L.vcm_end_iteration(b.ctx) != 0          # vcm_merge has not run
     assert b"vcm_merge" in L.vcm_last_error()
-    b.clear_framebuffer()                            # what the abandoned iteration had already splatted stays (documented)
-    b.run_iteration(0, 0, 10)                        # the context (and the arena) are usable again
+    assert L.vcm_iterations(b.ctx) == 0
+    b.build_grid()                                   # ... and the host carries on
+    b.trace_camera()
+    b.merge()
+    b.end()
+    assert L.vcm_iterations(b.ctx) == 1
     o = Oracle(sc, 4, threads=4)
     o.run_iteration(0, 0, 10)
     assert np.array_equal(b.framebuffer_sum(), o.framebuffer())
     r.close()
+
+
+@pytest.mark.parametrize("algo", [0, 4])
+def test_framebuffer_access_inside_an_iteration_waits_for_the_light_splats(algo):
+    """The light splats (K1c / K1d) run on a stream of their own from vcm_trace_light on; every accessor of the framebuffer
+    joins that stream first.  Light tracing: what is read right after vcm_trace_light is the whole image of
+    the iteration; a clear at that point removes all of it."""
+    sc = cornell_scene(1, 96, 96)
+    o = Oracle(sc, algo, threads=4)
+    o.run_iteration(0, 0, 10)
+    lt = Oracle(sc, 0, threads=4)
+    lt.run_iteration(0, 0, 10)
+    for clear in (False, True):
+        r = VertexCM(sc, algo, 0.003, 0.75, 1234)
+        b = r.backend
+        b.begin(0, 0, 10)
+        b.trace_light()
+        mid = b.framebuffer_sum()                    # joins the splat stream
+        if algo == 0:
+            assert np.array_equal(mid, o.framebuffer())
+        else:   # VCM: the MIS-weighted light image so far, complete or not started -- never torn
+            assert np.array_equal(mid, np.zeros_like(mid)) or mid.sum() > 0
+        if clear:
+            b.clear_framebuffer()
+        b.build_grid()
+        b.trace_camera()
+        b.merge()
+        b.end()
+        fin = b.framebuffer_sum()
+        if algo == 0:
+            assert np.array_equal(fin, np.zeros_like(fin) if clear else o.framebuffer())
+        elif not clear:
+            assert np.array_equal(fin, o.framebuffer())
+        r.close()

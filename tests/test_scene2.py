@@ -337,6 +337,20 @@ def test_scene_file_errors_are_reported(tmp_path):
     (tmp_path / "s.vcmscene").write_text("obj ok.obj\nfrobnicate 1 2 3\n")
     with pytest.raises(ValueError, match="unknown directive"):
         load_scene(str(tmp_path / "s.vcmscene"), 8, 8)
+    # a line of any length is read whole (a 4096-byte buffer cut a large polygon in the middle of an index): a
+    # 3000-gon on one `f` line of ~17 KB fans into 2998 triangles
+    n = 3000
+    import math
+    verts = "".join("v %.6f %.6f 0\n" % (math.cos(2 * math.pi * i / n), math.sin(2 * math.pi * i / n)) for i in range(n))
+    (tmp_path / "ngon.obj").write_text("mtllib a.mtl\n" + verts + "usemtl m\nf " + " ".join(str(i + 1) for i in range(n)) +
+                                       "\nv 0 0 2\nv 1 0 2\nv 0 1 2\nusemtl lamp\nf -3 -2 -1\n")
+    d = load_scene(str(tmp_path / "ngon.obj"), 16, 16)
+    assert d.nPrims == n - 2 + 1
+    # a material name defined twice (a second mtllib) is an error, not a silent duplicate
+    (tmp_path / "b.mtl").write_text("newmtl m\nKd 0.1 0.1 0.1\n")
+    (tmp_path / "twice.vcmscene").write_text("mtllib a.mtl\nmtllib b.mtl\nobj ok.obj\n")
+    with pytest.raises(ValueError, match="defined twice"):
+        load_scene(str(tmp_path / "twice.vcmscene"), 8, 8)
 
 
 @pytest.mark.gpu

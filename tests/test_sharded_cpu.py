@@ -24,7 +24,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 40, 2), (2, 1, 2, 40, 2), (3, 3, 4, 33, 1), (2, 0, 3, 32, 1)])
+@pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 40, 2), (2, 1, 2, 40, 2), (3, 3, 4, 33, 1), (2, 0, 3, 32, 1),
+                                                      (8, 1, 4, 40, 1)])   # the node's size: eight shards of one renderer
 def test_sharded_equals_unsharded(tmp_path, world, sid, algo, res, iters):
     port = _free_port()
     out = str(tmp_path / "fb.npy")
@@ -47,7 +48,8 @@ def test_sharded_equals_unsharded(tmp_path, world, sid, algo, res, iters):
     (4, 2, 1, 1, 4, 32, 5), (2, 1, 1, 1, 4, 32, 3), (3, 1, 1, 3, 2, 24, 2), (2, 2, 1, 1, 4, 32, 2),
     (2, 2, 2, 1, 4, 32, 5),     # one pair, two renderers in flight on it
     (4, 2, 2, 1, 2, 24, 7),     # two pairs x two in flight = 4 renderers, uneven iteration blocks
-    (2, 2, 3, 3, 4, 24, 2)])    # more renderers than iterations: the unused one must not count
+    (2, 2, 3, 3, 4, 24, 2),     # more renderers than iterations: the unused one must not count
+    (8, 2, 2, 1, 4, 24, 9)])    # eight ranks as bench.py --gpus 8 cuts them: four pairs x two in flight = 8 renderers
 def test_render_farm_equals_the_reference_render_loop(tmp_path, world, shards, inflight, sid, algo, res, iters):
     """RenderFarm = render() of src/smallvcm.cxx:52-151 with one "thread" per renderer: renderer i has seed
     base + i, runs the static-schedule block of iterations, the used renderers' means are averaged.  Renderers are
