@@ -175,6 +175,8 @@ typedef struct vcm_ctx vcm_ctx;
 
 int         vcm_device_count(void);
 const char *vcm_last_error(void);
+/* "default", or name and flags of a measurement build of the library (profiles/quick_ab.sh prints it per run) */
+const char *vcm_build_tag(void);
 
 /* Replaces `new VertexCM(scene, algo, radiusFactor, radiusAlpha, seed)`
  * (src/vertexcm.hxx:208-282, called from src/config.hxx:124-138).

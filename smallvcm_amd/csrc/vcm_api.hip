@@ -54,7 +54,7 @@ struct Scratch {
     LightStore store;                 /* S*nLocal slots (+ count[nLocal]) */
     int *dPathStart;                  /* nLocal+1 */
     int *dLocalTotal;                 /* 1 */
-    int *dTileSums[3];                /* scan scratch: [0] main stream, [1] side stream (grid build), [2] splat stream */
+    int *dTileSums[4];                /* scan scratch: [0] main stream, [1] side stream (grid build), [2] splat stream, [3] sort stream */
     int *dPixCount, *dPixStart;       /* N+2 each: light splats per pixel, and the start of every pixel's list (K1d) */
     int *dSplatArrival;               /* per light vertex: the place of its splat in its pixel's list */
     F4 *dSplatList;                   /* per light vertex: the splats grouped by pixel */
@@ -145,6 +145,10 @@ struct vcm_ctx : Scratch {
     bool gridInFlight;
     hipStream_t splat;                /* small frames: K1c / K1d (light splats) run here, next to the camera pass */
     hipEvent_t evSplatFork, evSplatDone;
+    hipStream_t sortq;                /* the query sort's scan + scatter run here, next to K3b (round 4) */
+    hipEvent_t evSortFork, evSorted;
+    hipEvent_t evZero;                /* the iteration's tables are zero (side stream, next to K1) */
+    bool prezeroed, sortInFlight;
     bool splatInFlight;
     bool deviceReady;
     ArenaPool *pool;                  /* the device's shared arenas (NULL: sharded context with a private one) */
@@ -228,7 +232,7 @@ static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
     DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
-    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums[0]); DFREE(s.dTileSums[1]); DFREE(s.dTileSums[2]);
+    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums[0]); DFREE(s.dTileSums[1]); DFREE(s.dTileSums[2]); DFREE(s.dTileSums[3]);
     DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
@@ -263,7 +267,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
-    for (int w = 0; w < 3; w++) if (dalloc(&s.dTileSums[w], maxScan / VCM_SCAN_TILE + 2)) return -1;
+    for (int w = 0; w < 4; w++) if (dalloc(&s.dTileSums[w], maxScan / VCM_SCAN_TILE + 2)) return -1;
     if (dalloc(&s.dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dSlotOfVertex, slots) || dalloc(&s.dSplat, slots)) return -1;
     if (dalloc(&s.dPixCount, cn + 2) || dalloc(&s.dPixStart, cn + 2) || dalloc(&s.dSplatArrival, slots) || dalloc(&s.dSplatList, slots)) return -1;
@@ -390,9 +394,10 @@ static int abort_iteration(vcm_ctx *c, int rc)
     if (rc != 0 && c && c->inIteration && c->holdsArena) {
         const std::string keep = g_err;   /* the message of the failure, not of the clean-up */
         (void)hipStreamSynchronize(c->stream);
-        if (c->deviceReady) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->splat); }
+        if (c->deviceReady) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->splat); (void)hipStreamSynchronize(c->sortq); }
         c->gridInFlight = false;
         c->splatInFlight = false;
+        c->sortInFlight = false;
         c->inIteration = false;
         arena_release(c, false);
         g_err = keep;
@@ -441,7 +446,11 @@ static int ensure_device(vcm_ctx *c)
                 HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
                 HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
             }
+            HIPCHK(hipStreamCreateWithFlags(&c->sortq, hipStreamNonBlocking));
         }
+        HIPCHK(hipEventCreateWithFlags(&c->evSortFork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evSorted, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evZero, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSplatFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSplatDone, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
@@ -672,6 +681,13 @@ extern "C" {
 
 const char *vcm_last_error(void) { return g_err.c_str(); }
 
+/* which build this is: "default", or the name and flags of a measurement variant (csrc/Makefile `variant`) -- so that an
+   A/B run can say which library actually served it */
+#ifndef VCM_BUILD_TAG
+#define VCM_BUILD_TAG "default"
+#endif
+const char *vcm_build_tag(void) { return VCM_BUILD_TAG; }
+
 int vcm_device_count(void)
 {
     int n = 0;
@@ -845,6 +861,9 @@ void vcm_destroy(vcm_ctx *c)
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamSynchronize(c->splat);
+        (void)hipStreamSynchronize(c->sortq);
+        (void)hipEventDestroy(c->evSortFork); (void)hipEventDestroy(c->evSorted); (void)hipEventDestroy(c->evZero);
+        (void)hipStreamDestroy(c->sortq);
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
         (void)hipEventDestroy(c->evSplatFork); (void)hipEventDestroy(c->evSplatDone);
         (void)hipStreamDestroy(c->side);
@@ -963,7 +982,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
                     c->vs.count, 32 * sizeof(int) /* queue counts [0..2]; chunk counter of K3 / k_path_trace [8] and of K1 [16] */,
                     c->dHdr, 6 * sizeof(uint32_t) /* bboxMinU / bboxMaxU: K1 accumulates into them with atomicMax */)) return -1;
     c->importedRecords = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->splatInFlight = c->bboxPreset = c->bboxFromLight = c->bboxFinal = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->splatInFlight = c->bboxPreset = c->bboxFromLight = c->bboxFinal = c->prezeroed = c->sortInFlight = false;
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -1025,7 +1044,8 @@ static int flush_light_splats(vcm_ctx *c)
         }
         int *pixCount = c->dPixCount, *arrival = c->dSplatArrival, *pixStart = c->dPixStart;
         F4 *list = c->dSplatList;
-        if (zero_ranges(q, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
+        if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));
+        else if (zero_ranges(q, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
         LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, q, c->dScene, c->P, c->store,
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
                            arrival, c->dStats);
@@ -1064,6 +1084,20 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     }
     int blocks, chunk;
     trace_launch_shape(c->nLocal, &blocks, &chunk, true);
+    if (c->world == 1 && !c->strictOrder) {
+        /* The tables the passes after K1 count into -- cells of the hash grid, pixels of the light splats, buckets of the
+           query sort: 100 MB at 2048^2 -- are zeroed NOW, on the side stream next to K1 (VALU-bound, 0.9 ms).  Zeroed where
+           they are used, the two memsets sat between K1 and K3 on the critical path and took 0.3 + 0.5 ms there, because
+           they shared the memory system with the light splats and the cell count (profiles/r06d_timeline2048.txt: K3
+           started 0.9 ms after K1 had ended).  The consumers wait for evZero on their own streams. */
+        HIPCHK(hipEventRecord(c->evFork, c->stream));   /* behind the previous users of the arena */
+        HIPCHK(hipStreamWaitEvent(c->side, c->evFork, 0));
+        if (zero_ranges(c->side, c->useVM ? c->dQueryCount : NULL, c->useVM ? ((size_t)c->P.nBuckets + 1) * sizeof(int) : 0,
+                        c->useVM ? c->dCellCount : NULL, c->useVM ? ((size_t)c->P.nCells + 1) * sizeof(int) : 0,
+                        (c->useVC || c->lightTraceOnly) ? c->dPixCount : NULL, ((size_t)c->N + 1) * sizeof(int))) return -1;
+        HIPCHK(hipEventRecord(c->evZero, c->side));
+        c->prezeroed = true;
+    }
     if (mark(c, EV_LIGHT_K0)) return -1;
     const bool wf = !c->strictOrder;
     if (wf)
@@ -1089,7 +1123,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
            also publishes the counts and the box K1 kept (k_set_counts / k_bbox_finalize folded in). */
         c->recordsValid = c->useVM && c->world > 1;
         const bool fold = c->world == 1;
-        hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
+        hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, (const DScene *)c->dScene, c->P, c->store, c->dPathStart,
                            c->dRecordsLocal, c->dSlotOfVertex, c->recordsValid ? 1 : 0, fold ? c->dHdr : (GridHeader *)NULL,
                            (const int *)c->dLocalTotal, (fold && c->bboxFromLight) ? 1 : 0);
         HIPCHK(hipGetLastError());
@@ -1112,7 +1146,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
 static int ensure_records(vcm_ctx *c)
 {
     if (c->recordsValid || !c->useVM) return 0;
-    hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, c->P, c->store, c->dPathStart,
+    hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, (const DScene *)c->dScene, c->P, c->store, c->dPathStart,
                        c->dRecordsLocal, c->dSlotOfVertex, 1, (GridHeader *)NULL, (const int *)c->dLocalTotal, 0);
     HIPCHK(hipGetLastError());
     c->recordsValid = true;
@@ -1262,11 +1296,14 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         recs.slotOfVertex = c->dSlotOfVertex;
         const int nCells = c->P.nCells;
         const dim3 g(2048), b(256);
-        if (zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
+        if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));   /* (q is the side stream itself unless the build runs in line) */
+        else if (zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
+        bool boxOnSide = false;
         if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
             if (c->bboxFromLight && !recs.records) {   /* K1 left the box of what it stored in the header's key words */
-                if (!c->bboxFinal) hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr, 1);
+                if (!c->bboxFinal) { hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr, 1); boxOnSide = true; }
             } else {
+                boxOnSide = true;
                 hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, q, c->dHdr, take_stamps(c, q));
                 hipLaunchKernelGGL(k_bbox, dim3(512), b, 0, q, recs, c->dHdr);
                 hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, q, c->dHdr, 0);
@@ -1280,14 +1317,16 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         hipLaunchKernelGGL(k_cell_scatter, g, b, 0, q, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
                            (const int *)c->dSortedIndex, (const int *)c->dCellStart,
                            recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
-        hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, q, (const GridHeader *)c->dHdr, recs,
+        hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, q, (const DScene *)c->dScene, (const GridHeader *)c->dHdr, recs,
                            (const int *)c->dCellStart, (const I4 *)c->dUnsorted, c->dGx,
                            c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
         if (mark_on(c, EV_GRID, q)) return -1;
         hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT, take_stamps(c, q));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->evGrid, q));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->evBbox, 0));
+        /* K3 needs the bounding box (query-sort keys), nothing else of the build: when k_compact_records has finalised the
+           box K1 kept, or the host has set it, the main stream does not wait for the side stream at all */
+        if (boxOnSide) HIPCHK(hipStreamWaitEvent(c->stream, c->evBbox, 0));
         c->gridInFlight = true;
         if (!c->P.wavefront && join_grid(c)) return -1;
     } else {
@@ -1335,7 +1374,10 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
-        if (c->countedInCamera && zero_ranges(c->stream, c->dQueryCount, ((size_t)c->P.nBuckets + 1) * sizeof(int))) return -1;
+        if (c->countedInCamera) {
+            if (c->prezeroed) HIPCHK(hipStreamWaitEvent(c->stream, c->evZero, 0));
+            else if (zero_ranges(c->stream, c->dQueryCount, ((size_t)c->P.nBuckets + 1) * sizeof(int))) return -1;
+        }
         LAUNCH_SC_MODE(c, k_camera_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
         if (mark(c, EV_CAMERA_K1)) return -1;
@@ -1358,6 +1400,21 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
+            if (c->countedInCamera && c->world == 1) {
+                /* The scan of the bucket table (16.8 M entries at 2048^2) and the scatter of the sorted order run on a stream
+                   of their own next to K3b: in line, between K3 and K3b, the scan took 0.9 ms -- 70 us alone, but it shared the
+                   memory system with the tail of the grid build and the light splats while the VALU idled
+                   (profiles/r06d_timeline2048.txt).  K4 waits for evSorted. */
+                HIPCHK(hipEventRecord(c->evSortFork, c->stream));   /* behind K3 */
+                HIPCHK(hipStreamWaitEvent(c->sortq, c->evSortFork, 0));
+                const StampArgs none = { { NULL, NULL, NULL, NULL } };
+                if (launch_scan_on<int>(c, 3, c->sortq, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1, none)) return -1;
+                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->sortq, c->vs, (const int *)c->dQueryKey,
+                                   (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
+                HIPCHK(hipEventRecord(c->evSorted, c->sortq));
+                c->sortInFlight = true;
+                c->scatteredInDI = false;
+            }
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
             LAUNCH_SC(c, k_connect_di, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
@@ -1395,7 +1452,10 @@ static int vcm_merge_impl(vcm_ctx *c)
                 hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
                                    (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount, take_stamps(c, c->stream));
             }
-            if (!c->scatteredInDI) {
+            if (c->sortInFlight) {   /* scan + scatter ran next to K3b */
+                HIPCHK(hipStreamWaitEvent(c->stream, c->evSorted, 0));
+                c->sortInFlight = false;
+            } else if (!c->scatteredInDI) {
                 if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
                 hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
                                    (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);

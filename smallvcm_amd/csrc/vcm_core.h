@@ -50,8 +50,13 @@ struct GridHeader {
     int   pad[2];
 };
 
-/* Light-vertex store: vertex j of local path lp lives in slot [j * nLocal + lp], a record of five
- * 16-byte fields (80 B).  K1 writes slot-major, so a wave (64 consecutive paths at the same bounce) fills one
+/* Light-vertex store: vertex j of local path lp lives in slot [j * nLocal + lp], a record of FOUR 16-byte fields = 64
+ * bytes, 64-byte aligned: whoever gathers a vertex (vertex connection K3c, camera connection K1c, the cell-sorted copy of
+ * the grid build) moves ONE 128-byte line for it.  Rounds 1-3 kept a fifth field (WorldDirFix | ContinuationProb, what only
+ * the merge records want): an 80-byte record lies in 1.5 lines, and the grid build, which wants fields 0, 1, 3 and 4, read
+ * two.  Round 4 rebuilds the fifth where the records are made (light_vertex_wdir_contprob): ~200 operations per vertex in
+ * kernels that wait for memory, against 0.14 GB less written by K1 and ~3 GB less gathered per 2048^2 iteration.
+ * History: the record was five 16-byte fields (80 B).  K1 writes slot-major, so a wave (64 consecutive paths at the same bounce) fills one
  * contiguous 5 KB region; the consumers GATHER a vertex (vertex connection K3c, the camera connection K1c, the
  * cell-sorted copy of the grid build) and a gather moves whole 128-byte lines (profiles/r05a_fetch_calib.json): an
  * 80-byte record lies in 1.5 of them on average.  Round 3 measured the alternative -- the four fields the connections
@@ -60,14 +65,13 @@ struct GridHeader {
  * 868 against 875 Mpaths/s (profiles/r05h_ab_summary.txt).  The camera-vertex records, below, ARE split.
  * (Five separate arrays were measured in round 1: five lines per gather, k_cell_rank_gather 1.16 ms instead of 0.6.)
  * Replaces the AoS std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
-#define VCM_LV_FIELDS 5
+#define VCM_LV_FIELDS 4
 struct LightStore {
     F4 *v;    /* [slot * 5 + k]:
                  k=0 hitpoint.xyz | pathLength (bits 0-7) , matID (bits 8-15)
                  k=1 throughput.xyz | dVCM
                  k=2 isect.normal.xyz | dVC
-                 k=3 localDirFix.xyz | dVM
-                 k=4 WorldDirFix().xyz | ContinuationProb()                  */
+                 k=3 localDirFix.xyz | dVM                                    */
     unsigned char *count;   /* stored vertices per local path (mPathEnds, :395) */
     uint32_t *lenMask;      /* per local path: bit L set <=> a vertex with pathLength L is stored (stored vertices have
                                increasing pathLength, so vertex j is the j-th set bit); valid while maxPathLength <= 31 */
@@ -85,6 +89,8 @@ struct GridStore {
     const F4 *g1;           /* WorldDirFix.xyz | light ContinuationProb */
     const F4 *g2;           /* throughput.xyz | dVCM */
     const F2 *g3;           /* dVM | pathLength bits */
+    /* (the three as ONE array of 48-byte records -- one or two cache lines per accepted photon instead of three -- was
+       measured in round 4: K4 itself 3.0 -> 2.7 ms, the grid build's strided writes slower by as much: profiles/r06i_ab.txt) */
     const GridHeader *hdr;
 };
 
@@ -2064,12 +2070,10 @@ VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, co
     RC_MARK(1);
     if (!bsdf.isDelta && (P.useVC || P.useVM || (MODE == 1 && P.lightTraceOnly))) {   /* :364-377 */
         const size_t slot = (size_t)lp.nStored * (size_t)P.nLocal + (size_t)lp.lp;
-        const V3 wdir = to_world(bsdf.frame, bsdf.localDirFix);   /* WorldDirFix bsdf.hxx:264 */
         lv(store, slot, 0) = mk4(hitPoint.x, hitPoint.y, hitPoint.z, u2f(st.pathLength | (shade_code(bsdf.matID, isect.prim) << 8)));
         lv(store, slot, 1) = mk4(st.throughput.x, st.throughput.y, st.throughput.z, st.dVCM);
         lv(store, slot, 2) = mk4(isect.normal.x, isect.normal.y, isect.normal.z, st.dVC);
         lv(store, slot, 3) = mk4(bsdf.localDirFix.x, bsdf.localDirFix.y, bsdf.localDirFix.z, st.dVM);
-        lv(store, slot, 4) = mk4(wdir.x, wdir.y, wdir.z, bsdf.contProb);
         lp.nStored++;
         box.mn[0] = fminf(box.mn[0], hitPoint.x); box.mn[1] = fminf(box.mn[1], hitPoint.y); box.mn[2] = fminf(box.mn[2], hitPoint.z);
         box.mx[0] = fmaxf(box.mx[0], hitPoint.x); box.mx[1] = fmaxf(box.mx[1], hitPoint.y); box.mx[2] = fmaxf(box.mx[2], hitPoint.z);
@@ -2086,6 +2090,18 @@ VCM_HD bool light_path_step(const SC &sc, const IterParams &P, LightPath &lp, co
     if (!goesOn) return false;
     ++st.pathLength;
     return true;
+}
+
+/* WorldDirFix() | ContinuationProb() of a STORED light vertex (bsdf.hxx:260-264; what RangeQuery::Process reads of the light
+ * BSDF, vertexcm.hxx:140, :161), rebuilt from the record: Setup's frame from the stored normal, ToWorld of the stored
+ * mLocalDirFix, GetComponentProbabilities of the stored material -- the operations the light pass ran, on the same values,
+ * hence the same bits. */
+VCM_HD F4 light_vertex_wdir_contprob(const DScene &sc, F4 field0, F4 field2, F4 field3, bool ldsMaterials)
+{
+    Bsdf b;
+    bsdf_restore(b, mk3(field2.x, field2.y, field2.z), mk3(field3.x, field3.y, field3.z), f2u(field0.w) >> 8, sc, ldsMaterials);
+    const V3 w = to_world(b.frame, b.localDirFix);
+    return mk4(w.x, w.y, w.z, b.contProb);
 }
 
 /* ConnectToCamera (:380-384, :862-933) for a STORED light vertex (wavefront mode) */

@@ -475,48 +475,56 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 struct alignas(8) WalkRun { int lo, hi; };
+/* first half of a query: hashgrid.hxx:116-155 -- bbox test, the 8 cells toward the nearer faces, and the NON-EMPTY ones'
+   ranges written to the lane's column of `runs`; returns their number, `total` = the query's candidates */
+__device__ __forceinline__ int merge_walk_runs(const IterParams &P, const GridStore &g, V3 queryPos, WalkRun *runs /* [k * stride + thread] */,
+                                               int stride, int &total)
+{
+    int n = 0;
+    total = 0;
+    const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
+    const V3 distMin = queryPos - bmin, distMax = bmax - queryPos;
+    const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
+                          distMin.z < 0.f || distMax.z < 0.f);
+    const V3 cellPt = P.invCellSize * distMin;
+    const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+    const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
+    const V3 fractCoord = cellPt - coordF;
+    const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+    const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+    const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+    /* (Round 3 tried to leave out the edge / corner probes that cannot hold a photon within the radius -- 21 % of the
+       edge probes, 48 % of the corner probes for evenly spread queries, decided from the query's position in its
+       cell with a 1 % margin and only when no other probe shares the bucket: bit-exact, 14 % fewer candidates, and
+       2 % SLOWER, profiles/r05b_ab_summary.txt: the wave walks until the lane with the MOST candidates is done,
+       and that is a lane near a cell corner, which skips nothing.) */
+    int lo[8], hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        lo[j] = 0; hi[j] = 0;
+        if (inside) {
+            const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
+            lo[j] = g.cellStart[cell];
+            hi[j] = g.cellStart[cell + 1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        total += hi[j] - lo[j];   /* one distance test per entry (:162-165) */
+        if (hi[j] > lo[j]) { WalkRun r; r.lo = lo[j]; r.hi = hi[j]; runs[n * stride] = r; n++; }
+    }
+    return n;
+}
+
+/* second half: walk the n runs of column `runs`, queue the accepted photons, drain (RangeQuery::Process) */
 template <bool IP>
 __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParams &P, const GridStore &g, const Bsdf &cameraBsdf,
                                                const SubPathState &st, V3 queryPos, LaneStats &ls, const MergeScratch &ms,
-                                               WalkRun *runs /* [k * stride + thread] */, int stride)
+                                               const WalkRun *runs /* [k * stride] */, int stride, int n)
 {
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     V3 contrib = sp3(0.f);
-    int n = 0;
     RC_DECL;
-    {   /* hashgrid.hxx:116-155: bbox test, the 8 cells toward the nearer faces */
-        const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
-        const V3 distMin = queryPos - bmin, distMax = bmax - queryPos;
-        const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
-                              distMin.z < 0.f || distMax.z < 0.f);
-        const V3 cellPt = P.invCellSize * distMin;
-        const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
-        const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
-        const V3 fractCoord = cellPt - coordF;
-        const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
-        const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
-        const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
-        /* (Round 3 tried to leave out the edge / corner probes that cannot hold a photon within the radius -- 21 % of the
-           edge probes, 48 % of the corner probes for evenly spread queries, decided from the query's position in its
-           cell with a 1 % margin and only when no other probe shares the bucket: bit-exact, 14 % fewer candidates, and
-           2 % SLOWER, profiles/r05b_ab_summary.txt: the wave walks until the lane with the MOST candidates is done,
-           and that is a lane near a cell corner, which skips nothing.) */
-        int lo[8], hi[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            lo[j] = 0; hi[j] = 0;
-            if (inside) {
-                const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
-                lo[j] = g.cellStart[cell];
-                hi[j] = g.cellStart[cell + 1];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            ls.mergeCandidates += (uint32_t)(hi[j] - lo[j]);   /* one distance test per entry (:162-165) */
-            if (hi[j] > lo[j]) { WalkRun r; r.lo = lo[j]; r.hi = hi[j]; runs[n * stride] = r; n++; }
-        }
-    }
     MergeEval ev;
     merge_eval_setup(ev, sc, P, cameraBsdf, st, false);
     RC_MARK(14);
@@ -604,10 +612,10 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             if (threadIdx.x == 0) {
                 int got = -1;
                 for (int v = 0; v < 8 && got < 0; v++) {   /* own slab first, then the others in turn */
-                    const int s = (xcd + v) & 7;
-                    const int lo = s * perSlab, hi = min(nBatches, lo + perSlab);
+                    const int s2 = (xcd + v) & 7;
+                    const int lo = s2 * perSlab, hi = min(nBatches, lo + perSlab);
                     if (lo >= hi) continue;
-                    const int k = atomicAdd(&slabCtr[s], 1);
+                    const int k = atomicAdd(&slabCtr[s2], 1);
                     if (lo + k < hi) got = lo + k;
                 }
                 sBatch = got;
@@ -630,7 +638,10 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
             SubPathState sps;
             sps.pathLength = f2u(bq.w) & 0xffu; sps.dVCM = c.w; sps.dVM = d.w;
-            const V3 contrib = merge_query_walk<IP>(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK);
+            int total;
+            const int n = merge_walk_runs(P, g, mk3(a.x, a.y, a.z), runs + threadIdx.x, VCM_MERGE_BLOCK, total);
+            ls.mergeCandidates += (uint32_t)total;
+            const V3 contrib = merge_query_walk<IP>(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK, n);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
             vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
@@ -1013,8 +1024,8 @@ __device__ __forceinline__ void bbox_finalize_component(GridHeader *hdr, int c, 
 }
 /* hdr != NULL (single rank): the first block also publishes the vertex counts (what k_set_counts does) and, with
    finalizeBox, turns the box K1 accumulated into floats -- two one-lane launches less per iteration */
-__global__ void __launch_bounds__(256) k_compact_records(IterParams P, LightStore store, const int *__restrict__ pathStart, float *records,
-                                  int *slotOfVertex, int writeRecords, GridHeader *hdr, const int *localTotal, int finalizeBox)
+__global__ void __launch_bounds__(256) k_compact_records(const DScene *__restrict__ scp, IterParams P, LightStore store, const int *__restrict__ pathStart,
+                                  float *records, int *slotOfVertex, int writeRecords, GridHeader *hdr, const int *localTotal, int finalizeBox)
 {
     if (hdr && blockIdx.x == 0 && threadIdx.x < 3) {
         const int n = *localTotal;
@@ -1030,7 +1041,8 @@ __global__ void __launch_bounds__(256) k_compact_records(IterParams P, LightStor
             const int vtx = base + j;
             slotOfVertex[vtx] = (int)slot;   /* dense vertex list for k_connect_camera */
             if (!writeRecords) continue;
-            const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), d = lv(store, slot, 3), e = lv(store, slot, 4);
+            const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), d = lv(store, slot, 3);
+            const F4 e = light_vertex_wdir_contprob(*scp, a, lv(store, slot, 2), d, false);
             float *r = records + (size_t)vtx * VCM_MERGE_RECORD_FLOATS;
             r[0] = a.x; r[1] = a.y; r[2] = a.z;
             r[3] = e.x; r[4] = e.y; r[5] = e.z;
@@ -1302,7 +1314,7 @@ __global__ void __launch_bounds__(256) k_cell_scatter(const GridHeader *__restri
  * cell with a smaller index; the vertex data is then written to its final
  * position, so the query reads contiguous, cell-sorted memory and needs no
  * mIndices indirection. */
-__global__ void __launch_bounds__(256) k_cell_rank_gather(const GridHeader *__restrict__ hdr, VertexSource src,
+__global__ void __launch_bounds__(256) k_cell_rank_gather(const DScene *__restrict__ scp, const GridHeader *__restrict__ hdr, VertexSource src,
                                    const int *__restrict__ cellStart, const I4 *__restrict__ unsorted,
                                    float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3, int *sortedIndex)
 {
@@ -1323,7 +1335,8 @@ __global__ void __launch_bounds__(256) k_cell_rank_gather(const GridHeader *__re
             t.x = r[10]; t.y = r[12];
         } else {   /* the same 13 values k_compact_records would have written */
             const size_t slot = (size_t)me.y;
-            const F4 a = lv(src.store, slot, 0), b = lv(src.store, slot, 1), d = lv(src.store, slot, 3), e = lv(src.store, slot, 4);
+            const F4 a = lv(src.store, slot, 0), b = lv(src.store, slot, 1), d = lv(src.store, slot, 3);
+            const F4 e = light_vertex_wdir_contprob(*scp, a, lv(src.store, slot, 2), d, false);   /* (one 64-byte record: one line) */
             gx[dst] = a.x; gy[dst] = a.y; gz[dst] = a.z;
             g1[dst] = e;
             g2[dst] = b;

@@ -244,11 +244,13 @@ int main(int argc, char **argv)
         ms += "]";
         printf("{\"scene\": %d, \"algorithm\": \"%s\", \"res\": [%d, %d], \"iterations\": %d, \"renderers\": %d, \"seed\": %d, "
                "\"gpus\": %d, \"rccl_ranks\": %d, \"wall_s\": %.6f, \"Mpaths_s\": %.3f, \"image_mean\": [%.6f, %.6f, %.6f], "
-               "\"last_iteration_ms\": %.3f, \"rank_iteration_ms\": %s, "
+               "\"last_iteration_ms\": %.3f, \"rank_iteration_ms\": %s, \"library\": \"%s\", "
+               "\"last_iteration_kernel_ms\": {\"light\": %.3f, \"camera\": %.3f, \"connect_di\": %.3f, \"merge\": %.3f, \"grid_side\": %.3f, \"light_phase\": %.3f, \"camera_phase\": %.3f}, "
                "\"last_iteration_counters\": {\"lightVertices\": %lld, \"lightRays\": %lld, \"cameraRays\": %lld, \"shadowRays\": %lld, "
                "\"mergeQueries\": %lld, \"mergeCandidates\": %lld, \"mergeAccepted\": %lld, \"connections\": %lld, \"lightSplats\": %lld}}\n",
                sceneID, algoName.c_str(), resX, resY, iterations, renderers, seed, gpus > 0 ? gpus : 1, rcclRanks, wall, paths / wall / 1e6,
-               mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal, ms.c_str(),
+               mean[0] / (n3 / 3), mean[1] / (n3 / 3), mean[2] / (n3 / 3), st.msTotal, ms.c_str(), vcm_build_tag(),
+               st.msLightKernel, st.msCameraKernel, st.msConnectKernels, st.msMergeKernel, st.msGrid, st.msLight, st.msCamera,
                st.lightVertices, st.lightRays, st.cameraRays, st.shadowRays, st.mergeQueries, st.mergeCandidates, st.mergeAccepted,
                st.connections, st.lightSplats);
     }

@@ -31,7 +31,7 @@ struct Emul {
     int seed, iterations;
     int resX, resY, N, p0, nLocal;
     IterParams P;
-    std::vector<F4> v0 /* the light store: 5 fields per slot */, g1, g2, camOut;
+    std::vector<F4> v0 /* the light store: 4 fields per slot */, g1, g2, camOut;
     std::vector<F2> g3;
     std::vector<float> gx, gy, gz, fb, records;
     std::vector<unsigned char> count, rngL, rngC;
@@ -172,7 +172,8 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     for (int lp = 0; lp < e.nLocal; lp++)
         for (int j = 0; j < e.count[lp]; j++) {
             const size_t slot = (size_t)j * e.nLocal + lp;
-            const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), d = lv(store, slot, 3), w = lv(store, slot, 4);
+            const F4 a = lv(store, slot, 0), b = lv(store, slot, 1), d = lv(store, slot, 3);
+            const F4 w = light_vertex_wdir_contprob(e.sc, a, lv(store, slot, 2), d, false);
             const float r[13] = { a.x, a.y, a.z, w.x, w.y, w.z, b.x, b.y, b.z, b.w, d.w, w.w, u2f(f2u(a.w) & 0xffu) };
             e.records.insert(e.records.end(), r, r + 13);
         }
