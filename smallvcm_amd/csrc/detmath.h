@@ -311,6 +311,16 @@ VCM_HD float dm_powf_wave(float xf, float yf, bool lds = true, bool intOnly = fa
     if (y0 >= 1.0f && y0 <= 65536.0f && y0 == floorf(y0) && __builtin_amdgcn_ballot_w64(!(yf == y0)) == 0ull) {   /* wave-uniform */
         unsigned n = (unsigned)y0;
         double b = (double)xf, r = 1.0;
+        if (n == 90u) {
+            /* the exponent of the reference's glossy floor (scene.hxx:173), straight-line: the products the loop below forms
+               for n = 1011010b, least-significant bit first -- 1.0 * b^2 is b^2 exactly -- six squarings and three
+               multiplies, no select, no branch */
+            const double b2 = b * b, b4 = b2 * b2, b8 = b4 * b4, b16 = b8 * b8, b32 = b16 * b16, b64 = b32 * b32;
+            r = b2 * b8;
+            r = r * b16;
+            r = r * b64;
+            return (float)r;
+        }
         for (;;) {
             if (n & 1u) r = r * b;
             n >>= 1;

@@ -2332,18 +2332,25 @@ template <bool IP>
 VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval &e, const MergeScratch &ms, int qn,
                         V3 &contrib)
 {
-    /* software-pipelined: the loads of entry k+1 are in flight while entry k is evaluated */
+    /* software-pipelined: the loads of entry k+1 are in flight while entry k is evaluated.  Unrolled by two with the two
+       register sets taking turns (round 4): as a rotating pair the compiler copied the eleven registers of `nxt` into `cur`
+       every step, 10 of the step's ~150 instructions (profiles/r06n_ab.txt) */
     if (!wave_any(0 < qn)) return;
-    MergePhoton cur, nxt;
-    merge_photon_load(g, ms, 0, qn, cur);
-    for (int k = 0; k < ms.cap; k++) {
-        const bool more = wave_any(k + 1 < qn);
-        if (more) merge_photon_load(g, ms, k + 1, qn, nxt);
+    MergePhoton pa, pb;
+    merge_photon_load(g, ms, 0, qn, pa);
+    for (int k = 0; k < ms.cap; k += 2) {
+        const bool more1 = wave_any(k + 1 < qn);
+        if (more1) merge_photon_load(g, ms, k + 1, qn, pb);
         if (k < qn)
-            merge_eval_photon<IP>(e, P, f2u(cur.lenBits), mk3(cur.b.x, cur.b.y, cur.b.z), cur.b.w,
-                                  mk3(cur.c.x, cur.c.y, cur.c.z), cur.c.w, cur.dVM, contrib);
-        if (!more) break;
-        cur = nxt;
+            merge_eval_photon<IP>(e, P, f2u(pa.lenBits), mk3(pa.b.x, pa.b.y, pa.b.z), pa.b.w,
+                                  mk3(pa.c.x, pa.c.y, pa.c.z), pa.c.w, pa.dVM, contrib);
+        if (!more1) break;
+        const bool more2 = wave_any(k + 2 < qn);
+        if (more2) merge_photon_load(g, ms, k + 2, qn, pa);
+        if (k + 1 < qn)
+            merge_eval_photon<IP>(e, P, f2u(pb.lenBits), mk3(pb.b.x, pb.b.y, pb.b.z), pb.b.w,
+                                  mk3(pb.c.x, pb.c.y, pb.c.z), pb.c.w, pb.dVM, contrib);
+        if (!more2) break;
     }
 }
 
