@@ -145,8 +145,7 @@ struct vcm_ctx : Scratch {
     bool gridInFlight;
     hipStream_t splat;                /* small frames: K1c / K1d (light splats) run here, next to the camera pass */
     hipEvent_t evSplatFork, evSplatDone;
-    hipStream_t sortq;                /* the query sort's scan + scatter run here, next to K3b (round 4) */
-    hipEvent_t evSortFork, evSorted;
+    hipEvent_t evSortFork, evSorted;  /* the query sort's scan + scatter run on `side`, behind the grid build and next to K3b (round 4) */
     hipEvent_t evZero;                /* the iteration's tables are zero (side stream, next to K1) */
     bool prezeroed, sortInFlight;
     bool splatInFlight;
@@ -394,7 +393,7 @@ static int abort_iteration(vcm_ctx *c, int rc)
     if (rc != 0 && c && c->inIteration && c->holdsArena) {
         const std::string keep = g_err;   /* the message of the failure, not of the clean-up */
         (void)hipStreamSynchronize(c->stream);
-        if (c->deviceReady) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->splat); (void)hipStreamSynchronize(c->sortq); }
+        if (c->deviceReady) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->splat); }
         c->gridInFlight = false;
         c->splatInFlight = false;
         c->sortInFlight = false;
@@ -446,7 +445,6 @@ static int ensure_device(vcm_ctx *c)
                 HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
                 HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
             }
-            HIPCHK(hipStreamCreateWithFlags(&c->sortq, hipStreamNonBlocking));
         }
         HIPCHK(hipEventCreateWithFlags(&c->evSortFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSorted, hipEventDisableTiming));
@@ -861,9 +859,7 @@ void vcm_destroy(vcm_ctx *c)
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamSynchronize(c->splat);
-        (void)hipStreamSynchronize(c->sortq);
         (void)hipEventDestroy(c->evSortFork); (void)hipEventDestroy(c->evSorted); (void)hipEventDestroy(c->evZero);
-        (void)hipStreamDestroy(c->sortq);
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
         (void)hipEventDestroy(c->evSplatFork); (void)hipEventDestroy(c->evSplatDone);
         (void)hipStreamDestroy(c->side);
@@ -1401,17 +1397,19 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
             if (c->countedInCamera && c->world == 1) {
-                /* The scan of the bucket table (16.8 M entries at 2048^2) and the scatter of the sorted order run on a stream
-                   of their own next to K3b: in line, between K3 and K3b, the scan took 0.9 ms -- 70 us alone, but it shared the
-                   memory system with the tail of the grid build and the light splats while the VALU idled
-                   (profiles/r06d_timeline2048.txt).  K4 waits for evSorted. */
+                /* The scan of the bucket table (16.8 M entries at 2048^2) and the scatter of the sorted order run on the SIDE
+                   stream, behind the grid build and next to K3b: in line, between K3 and K3b, the scan took 0.9 ms -- 70 us
+                   alone, but it shared the memory system with the tail of the grid build and the light splats while the VALU
+                   idled (profiles/r06d_timeline2048.txt).  K4 waits for evSorted.  (Not a stream of its own: HIP maps the
+                   streams of a process onto four hardware queues, a fifth stream shared the splat stream's and its work
+                   queued behind K3c -- at 512^2 the main stream then idled 0.3 of 1.33 ms, profiles/r06r_timeline512.txt.) */
                 HIPCHK(hipEventRecord(c->evSortFork, c->stream));   /* behind K3 */
-                HIPCHK(hipStreamWaitEvent(c->sortq, c->evSortFork, 0));
+                HIPCHK(hipStreamWaitEvent(c->side, c->evSortFork, 0));
                 const StampArgs none = { { NULL, NULL, NULL, NULL } };
-                if (launch_scan_on<int>(c, 3, c->sortq, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1, none)) return -1;
-                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->sortq, c->vs, (const int *)c->dQueryKey,
+                if (launch_scan_on<int>(c, 3, c->side, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1, none)) return -1;
+                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->side, c->vs, (const int *)c->dQueryKey,
                                    (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
-                HIPCHK(hipEventRecord(c->evSorted, c->sortq));
+                HIPCHK(hipEventRecord(c->evSorted, c->side));
                 c->sortInFlight = true;
                 c->scatteredInDI = false;
             }
