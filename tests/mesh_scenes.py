@@ -6,14 +6,14 @@ import numpy as np
 from smallvcm_amd.scene2 import SceneBuilder
 
 
-def bumpy_room(grid=24, resx=64, resy=64, spheres=True, sun=False, background=False, seed=5):
+def bumpy_room(grid=24, resx=64, resy=64, spheres=True, sun=False, background=False, seed=5, exponent=90.0):
     """2 * grid^2 floor triangles + 8 wall / ceiling triangles + 2 emissive triangles (+ 2 spheres)"""
     rng = np.random.default_rng(seed)
     b = SceneBuilder()
     white = b.material(diffuse=(0.803922, 0.803922, 0.803922))
     green = b.material(diffuse=(0.156863, 0.803922, 0.172549))
     red = b.material(diffuse=(0.803922, 0.152941, 0.152941))
-    glossy = b.material(diffuse=(0.1, 0.1, 0.1), phong=(0.7, 0.7, 0.7), exponent=90.0)
+    glossy = b.material(diffuse=(0.1, 0.1, 0.1), phong=(0.7, 0.7, 0.7), exponent=float(exponent))
     mirror = b.material(mirror=(1, 1, 1))
     glass = b.material(mirror=(1, 1, 1), ior=1.6)
     lo, hi = -1.25, 1.25
@@ -49,11 +49,13 @@ def bumpy_room(grid=24, resx=64, resy=64, spheres=True, sun=False, background=Fa
                    resx, resy)
 
 
-def tilted_room(resx=64, resy=64, angle=0.37, sun=False):
+def tilted_room(resx=64, resy=64, angle=0.37, sun=False, exponents=(90.0, 90.0)):
     """A Cornell-like room of at most 32 primitives whose every vertex is rotated about a skew axis: NO triangle pair is
     axis-aligned, so the brute-force list takes its general path (two plane parts per entry) instead of the one the
     reference's own boxes take; it also holds a lone triangle between two spheres (an entry with one triangle), two
-    consecutive unrelated triangles (an entry whose triangles share no edge) and a sphere resting on the floor."""
+    consecutive unrelated triangles (an entry whose triangles share no edge) and a sphere resting on the floor.
+    `exponents`: Phong exponents of the floor and of the back wall's gloss -- other integers than the reference's 90, or
+    fractions (the general powf of smallvcm_amd/csrc/detmath.h where a lobe is evaluated)."""
     axis = np.array([0.3, -0.5, 0.81], np.float64)
     axis /= np.linalg.norm(axis)
     K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
@@ -65,13 +67,14 @@ def tilted_room(resx=64, resy=64, angle=0.37, sun=False):
     white = b.material(diffuse=(0.803922, 0.803922, 0.803922))
     green = b.material(diffuse=(0.156863, 0.803922, 0.172549))
     red = b.material(diffuse=(0.803922, 0.152941, 0.152941))
-    glossy = b.material(diffuse=(0.1, 0.1, 0.1), phong=(0.7, 0.7, 0.7), exponent=90.0)
+    glossy = b.material(diffuse=(0.1, 0.1, 0.1), phong=(0.7, 0.7, 0.7), exponent=float(exponents[0]))
+    gloss2 = white if exponents[1] == exponents[0] else b.material(diffuse=(0.5, 0.5, 0.5), phong=(0.3, 0.3, 0.3), exponent=float(exponents[1]))
     mirror = b.material(mirror=(1, 1, 1))
     glass = b.material(mirror=(1, 1, 1), ior=1.6)
     lo, hi = -1.25, 1.25
     c = [rot(v) for v in [(lo, hi, lo), (hi, hi, lo), (hi, hi, hi), (lo, hi, hi), (lo, lo, lo), (hi, lo, lo), (hi, lo, hi), (lo, lo, hi)]]
     b.triangle(c[0], c[4], c[5], glossy); b.triangle(c[5], c[1], c[0], glossy)     # floor
-    b.triangle(c[0], c[1], c[2], white); b.triangle(c[2], c[3], c[0], white)       # back wall
+    b.triangle(c[0], c[1], c[2], gloss2); b.triangle(c[2], c[3], c[0], gloss2)     # back wall
     b.triangle(c[3], c[7], c[4], green); b.triangle(c[4], c[0], c[3], green)       # left
     b.triangle(c[1], c[5], c[6], red); b.triangle(c[6], c[2], c[1], red)           # right
     b.triangle(c[2], c[6], c[7], white); b.triangle(c[7], c[3], c[2], white)       # ceiling

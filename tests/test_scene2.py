@@ -135,7 +135,9 @@ def test_device_functions_with_bvh_equal_oracle_on_mesh_scenes(kw, algo, res, ni
         assert so[k] == se[k], k
 
 
-TILTED_CASES = [({}, 4, 96, 2), ({"sun": True}, 4, 64, 1), ({}, 2, 64, 1), ({}, 3, 64, 1), ({"angle": 1.1}, 5, 64, 1)]
+TILTED_CASES = [({}, 4, 96, 2), ({"sun": True}, 4, 64, 1), ({}, 2, 64, 1), ({}, 3, 64, 1), ({"angle": 1.1}, 5, 64, 1),
+                # Phong exponents other than the reference's 90 (integers that differ inside a wave; fractions: glibc's table walk)
+                ({"exponents": (17.0, 200.0)}, 4, 48, 2), ({"exponents": (37.5, 90.0)}, 4, 48, 1), ({"exponents": (0.75, 12.25)}, 2, 40, 1)]
 
 
 @needs_ref
@@ -177,7 +179,12 @@ def test_device_functions_on_a_tilted_list_scene_equal_oracle(kw, algo, res, nit
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kw,algo,res,nit", [({}, 4, 256, 2), ({"sun": True}, 4, 128, 1), ({}, 2, 128, 1), ({"angle": 1.1}, 3, 128, 1), ({}, 5, 128, 2)])
+@pytest.mark.parametrize("kw,algo,res,nit", [({}, 4, 256, 2), ({"sun": True}, 4, 128, 1), ({}, 2, 128, 1), ({"angle": 1.1}, 3, 128, 1), ({}, 5, 128, 2),
+                                             # Phong exponents other than the reference's 90: two different integers in one
+                                             # wave (the per-lane binary exponentiation), fractions (the general powf where a
+                                             # lobe is evaluated: SceneList kernels, k_merge_walk<false>)
+                                             ({"exponents": (17.0, 200.0)}, 4, 128, 2), ({"exponents": (37.5, 90.0)}, 4, 128, 2),
+                                             ({"exponents": (0.75, 12.25)}, 2, 128, 1), ({"exponents": (37.5, 8.0)}, 5, 128, 1)])
 def test_gpu_tilted_list_scene_equals_oracle_and_reference(kw, algo, res, nit):
     """The same on the GPU (SceneList kernels, general filter path): tape, counters, framebuffer bit for bit against the
     oracle and, through the tape, against the unmodified reference."""
@@ -210,12 +217,13 @@ def test_gpu_tilted_list_scene_equals_oracle_and_reference(kw, algo, res, nit):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid,algo,res,nit", [(72, 4, 128, 2), (72, 2, 96, 1), (40, 5, 128, 2), (72, 3, 96, 1)])
-def test_gpu_mesh_scene_through_the_bvh_equals_oracle_and_reference(grid, algo, res, nit):
+@pytest.mark.parametrize("grid,algo,res,nit,exponent", [(72, 4, 128, 2, 90.0), (72, 2, 96, 1, 90.0), (40, 5, 128, 2, 90.0), (72, 3, 96, 1, 90.0),
+                                                        (40, 4, 96, 2, 37.5)])   # a fractional Phong exponent: the SceneBvhG kernels
+def test_gpu_mesh_scene_through_the_bvh_equals_oracle_and_reference(grid, algo, res, nit, exponent):
     """> 10 000 triangles on the GPU (BVH) against the oracle's brute force -- tape, counters, framebuffer bit for bit --
     and, through the tape, against the unmodified reference."""
     from smallvcm_amd.renderer import VertexCM
-    sc = bumpy_room(grid=grid, resx=res, resy=res)
+    sc = bumpy_room(grid=grid, resx=res, resy=res, exponent=exponent)
     assert sc.nPrims > (10000 if grid >= 72 else 3000)
     import os
     o = Oracle(sc, algo, threads=os.cpu_count() or 1)
