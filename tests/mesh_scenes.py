@@ -165,3 +165,76 @@ if __name__ == "__main__":   # python tests/mesh_scenes.py: regenerate the commi
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes")
     os.makedirs(d, exist_ok=True)
     print(write_bumpy_room_files(d, grid=72))
+
+
+def random_scene(seed, resx=48, resy=48):
+    """A scene drawn from `seed` (TEST INPUT): a room of randomly displaced wall quads with random triangles and spheres
+    inside, random materials (diffuse / Phong with integer or fractional exponents / mirror / glass and their mixes),
+    and one of: area lights, a point light, a directional light, a background light, or a mix of two kinds.  Half the
+    seeds stay at <= 32 primitives (the brute-force list), the others go through the BVH.  Nothing degenerate: every
+    triangle has an area, every sphere a radius, every material some albedo."""
+    rng = np.random.default_rng(1000 + seed)
+    b = SceneBuilder()
+
+    def u(lo, hi, n=None):
+        return (rng.random(n) * (hi - lo) + lo).astype(np.float32) if n else np.float32(rng.random() * (hi - lo) + lo)
+
+    mats = [b.material(diffuse=u(0.2, 0.8, 3))]
+    for _ in range(int(rng.integers(3, 8))):
+        kind = int(rng.integers(0, 6))
+        expo = float(rng.choice([1.0, 2.0, 7.0, 90.0, 90.0, 500.0, 0.5, 3.25, 37.5, 1024.0, 70000.0]))
+        if kind == 0:
+            mats.append(b.material(diffuse=u(0.1, 0.9, 3)))
+        elif kind == 1:
+            mats.append(b.material(diffuse=u(0.0, 0.3, 3), phong=u(0.2, 0.65, 3), exponent=expo))
+        elif kind == 2:
+            mats.append(b.material(mirror=u(0.5, 1.0, 3)))
+        elif kind == 3:
+            mats.append(b.material(mirror=(1, 1, 1), ior=float(u(1.1, 2.2))))
+        elif kind == 4:
+            mats.append(b.material(diffuse=u(0.05, 0.3, 3), phong=u(0.05, 0.3, 3), exponent=expo, mirror=u(0.05, 0.3, 3)))
+        else:
+            mats.append(b.material(phong=u(0.3, 0.9, 3), exponent=expo))
+
+    def mat():
+        return mats[int(rng.integers(0, len(mats)))]
+
+    def opaque():
+        return mats[0]
+
+    lo, hi = -1.25, 1.25
+    c = np.array([(lo, hi, lo), (hi, hi, lo), (hi, hi, hi), (lo, hi, hi), (lo, lo, lo), (hi, lo, lo), (hi, lo, hi), (lo, lo, hi)], np.float32)
+    c = c + u(-0.08, 0.08, c.size).reshape(c.shape)        # nothing axis-aligned
+    light_kind = int(rng.integers(0, 6))                   # 0, 1 area; 2 point; 3 directional; 4 background; 5 area + point
+    walls = [(0, 1, 2, 3), (3, 7, 4, 0), (1, 5, 6, 2), (0, 4, 5, 1)]   # back, left, right, floor
+    if light_kind not in (3, 4):
+        walls.append((2, 6, 7, 3))                          # a ceiling unless the light comes from outside
+    for q in walls:
+        m = mat() if rng.random() < 0.5 else opaque()
+        b.triangle(c[q[0]], c[q[1]], c[q[2]], m)
+        b.triangle(c[q[2]], c[q[3]], c[q[0]], m)
+    big = seed % 2 == 1
+    for _ in range(int(rng.integers(40, 400)) if big else int(rng.integers(0, 8))):
+        p = u(-1.0, 1.0, 3)
+        size = float(u(0.05, 0.5))
+        e1, e2 = u(-1, 1, 3) * np.float32(size), u(-1, 1, 3) * np.float32(size)
+        if np.linalg.norm(np.cross(e1, e2)) < 1e-3:
+            continue
+        b.triangle(p, p + e1, p + e2, mat())
+    for _ in range(int(rng.integers(0, 5))):
+        b.sphere(u(-0.9, 0.9, 3), float(u(0.08, 0.45)), mat())
+    if light_kind in (0, 1, 5):
+        for _ in range(1 + light_kind % 2):
+            p = np.float32([u(-0.6, 0.6), u(-0.6, 0.6), u(0.9, 1.15)])
+            e1, e2 = np.float32([u(0.2, 0.5), u(-0.1, 0.1), u(-0.05, 0.05)]), np.float32([u(-0.1, 0.1), u(0.2, 0.5), u(-0.05, 0.05)])
+            b.emissive_triangle(p, p + e1, p + e2, u(5.0, 40.0, 3))     # faces down: e1 x e2 points up, the reference's light emits along -normal? both signs occur
+            if rng.random() < 0.5:
+                b.emissive_triangle(p + e1 + e2, p + e2, p + e1, u(5.0, 40.0, 3))
+    if light_kind in (2, 5):
+        b.point_light(u(-0.7, 0.7, 3), u(10.0, 70.0, 3))
+    if light_kind == 3:
+        b.directional_light((float(u(-1, 1)), float(u(-1, 1)), -1.0), u(1.0, 12.0, 3))
+    if light_kind == 4:
+        b.background_light(float(u(0.5, 2.0)))
+    return b.build((float(u(-0.3, 0.3)), -4.1, float(u(-0.2, 0.4))), (float(u(-0.05, 0.05)), 1.0, float(u(-0.08, 0.02))),
+                   (3.7e-4, 0.054, 0.9985), float(u(35, 60)), resx, resy)
