@@ -2,7 +2,7 @@
 // boxes, fixed capacities; vcm_scene_desc2: any counts) into owned arrays and builds what the intersection code walks:
 //   * <= VCM_MAX_PRIMS primitives: GeometryList order, consecutive triangles packed in pairs (vcm_core.h TriPair) --
 //     the brute-force loop of Scene::Intersect (scene.hxx:53-70), which is what the reference does for every scene;
-//   * more (or SMALLVCM_AMD_FORCE_BVH=1): a binary BVH over the primitives' boxes, SAH-binned, at most 4 primitives per
+//   * more (or SMALLVCM_AMD_FORCE_BVH=1): a binary BVH over the primitives' boxes, SAH-binned over the three axes, at most 2 primitives per
 //     leaf, nodes in depth-first order with escape indices (stackless traversal, vcm_core.h bvh_intersect).  The
 //     reference has no acceleration structure (README:208-209); results are the same because the traversal only decides
 //     WHICH primitives are tested, never how (vcm_core.h explains the tie rule).
@@ -285,6 +285,13 @@ inline void scene_host_build_fast(SceneHost &s)
 }
 
 /* ---- BVH ---- */
+/* primitives per leaf.  A wave pays for its slowest lane in both halves of the traversal, and with up to four primitives per
+   leaf the leaf half was the longer one: replayed as waves of 64 rays over the mesh scene (profiles/tools/bvh_sim.py) a
+   closest-hit ray costs 9.0 inner steps + 2.7 triangle tests with two, 7.4 + 7.2 with four -- a fifth fewer
+   wave-instructions at the same lane utilisation.  (The descriptor holds up to 15: coincident centroids stay together.) */
+#ifndef VCM_BVH_LEAF_MAX
+#define VCM_BVH_LEAF_MAX 2
+#endif
 struct BvhBuildPrim { float lo[3], hi[3], c[3]; int index; };
 
 inline void bvh_prim_box(const vcm_prim &p, float lo[3], float hi[3])
@@ -315,41 +322,47 @@ inline int bvh_build_node(SceneHost &s, std::vector<BvhBuildPrim> &bp, int first
     int axis = 0;
     for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
     const bool flat = !(chi[axis] - clo[axis] > 0.f);
-    if (count <= 4 || (flat && count <= 15)) {
+    if (count <= VCM_BVH_LEAF_MAX || (flat && count <= 15)) {
         s.nodes[me].leaf = ((int)s.leafPrims.size() << 4) | count;
         for (int i = first; i < first + count; i++) s.leafPrims.push_back(bp[i].index);
         s.nodes[me].escape = (int)s.nodes.size();
         return me;
     }
-    /* binned surface-area heuristic along the axis of the largest centroid extent; median split as the fallback */
+    /* binned surface-area heuristic over all three axes (16 bins each; the axis of the largest centroid extent alone --
+       rounds 2-3 -- left the room's large wall triangles in the floor mesh's subtrees); median split as the fallback */
     int mid = first + count / 2;
     if (!flat) {
         const int B = 16;
-        float blo[B][3], bhi[B][3]; int bn[B];
-        for (int b = 0; b < B; b++) { bn[b] = 0; for (int k = 0; k < 3; k++) { blo[b][k] = 1e36f; bhi[b][k] = -1e36f; } }
-        const float scale = (float)B / (chi[axis] - clo[axis]);
-        auto bin_of = [&](const BvhBuildPrim &p) { int b = (int)((p.c[axis] - clo[axis]) * scale); return b < 0 ? 0 : (b >= B ? B - 1 : b); };
-        for (int i = first; i < first + count; i++) {
-            const int b = bin_of(bp[i]);
-            bn[b]++;
-            for (int k = 0; k < 3; k++) { blo[b][k] = std::min(blo[b][k], bp[i].lo[k]); bhi[b][k] = std::max(bhi[b][k], bp[i].hi[k]); }
-        }
         auto area = [](const float *l, const float *h) { const float x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2]; return x * y + y * z + z * x; };
-        float best = 1e36f; int bestSplit = -1;
-        for (int sp = 1; sp < B; sp++) {
-            float l0[3] = { 1e36f, 1e36f, 1e36f }, h0[3] = { -1e36f, -1e36f, -1e36f }, l1[3] = { 1e36f, 1e36f, 1e36f }, h1[3] = { -1e36f, -1e36f, -1e36f };
-            int n0 = 0, n1 = 0;
-            for (int b = 0; b < B; b++) {
-                if (!bn[b]) continue;
-                float *l = b < sp ? l0 : l1, *h = b < sp ? h0 : h1;
-                (b < sp ? n0 : n1) += bn[b];
-                for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], blo[b][k]); h[k] = std::max(h[k], bhi[b][k]); }
+        float best = 1e36f; int bestSplit = -1, bestAxis = axis;
+        for (int ax = 0; ax < 3; ax++) {
+            if (!(chi[ax] - clo[ax] > 0.f)) continue;
+            float blo[B][3], bhi[B][3]; int bn[B];
+            for (int b = 0; b < B; b++) { bn[b] = 0; for (int k = 0; k < 3; k++) { blo[b][k] = 1e36f; bhi[b][k] = -1e36f; } }
+            const float scale = (float)B / (chi[ax] - clo[ax]);
+            for (int i = first; i < first + count; i++) {
+                int b = (int)((bp[i].c[ax] - clo[ax]) * scale); b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+                bn[b]++;
+                for (int k = 0; k < 3; k++) { blo[b][k] = std::min(blo[b][k], bp[i].lo[k]); bhi[b][k] = std::max(bhi[b][k], bp[i].hi[k]); }
             }
-            if (!n0 || !n1) continue;
-            const float cost = area(l0, h0) * n0 + area(l1, h1) * n1;
-            if (cost < best) { best = cost; bestSplit = sp; }
+            for (int sp = 1; sp < B; sp++) {
+                float l0[3] = { 1e36f, 1e36f, 1e36f }, h0[3] = { -1e36f, -1e36f, -1e36f }, l1[3] = { 1e36f, 1e36f, 1e36f }, h1[3] = { -1e36f, -1e36f, -1e36f };
+                int n0 = 0, n1 = 0;
+                for (int b = 0; b < B; b++) {
+                    if (!bn[b]) continue;
+                    float *l = b < sp ? l0 : l1, *h = b < sp ? h0 : h1;
+                    (b < sp ? n0 : n1) += bn[b];
+                    for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], blo[b][k]); h[k] = std::max(h[k], bhi[b][k]); }
+                }
+                if (!n0 || !n1) continue;
+                const float cost = area(l0, h0) * n0 + area(l1, h1) * n1;
+                if (cost < best) { best = cost; bestSplit = sp; bestAxis = ax; }
+            }
         }
         if (bestSplit > 0) {
+            axis = bestAxis;
+            const float scale = (float)B / (chi[axis] - clo[axis]);
+            auto bin_of = [&](const BvhBuildPrim &p) { int b = (int)((p.c[axis] - clo[axis]) * scale); return b < 0 ? 0 : (b >= B ? B - 1 : b); };
             auto it = std::stable_partition(bp.begin() + first, bp.begin() + first + count, [&](const BvhBuildPrim &p) { return bin_of(p) < bestSplit; });
             mid = (int)(it - bp.begin());
         }

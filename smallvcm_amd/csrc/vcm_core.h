@@ -780,12 +780,21 @@ VCM_HD bool bvh_box_near(const BvhNode &nd, V3 org, V3 invDir, float tmax, float
 {
     return bvh_box_near6(nd.bmin, nd.bmax, org, invDir, tmax, tnear);
 }
+/* host-only measurement hook (profiles/tools/bvh_sim.py): the event stream of a traversal -- B/b begin (closest / any hit),
+   I inner step, p pop inside it, L leaf primitive, P pop after a leaf, O end of an outer round.  Nothing on the device. */
+#if defined(VCM_BVH_PROFILE) && !defined(__HIP_DEVICE_COMPILE__)
+void vcm_bvh_event(char e);
+#define VCM_BVH_EV(e) vcm_bvh_event(e)
+#else
+#define VCM_BVH_EV(e) ((void)0)
+#endif
 /* the primitives of one leaf (descriptor (first << 4) | count) against the hit held so far: lexicographic on
    (distance, list index), see below */
 VCM_HD void bvh_leaf(const DScene &sc, int leaf, const Ray &ray, Isect &res, bool &any, bool &ambiguous, bool &bestIsSphere)
 {
     const int first = leaf >> 4, count = leaf & 15;
     for (int k = 0; k < count; k++) {
+        VCM_BVH_EV('L');
         const LeafPrim &lp = sc.leafData()[first + k];
         const vcm_prim &pr = lp.prim;
         const int pi = lp.index;
@@ -819,6 +828,7 @@ VCM_HD bool bvh_leaf_occluded(const DScene &sc, int leaf, const Ray &ray, float 
     const int first = leaf >> 4, count = leaf & 15;
     bool occluded = false;
     for (int k = 0; k < count; k++) {
+        VCM_BVH_EV('L');
         const LeafPrim &lp = sc.leafData()[first + k];
         const vcm_prim &pr = lp.prim;
         const int pi = lp.index;
@@ -872,6 +882,7 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
     const int stride = 1;
 #endif
     int sp = 0, ref = VCM_BVH_NONE;
+    VCM_BVH_EV('B');
 #if defined(VCM_BVH_THREADED)   /* measurement switch: the threaded walk only */
     overflow = true;
 #else
@@ -883,6 +894,7 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
 #endif
     for (;;) {
         while (ref < 0) {   /* an inner node: one 64-byte record, two slab tests */
+            VCM_BVH_EV('I');
             const BvhWide w = sc.wide()[-1 - ref];
             float tl, tr;
             const bool hl = bvh_box_near6(w.lmin, w.lmax, ray.org, invDir, res.dist, tl);
@@ -897,6 +909,7 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
             else {   /* next pending subtree that can still hold a closer (or equal: the tie rule) hit */
                 ref = VCM_BVH_NONE;
                 while (ref == VCM_BVH_NONE && sp > 0) {
+                    VCM_BVH_EV('p');
                     sp--;
                     const BvhNode nd = sc.nodes()[sn[sp * stride]];
                     float t;
@@ -908,11 +921,13 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
         bvh_leaf(sc, ref, ray, res, any, ambiguous, bestIsSphere);
         ref = VCM_BVH_NONE;
         while (ref == VCM_BVH_NONE && sp > 0) {
+            VCM_BVH_EV('P');
             sp--;
             const BvhNode nd = sc.nodes()[sn[sp * stride]];
             float t;
             if (bvh_box_near(nd, ray.org, invDir, res.dist, t)) ref = nd.leaf;
         }
+        VCM_BVH_EV('O');
         if (ref == VCM_BVH_NONE) break;
     }
     if (overflow) {   /* deeper than the stack: the threaded walk over the whole tree (order-free, same result) */
@@ -947,6 +962,7 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
     const int stride = 1;
 #endif
     int sp = 0, ref = VCM_BVH_NONE;
+    VCM_BVH_EV('b');
 #if defined(VCM_BVH_THREADED)
     overflow = true;
 #else
@@ -957,6 +973,7 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
 #endif
     while (!overflow) {
         while (ref < 0) {
+            VCM_BVH_EV('I');
             const BvhWide w = sc.wide()[-1 - ref];
             float tl, tr;
             const bool hl = bvh_box_near6(w.lmin, w.lmax, ray.org, invDir, tmaxp, tl);
@@ -972,6 +989,7 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
         }
         if (ref == VCM_BVH_NONE) break;
         if (bvh_leaf_occluded(sc, ref, ray, tmaxp)) { occluded = true; break; }
+        VCM_BVH_EV('O');
         if (sp > 0) { sp--; ref = sn[sp * stride]; }
         else break;
     }

@@ -12,6 +12,92 @@
 
 using namespace vcm;
 
+#if defined(VCM_BVH_PROFILE)   /* measurement build (libemul_prof.so, profiles/tools/bvh_sim.py): the traversals' event stream */
+static std::vector<char> g_bvhLog;
+namespace vcm { void vcm_bvh_event(char e) { g_bvhLog.push_back(e); } }
+extern "C" long long emul_bvh_log_size() { return (long long)g_bvhLog.size(); }
+extern "C" void emul_bvh_log_get(char *out) { memcpy(out, g_bvhLog.data(), g_bvhLog.size()); }
+extern "C" void emul_bvh_log_clear() { g_bvhLog.clear(); }
+#define EMUL_PATH_MARK(c) g_bvhLog.push_back(c)
+/* A wave of 64 lanes running vcm_core.h's while-while traversal over the logged rays, in lockstep: what one wave-level
+ * instruction stream costs against what its lanes needed.  kind: 'B' closest hit, 'b' any hit; `which`: 0 = every ray of
+ * that kind in log order, k > 0 = only the k-th closest-hit ray of each path (the wave of bounce k, dead paths replaced by
+ * the next path as the refill does).  refill > 0: lanes that finish take the next ray as soon as `refill` lanes are idle
+ * (persistent lanes with dynamic fetch), paying cTask wave-instructions per fetch round; 0 = one ray per lane, as built.
+ * out: [rays, lane cost, wave cost x 64, mean I, mean L, max I, max L, wave rounds] */
+extern "C" void emul_bvh_simulate(int kind, int which, int pathKind, int refill, double cI, double cP, double cL, double cTask, double *out)
+{
+    struct RaySpan { size_t b, e; };
+    std::vector<RaySpan> rays;
+    const size_t n = g_bvhLog.size();
+    char curPath = 0; int nthB = 0;
+    for (size_t i = 0; i < n; i++) {
+        const char c = g_bvhLog[i];
+        if (c == 'l' || c == 'c') { curPath = c; nthB = 0; continue; }
+        if (c == 'B' || c == 'b') {
+            if (c == 'B') nthB++;
+            size_t j = i + 1;
+            while (j < n && g_bvhLog[j] != 'B' && g_bvhLog[j] != 'b' && g_bvhLog[j] != 'l' && g_bvhLog[j] != 'c') j++;
+            const bool take = c == (char)kind && (pathKind == 0 || curPath == (char)pathKind) && (which == 0 || (c == 'B' && nthB == which));
+            if (take) rays.push_back(RaySpan{ i + 1, j });
+            i = j - 1;
+        }
+    }
+    double laneCost = 0, waveCost = 0, sumI = 0, sumL = 0, maxI = 0, maxL = 0, rounds = 0;
+    for (const RaySpan &r : rays) {
+        double nI = 0, nL = 0;
+        for (size_t i = r.b; i < r.e; i++) {
+            const char c = g_bvhLog[i];
+            if (c == 'I') { laneCost += cI; nI++; } else if (c == 'p' || c == 'P') laneCost += cP; else if (c == 'L') { laneCost += cL; nL++; }
+        }
+        sumI += nI; sumL += nL; maxI = std::max(maxI, nI); maxL = std::max(maxL, nL);
+    }
+    size_t next = 0;
+    while (next < rays.size()) {
+        size_t pos[64], end[64]; int live = 0;
+        for (int l = 0; l < 64; l++) { if (next < rays.size()) { pos[l] = rays[next].b; end[l] = rays[next].e; next++; live++; } else pos[l] = end[l] = 0; }
+        if (refill > 0) { waveCost += cTask; laneCost += cTask * live / 64.0 * 0; }
+        auto ev = [&](int l) -> char { return pos[l] < end[l] ? g_bvhLog[pos[l]] : 0; };
+        for (;;) {
+            bool anyLeft = false;
+            for (int l = 0; l < 64; l++) if (pos[l] < end[l]) anyLeft = true;
+            if (!anyLeft) break;
+            rounds++;
+            for (;;) {   /* the inner-node loop */
+                bool in[64]; bool any = false;
+                for (int l = 0; l < 64; l++) { in[l] = ev(l) == 'I'; if (in[l]) { any = true; pos[l]++; } }
+                if (!any) break;
+                waveCost += cI;
+                for (;;) {
+                    bool anyP = false;
+                    for (int l = 0; l < 64; l++) if (in[l] && ev(l) == 'p') { anyP = true; pos[l]++; } else in[l] = false;
+                    if (!anyP) break;
+                    waveCost += cP;
+                }
+            }
+            int mL = 0, mP = 0;
+            for (int l = 0; l < 64; l++) { int k = 0; while (ev(l) == 'L') { pos[l]++; k++; } mL = std::max(mL, k); }
+            waveCost += mL * cL;
+            for (int l = 0; l < 64; l++) { int k = 0; while (ev(l) == 'P') { pos[l]++; k++; } mP = std::max(mP, k); }
+            waveCost += mP * cP;
+            for (int l = 0; l < 64; l++) if (ev(l) == 'O') pos[l]++;
+            if (refill > 0) {   /* dynamic fetch: idle lanes take new rays once enough of them wait */
+                int idle = 0;
+                for (int l = 0; l < 64; l++) if (pos[l] >= end[l]) idle++;
+                if (idle >= refill && next < rays.size()) {
+                    for (int l = 0; l < 64; l++) if (pos[l] >= end[l] && next < rays.size()) { pos[l] = rays[next].b; end[l] = rays[next].e; next++; }
+                    waveCost += cTask;
+                }
+            }
+        }
+    }
+    out[0] = (double)rays.size(); out[1] = laneCost; out[2] = waveCost * 64.0;
+    out[3] = rays.empty() ? 0 : sumI / rays.size(); out[4] = rays.empty() ? 0 : sumL / rays.size(); out[5] = maxI; out[6] = maxL; out[7] = rounds;
+}
+#else
+#define EMUL_PATH_MARK(c) ((void)0)
+#endif
+
 /* the ray-casting functions are instantiated per kind of scene (vcm_core.h SceneList / SceneBvh): pick like the
    product's launches do */
 template <class F> static void with_scene(const DScene &sc, F &&f)
@@ -160,6 +246,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
     /* K1 */
     for (int lp = 0; lp < e.nLocal; lp++) {
         LightPath path;
+        EMUL_PATH_MARK('l');
         light_path_begin(e.sc, P, path, lp);
         LaneBox box; lane_box_init(box);
         with_scene(e.sc, [&](const auto &sc) { while (light_path_step<0>(sc, P, path, store, e.fb.data(), e.ls, box)) {} });
@@ -217,6 +304,7 @@ void emul_run_iteration(void *h, int iteration, unsigned minLen, unsigned maxLen
             CameraPath path;
             uint32_t q[VCM_MERGE_Q + 1];
             MergeScratch ms; ms.q = q; ms.stride = 1; ms.cap = VCM_MERGE_Q;
+            EMUL_PATH_MARK('c');
             camera_path_begin(e.sc, P, path, lp);
             VertexStore vs; memset(&vs, 0, sizeof(vs));
             int wqState[6] = {0, 0, 0, 0, 0, 0};
