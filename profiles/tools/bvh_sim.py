@@ -29,18 +29,18 @@ CI, CP, CL, CT = 62.0, 36.0, 66.0, 450.0   # wave-instructions per inner step / 
 
 
 def sim(kind, which, path, refill=0, ct=0.0):
-    out = (C.c_double * 8)()
+    out = (C.c_double * 9)()
     E.emul_bvh_simulate(ord(kind), which, ord(path) if path else 0, refill, CI, CP, CL, ct, out)
     return list(out)
 
 
-print("%-46s %9s %7s %7s %6s %6s %9s %9s" % ("rays", "count", "mean I", "mean L", "max I", "max L", "lane util", "wave/ray"))
+print("%-46s %9s %7s %7s %6s %6s %9s %9s %7s" % ("rays", "count", "mean I", "mean L", "max I", "max L", "lane util", "wave/ray", "bound"))
 for name, kind, which, path in [("camera: primary (bounce 1)", "B", 1, "c"), ("camera: bounce 2", "B", 2, "c"), ("camera: bounce 3", "B", 3, "c"),
                                 ("camera: bounce 5", "B", 5, "c"), ("camera: all closest-hit rays, log order", "B", 0, "c"),
                                 ("light: bounce 1", "B", 1, "l"), ("light: bounce 2", "B", 2, "l"), ("light: all closest-hit", "B", 0, "l"),
                                 ("camera paths: shadow rays (DI + VC)", "b", 0, "c"), ("light paths: shadow rays (to the camera)", "b", 0, "l")]:
     o = sim(kind, which, path)
-    print("%-46s %9d %7.1f %7.1f %6d %6d %9.3f %9.1f" % (name, o[0], o[3], o[4], o[5], o[6], o[1] / max(o[2], 1), o[2] / 64.0 / max(o[0], 1)))
+    print("%-46s %9d %7.1f %7.1f %6d %6d %9.3f %9.1f %7.3f" % (name, o[0], o[3], o[4], o[5], o[6], o[1] / max(o[2], 1), o[2] / 64.0 / max(o[0], 1), o[1] / max(o[8], 1)))
 print("\ndynamic fetch (a finished lane takes the next ray once `refill` lanes are idle).  Traversal wave cost relative to one ray per lane,")
 print("and the fetch rounds per 64 rays (each round runs the task's set-up / evaluation code for the lanes it serves; as built: 1):")
 for name, kind, path in (("camera paths: shadow rays", "b", "c"), ("camera: closest-hit rays", "B", "c"), ("light: closest-hit rays", "B", "l")):

@@ -2485,6 +2485,9 @@ VCM_HD V3 merge_query(const DScene &sc, const IterParams &P, const GridStore &g,
  * 2x2x2 block of cells in arrival order, a wave of K4 then touched ~21 distinct cells instead of ~13, and K4 jumped
  * from 3.9 to 5.4 ms.  Halving ONE axis at a time keeps a bucket at 1, 2, 4 ... cells, and the full table is used
  * before anything is coarsened: 257 x 251 x 257 still fits 2^24.) */
+/* (Keyed by the lattice CORNER nearest to the query instead -- floor(cellPt + 0.5): the 2x2x2 block HashGrid::Process probes,
+ * hashgrid.hxx:124-141, so equal keys walk the same eight buckets -- K4 was no faster and the iteration 1.5 % slower,
+ * three runs of 40 iterations each way: profiles/r06k_ab.txt.  With ~2 queries per cell there is little to share.) */
 struct QueryBuckets { uint32_t nx, ny; int sx, sy, sz; };
 VCM_HD QueryBuckets query_buckets(const IterParams &P, const GridHeader *hdr)
 {   /* wave-uniform */

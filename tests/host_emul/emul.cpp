@@ -24,7 +24,8 @@ extern "C" void emul_bvh_log_clear() { g_bvhLog.clear(); }
  * that kind in log order, k > 0 = only the k-th closest-hit ray of each path (the wave of bounce k, dead paths replaced by
  * the next path as the refill does).  refill > 0: lanes that finish take the next ray as soon as `refill` lanes are idle
  * (persistent lanes with dynamic fetch), paying cTask wave-instructions per fetch round; 0 = one ray per lane, as built.
- * out: [rays, lane cost, wave cost x 64, mean I, mean L, max I, max L, wave rounds] */
+ * out: [rays, lane cost, wave cost x 64, mean I, mean L, max I, max L, wave rounds, bound x 64], bound = the wave cost if a wave
+ * paid max-over-lanes of each event kind's TOTAL (no alternation between the two halves: what postponing leaves could reach) */
 extern "C" void emul_bvh_simulate(int kind, int which, int pathKind, int refill, double cI, double cP, double cL, double cTask, double *out)
 {
     struct RaySpan { size_t b, e; };
@@ -91,6 +92,17 @@ extern "C" void emul_bvh_simulate(int kind, int which, int pathKind, int refill,
             }
         }
     }
+    double bound = 0;
+    for (size_t b = 0; b < rays.size(); b += 64) {
+        double mI = 0, mP = 0, mL = 0;
+        for (size_t r = b; r < std::min(rays.size(), b + 64); r++) {
+            double nI = 0, nP = 0, nL = 0;
+            for (size_t i = rays[r].b; i < rays[r].e; i++) { const char c = g_bvhLog[i]; if (c == 'I') nI++; else if (c == 'p' || c == 'P') nP++; else if (c == 'L') nL++; }
+            mI = std::max(mI, nI); mP = std::max(mP, nP); mL = std::max(mL, nL);
+        }
+        bound += mI * cI + mP * cP + mL * cL;
+    }
+    out[8] = bound * 64.0;
     out[0] = (double)rays.size(); out[1] = laneCost; out[2] = waveCost * 64.0;
     out[3] = rays.empty() ? 0 : sumI / rays.size(); out[4] = rays.empty() ? 0 : sumL / rays.size(); out[5] = maxI; out[6] = maxL; out[7] = rounds;
 }
