@@ -28,6 +28,10 @@ NAMES = {
     26: ("K1 sample_scattering", "Russian roulette + MIS update"),
     27: ("K3 sample_scattering", "rng_peek (Philox)"), 28: ("K3 sample_scattering", "bsdf_sample"), 29: ("K3 sample_scattering", "bsdf_pdf (reverse)"),
     30: ("K3 sample_scattering", "Russian roulette + MIS update"),
+    32: ("K1+K3 bsdf_sample", "event pick, material, sincos"), 33: ("K1+K3 bsdf_sample", "diffuse branch"), 34: ("K1+K3 bsdf_sample", "Phong branch"),
+    35: ("K1+K3 bsdf_sample", "mirror branch"), 36: ("K1+K3 bsdf_sample", "refraction branch"),
+    38: ("K1+K3 scene_intersect", "certified filter over the list"), 39: ("K1+K3 scene_intersect", "the winner's exact arithmetic (triangle)"),
+    41: ("K1+K3 scene_intersect", "the winner's exact arithmetic (sphere, binary64)"), 40: ("K1+K3 scene_intersect", "exact list walk (a lane was uncertain)"),
     14: ("K4", "cells + set-up"), 15: ("K4", "scan"), 16: ("K4", "drain (RangeQuery::Process)"),
 }
 
@@ -48,7 +52,8 @@ def main():
     for it in range(5):
         r.RunIteration(it)
     r.backend.synchronize()
-    buf = (C.c_ulonglong * 64)()
+    IDS = 64
+    buf = (C.c_ulonglong * (3 * IDS))()
     assert L.region_clock_read(buf, 1) == 0
     n = 10
     for it in range(5, 5 + n):
@@ -57,13 +62,15 @@ def main():
     assert L.region_clock_read(buf, 0) == 0
     per = {}
     for rid, (k, name) in NAMES.items():
-        per.setdefault(k, []).append((rid, name, buf[rid] / n, buf[32 + rid] / n))
+        per.setdefault(k, []).append((rid, name, buf[rid] / n, buf[IDS + rid] / n, buf[2 * IDS + rid] / n))
     print("scene %s %dx%d, mean of %d iterations; cycles are wave-residence shader clocks summed over waves" % (scene_id, res, res, n))
     for k, rows in per.items():
         tot = sum(x[2] for x in rows) or 1.0
         print("%s: %.1f M wave-cycles per iteration" % (k, tot / 1e6))
-        for rid, name, cyc, marks in rows:
-            print("   %-44s %6.1f %%  %9.0f marks  %8.0f cycles per mark" % (name, 100.0 * cyc / tot, marks, cyc / marks if marks else 0.0))
+        lanes = sum(x[4] for x in rows)
+        print("   (time-weighted lanes at the marks: %.2f of 64)" % (lanes / tot / 64.0))
+        for rid, name, cyc, marks, lc in rows:
+            print("   %-44s %6.1f %%  %9.0f marks  %8.0f cycles per mark  lanes %.2f" % (name, 100.0 * cyc / tot, marks, cyc / marks if marks else 0.0, lc / cyc / 64.0 if cyc else 0.0))
     r.close()
 
 

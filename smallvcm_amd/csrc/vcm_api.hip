@@ -1891,13 +1891,14 @@ unsigned vcm_sizeof_stats(void) { return (unsigned)sizeof(vcm_stats); }
 } // extern "C"
 
 #if defined(VCM_REGION_CLOCK)   /* measurement variant only: profiles/tools/region_clock.py */
-extern "C" int region_clock_read(unsigned long long *out64, int reset)
+extern "C" int region_clock_read(unsigned long long *out, int reset)   /* out: 3 x VCM_RC_IDS words */
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    std::vector<unsigned long long> all((size_t)VCM_RC_SLOTS * 64);
-    if (out64) {
+    const int W = 3 * VCM_RC_IDS;
+    std::vector<unsigned long long> all((size_t)VCM_RC_SLOTS * W);
+    if (out) {
         if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(vcm::g_regionClock), all.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
-        for (int k = 0; k < 64; k++) { out64[k] = 0; for (int s = 0; s < VCM_RC_SLOTS; s++) out64[k] += all[(size_t)s * 64 + k]; }
+        for (int k = 0; k < W; k++) { out[k] = 0; for (int s = 0; s < VCM_RC_SLOTS; s++) out[k] += all[(size_t)s * W + k]; }
     }
     if (reset) {
         std::fill(all.begin(), all.end(), 0ull);

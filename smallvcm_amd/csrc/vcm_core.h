@@ -151,24 +151,36 @@ VCM_HD void lane_stats_zero(LaneStats &s)
  * mark of this wave to region `id` (first active lane: one atomic per wave and mark).  Compiles to nothing otherwise. */
 #if defined(VCM_REGION_CLOCK) && defined(__HIPCC__)
 #define VCM_RC_SLOTS 2048   /* one row per (wave mod SLOTS): the marks of a launch would otherwise queue on a dozen words */
-__device__ unsigned long long g_regionClock[VCM_RC_SLOTS * 64];   /* row: [id] cycles, [32 + id] marks */
+#define VCM_RC_IDS 64
+__device__ unsigned long long g_regionClock[VCM_RC_SLOTS * 3 * VCM_RC_IDS];   /* row: [id] cycles, [IDS + id] marks, [2 IDS + id] cycles x lanes at the mark */
 #endif
 #if defined(VCM_REGION_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
-struct RegionClock { unsigned long long t; };
-__device__ __forceinline__ void rc_mark(RegionClock &r, int id)
+/* The clock is the WAVE's (one word of LDS per wave): a mark charges the cycles since the wave's previous mark -- whichever
+   lanes executed that one -- so the branches of a divergent region, which the wave runs one after the other, are each
+   charged their own time, with the lanes that ran them. */
+__device__ __forceinline__ unsigned long long *rc_slot()
+{
+    __shared__ unsigned long long rcT[16];
+    return &rcT[(threadIdx.x >> 6) & 15];
+}
+__device__ __forceinline__ void rc_reset() { *rc_slot() = clock64(); }
+__device__ __forceinline__ void rc_mark(int id)
 {
     const unsigned long long n = clock64();
     const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+    unsigned long long *t = rc_slot();
     if ((int)__lane_id() == __ffsll((long long)m) - 1) {
-        unsigned long long *row = g_regionClock + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (VCM_RC_SLOTS - 1)) * 64;
-        atomicAdd(&row[id], n - r.t);
-        atomicAdd(&row[32 + id], 1ull);
+        const unsigned long long d = n - *t;
+        unsigned long long *row = g_regionClock + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (VCM_RC_SLOTS - 1)) * (3 * VCM_RC_IDS);
+        atomicAdd(&row[id], d);
+        atomicAdd(&row[VCM_RC_IDS + id], 1ull);
+        atomicAdd(&row[2 * VCM_RC_IDS + id], d * (unsigned long long)__popcll(m));
+        *t = clock64();
     }
-    r.t = clock64();
 }
-#define RC_DECL RegionClock rc_; rc_.t = clock64()
-#define RC_MARK(id) rc_mark(rc_, id)
-#define RC_RESET rc_.t = clock64()
+#define RC_DECL rc_reset()
+#define RC_MARK(id) rc_mark(id)
+#define RC_RESET rc_reset()
 #else
 #define RC_DECL
 #define RC_MARK(id)
@@ -1432,6 +1444,7 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
         const bool cert = !fr.noRoot && fr.ok && (loValid || (loInvalid && (fr.hi - fr.eHi > ray.tmin))) && (U < res.dist);
         fast_offer(fb, cand, cert, L, U, wave_uniform(p.prim));
     }
+    RC_MARK(38);
     if (fb.poison) { certain = false; return false; }
     if (fb.best < 0) { certain = true; return false; }   /* every primitive certainly missed */
     certain = fb.bestCertain && (fb.minL2 > fb.bestU);
@@ -1450,7 +1463,9 @@ VCM_HD bool list_intersect_filtered(const DScene &sc, const Ray &ray, Isect &res
     } else {
         hit = sph_intersect(pr, fb.best, ray, res);
         if (!hit) certain = false;
+        RC_MARK(41);
     }
+    RC_MARK(39);
     if (hit) res.lightID = scene_mat2light(sc, res.matID);
     return hit;
 }
@@ -1545,7 +1560,9 @@ VCM_HD bool scene_intersect(const SC &sc, const Ray &ray, Isect &res)
 #endif
     if (!wave_any(!certain)) { res = fast; return hit; }
 #endif
-    return pairs_intersect(sc, ray, res);
+    const bool exactHit = pairs_intersect(sc, ray, res);
+    RC_MARK(40);
+    return exactHit;
 }
 /* Scene::Occluded scene.hxx:72-85 (+ GeometryList::IntersectP geometry.hxx:80-91) */
 template <class SC>
@@ -1717,6 +1734,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const S &sc, bool fixIsLight, float r0, flo
     V3 gen = sp3(0.f);
     float sinPhi = 0.f, cosPhi = 0.f;   /* of term1 = 2 pi r0 (utils.hxx:91, :177), for the two branches that sample a lobe */
     if (sampledEvent == kDiffuse || sampledEvent == kPhong) dm_sincosf(2.f * VCM_PI_F * r0, sinPhi, cosPhi);
+    RC_MARK(32);
 
     if (sampledEvent == kDiffuse) {
         if (b.localDirFix.z < VCM_EPS_COSINE) return sp3(0.f);
@@ -1726,6 +1744,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const S &sc, bool fixIsLight, float r0, flo
         result = result + ld3(m.diffuse) * VCM_INV_PI_F;
         if (iszero(result)) return sp3(0.f);
         result = result + bsdf_eval_phong(b, m, gen, &pdfW, (float *)0, S::kIntPhong);
+        RC_MARK(33);
     } else if (sampledEvent == kPhong) {
         gen = sample_power_cos_hemisphere(sinPhi, cosPhi, r1, m.phongExp);
         const V3 refl = reflect_local(b.localDirFix);
@@ -1744,11 +1763,13 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const S &sc, bool fixIsLight, float r0, flo
         result = result + rho * pw;
         if (iszero(result)) return sp3(0.f);
         result = result + bsdf_eval_diffuse(b, m, gen, &pdfW, (float *)0);
+        RC_MARK(34);
     } else if (sampledEvent == kReflect) {
         gen = reflect_local(b.localDirFix);
         pdfW += b.reflProb;
         result = result + b.reflectCoeff * ld3(m.mirror) / fabsf(gen.z);
         if (iszero(result)) return sp3(0.f);
+        RC_MARK(35);
     } else {
         if (m.ior < 0.f) return sp3(0.f);
         float cosI = b.localDirFix.z;
@@ -1768,6 +1789,7 @@ VCM_HD V3 bsdf_sample(const Bsdf &b, const S &sc, bool fixIsLight, float r0, flo
             return sp3(0.f);
         }
         if (iszero(result)) return sp3(0.f);
+        RC_MARK(36);
     }
 
     cosThetaGen = fabsf(gen.z);
