@@ -121,7 +121,15 @@ struct VertexStore {
     int *vcTask;     /* VC task -> (vertex, index j of the light vertex)          */
     /* What k_resolve reads per vertex is indexed by the vertex's PATH SLOT (pathLength-1)*nLocal + lp, not by its
        queue position: lanes of k_resolve hold neighbouring paths, so these reads coalesce (the queue order is the
-       order in which waves happened to append). */
+       order in which waves happened to append).  k_resolve is bound by its fetches (2.3 GB for 1.0 GB of use: the planes
+       of the longer path lengths are sparse, and a 16-byte entry read there is a 64-byte fetch from each array); three
+       other layouts were measured in round 4 and none kept:  indexed by queue position (dense arrays + a 4-byte
+       slot -> vertex plane) k_resolve fetched 20 % MORE -- a wave of K3 appends the vertices of 64 paths at different
+       depths, neighbouring paths' vertices of one length are not neighbours in the queue (profiles/r06v_fetch.txt);
+       one 32-byte record per slot {di.xyz, mg.xyz, first VC task, count} -35 % fetch and k_resolve 413 -> 320 us, one
+       48-byte record {meta, di, mg} -23 % and 353 us -- but K3b's and K4's stores, 16 bytes next to their neighbours' in
+       an array of their own, become strided partial lines: K3b 420 -> 525 / 574 us, the iteration 1.5 % / 3 % SLOWER
+       (profiles/r06w_ab_slot32.txt, r06x_ab_slot48.txt). */
     F4 *diOut;       /* per path slot: throughput * DirectIllumination()  (:491)   */
     F4 *vcOut;       /* per VC task:   throughput * lvThroughput * ConnectVertices() (:523) */
     F4 *mergeOut;    /* per path slot: throughput * vmNormalization * contrib (:534) */
