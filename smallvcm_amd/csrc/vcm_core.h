@@ -129,7 +129,8 @@ struct VertexStore {
        one 32-byte record per slot {di.xyz, mg.xyz, first VC task, count} -35 % fetch and k_resolve 413 -> 320 us, one
        48-byte record {meta, di, mg} -23 % and 353 us -- but K3b's and K4's stores, 16 bytes next to their neighbours' in
        an array of their own, become strided partial lines: K3b 420 -> 525 / 574 us, the iteration 1.5 % / 3 % SLOWER
-       (profiles/r06w_ab_slot32.txt, r06x_ab_slot48.txt). */
+       (profiles/r06w_ab_slot32.txt, r06x_ab_slot48.txt); {meta, di} as one 32-byte record that K3b writes whole, so that K3 has
+       no slot store of its own: K3 -0.23 GB written, k_resolve -39 us, K3b +52 us, the iteration equal (r06y_ab_metadi.txt). */
     F4 *diOut;       /* per path slot: throughput * DirectIllumination()  (:491)   */
     F4 *vcOut;       /* per VC task:   throughput * lvThroughput * ConnectVertices() (:523) */
     F4 *mergeOut;    /* per path slot: throughput * vmNormalization * contrib (:534) */
