@@ -870,7 +870,9 @@ VCM_HD bool bvh_leaf_occluded(const DScene &sc, int leaf, const Ray &ray, float 
 /* The traversal stack: 32 levels per lane, in LDS on the device ([level][thread], no bank conflicts; 32 KB per block of
  * 256 lanes), ONE array for the closest-hit and the any-hit traversal -- a kernel that runs both (strict mode) never
  * has both alive.  A deeper tree finishes the ray with the threaded walk. */
+#ifndef VCM_BVH_STACK
 #define VCM_BVH_STACK 32
+#endif
 #define VCM_BVH_NONE 0x7fffffff
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ int *bvh_stack(int &stride)
