@@ -17,7 +17,7 @@ from mesh_scenes import random_scene
 needs_ref = pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built (no /root/reference)")
 COUNTERS = ("lightVertices", "lightRays", "cameraRays", "shadowRays", "mergeQueries", "mergeCandidates", "mergeAccepted",
             "connections", "lightSplats")
-ALGOS = (4, 2, 3, 5, 1, 0)   # VCM, PPM, BPM, BPT, light tracing, and index 0
+ALGOS = (4, 2, 3, 5, 1, 0, 6)   # VCM, BPM, BPT, PathTracer, PPM, light tracing, EyeLight (include/smallvcm_amd.h vcm_algorithm)
 
 
 def _oracle_run(sc, algo, nit):
@@ -32,7 +32,7 @@ def _oracle_run(sc, algo, nit):
 
 
 @needs_ref
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(14))
 def test_oracle_equals_the_unmodified_reference_on_random_scenes(seed):
     algo = ALGOS[seed % len(ALGOS)]
     sc = random_scene(seed, 40, 40)
@@ -44,7 +44,7 @@ def test_oracle_equals_the_unmodified_reference_on_random_scenes(seed):
     assert np.isfinite(fb).all()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(14))
 def test_device_functions_equal_the_oracle_on_random_scenes(seed):
     algo = ALGOS[seed % len(ALGOS)]
     sc = random_scene(seed, 40, 40)
@@ -66,7 +66,7 @@ def test_gpu_equals_the_oracle_on_random_scenes(seed):
     from smallvcm_amd.renderer import VertexCM
     res = 96 if seed % 3 else 160
     sc = random_scene(seed, res, res)
-    for algo in (4, ALGOS[1 + seed % 4]):
+    for algo in (4, ALGOS[1 + seed % 6]):
         o = Oracle(sc, algo, threads=os.cpu_count() or 1)
         r = VertexCM(sc, algo, 0.003, 0.75, 1234)
         r.mMaxPathLength = 10
