@@ -49,3 +49,15 @@ for name, kind, path in (("camera paths: shadow rays", "b", "c"), ("camera: clos
         a, b = sim(kind, 0, path, refill, 0.0), sim(kind, 0, path, refill, 1.0)
         rounds = (b[2] - a[2]) / 64.0
         print("  %-26s refill %2d: traversal %.3f, lane util %.3f, fetch rounds per 64 rays %.2f" % (name, refill, a[2] / base[2], a[1] / a[2], rounds / (base[0] / 64.0)))
+
+print("\nshadow rays ordered by a key before they are dealt to the waves -- what sorting the tasks of K3b / K3c would buy:")
+E.emul_bvh_sort.argtypes = [C.c_int]
+E.emul_bvh_sort_mode.argtypes = [C.c_int]
+for mode, name in ((0, "origin cell, direction octant"), (1, "origin cell, end-point cell"), (3, "origin cell alone")):
+    E.emul_bvh_sort_mode(mode)
+    for cells in (0, 4, 8, 16, 32):
+        E.emul_bvh_sort(cells)
+        for kind, path, what in (("b", "c", "camera shadow rays"), ("b", "l", "light->camera rays")):
+            o = sim(kind, 0, path)
+            print("  %-30s grid %2d^3  %-20s lane util %.3f, wave cost per ray %.1f" % (name, cells, what, o[1] / max(o[2], 1), o[2] / 64.0 / max(o[0], 1)))
+E.emul_bvh_sort(0)

@@ -807,9 +807,12 @@ VCM_HD bool bvh_box_near(const BvhNode &nd, V3 org, V3 invDir, float tmax, float
    I inner step, p pop inside it, L leaf primitive, P pop after a leaf, O end of an outer round.  Nothing on the device. */
 #if defined(VCM_BVH_PROFILE) && !defined(__HIP_DEVICE_COMPILE__)
 void vcm_bvh_event(char e);
+void vcm_bvh_ray(const float *org, const float *dir, float tmax);
 #define VCM_BVH_EV(e) vcm_bvh_event(e)
+#define VCM_BVH_RAY(r, t) do { const float o_[3] = { (r).org.x, (r).org.y, (r).org.z }, d_[3] = { (r).dir.x, (r).dir.y, (r).dir.z }; vcm_bvh_ray(o_, d_, t); } while (0)
 #else
 #define VCM_BVH_EV(e) ((void)0)
+#define VCM_BVH_RAY(r, t) ((void)0)
 #endif
 /* the primitives of one leaf (descriptor (first << 4) | count) against the hit held so far: lexicographic on
    (distance, list index), see below */
@@ -907,7 +910,7 @@ VCM_HD bool bvh_intersect(const DScene &sc, const Ray &ray, Isect &res)
     const int stride = 1;
 #endif
     int sp = 0, ref = VCM_BVH_NONE;
-    VCM_BVH_EV('B');
+    VCM_BVH_EV('B'); VCM_BVH_RAY(ray, res.dist);
 #if defined(VCM_BVH_THREADED)   /* measurement switch: the threaded walk only */
     overflow = true;
 #else
@@ -987,7 +990,7 @@ VCM_HD bool bvh_occluded(const DScene &sc, const Ray &ray, float tmaxp)
     const int stride = 1;
 #endif
     int sp = 0, ref = VCM_BVH_NONE;
-    VCM_BVH_EV('b');
+    VCM_BVH_EV('b'); VCM_BVH_RAY(ray, tmaxp);
 #if defined(VCM_BVH_THREADED)
     overflow = true;
 #else

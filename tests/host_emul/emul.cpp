@@ -14,10 +14,12 @@ using namespace vcm;
 
 #if defined(VCM_BVH_PROFILE)   /* measurement build (libemul_prof.so, profiles/tools/bvh_sim.py): the traversals' event stream */
 static std::vector<char> g_bvhLog;
-namespace vcm { void vcm_bvh_event(char e) { g_bvhLog.push_back(e); } }
+static std::vector<float> g_bvhRays;   /* org, dir of every logged ray, in log order */
+namespace vcm { void vcm_bvh_event(char e) { g_bvhLog.push_back(e); }
+                void vcm_bvh_ray(const float *o, const float *d, float t) { for (int k = 0; k < 3; k++) g_bvhRays.push_back(o[k]); for (int k = 0; k < 3; k++) g_bvhRays.push_back(d[k]); g_bvhRays.push_back(t); } }
 extern "C" long long emul_bvh_log_size() { return (long long)g_bvhLog.size(); }
 extern "C" void emul_bvh_log_get(char *out) { memcpy(out, g_bvhLog.data(), g_bvhLog.size()); }
-extern "C" void emul_bvh_log_clear() { g_bvhLog.clear(); }
+extern "C" void emul_bvh_log_clear() { g_bvhLog.clear(); g_bvhRays.clear(); }
 #define EMUL_PATH_MARK(c) g_bvhLog.push_back(c)
 /* A wave of 64 lanes running vcm_core.h's while-while traversal over the logged rays, in lockstep: what one wave-level
  * instruction stream costs against what its lanes needed.  kind: 'B' closest hit, 'b' any hit; `which`: 0 = every ray of
@@ -26,10 +28,16 @@ extern "C" void emul_bvh_log_clear() { g_bvhLog.clear(); }
  * (persistent lanes with dynamic fetch), paying cTask wave-instructions per fetch round; 0 = one ray per lane, as built.
  * out: [rays, lane cost, wave cost x 64, mean I, mean L, max I, max L, wave rounds, bound x 64], bound = the wave cost if a wave
  * paid max-over-lanes of each event kind's TOTAL (no alternation between the two halves: what postponing leaves could reach) */
+static int g_bvhSortMode = 0;   /* 0: (origin cell, direction octant); 1: (origin cell, end-point cell); 2: (end-point cell, origin cell); 3: origin cell alone */
+extern "C" void emul_bvh_sort_mode(int m) { g_bvhSortMode = m; }
+static int g_bvhSortCells = 0;   /* > 0: the rays of a replay are first ordered by (origin cell on a grid of that many cells per axis over
+                                    [-1.5, 1.5]^3, direction octant) -- what a sort of the shadow-ray tasks before K3b / K3c would do */
+extern "C" void emul_bvh_sort(int cells) { g_bvhSortCells = cells; }
 extern "C" void emul_bvh_simulate(int kind, int which, int pathKind, int refill, double cI, double cP, double cL, double cTask, double *out)
 {
-    struct RaySpan { size_t b, e; };
+    struct RaySpan { size_t b, e; long long key; };
     std::vector<RaySpan> rays;
+    size_t rayNo = 0;
     const size_t n = g_bvhLog.size();
     char curPath = 0; int nthB = 0;
     for (size_t i = 0; i < n; i++) {
@@ -40,10 +48,30 @@ extern "C" void emul_bvh_simulate(int kind, int which, int pathKind, int refill,
             size_t j = i + 1;
             while (j < n && g_bvhLog[j] != 'B' && g_bvhLog[j] != 'b' && g_bvhLog[j] != 'l' && g_bvhLog[j] != 'c') j++;
             const bool take = c == (char)kind && (pathKind == 0 || curPath == (char)pathKind) && (which == 0 || (c == 'B' && nthB == which));
-            if (take) rays.push_back(RaySpan{ i + 1, j });
+            if (take) {
+                long long key = 0;
+                if (g_bvhSortCells > 0 && (rayNo + 1) * 7 <= g_bvhRays.size()) {
+                    const float *r = &g_bvhRays[rayNo * 7];
+                    int c[3];
+                    for (int k = 0; k < 3; k++) { int v = (int)((r[k] + 1.5f) / 3.0f * g_bvhSortCells); c[k] = v < 0 ? 0 : (v >= g_bvhSortCells ? g_bvhSortCells - 1 : v); }
+                    const int oct = (r[3] < 0.f ? 1 : 0) | (r[4] < 0.f ? 2 : 0) | (r[5] < 0.f ? 4 : 0);
+                    key = ((((long long)c[2] * g_bvhSortCells + c[1]) * g_bvhSortCells + c[0]) << 3) | oct;
+                    if (g_bvhSortMode > 0) {
+                        int e[3];
+                        const float t = r[6] > 10.f ? 10.f : r[6];
+                        for (int k = 0; k < 3; k++) { int v = (int)((r[k] + r[3 + k] * t + 1.5f) / 3.0f * g_bvhSortCells); e[k] = v < 0 ? 0 : (v >= g_bvhSortCells ? g_bvhSortCells - 1 : v); }
+                        const long long ko = ((long long)c[2] * g_bvhSortCells + c[1]) * g_bvhSortCells + c[0], ke = ((long long)e[2] * g_bvhSortCells + e[1]) * g_bvhSortCells + e[0];
+                        const long long n3 = (long long)g_bvhSortCells * g_bvhSortCells * g_bvhSortCells;
+                        key = g_bvhSortMode == 1 ? ko * n3 + ke : (g_bvhSortMode == 2 ? ke * n3 + ko : ko);
+                    }
+                }
+                rays.push_back(RaySpan{ i + 1, j, key });
+            }
+            rayNo++;
             i = j - 1;
         }
     }
+    if (g_bvhSortCells > 0) std::stable_sort(rays.begin(), rays.end(), [](const RaySpan &a, const RaySpan &b) { return a.key < b.key; });
     double laneCost = 0, waveCost = 0, sumI = 0, sumL = 0, maxI = 0, maxL = 0, rounds = 0;
     for (const RaySpan &r : rays) {
         double nI = 0, nL = 0;
