@@ -54,11 +54,7 @@ struct Scratch {
     LightStore store;                 /* S*nLocal slots (+ count[nLocal]) */
     int *dPathStart;                  /* nLocal+1 */
     int *dLocalTotal;                 /* 1 */
-    int *dTileSums[6];                /* scan scratch: [0] main stream, [1] side stream (grid build), [2] splat stream, [3] sort stream,
-                                         [4], [5] the task sorts of K3b / K3c */
-    /* task order of K3b / K3c for scenes behind a BVH (vcm_kernels.h, k_task_key_*): allocated when such a scene first borrows the arena */
-    int *dDiKey, *dDiOrder, *dVcKey, *dVcOrder;   /* per DI / VC task slot */
-    int *dTaskCount, *dTaskStart;     /* histogram and scan: BINS_DI + 2 words for the DI tasks, then BINS_VC + 2 for the VC tasks */
+    int *dTileSums[4];                /* scan scratch: [0] main stream, [1] side stream (grid build), [2] splat stream, [3] sort stream */
     int *dPixCount, *dPixStart;       /* N+2 each: light splats per pixel, and the start of every pixel's list (K1d) */
     int *dSplatArrival;               /* per light vertex: the place of its splat in its pixel's list */
     F4 *dSplatList;                   /* per light vertex: the splats grouped by pixel */
@@ -96,7 +92,7 @@ struct Arena {
     unsigned long long ownerThread;   /* host thread that borrowed it, 0 = none */
     int device;
     Scratch s;
-    size_t capLocal, capN; int capS, capL; bool capSharded, capTaskSort;
+    size_t capLocal, capN; int capS, capL; bool capSharded;
     size_t bytes;                     /* device memory held */
     bool allocated;
     hipEvent_t lastUse; bool eventReady, lastValid;
@@ -209,7 +205,7 @@ static Arena *arena_new(int device, ArenaPool *pool)
     Arena *a = new Arena();
     a->device = device;
     memset((void *)&a->s, 0, sizeof(Scratch));
-    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false; a->capTaskSort = false; a->bytes = 0;
+    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false; a->bytes = 0;
     a->allocated = false; a->eventReady = a->lastValid = false; a->lastUser = NULL;
     a->pool = pool; a->ownerThread = 0; a->busy = false;
     a->mtx = pool ? &pool->m : &a->ownMtx;
@@ -235,8 +231,7 @@ static void arena_free_buffers(Arena *a)
 {
     Scratch &s = a->s;
     DFREE(s.store.v); DFREE(s.store.count); DFREE(s.store.lenMask);
-    DFREE(s.dPathStart); DFREE(s.dLocalTotal); for (int w = 0; w < 6; w++) DFREE(s.dTileSums[w]);
-    DFREE(s.dDiKey); DFREE(s.dDiOrder); DFREE(s.dVcKey); DFREE(s.dVcOrder); DFREE(s.dTaskCount); DFREE(s.dTaskStart);
+    DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums[0]); DFREE(s.dTileSums[1]); DFREE(s.dTileSums[2]); DFREE(s.dTileSums[3]);
     DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
@@ -246,21 +241,19 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
     DFREE(s.dQueryKey); DFREE(s.dSortedVertex); DFREE(s.dQueryStart); DFREE(s.dQueryCount); DFREE(s.dQueryArrival);
     a->allocated = false;
-    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false; a->capTaskSort = false;
+    a->capLocal = a->capN = 0; a->capS = a->capL = 0; a->capSharded = false;
 }
 
-static bool task_sort_wanted(const vcm_ctx *c);
 /* called by the context that holds the busy token; grows the arena to what this context needs */
-static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sharded, bool taskSort)
+static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sharded)
 {
     if (!a->eventReady) { HIPCHK(hipEventCreateWithFlags(&a->lastUse, hipEventDisableTiming)); a->eventReady = true; }
-    if (a->allocated && nLocal <= a->capLocal && N <= a->capN && S <= a->capS && L <= a->capL && (!sharded || a->capSharded) &&
-        (!taskSort || a->capTaskSort))
+    if (a->allocated && nLocal <= a->capLocal && N <= a->capN && S <= a->capS && L <= a->capL && (!sharded || a->capSharded))
         return 0;
     HIPCHK(hipDeviceSynchronize());   /* rare: another context's kernels may still use the old buffers */
     const size_t cl = nLocal > a->capLocal ? nLocal : a->capLocal, cn = N > a->capN ? N : a->capN;
     const int cs = S > a->capS ? S : a->capS, cL = L > a->capL ? L : a->capL;
-    const bool sh = sharded || a->capSharded, ts = taskSort || a->capTaskSort;
+    const bool sh = sharded || a->capSharded;
     arena_free_buffers(a);
     a->lastValid = false;
     a->lastUser = NULL;   /* the previous borrower's Scratch copy points at freed memory now */
@@ -273,7 +266,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dPathStart, cl + 1) || dalloc(&s.dLocalTotal, 1)) return -1;
     size_t maxScan = (cn > cl ? cn : cl) + 1;
     if (maxScan < (size_t)VCM_QSORT_BUCKETS + 1) maxScan = (size_t)VCM_QSORT_BUCKETS + 1;
-    for (int w = 0; w < 6; w++) if (dalloc(&s.dTileSums[w], maxScan / VCM_SCAN_TILE + 2)) return -1;
+    for (int w = 0; w < 4; w++) if (dalloc(&s.dTileSums[w], maxScan / VCM_SCAN_TILE + 2)) return -1;
     if (dalloc(&s.dRecordsLocal, slots * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dSlotOfVertex, slots) || dalloc(&s.dSplat, slots)) return -1;
     if (dalloc(&s.dPixCount, cn + 2) || dalloc(&s.dPixStart, cn + 2) || dalloc(&s.dSplatArrival, slots) || dalloc(&s.dSplatList, slots)) return -1;
@@ -303,10 +296,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     const size_t qsN = (cn > (size_t)VCM_QSORT_BUCKETS ? cn : (size_t)VCM_QSORT_BUCKETS) + 2;   /* also pixStart of K1d */
     if (dalloc(&s.dQueryStart, qsN) || dalloc(&s.dQueryCount, (size_t)VCM_QSORT_BUCKETS + 2) ||
         dalloc(&s.dQueryArrival, vslots)) return -1;
-    if (ts && (dalloc(&s.dDiKey, vslots) || dalloc(&s.dDiOrder, vslots) || dalloc(&s.dVcKey, vcslots) || dalloc(&s.dVcOrder, vcslots) ||
-               dalloc(&s.dTaskCount, (size_t)VCM_TASKSORT_BINS_DI + VCM_TASKSORT_BINS_VC + 4) ||
-               dalloc(&s.dTaskStart, (size_t)VCM_TASKSORT_BINS_DI + VCM_TASKSORT_BINS_VC + 4))) return -1;
-    a->capLocal = cl; a->capN = cn; a->capS = cs; a->capL = cL; a->capSharded = sh; a->capTaskSort = ts;
+    a->capLocal = cl; a->capN = cn; a->capS = cs; a->capL = cL; a->capSharded = sh;
     a->allocated = true;
     a->bytes = g_allocBytes - bytesBefore;
     return 0;
@@ -376,7 +366,7 @@ static int arena_acquire(vcm_ctx *c, int S, int L)
         if (a->lastUser != c) a->lastUser = NULL;
     }
     c->holdsArena = true;
-    if (arena_ensure(a, (size_t)c->nLocal, (size_t)c->N, S, L, c->world > 1, task_sort_wanted(c))) return -1;
+    if (arena_ensure(a, (size_t)c->nLocal, (size_t)c->N, S, L, c->world > 1)) return -1;
     *static_cast<Scratch *>(c) = a->s;
     if (wait && a->lastValid) HIPCHK(hipStreamWaitEvent(c->stream, a->lastUse, 0));
     return 0;
@@ -1002,30 +992,6 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
  * are resident (6 waves per SIMD); the 2048 of round 1 meant a second round that occupied a third of the chip.
  * Measured (1024 / 1536 / 1792 / 2048 / 3072 / 4608 / 8192): K3b+c 2.16 / 1.96 / 2.06 / 1.99 / 1.83 / 1.82 / 1.88 ms
  * next to the tail of the grid build (profiles/r03j_ab_summary.txt). */
-/* K3b / K3c deal their tasks out by where the shadow ray starts and ends when the scene sits behind a BVH (vcm_kernels.h).
-   SMALLVCM_AMD_TASK_SORT=0: queue order, as for the brute-force scenes. */
-static bool task_sort_wanted(const vcm_ctx *c)
-{
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("SMALLVCM_AMD_TASK_SORT"); off = (e && e[0] == '0') ? 1 : 0; }
-    return !off && !c->scene->nodes.empty();
-}
-/* histogram -> scan -> scatter of one task queue on stream q; the kernel that follows reads order[0 .. *total) */
-static int launch_task_sort(vcm_ctx *c, hipStream_t q, bool vc, int scanSlot)
-{
-    const int nk = vc ? VCM_TASKSORT_BINS_VC : VCM_TASKSORT_BINS_DI;
-    int *count = c->dTaskCount + (vc ? VCM_TASKSORT_BINS_DI + 2 : 0), *start = c->dTaskStart + (vc ? VCM_TASKSORT_BINS_DI + 2 : 0);
-    if (zero_ranges(q, count, ((size_t)nk + 1) * sizeof(int))) return -1;
-    if (vc) hipLaunchKernelGGL(k_task_key<true>, dim3(2048), dim3(256), 0, q, c->dScene, c->P, c->vs, c->store, c->dVcKey, count);
-    else hipLaunchKernelGGL(k_task_key<false>, dim3(2048), dim3(256), 0, q, c->dScene, c->P, c->vs, c->store, c->dDiKey, count);
-    const StampArgs none = { { NULL, NULL, NULL, NULL } };
-    /* the number of tasks that are not holes goes to count[nk], where K3b / K3c read it (the scatter advances the starts) */
-    if (launch_scan_on<int>(c, scanSlot, q, count, nk, start, count + nk, 0, none)) return -1;
-    if (vc) hipLaunchKernelGGL(k_task_scatter<VCM_TASKSORT_KEYS_VC>, dim3(2048), dim3(256), 0, q, (const int *)(c->vs.count + 2), (const int *)c->dVcKey, start, c->dVcOrder);
-    else hipLaunchKernelGGL(k_task_scatter<VCM_TASKSORT_KEYS_DI>, dim3(2048), dim3(256), 0, q, (const int *)(c->vs.count + 1), (const int *)c->dDiKey, start, c->dDiOrder);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
 static int task_blocks(int nLocal)
 {
     static int n = -1;
@@ -1419,20 +1385,11 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             static int vcForce = -2;
             if (vcForce == -2) { const char *e = getenv("SMALLVCM_AMD_VC_STREAM"); vcForce = e ? (e[0] == '1' ? 1 : 0) : -1; }
             const bool vcAside = (vcForce != 0) && c->world == 1;
-            const bool taskSort = task_sort_wanted(c);
-#if defined(VCM_TASKSORT_NO_VC)
-            const bool taskSortVc = false;
-#else
-            const bool taskSortVc = taskSort;
-#endif
-            const int *diOrder = taskSort ? c->dDiOrder : NULL, *diTotal = taskSort ? c->dTaskCount + VCM_TASKSORT_BINS_DI : NULL;
-            const int *vcOrder = taskSortVc ? c->dVcOrder : NULL, *vcTotal = taskSortVc ? c->dTaskCount + VCM_TASKSORT_BINS_DI + 2 + VCM_TASKSORT_BINS_VC : NULL;
             if (vcAside) {
                 HIPCHK(hipEventRecord(c->evSplatFork, c->stream));   /* behind K3 */
                 HIPCHK(hipStreamWaitEvent(c->splat, c->evSplatFork, 0));
-                if (taskSortVc && launch_task_sort(c, c->splat, true, 5)) return -1;
                 LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->splat, c->dScene, c->P, c->vs,
-                                   c->store, c->dStats, vcOrder, vcTotal);
+                                   c->store, c->dStats);
                 HIPCHK(hipEventRecord(c->evSplatDone, c->splat));   /* also behind the light splats: same stream */
                 c->splatInFlight = true;
             }
@@ -1457,15 +1414,12 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                 c->scatteredInDI = false;
             }
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
-            if (taskSort && launch_task_sort(c, c->stream, false, 4)) return -1;
             LAUNCH_SC(c, k_connect_di, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
-                               c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream), diOrder, diTotal);
-            if (!vcAside) {
-                if (taskSortVc && launch_task_sort(c, c->stream, true, 5)) return -1;
+                               c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
+            if (!vcAside)
                 LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
-                                   c->store, c->dStats, vcOrder, vcTotal);
-            }
+                                   c->store, c->dStats);
         }
         if (mark(c, EV_CONNECT_K1)) return -1;
     } else {

@@ -317,115 +317,12 @@ k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned c
  * not offer: there the connection loop ran at the trip count of the busiest
  * lane and at 23 % lane utilisation (profiles/r01b_pmc_*). */
 #define VCM_TASK_BLOCK 256
-/* ---------------- task order for scenes behind a BVH ---------------- */
-/* A wave of K3b / K3c traverses the hierarchy with 64 shadow rays in lockstep and pays for the longest of them in every
- * round; in queue order -- the order in which the waves of K3 happened to append -- a wave mixes rays from all over the
- * scene and 0.29 of its lanes work (SQ counters; the host replay profiles/tools/bvh_sim.py gives the same figure).  Dealt
- * out by (cell of the ray's origin, cell of its end point) on a coarse grid over the scene's bounding cube, the rays of a
- * wave walk the same subtrees: 0.55-0.58 in the replay, half the wave-instructions per ray.  A counting sort: key +
- * histogram, scan, scatter (the place inside a bucket is whatever the atomics hand out: every task writes its result by
- * its own index, the order changes nothing but speed).  Holes of the queues drop out on the way.  The brute-force list
- * walks every primitive for every ray: nothing to gain there, and these kernels are not launched. */
-#define VCM_TASKSORT_G_DI 8                                 /* DI tasks: cells per axis of the origin's grid */
-#define VCM_TASKSORT_G_VC 4                                 /* VC tasks: cells per axis, origin and end point */
-#define VCM_TASKSORT_KEYS_DI (VCM_TASKSORT_G_DI * VCM_TASKSORT_G_DI * VCM_TASKSORT_G_DI)                                  /* 512 */
-#define VCM_TASKSORT_KEYS_VC (VCM_TASKSORT_G_VC * VCM_TASKSORT_G_VC * VCM_TASKSORT_G_VC * VCM_TASKSORT_G_VC * VCM_TASKSORT_G_VC * VCM_TASKSORT_G_VC)   /* 4096 */
-/* A surface fills a few cells, so a few keys hold most of the tasks: one global atomic per task put a hundred thousand of
-   them on one word (the first version: 6.6 ms for the two sorts of the mesh scene at 1024^2; a wave adding once per distinct
-   key it holds: still 0.35 ms per pass).  A workgroup therefore takes a CHUNK of consecutive tasks, builds the chunk's
-   histogram in LDS, and goes to the global table once per key it met -- and every key has SUB global bins, a chunk using
-   the one of its number (inside a key the order is free). */
-#define VCM_TASKSORT_CHUNK 2048
-#define VCM_TASKSORT_SUB 8
-#define VCM_TASKSORT_BINS_DI (VCM_TASKSORT_KEYS_DI * VCM_TASKSORT_SUB)
-#define VCM_TASKSORT_BINS_VC (VCM_TASKSORT_KEYS_VC * VCM_TASKSORT_SUB)
-template <int G>
-__device__ __forceinline__ int tasksort_cell(const DScene &sc, float x, float y, float z)
-{
-    const float inv = (float)G / (2.f * sc.sceneRadius);
-    const int cx = min(max((int)((x - (sc.sceneCenter[0] - sc.sceneRadius)) * inv), 0), G - 1);
-    const int cy = min(max((int)((y - (sc.sceneCenter[1] - sc.sceneRadius)) * inv), 0), G - 1);
-    const int cz = min(max((int)((z - (sc.sceneCenter[2] - sc.sceneRadius)) * inv), 0), G - 1);
-    return (cz * G + cy) * G + cx;
-}
-/* key of every task (-1: a hole of the queue) + the histogram.  VC: camera vertex -> light vertex; DI: the ray ends on a
-   light the task has yet to sample -- the origin's cell alone, on a finer grid */
-template <bool VC>
-__global__ void __launch_bounds__(256) k_task_key(const DScene *__restrict__ scp, IterParams P, VertexStore vs, LightStore store, int *key, int *count)
-{
-    constexpr int KEYS = VC ? VCM_TASKSORT_KEYS_VC : VCM_TASKSORT_KEYS_DI;
-    __shared__ int hist[KEYS];
-    const int n = vs.count[VC ? 2 : 1];
-    for (int c0 = blockIdx.x * VCM_TASKSORT_CHUNK; c0 < n; c0 += gridDim.x * VCM_TASKSORT_CHUNK) {
-        for (int i = threadIdx.x; i < KEYS; i += 256) hist[i] = 0;
-        __syncthreads();
-        /* every load of the eight tasks in flight before the first is used: no early exit inside the loops */
-        int vi[VCM_TASKSORT_CHUNK / 256], k[VCM_TASKSORT_CHUNK / 256];
-        F4 a[VCM_TASKSORT_CHUNK / 256];
-#pragma unroll
-        for (int u = 0; u < VCM_TASKSORT_CHUNK / 256; u++) {
-            const int t = c0 + u * 256 + (int)threadIdx.x;
-            vi[u] = t < n ? (VC ? vs.vcTask[2 * t] : vs.diTask[t]) : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < VCM_TASKSORT_CHUNK / 256; u++) a[u] = vi[u] >= 0 ? vq(vs, 0, vi[u]) : mk4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < VCM_TASKSORT_CHUNK / 256; u++) {
-            const int t = c0 + u * 256 + (int)threadIdx.x;
-            k[u] = -1;
-            if (vi[u] >= 0) {
-                if (VC) {
-                    const F4 b = lv(store, (size_t)vs.vcTask[2 * t + 1] * (size_t)P.nLocal + (size_t)f2u(a[u].w), 0);
-                    k[u] = tasksort_cell<VCM_TASKSORT_G_VC>(*scp, a[u].x, a[u].y, a[u].z) * (VCM_TASKSORT_G_VC * VCM_TASKSORT_G_VC * VCM_TASKSORT_G_VC) +
-                           tasksort_cell<VCM_TASKSORT_G_VC>(*scp, b.x, b.y, b.z);
-                } else k[u] = tasksort_cell<VCM_TASKSORT_G_DI>(*scp, a[u].x, a[u].y, a[u].z);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < VCM_TASKSORT_CHUNK / 256; u++) {
-            const int t = c0 + u * 256 + (int)threadIdx.x;
-            if (k[u] >= 0) atomicAdd(&hist[k[u]], 1);
-            if (t < n) key[t] = k[u];
-        }
-        __syncthreads();
-        const int sub = (c0 / VCM_TASKSORT_CHUNK) & (VCM_TASKSORT_SUB - 1);
-        for (int i = threadIdx.x; i < KEYS; i += 256) if (hist[i]) atomicAdd(&count[i * VCM_TASKSORT_SUB + sub], hist[i]);
-        __syncthreads();
-    }
-}
-/* `cursor` = the bins' starts (the scan of the histogram), advanced by a chunk's share as the chunks arrive */
-template <int KEYS>
-__global__ void __launch_bounds__(256) k_task_scatter(const int *__restrict__ nTasks, const int *__restrict__ key, int *cursor, int *order)
-{
-    __shared__ int hist[KEYS];
-    const int n = *nTasks;
-    for (int c0 = blockIdx.x * VCM_TASKSORT_CHUNK; c0 < n; c0 += gridDim.x * VCM_TASKSORT_CHUNK) {
-        for (int i = threadIdx.x; i < KEYS; i += 256) hist[i] = 0;
-        __syncthreads();
-        int k[VCM_TASKSORT_CHUNK / 256], r[VCM_TASKSORT_CHUNK / 256];
-#pragma unroll
-        for (int u = 0; u < VCM_TASKSORT_CHUNK / 256; u++) {
-            const int t = c0 + u * 256 + (int)threadIdx.x;
-            k[u] = t < n ? key[t] : -1;
-            r[u] = k[u] >= 0 ? atomicAdd(&hist[k[u]], 1) : 0;   /* the task's place among the chunk's tasks of its key */
-        }
-        __syncthreads();
-        const int sub = (c0 / VCM_TASKSORT_CHUNK) & (VCM_TASKSORT_SUB - 1);
-        {   /* the returning atomics of a thread's bins go out together */
-            int base[KEYS / 256];
-#pragma unroll
-            for (int j = 0; j < KEYS / 256; j++) { const int i = j * 256 + (int)threadIdx.x, h = hist[i]; base[j] = h ? atomicAdd(&cursor[i * VCM_TASKSORT_SUB + sub], h) : 0; }
-#pragma unroll
-            for (int j = 0; j < KEYS / 256; j++) hist[j * 256 + (int)threadIdx.x] = base[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < VCM_TASKSORT_CHUNK / 256; u++)
-            if (k[u] >= 0) order[hist[k[u]] + r[u]] = c0 + u * 256 + (int)threadIdx.x;
-        __syncthreads();
-    }
-}
-
+/* (Round 4 dealt the tasks of K3b / K3c out by (cell of the ray's origin, cell of its end point) for scenes behind a BVH --
+ * a counting sort with chunk histograms in LDS.  The host replay had promised half the wave-instructions per ray
+ * (profiles/r06m1_bvh_sim.txt) and the kernels delivered: K3b 850 -> 360 us, K3c 1040 -> 700 us on the mesh scene.  The two
+ * sorts cost what they saved -- 452 against 455 Mpaths/s, the same on meshes of 80 000 and 320 000 triangles -- because
+ * everything behind K3 is throughput-bound there and K4 is the longest of it: profiles/r06ts_tasksort_m1.txt.  Commit ce1ce6b
+ * has the code.) */
 #if defined(VCM_TASK_WAVES)   /* experiment: cap the registers of K3b / K3c for more waves per SIMD */
 #define VCM_TASK_ATTR __attribute__((amdgpu_waves_per_eu(VCM_TASK_WAVES, VCM_TASK_WAVES)))
 #else
@@ -434,16 +331,14 @@ __global__ void __launch_bounds__(256) k_task_scatter(const int *__restrict__ nT
 template <class SC>
 __global__ void __launch_bounds__(VCM_TASK_BLOCK) VCM_TASK_ATTR
 k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsigned long long *gstats,
-             const int *__restrict__ bucketStart, int *sortedVertex, StampArgs st,
-             const int *__restrict__ order /* NULL: queue order */, const int *__restrict__ nOrdered)
+             const int *__restrict__ bucketStart, int *sortedVertex, StampArgs st)
 {
     stamp_entry(st);
     const SC &sc = *static_cast<const SC *>(scp);
     stage_scene_tables(sc);
-    const int n = order ? *nOrdered : vs.count[1];
+    const int n = vs.count[1];
     LaneStats ls; lane_stats_zero(ls);
-    for (int i = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; i < n; i += gridDim.x * VCM_TASK_BLOCK) {
-        const int t = order ? order[i] : i;
+    for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
         const int vi = vs.diTask[t];
         if (vi < 0) continue;   /* hole */
         size_t ps;
@@ -460,14 +355,13 @@ k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsig
 template <class SC>
 __global__ void __launch_bounds__(VCM_TASK_BLOCK) VCM_TASK_ATTR
 k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, LightStore store,
-             unsigned long long *gstats, const int *__restrict__ order /* NULL: queue order */, const int *__restrict__ nOrdered)
+             unsigned long long *gstats)
 {
     const SC &sc = *static_cast<const SC *>(scp);
     stage_scene_tables(sc);
-    const int n = order ? *nOrdered : vs.count[2];
+    const int n = vs.count[2];
     LaneStats ls; lane_stats_zero(ls);
-    for (int i = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; i < n; i += gridDim.x * VCM_TASK_BLOCK) {
-        const int t = order ? order[i] : i;
+    for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
         const int vi = vs.vcTask[2 * t];
         if (vi < 0) continue;   /* hole */
         const V3 v = eval_vc_task(sc, P, vs, store, vi, vs.vcTask[2 * t + 1], ls);

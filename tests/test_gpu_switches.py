@@ -28,9 +28,7 @@ SWITCHES = [
     "SMALLVCM_AMD_MERGE_BLOCKS=64",
     "SMALLVCM_AMD_NO_RECTS=1",                 # the Pluecker filter (SceneQuads kernels) instead of the rectangles
     "SMALLVCM_AMD_NO_RECTS=1 SMALLVCM_AMD_NO_ONEPLANE=1",   # ... and the general list (SceneList kernels)
-    "SMALLVCM_AMD_FORCE_BVH=1",                # the boxes through the BVH kernels (K3b / K3c then take their tasks in sorted order)
-    "SMALLVCM_AMD_FORCE_BVH=1 SMALLVCM_AMD_TASK_SORT=0",   # ... in queue order
-    "SMALLVCM_AMD_FORCE_BVH=1 SMALLVCM_AMD_VC_STREAM=0",   # ... both sorts on the main stream
+    "SMALLVCM_AMD_FORCE_BVH=1",                # the boxes through the BVH kernels
     "SMALLVCM_AMD_GENERAL_POW=1",              # the kernels that keep the general powf (non-integer Phong exponents)
     "SMALLVCM_AMD_GENERAL_POW=1 SMALLVCM_AMD_FORCE_BVH=1",   # SceneBvhG
     "SMALLVCM_AMD_NO_SIDE=1",                  # grid build in line
