@@ -104,3 +104,23 @@ def test_product_does_not_reference_oracle():
                     if re.search(r"#\s*include.*oracle|import\s+oracle|from\s+oracle|liboracle|oracle_lib", line):
                         bad.append((f, line.strip()))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("value", ["", "all", "current", "0", "0,0,0", "0,99,0", "7,8", "nonsense", "0,,"])
+def test_the_device_list_of_vcm_next_device_is_parsed_safely(value):
+    """SMALLVCM_AMD_DEVICES (which devices a renderer-per-host-core host is dealt, smallvcm.cxx:61-72) is read once
+    per process: a process per value.  Whatever the variable holds, the answer is a device that exists -- device 0 on a box with
+    one GPU or none -- three times in a row (the list is dealt round-robin)."""
+    import sys
+    code = ("import ctypes as C\n"
+            "L = C.CDLL(%r)\n"
+            "L.vcm_next_device.restype = C.c_int\n"
+            "L.vcm_device_count.restype = C.c_int\n"
+            "n = L.vcm_device_count()\n"
+            "d = [L.vcm_next_device() for _ in range(3)]\n"
+            "assert all(0 <= x < max(n, 1) for x in d), (n, d)\n"
+            "print(n, d)\n" % LIB_PATH)
+    env = dict(os.environ)
+    env["SMALLVCM_AMD_DEVICES"] = value
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-400:]
