@@ -124,3 +124,32 @@ def test_the_device_list_of_vcm_next_device_is_parsed_safely(value):
     env["SMALLVCM_AMD_DEVICES"] = value
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-400:]
+
+
+def test_every_entry_point_refuses_a_null_context():
+    """Every function of include/smallvcm_amd.h that takes a vcm_ctx* returns -1 (vcm_destroy: does nothing) for NULL: a host
+    whose vcm_create failed and went unchecked gets errors, not a crash.  The prototypes are read from the header; in a
+    process of its own."""
+    import sys
+    code = r'''
+import ctypes as C, re
+L = C.CDLL(%r)
+hdr = re.sub(r'/\*.*?\*/', '', open(%r).read(), flags=re.S)
+seen = 0
+for m in re.finditer(r'\b(int|void)\s+(vcm_\w+)\s*\(\s*vcm_ctx\s*\*\s*\w+\s*([^)]*)\)\s*;', hdr):
+    ret, name, rest = m.group(1), m.group(2), m.group(3)
+    args = [C.c_void_p(None)]
+    for p in [p.strip() for p in rest.split(',') if p.strip()]:
+        if 'float' in p and '*' not in p: args.append(C.c_float(0.0))
+        elif '*' in p: args.append(C.c_void_p(None))
+        elif 'long long' in p: args.append(C.c_longlong(0))
+        else: args.append(C.c_int(0))
+    f = getattr(L, name)
+    f.restype = C.c_int if ret == 'int' else None
+    r = f(*args)
+    seen += 1
+    if ret == 'int' and name not in ('vcm_is_wavefront', 'vcm_iterations'): assert r == -1, (name, r)
+assert seen >= 28, seen
+''' % (LIB_PATH, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "smallvcm_amd.h"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-600:])
