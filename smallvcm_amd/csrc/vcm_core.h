@@ -2865,6 +2865,11 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
 #if defined(VCM_NO_DEFER)   /* measurement switch: store on the spot */
                 if (k >= 0) vs.sortArrival[vi] = atomicAdd(&vs.bucketCount[k], 1);
 #else
+                /* the place the atomic hands back goes to memory at the lane's NEXT append (or when the kernel ends): a whole bounce
+                   later, so no wave waits for the round trip (stored at the end of the same step -- rounds 3-4 -- the wait was
+                   still visible at the end of the step: +0.6 %, four pairs of 40 iterations, profiles/r06zd_defer_ab.txt) */
+                if (wqs.pendingVertex >= 0) vs.sortArrival[wqs.pendingVertex] = wqs.pendingArrival;
+                wqs.pendingVertex = -1;
                 if (k >= 0) { wqs.pendingVertex = vi; wqs.pendingArrival = atomicAdd(&vs.bucketCount[k], 1); }
 #endif
                 else vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */

@@ -233,9 +233,6 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
         if (alive) {
             alive = camera_path_step<MODE>(sc, P, path, store, grid, ls, ms, vs, wqs, qk);
             RC_RESET;
-#if !defined(VCM_NO_DEFER)
-            if (MODE == 1 && wqs.pendingVertex >= 0) { vs.sortArrival[wqs.pendingVertex] = wqs.pendingArrival; wqs.pendingVertex = -1; }
-#endif
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
@@ -245,6 +242,7 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
         }
         RC_MARK(22);
     }
+    if (MODE == 1 && wqs.pendingVertex >= 0) vs.sortArrival[wqs.pendingVertex] = wqs.pendingArrival;   /* the last append's place (vcm_core.h) */
     if (MODE == 1) {   /* mark the unused tails of this wave's last blocks as holes */
         const int vb = wq_load(wqs.v.p), vl = wq_load(wqs.v.p + 1), db = wq_load(wqs.di.p), dl = wq_load(wqs.di.p + 1), cb = wq_load(wqs.vc.p), cl = wq_load(wqs.vc.p + 1);
         for (int i = (int)lane; i < vl; i += VCM_WAVE) {
