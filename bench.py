@@ -6,19 +6,26 @@ src/vertexcm.hxx:284-548) on BASELINE.json's workloads.
   python bench.py --scene 3 --algo vcm --res 1024                any other built-in configuration (named in the line)
 
 A "step" is one RunIteration = N light sub-paths + N camera sub-paths, N = res*res.
-Mpaths/s = 2*N*steps / seconds / 1e6.  One JSON line on stdout:
+Mpaths/s = 2*N*steps / seconds / 1e6 (BASELINE.md).
 
-  value         whole-job Mpaths/s of the timed region (K steps after W warm-up steps, barrier + synchronize
-                on both sides, max over ranks); `metric` and `config.workload` name what was actually run;
-  roofline      for the kernel with the largest mean time in the timed region: its share of the algorithmic
-                bytes (split per kernel in DESIGN.md section 5, evaluated with the run's
-                own counters) / its HIP-event time / 8 TB/s; `traffic` = HBM bytes per launch of that kernel
-                measured by TWO CHILD RUNS of this file under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-                (counter passes on their own, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM), i.e. of
-                this binary on this box; if the profiler is not available the figure of profiles/*_traffic.json is
-                used when it was collected on the same kernel sources (hash compared), else null;
+STDOUT IS ONE SHORT JSON LINE (< 4 KB: the driver keeps a tail of stdout and parses its last line; round 4's 20 KB line did
+not survive that).  Everything else the run measured -- per-kernel blocks, counters, the config blocks, CPU samples --
+goes to bench_detail.json (repository root, copied to gpurun_out/ when that exists); the line names the file.
+
+  value         whole-job Mpaths/s of the timed region (K steps after W warm-up steps, barrier + synchronize on both sides,
+                max over ranks); `metric` and `config.workload` name what was actually run;
+  roofline      for the kernel with the largest mean time in the timed region (device-clock stamps / HIP events on the
+                stream the kernel runs on, vcm_api.hip mark()).  `frac` is a fraction (<= 1) or null: with counters it is
+                max(measured HBM traffic / kernel time / 8 TB/s, class-weighted VALU issue time / kernel time) and `bound`
+                says which; `traffic` = HBM bytes per launch from TWO CHILD RUNS of this file under `rocprofv3 --pmc
+                FETCH_SIZE` / `--pmc WRITE_SIZE` (counter passes on their own; FETCH_SIZE doubled per MI355X_MICROARCH.md
+                section HBM), a third pass collects the SQ VALU group; without a profiler the recording
+                profiles/*_counters_<config>.json is used if it was made on the same kernel sources (hash compared), else
+                frac is null.  SURVEY 8(d)'s gather model stays beside it as frac_algorithmic (it exceeds 1 for the
+                cell-sorted merge and bounds nothing); iteration_frac = the whole iteration's algorithmic bytes / time / peak;
   configs       N = 1, headline run only: BASELINE.json's other single-GPU configurations (C1 scene 1 vcm 512^2,
-                C2 scene 3 vcm 1024^2, C3 scene 1 bpm 2048^2), each timed the same way with its own roofline block;
+                C2 scene 3 vcm 1024^2, C3 scene 1 bpm 2048^2) timed the same way, C1-C3 with their own counter passes;
+                one summary each in the line, the blocks in the detail file;
   cpu_baseline  rank 0, N = 1: the UNMODIFIED reference (oracle/_ref/libsmallvcm_ref_stock.so = /root/reference/src
                 built with the flags of its Makefile:5, its own render() loop: one renderer per thread, iterations
                 dealt out, smallvcm.cxx:52-151) timed on this box's host cores in this run, wall clock, on the same
@@ -26,12 +33,12 @@ Mpaths/s = 2*N*steps / seconds / 1e6.  One JSON line on stdout:
                 path-parallel over all cores, on a bounded sample.  Baseline only.
 
 N = 1 and N > 1 are timed by the SAME host: the C++ farm (one rank thread at N = 1; `host_cross_check` repeats the headline
-through the Python / ctypes loop).  N > 1 runs the reference's render() decomposition (smallvcm.cxx:61-72, :99-108, :116-142) on the C++ host
-(smallvcm_amd/host/vcm_farm.cpp behind include/smallvcm_amd_farm.h: one host thread per GPU, RCCL between them) with a
-GROUP of --shards GPUs as one "thread": inside a group the paths of an iteration are sharded by index and the
-light-vertex merge records are all-gathered (RCCL) every iteration; two renderers take turns on every group
-(--inflight); one framebuffer all-reduce at read-out.  --shards N = one renderer across all GPUs ("strong"); the default
-is pairs ("weak").  Both ways of launching work:
+through the Python / ctypes loop).  N > 1 DEFAULT = north_star's decomposition: ONE renderer whose light paths and pixels
+are sharded by index over all N GPUs; every iteration each rank sorts its own light vertices by hash cell, the ranks
+all-gather them (RCCL), place them into the identical grid, merge their own pixels; one framebuffer all-reduce at
+read-out ("scaling": "strong").  The replica hybrid of round 4 (pairs of GPUs x 2 renderers in flight = mostly the
+reference's iteration parallelism, smallvcm.cxx:61-72; "weak") is timed beside it as hybrid_decomposition
+(--shards / --inflight select any other shape).  Both ways of launching work:
   python bench.py --gpus N                                      one process, N rank threads (ncclCommInitRank x N in a group)
   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N     one process per GPU; rank 0 makes the RCCL ids,
                                                                 a gloo broadcast ships them, the farm does the rest
@@ -55,9 +62,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-# VALU issue roofline: a wave64 VALU instruction occupies its SIMD (16 lanes wide) for 4 cycles; 256 CUs x 4 SIMDs at the
-# nominal 2.4 GHz.  frac = SQ_INSTS_VALU x 4 / (1024 x 2.4e9) / kernel seconds; x lane utilisation = useful lane-throughput.
-VALU_SIMDS, VALU_CLK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 4
+# VALU issue roofline.  MI355X_MICROARCH.md "Wave scheduling": 4 SIMD-32 per CU, a wave64 instruction issues over 2 cycles
+# (157.3 TFLOP/s fp32 = 1024 SIMDs x 32 lanes x 2 x 2.4 GHz).  What a SIMD actually sustains was measured on this chip by
+# profiles/tools/valu_bench.hip (profiles/r02h_valu_bench.txt, >= 2 waves per SIMD, in cycles of the nominal clock): plain
+# fp32 / int32 2.7, binary64 add / mul / fma 5.2, transcendentals (rcp, sqrt, ...) 8.4.  The roof weighs the run's
+# instruction mix with THOSE costs (rounds 2-4 used a flat 4 cycles, which is no peak: kernels printed 1.04-1.12 of it):
+#   issue_ms = (plain x 2.7 + f64 x 5.2 + trans x 8.4) / (1024 SIMDs x 2.4 GHz);  frac = issue_ms / kernel_ms  (<= 1)
+# binary64 fma has no counter in the group collected here and is priced as plain: issue_ms is a lower bound, frac errs low.
+VALU_SIMDS, VALU_CLK_HZ = 1024, 2.4e9
+VALU_CYCLES = {"plain": 2.7, "f64": 5.2, "trans": 8.4}
+LINE_LIMIT = 4096        # the driver keeps a tail of stdout: the JSON line must fit it with room to spare
 # kernel-name PREFIXES as rocprofv3 prints them (the ray-casting kernels are templates over the kind of scene:
 # "vcm::k_camera_trace<1, vcm::SceneList>")
 KERNEL_KEYS = {"k_light_trace": ["vcm::k_light_trace<1"], "k_camera_trace": ["vcm::k_camera_trace<1"],
@@ -128,6 +142,35 @@ def recorded_traffic(kernel):
     return None, None
 
 
+def counters_file(tag, config_name):
+    return os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (tag, config_name))
+
+
+def save_counters(tag, config_name, workload, counters, note):
+    """a live counter set (the three --pmc child runs) as a recording for runs without a profiler: keyed by configuration
+    and by the hash of the kernel sources it was collected on"""
+    rec = {"config": config_name, "workload": workload, "kernel_src_sha16": kernel_source_hash(), "note": note,
+           "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch (FETCH_SIZE before its calibration factor), SQ_* as counted, _us_* = "
+                    "mean kernel duration under the profiler (serialised dispatches), _n_* = dispatches",
+           "kernels": counters}
+    with open(counters_file(tag, config_name), "w") as f:
+        json.dump(_clean(rec), f, indent=1)
+        f.write("\n")
+
+
+def recorded_counters(config_name):
+    """profiles/*_counters_<config>.json collected on THESE kernel sources, newest first -> (counters, file) or (None, None)"""
+    want = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters_%s.json" % config_name)), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("kernel_src_sha16") == want and d.get("config") == config_name and d.get("kernels"):
+                return d["kernels"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def _pmc_table(csv_path, skip):
     """{kernel base name: {counter: mean per dispatch, "_us": mean duration, "_n": dispatches per iteration}} with the first
     `skip` dispatches ... of each kernel dropped (a kernel launched k times per iteration: the first skip * k)"""
@@ -160,28 +203,39 @@ def live_counters(args):
     if exe is None:
         return None, "rocprofv3 not found"
     warm, steps = args.warmup, args.steps   # the SAME iteration window as the timed run: traffic, VALU counters and kernel_ms agree
-    groups = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
-              "valu": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]}
+    # per group: the counter lists to try in turn (the second VALU list is rounds 2-4's, without the instruction classes)
+    groups = {"fetch": [["FETCH_SIZE"]], "write": [["WRITE_SIZE"]],
+              "valu": [["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                        "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F32"],
+                       ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]]}
     merged = {}
-    for gname, counters in groups.items():
-        d = tempfile.mkdtemp(prefix="vcm_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.abspath(__file__), "--child", "--res", str(args.res), "--scene", str(args.scene), "--algo", args.algo,
-               "--steps", str(steps), "--warmup", str(warm)]
-        try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.PIPE, timeout=600)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, "rocprofv3 --pmc %s failed (rc %d)" % (" ".join(counters), r.returncode)
-            for k, v in _pmc_table(files[0], warm / float(warm + steps)).items():
-                m = merged.setdefault(k, {})
-                for c, x in v.items():
-                    m[c if not c.startswith("_") else c + "_" + gname] = x
-        except Exception as e:
-            return None, "rocprofv3 --pmc %s: %r" % (counters[0], e)
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+    for gname, alternatives in groups.items():
+        err = None
+        for counters in alternatives:
+            d = tempfile.mkdtemp(prefix="vcm_pmc_", dir="/tmp")
+            cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--child", "--res", str(args.res), "--scene", str(args.scene), "--algo", args.algo,
+                   "--steps", str(steps), "--warmup", str(warm)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.PIPE, timeout=600)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    err = "rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(counters), r.returncode,
+                                                                     r.stderr.decode("utf-8", "replace").strip()[-160:])
+                    continue
+                for k, v in _pmc_table(files[0], warm / float(warm + steps)).items():
+                    m = merged.setdefault(k, {})
+                    for c, x in v.items():
+                        m[c if not c.startswith("_") else c + "_" + gname] = x
+                err = None
+                break
+            except Exception as e:
+                err = "rocprofv3 --pmc %s: %r" % (counters[0], e)
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        if err is not None:
+            return None, err
     return merged, ("live: rocprofv3 --pmc child runs of this workload (FETCH_SIZE | WRITE_SIZE | SQ VALU group), iterations %d..%d "
                     "= the timed window" % (warm, warm + steps - 1))
 
@@ -198,11 +252,18 @@ def valu_block(counters, prefixes, kernel_ms):
     thr = _sum_over(counters, prefixes, "SQ_THREAD_CYCLES_VALU")
     if not insts or not active or not thr or kernel_ms <= 0:
         return None
-    t_min = insts * VALU_CYCLES_PER_INST / (VALU_SIMDS * VALU_CLK_HZ)
+    f64 = (_sum_over(counters, prefixes, "SQ_INSTS_VALU_ADD_F64") or 0) + (_sum_over(counters, prefixes, "SQ_INSTS_VALU_MUL_F64") or 0)
+    trans = _sum_over(counters, prefixes, "SQ_INSTS_VALU_TRANS_F32") or 0
+    classes = _sum_over(counters, prefixes, "SQ_INSTS_VALU_TRANS_F32") is not None
+    plain = max(insts - f64 - trans, 0)
+    cycles = plain * VALU_CYCLES["plain"] + f64 * VALU_CYCLES["f64"] + trans * VALU_CYCLES["trans"]
+    t_min = cycles / (VALU_SIMDS * VALU_CLK_HZ)
     lane = thr / (active * 64.0)
     frac = t_min / (kernel_ms / 1e3)
     wc, wa = _sum_over(counters, prefixes, "SQ_WAVE_CYCLES"), _sum_over(counters, prefixes, "SQ_WAIT_ANY")
-    return {"insts": int(insts), "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": VALU_SIMDS, "clk_GHz": VALU_CLK_HZ / 1e9,
+    return {"insts": int(insts), "insts_f64": int(f64), "insts_trans": int(trans), "cycles_per_inst": round(cycles / insts, 3),
+            "class_costs": VALU_CYCLES if classes else "classes not collected: every instruction at %.1f cycles" % VALU_CYCLES["plain"],
+            "simds": VALU_SIMDS, "clk_GHz": VALU_CLK_HZ / 1e9,
             "issue_ms": round(t_min * 1e3, 3), "lane_util": round(lane, 3), "frac": round(frac, 4),
             "frac_useful_lanes": round(frac * lane, 4), "wait_share_of_wave_cycles": round(wa / wc, 3) if wc and wa else None}
 
@@ -312,31 +373,40 @@ def add_counters(roof, dom, counters, note, st, n_local):
         roof["iteration_traffic_over_design"] = round(tot / float(max(roof["iteration_design_bytes"], 1)), 3)
 
 
-VALU_PEAK_GINST = VALU_SIMDS * VALU_CLK_HZ / VALU_CYCLES_PER_INST / 1e9   # 614.4 G wave-instructions/s
-
-
 def finalize_roofline(roof):
-    """The line's `frac` must be the fraction of the roofline that BINDS the dominant kernel.  SURVEY 8(d)'s gather model
-    prices every merge candidate as an HBM read; the cell-sorted, query-sorted merge serves most of them from cache, so the
-    model exceeds the peak (> 1) and bounds nothing.  Then: frac = max(measured HBM traffic / time / 8 TB/s, VALU issue
-    fraction), `bound` says which, achieved / peak / unit belong to it, and the model's figure stays as frac_algorithmic.
-    Without counters (no rocprofv3) the algorithmic figure is all there is.  Returns the block with the figures a reader
-    needs first."""
+    """The line's `frac` is the fraction of the roof that BINDS the dominant kernel, and it is a fraction: <= 1, or null.
+
+    SURVEY 8(d)'s gather model prices every merge candidate as an HBM read; the cell-sorted, query-sorted merge serves most
+    of them from cache, so for K4 the model reads more than the 8 TB/s peak and bounds nothing; for K1 / K3 it counts 24
+    bytes per pixel and says nothing either.  So, with counters (live child runs, or a recording made on these kernel
+    sources): frac = max(measured HBM traffic / time / 8 TB/s, class-weighted VALU issue time / time), `bound` says
+    which, achieved / peak / unit belong to it.  Without counters: the model's figure if it is <= 1, else null -- never a
+    number above 1.  The model's own figure always stays beside it as frac_algorithmic.  Returns the block with the
+    figures a reader needs first."""
     alg = {"frac_algorithmic": roof["frac"], "achieved_algorithmic_GBs": roof["achieved"]}
     ft = roof.get("frac_traffic")
     vf = (roof.get("valu") or {}).get("frac")
     head = {"bound": "hbm", "kernel": roof["kernel"], "achieved": roof["achieved"], "peak": roof["peak"], "unit": roof["unit"],
             "frac": roof["frac"]}
-    if roof.get("frac_model_invalid") and (ft is not None or vf is not None):
+    if ft is not None or vf is not None:
         if vf is not None and vf >= (ft or 0.0):
-            insts = roof["valu"]["insts"]
-            head.update({"bound": "valu", "achieved": round(insts / (roof["kernel_ms"] / 1e3) / 1e9, 2), "peak": round(VALU_PEAK_GINST, 1),
-                         "unit": "G wave-instructions/s (1024 SIMDs x 2.4 GHz / 4 cycles)", "frac": vf})
+            v = roof["valu"]
+            peak = VALU_SIMDS * VALU_CLK_HZ / v["cycles_per_inst"] / 1e9
+            head.update({"bound": "valu", "achieved": round(v["insts"] / (roof["kernel_ms"] / 1e3) / 1e9, 2), "peak": round(peak, 1),
+                         "unit": "G wave-instr/s (1024 SIMDs x 2.4 GHz / %.2f cyc)" % v["cycles_per_inst"], "frac": vf})
         else:
             head.update({"bound": "hbm", "achieved": roof["achieved_traffic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (measured HBM traffic)",
                          "frac": ft})
-    elif roof.get("frac_model_invalid"):
-        head["frac_note"] = "SURVEY's gather model exceeds the peak and no counters were collected: frac bounds nothing here"
+    elif roof["kernel"] in ("k_light_trace", "k_camera_trace"):
+        # SURVEY 8(d) gives the trace kernels 68 B per stored vertex / 24 B per pixel: they are bound by the latency of their
+        # dependent chain and by VALU issue, and a byte model says nothing about them -- no counters, no fraction
+        head["frac_note"] = "no counters: SURVEY 8(d)'s bytes do not bound a trace kernel; see frac_algorithmic"
+        head["frac"] = None
+    if head["frac"] is not None and not (0.0 <= head["frac"] <= 1.0):
+        head["frac_note"] = ("%.3f of the %s roof is not a fraction (%s): reported as null" %
+                             (head["frac"], head["bound"], "SURVEY 8(d)'s gather model, no counters" if ft is None and vf is None
+                              else "the roof's peak is not one for this kernel"))
+        head["frac"] = None
     head["limiter"] = roof.get("limiter")
     if roof.get("valu"):
         head["valu_frac"] = roof["valu"]["frac"]
@@ -349,6 +419,115 @@ def finalize_roofline(roof):
         if k not in head and k not in ("frac", "achieved", "peak", "unit", "bound"):
             head[k] = v
     return head
+
+
+def _clean(o):
+    """NaN / inf never reach the line (json.dumps(allow_nan=False) would refuse them): they become null"""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _clean(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_clean(v) for v in o]
+    return o
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def write_detail(full):
+    """everything the run measured (per-kernel blocks, counters, config blocks, CPU samples) -> bench_detail.json; the
+    stdout line only names the file.  -> path relative to the repository (or absolute, if the tree is read-only)"""
+    text = json.dumps(_clean(full), indent=1, allow_nan=False)
+    want = os.environ.get("SMALLVCM_AMD_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    for path in (want, os.path.join(tempfile.gettempdir(), "smallvcm_amd_bench_detail.json")):
+        try:
+            with open(path, "w") as f:
+                f.write(text + "\n")
+            out_dir = os.path.join(ROOT, "gpurun_out")   # on a gpurun box this directory travels back
+            if os.path.isdir(out_dir) and os.path.dirname(os.path.abspath(path)) != out_dir:
+                shutil.copyfile(path, os.path.join(out_dir, "bench_detail.json"))
+            return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+        except OSError:
+            continue
+    return None
+
+
+ROOF_LINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "frac_algorithmic",
+                  "valu_frac", "valu_lane_util", "kernel_ms", "iteration_frac", "iteration_ms", "traffic_source", "frac_note")
+
+
+def short_line(full, detail_path):
+    """The ONE stdout line: what the driver's contract names, the roofline and CPU baseline in figures, one summary per
+    configuration, and where the rest is.  Always below LINE_LIMIT bytes: optional parts go first if it ever is not."""
+    roof = full.get("roofline") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype")}
+    line["data"] = _short(full.get("data", "synthetic"), 80)
+    cfg = full.get("config") or {}
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 200), "baseline_config": _short(cfg.get("baseline_config", ""), 48),
+                      "paths_per_step": cfg.get("paths_per_step"), "parallelism": _short(cfg.get("parallelism", ""), 200)}
+    r = {k: roof.get(k) for k in ROOF_LINE_KEYS if k in roof or k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if "unit" in r:
+        r["unit"] = _short(r["unit"], 60)
+    if r.get("traffic_source"):
+        r["traffic_source"] = _short(r["traffic_source"], 140)
+    if r.get("frac_note"):
+        r["frac_note"] = _short(r["frac_note"], 120)
+    line["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "wall_s", "host_cores") if k in cb}
+        if cb.get("sample"):
+            c["sample"] = _short(cb["sample"], 160)
+        if isinstance(cb.get("all_cores"), dict) and "value" in cb["all_cores"]:
+            c["all_cores"] = {k: cb["all_cores"].get(k) for k in ("value", "cores", "wall_s", "res")}
+        port = cb.get("port") if cb.get("kind") == "reference" else None
+        if isinstance(port, dict) and "value" in port:
+            c["port"] = {"value": port["value"], "cores": port.get("cores")}
+        if "error" in cb:
+            c["error"] = _short(cb["error"], 120)
+        line["cpu_baseline"] = c
+    if full.get("configs"):
+        line["configs"] = []
+        for c in full["configs"]:
+            if "error" in c:
+                line["configs"].append({"name": c.get("name"), "error": _short(c["error"], 60)})
+                continue
+            cr = c.get("roofline") or {}
+            line["configs"].append({"name": c["name"], "value": c["value"], "ms_per_step": c["ms_per_step"],
+                                    "iteration_frac": cr.get("iteration_frac"), "frac": cr.get("frac"), "bound": cr.get("bound"),
+                                    "kernel": cr.get("kernel")})
+    if full.get("host_cross_check"):
+        line["host_cross_check"] = {"value": full["host_cross_check"]["value"], "host": "python/ctypes"}
+    if full.get("strong_decomposition"):
+        sd = full["strong_decomposition"]
+        line["strong_decomposition"] = {k: sd.get(k) for k in ("value", "ms_per_step", "scaling", "paths_per_step")}
+    if full.get("hybrid_decomposition"):
+        sd = full["hybrid_decomposition"]
+        line["hybrid_decomposition"] = {k: sd.get(k) for k in ("value", "ms_per_step", "scaling", "paths_per_step", "shards", "inflight")}
+    if full.get("image_mean"):
+        line["image_mean"] = full["image_mean"]
+    line["detail"] = detail_path
+    line = _clean(line)
+    for drop in (None, "image_mean", "host_cross_check", "configs", "cpu_baseline.sample", "config.parallelism"):
+        if drop:
+            a, _, b = drop.partition(".")
+            if b:
+                (line.get(a) or {}).pop(b, None)
+            else:
+                line.pop(a, None)
+        if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT:
+            break
+    return line
+
+
+def emit(full):
+    """detail file + the one short line on stdout"""
+    line = short_line(full, write_detail(full))
+    print(json.dumps(line, allow_nan=False), flush=True)
 
 
 def workload_name(scene, algo, res, replicas, first, last):
@@ -480,10 +659,15 @@ def multi_gpu(args):
         r["value"] = 2.0 * n_paths * args.steps * R / r["wall_s"] / 1e6
         return r
 
-    shards = args.shards if args.shards > 0 else (2 if N % 2 == 0 else N)
-    inflight = args.inflight if args.inflight > 0 else (2 if shards > 1 else 1)
+    # Default = north_star's decomposition: ONE renderer, its light paths and pixels sharded over all N GPUs, the light
+    # vertices all-gathered every iteration, one framebuffer reduce at read-out ("strong": the work of a step is fixed).
+    # The replica hybrid (pairs of GPUs x 2 renderers in flight: mostly the reference's own iteration parallelism,
+    # smallvcm.cxx:61-72, "weak") is timed beside it and reported as hybrid_decomposition.
+    shards = args.shards if args.shards > 0 else N
+    inflight = args.inflight if args.inflight > 0 else 1
     main_run = run(shards, inflight)
-    strong = run(N, 1) if (shards != N or inflight != 1) else None
+    strong = None
+    hybrid = run(2, 2) if (args.shards <= 0 and args.inflight <= 0 and N % 2 == 0 and not args.no_hybrid) else None
     if rank == 0:
         st = main_run["stats"]
         n_local = n_paths // shards
@@ -516,14 +700,14 @@ def multi_gpu(args):
         }
         roof["scope"] = "world rank 0 (1 of %d shards of renderer 0), mean over its timed iterations" % shards
         out["roofline"] = finalize_roofline(roof)
-        if strong is not None:
-            out["strong_decomposition"] = {
-                "value": round(strong["value"], 3), "unit": "Mpaths/s", "scaling": "strong",
-                "ms_per_step": round(strong["wall_s"] / args.steps * 1e3, 3), "paths_per_step": 2 * n_paths,
-                "parallelism": "1 renderer on %d path-index shards (RCCL all-gather of the light vertices every iteration, "
-                               "framebuffer all-reduce at read-out), 1 renderer in flight" % N,
-                "rccl_ranks": strong["rccl_ranks"], "rank_iteration_ms": [round(x, 3) for x in strong["rank_iteration_ms"]]}
-        print(json.dumps(out), flush=True)
+        if hybrid is not None:
+            out["hybrid_decomposition"] = {
+                "value": round(hybrid["value"], 3), "unit": "Mpaths/s", "scaling": "weak", "shards": 2, "inflight": 2,
+                "ms_per_step": round(hybrid["wall_s"] / args.steps * 1e3, 3), "paths_per_step": 2 * n_paths * hybrid["R"],
+                "parallelism": "%d renderers (iteration-parallel, smallvcm.cxx:61-108), each on 2 path-index shards, 2 in flight per "
+                               "GPU pair: every step renders %d iterations" % (hybrid["R"], hybrid["R"]),
+                "rccl_ranks": hybrid["rccl_ranks"], "rank_iteration_ms": [round(x, 3) for x in hybrid["rank_iteration_ms"]]}
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -539,9 +723,10 @@ def main():
     ap.add_argument("--algo", default="vcm")
     ap.add_argument("--scene-file", default="", help="a .vcmscene / .obj scene file (relative to the repository) instead of --scene")
     ap.add_argument("--shards", type=int, default=0,
-                    help="GPUs that share one iteration (default: 2 when --gpus is even, else all)")
+                    help="GPUs that share one iteration (default: all of them = north_star's decomposition)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="renderers taking turns on each group of --shards GPUs (default: 2 when shards > 1, else 1)")
+                    help="renderers taking turns on each group of --shards GPUs (default 1)")
+    ap.add_argument("--no-hybrid", action="store_true", help="N > 1: skip the second timing (pairs of GPUs x 2 renderers in flight)")
     ap.add_argument("--collectives", default="rccl", choices=["rccl", "threads"],
                     help="threads: in-process stand-in for RCCL so that --gpus N ranks can share one GPU (tests)")
     ap.add_argument("--cpu-baseline", default="reference", choices=["reference", "port", "none"],
@@ -553,6 +738,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's other single-GPU configs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 child runs (HBM traffic, VALU counters)")
     ap.add_argument("--no-cross-check", action="store_true", help="skip the second timing of the headline through the Python host")
+    ap.add_argument("--record-counters", default="", metavar="TAG",
+                    help="keep the live counter sets as profiles/TAG_counters_<config>.json (the fallback of runs without a profiler)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # inner run under rocprofv3: GPU loop only
     args = ap.parse_args()
     if args.no_cpu_baseline:
@@ -563,13 +750,21 @@ def main():
     if args.gpus > 1:
         return multi_gpu(args)
 
-    import torch
     from smallvcm_amd._abi import ALGO_BY_NAME
-    from smallvcm_amd.renderer import HipBackend, RenderFarm, cornell_scene
+    from smallvcm_amd.renderer import HipBackend, RenderFarm, cornell_scene, load_library
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if args.child and not isinstance(args.scene, str):
+        # inner run under rocprofv3: the C++ farm's loop over the C-ABI alone -- no torch import (1-2 s per counter pass)
+        from smallvcm_amd import farm as F
+        F.farm_render(cornell_scene(args.scene, args.res, args.res), ALGO_BY_NAME[args.algo], iterations=args.steps * max(args.inflight, 1),
+                      ranks=1, shards=1, inflight=max(args.inflight, 1), devices=[local_rank], warmup=args.warmup, same_window=True,
+                      collectives="threads")
+        return
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
 
     def sync():
@@ -659,11 +854,33 @@ def main():
     }
     if cross is not None:
         out["host_cross_check"] = cross
-    counters, src = (None, "disabled (--no-traffic)") if args.no_traffic else live_counters(args)
+    def counters_for(cfg_name, scene, algo_name, r, workload):
+        """live child runs under rocprofv3; without a profiler the recording made on these kernel sources, if there is one"""
+        if args.no_traffic:
+            return None, "disabled (--no-traffic)"
+        if isinstance(scene, str):
+            return None, "scene files have no child runs"
+        ns = argparse.Namespace(res=r, scene=scene, algo=algo_name, steps=args.steps, warmup=args.warmup)
+        counters, src = live_counters(ns)
+        if counters is not None:
+            if args.record_counters:
+                try:
+                    save_counters(args.record_counters, cfg_name, workload, counters, src)
+                except OSError as e:
+                    src += "; not recorded: %r" % (e,)
+            return counters, src
+        rec, path = recorded_counters(cfg_name)
+        if rec is not None:
+            return rec, "recorded: %s (same kernel sources, hash %s); live measurement unavailable: %s" % (path, kernel_source_hash(), src)
+        return None, src
+
+    cfg_name = {(1, "vcm", 2048): "C4", (1, "vcm", 512): "C1", (3, "vcm", 1024): "C2", (1, "bpm", 2048): "C3"}.get(
+        (args.scene, args.algo, res), "other") if replicas == 1 else "other"
+    counters, src = counters_for(cfg_name, args.scene, args.algo, res, out["config"]["workload"])
     if counters is not None:
         add_counters(roof, dom, counters, src, st, n_local)
     else:
-        rec, path = recorded_traffic(dom)
+        rec, path = recorded_traffic(dom) if headline else (None, None)
         if rec is not None:
             roof["traffic"] = rec
             roof["traffic_source"] = "recorded: %s (same kernel sources, hash %s); live measurement unavailable: %s" % (
@@ -672,7 +889,7 @@ def main():
             roof["frac_traffic"] = round(rec / (roof["kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
             roof["traffic_over_algorithmic"] = round(rec / max(roof["algorithmic_bytes_per_launch"], 1), 4)
         else:
-            roof["traffic_source"] = "null: %s; no profiles/*_traffic.json for kernel sources %s" % (src, kernel_source_hash())
+            roof["traffic_source"] = "null: %s; no recording in profiles/ for kernel sources %s" % (src, kernel_source_hash())
     out["roofline"] = finalize_roofline(roof)
     if headline and not args.no_configs:
         cfgs = []
@@ -686,7 +903,13 @@ def main():
                 else:
                     e2, s2, _, _ = farm_run(scene, algo_name, r, nfl, args.steps, args.warmup)
                     nl = r * r
-                _, roof2 = roofline_block(s2, nl, r * r)
+                dom2, roof2 = roofline_block(s2, nl, r * r)
+                if nfl == 1 and name in ("C1", "C2", "C3"):   # BASELINE configs: their own counter passes
+                    c2, src2 = counters_for(name, scene, algo_name, r, workload_name(scene, algo_name, r, nfl, args.warmup, args.warmup + args.steps - 1))
+                    if c2 is not None:
+                        add_counters(roof2, dom2, c2, src2, s2, nl)
+                    else:
+                        roof2["traffic_source"] = "null: %s" % src2
                 if nfl > 1:
                     roof2["scope"] = "first of the %d renderers; its kernels share the GPU with the others', so per-kernel " \
                                      "times are longer than alone" % nfl
@@ -724,7 +947,7 @@ def main():
                     try:
                         allc = cpu_reference(args.scene, args.algo, 512, args.warmup, args.steps, cores)
                         base["all_cores"] = {"value": allc["value"], "unit": "Mpaths/s", "cores": cores, "wall_s": allc["wall_s"],
-                                             "sample": allc["sample"],
+                                             "res": 512, "sample": allc["sample"],
                                              "recorded_2048": "profiles/r01_cpu_reference_timing.json, r01_cpu_reference_timing_128.json: "
                                                               "1.89 Mpaths/s on 32 threads, 1.79 on 128 threads at 2048^2 on this host type"}
                     except Exception as e:
@@ -732,7 +955,7 @@ def main():
             except Exception as e:
                 port["reference_error"] = repr(e)
         out["cpu_baseline"] = base if base is not None else port
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 if __name__ == "__main__":
