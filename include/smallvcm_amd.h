@@ -292,6 +292,27 @@ int vcm_import_light_records(vcm_ctx *ctx, const void *devPtr,
                              const long long *counts, int nSeg,
                              long long strideRecords);
 
+/* The SORTED exchange of a sharded renderer (round 5; replaces the three calls above on the hot path -- they stay for hosts
+ * that want the records in the reference's order).  Path-index blocks are contiguous per rank, so a cell's vertices in
+ * HashGrid::Build's stable order (hashgrid.hxx:83-88) are rank 0's in their local order, then rank 1's, ...: every rank
+ * counting-sorts ONLY ITS OWN vertices by hash cell (1 / worldSize of the grid build), the ranks all-gather the sorted
+ * slabs, and vcm_build_grid merges them cell block by cell block in one streaming pass -- no rank ever counts, scans or
+ * ranks the other ranks' vertices (rounds 2-4: the whole build replicated on every rank).
+ *   vcm_sorted_slab_words    4-byte words one rank's slab takes for `strideRecords` records: the records (13 words each,
+ *                            cell order) + one block-start word per block of cells (+ padding to 16 bytes); -1 with
+ *                            vcm_last_error() when the context cannot use the sorted exchange (not sharded, no merging
+ *                            algorithm, more than 256 shards, 2^24 or more records in a shard): use the calls above.
+ *   vcm_sort_light_records   after vcm_set_grid_bbox (the cell of a vertex depends on the box of ALL vertices): sorts the
+ *                            local vertices and writes the slab to dstDev (device memory of the caller, e.g. the send
+ *                            buffer of ncclAllGather).  Asynchronous on the context's stream.
+ *   vcm_import_sorted_light_records   `gathered` = worldSize slabs of vcm_sorted_slab_words(strideRecords) words, rank
+ *                            order, counts[s] = records of rank s; vcm_build_grid then merges them.  The memory must stay
+ *                            valid until vcm_merge has been enqueued. */
+long long vcm_sorted_slab_words(vcm_ctx *ctx, long long strideRecords);
+int vcm_sort_light_records(vcm_ctx *ctx, void *dstDev, long long strideRecords);
+int vcm_import_sorted_light_records(vcm_ctx *ctx, const void *gathered, const long long *counts, int nSeg,
+                                    long long strideRecords);
+
 /* The image in the reference's two 8-bit output encodings, converted on the device (a quarter / a third of
  * the bytes of the fp32 framebuffer cross PCIe).  The framebuffer (running sum) is scaled by `scale` first --
  * 1 / iterations gives what GetFramebuffer returns (renderer.hxx:49-55).

@@ -14,7 +14,7 @@ R="./vcm_render -s $SCENE -a $ALGO -i $ITER --warmup $WARM --res $RES $RES --jso
 p() { python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('last_iteration_kernel_ms',{}); print('%8.1f Mpaths/s  K1 %.2f K3 %.2f K3b %.2f K4 %.2f grid %.2f  [%s]' % (d['Mpaths_s'], k.get('light',0), k.get('camera',0), k.get('connect_di',0), k.get('merge',0), k.get('grid_side',0), d.get('library','?')))"; }
 RB="../../profiles/ab_base/host/vcm_render -s $SCENE -a $ALGO -i $ITER --warmup $WARM --res $RES $RES --json"
 for rep in $(seq 1 $REPS); do
-  printf "%-28s" "default"; timeout 30 $R -o /tmp/qab_a.pfm | p
+  printf "%-28s" "default"; timeout 60 $R -o /tmp/qab_a.pfm | p
   if [ -n "${BASE:-}" ]; then   # another REVISION: its own host + library (profiles/make_ab_base.sh)
     printf "%-28s" "base $(cat ../../profiles/ab_base/REV)"; timeout 30 $RB -o /tmp/qab_b.pfm | p
     cmp -s /tmp/qab_a.pfm /tmp/qab_b.pfm && echo "    same bits as the default" || echo "    DIFFERS from the default"
@@ -24,7 +24,7 @@ for rep in $(seq 1 $REPS); do
     cmp -s /tmp/qab_a.pfm /tmp/qab_b.pfm && echo "    same bits as the default" || echo "    DIFFERS from the default"
   done
   for e in ${ENVS:-}; do
-    printf "%-28s" "$e"; env "$e" timeout 30 $R -o /tmp/qab_b.pfm | p
+    printf "%-44s" "$e"; env ${e//,/ } timeout 60 $R -o /tmp/qab_b.pfm | p
     cmp -s /tmp/qab_a.pfm /tmp/qab_b.pfm && echo "    same bits as the default" || echo "    DIFFERS from the default"
   done
 done

@@ -166,6 +166,9 @@ struct vcm_ctx : Scratch {
     double stampKHz;
 
     bool importedRecords;
+    bool importedSorted;              /* vcm_import_sorted_light_records: the grid build merges the ranks' cell-sorted slabs */
+    bool sortedExchange;              /* sharded context that expects the sorted exchange: K1b does not materialise the records */
+    SortedSlabs sortedIn;
     bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI, bboxPreset;
     bool bboxFromLight;               /* K1 of this iteration accumulated the vertices' box into dHdr (single rank) */
     bool bboxFinal;                   /* ... and k_compact_records has turned it into floats already */
@@ -750,6 +753,8 @@ static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor
     }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
+    { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE");   /* 0: the host will use the unsorted exchange of rounds 1-4 */
+      c->sortedExchange = worldSize > 1 && worldSize <= 256 && c->useVM && !(e && e[0] == '0'); }
     { const char *e = getenv("SMALLVCM_AMD_MERGE");
       c->mergeKind = (e && !strcmp(e, "staged")) ? VCM_MERGE_STAGED : (e && !strcmp(e, "walk")) ? VCM_MERGE_WALK : (e && !strcmp(e, "lane")) ? VCM_MERGE_LANE : VCM_MERGE_DEFAULT; }
     return c;
@@ -978,6 +983,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
                     c->vs.count, 32 * sizeof(int) /* queue counts [0..2]; chunk counter of K3 / k_path_trace [8] and of K1 [16] */,
                     c->dHdr, 6 * sizeof(uint32_t) /* bboxMinU / bboxMaxU: K1 accumulates into them with atomicMax */)) return -1;
     c->importedRecords = false;
+    c->importedSorted = false;
     c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->splatInFlight = c->bboxPreset = c->bboxFromLight = c->bboxFinal = c->prezeroed = c->sortInFlight = false;
     c->inIteration = true;
     c->evValid = false;
@@ -996,9 +1002,15 @@ static int task_blocks(int nLocal)
 {
     static int n = -1;
     if (n < 0) { const char *e = getenv("SMALLVCM_AMD_TASK_BLOCKS"); n = (e && atoi(e) > 0) ? atoi(e) : 0; }
-    /* frames up to 1024^2 keep the 2048 of round 1: with a task or two per thread more workgroups only cost their
-       dispatch (512^2: K3b+c 0.31 -> 0.38 ms with 3072, profiles/r03m_ab_summary.txt) */
-    return n ? n : (nLocal >= (1 << 21) ? 256 * 12 : 256 * 8);
+    /* Small frames (round 5, profiles/r07c_ab_*.txt, r07d_ab_*.txt; 400-iteration runs): rounds 1-4 kept 2048 workgroups up to
+       1024^2 -- 8192 waves where ~6144 are resident, for one or two tasks per thread, next to K3c / K4 which want wave slots at
+       the same time.  512 workgroups at 512^2 (five tasks per thread; 256 / 384 / 512 / 768 / 1024 / 1536 / 2048: 531 / 534 /
+       543 / 503 / 497 / 447 / 426 Mpaths/s) and 1024 at 1024^2 (512 / 768 / 1024 / 1536 / 2048 / 3072: 1013 / 1036 / 1070 / 1006 /
+       1001 / 957 on scene 3): +19 % and +7 % for the iteration. */
+    if (n) return n;
+    if (nLocal >= (1 << 21)) return 256 * 12;
+    const int b = nLocal / 1024;
+    return b < 512 ? 512 : (b > 1024 ? 1024 : b);
 }
 /* workgroups of k_merge_walk (multiple of 8: they are dealt to the XCDs).  1024 are resident (126 VGPRs, 37 KB of
  * LDS); with 2048 every workgroup walked ~20 batches of 256 queries and the last ones to finish set the kernel's time,
@@ -1008,8 +1020,24 @@ static int merge_blocks(int nLocal)
 {
     static int n = -1;
     if (n < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_BLOCKS"); n = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 0; }
-    /* smaller frames have fewer batches than that: 2048 as before (16384 at 1024^2: 0.40 -> 1.08 ms, r03m) */
-    return n ? n : (nLocal >= (1 << 21) ? 16384 : 256 * 8);
+    /* smaller frames have fewer batches than that.  2048 until round 4 (16384 at 1024^2: 0.40 -> 1.08 ms, r03m); round 5
+       measured the small end: 512^2 with 512 / 768 / 1024 / 1536 / 2048 / 4096 workgroups: K4 0.18 / 0.19 / 0.21 / 0.24 / 0.27 /
+       0.31 ms (571 / 559 / 543 / 529 / 497 / 475 Mpaths/s with 512 task workgroups); 1024^2 scene 3 with 1024 / 2048 / 4096 /
+       8192: K4 0.40 / 0.42 / 0.52 / 0.86 ms (profiles/r07d_ab_*.txt) */
+    if (n) return n;
+    if (nLocal >= (1 << 21)) return 16384;
+    const int b = (nLocal / 1024) & ~7;
+    return b < 512 ? 512 : (b > 2048 ? 2048 : b);
+}
+/* workgroups of the streaming helper kernels (compaction, grid build, splat lists, query scatter, resolve: grid-stride loops over
+ * paths, vertices or pixels).  2048 = 524 288 threads; a 512^2 frame has 262 144 paths and ~560 000 vertices: half the threads
+ * found nothing to do.  SMALLVCM_AMD_AUX_BLOCKS overrides. */
+static int aux_blocks(int nLocal)
+{
+    static int n = -1;
+    if (n < 0) { const char *e = getenv("SMALLVCM_AMD_AUX_BLOCKS"); n = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    if (n) return n;
+    return 2048;
 }
 /* the main stream continues only after the splat stream's K1c / K1d (before anything else touches the framebuffer) */
 static int join_splats(vcm_ctx *c)
@@ -1046,13 +1074,13 @@ static int flush_light_splats(vcm_ctx *c)
                            (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, c->dSplat, pixCount,
                            arrival, c->dStats);
         if (launch_scan_on<int>(c, overlap ? 2 : 0, q, pixCount, c->N, pixStart, NULL, 1, overlap ? none : take_stamps(c, q))) return -1;
-        hipLaunchKernelGGL(k_splat_scatter, dim3(2048), dim3(256), 0, q, (const F4 *)c->dSplat,
+        hipLaunchKernelGGL(k_splat_scatter, dim3(aux_blocks(c->nLocal)), dim3(256), 0, q, (const F4 *)c->dSplat,
                            (const int *)c->dLocalTotal, (const int *)pixStart, (const int *)arrival, list, pixCount);
         /* pixels with more than VCM_SPLAT_REG splats are queued (pixCount[0] = their number, `arrival` = the queue:
            both dead since the scatter) and handled by one wave each; `sorted` = the vertex-ordered splat array */
         static int splatLong = -1;   /* SMALLVCM_AMD_SPLAT_LONG: tests send short lists down the one-wave-per-pixel path too */
         if (splatLong < 0) { const char *e = getenv("SMALLVCM_AMD_SPLAT_LONG"); splatLong = (e && atoi(e) >= VCM_SPLAT_REG) ? atoi(e) : VCM_SPLAT_LONG; }
-        hipLaunchKernelGGL(k_splat_apply, dim3(2048), dim3(256), 0, q, c->N, (const int *)pixStart,
+        hipLaunchKernelGGL(k_splat_apply, dim3(aux_blocks(c->nLocal)), dim3(256), 0, q, c->N, (const int *)pixStart,
                            (const F4 *)list, c->dFb, arrival, pixCount, splatLong);
         hipLaunchKernelGGL(k_splat_apply_long, dim3(1024), dim3(256), 0, q, (const int *)pixStart, (const F4 *)list,
                            c->dSplat, c->dFb, (const int *)arrival, (const int *)pixCount);
@@ -1117,9 +1145,9 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         /* a sharded renderer ships the records to the other ranks; a single-rank one builds its grid straight
            from the store and materialises them only when somebody asks (ensure_records).  On a single rank the kernel
            also publishes the counts and the box K1 kept (k_set_counts / k_bbox_finalize folded in). */
-        c->recordsValid = c->useVM && c->world > 1;
+        c->recordsValid = c->useVM && c->world > 1 && !c->sortedExchange;   /* (vcm_export_light_records still materialises them on demand) */
         const bool fold = c->world == 1;
-        hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, (const DScene *)c->dScene, c->P, c->store, c->dPathStart,
+        hipLaunchKernelGGL(k_compact_records, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, (const DScene *)c->dScene, c->P, c->store, c->dPathStart,
                            c->dRecordsLocal, c->dSlotOfVertex, c->recordsValid ? 1 : 0, fold ? c->dHdr : (GridHeader *)NULL,
                            (const int *)c->dLocalTotal, (fold && c->bboxFromLight) ? 1 : 0);
         HIPCHK(hipGetLastError());
@@ -1142,7 +1170,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
 static int ensure_records(vcm_ctx *c)
 {
     if (c->recordsValid || !c->useVM) return 0;
-    hipLaunchKernelGGL(k_compact_records, dim3(2048), dim3(256), 0, c->stream, (const DScene *)c->dScene, c->P, c->store, c->dPathStart,
+    hipLaunchKernelGGL(k_compact_records, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, (const DScene *)c->dScene, c->P, c->store, c->dPathStart,
                        c->dRecordsLocal, c->dSlotOfVertex, 1, (GridHeader *)NULL, (const int *)c->dLocalTotal, 0);
     HIPCHK(hipGetLastError());
     c->recordsValid = true;
@@ -1260,6 +1288,87 @@ static int vcm_import_light_records_impl(vcm_ctx *c, const void *devPtr, const l
     return 0;
 }
 
+/* ---- the sorted exchange of a sharded renderer (include/smallvcm_amd.h; kernels: vcm_kernels.h "K2 of a SHARDED renderer") ---- */
+static int sorted_shape(vcm_ctx *c, long long strideRecords, int *K, int *nBlocks, long long *slabWords, const char *who)
+{
+    if (!c) return fail(who, "ctx is NULL");
+    if (c->world <= 1) return fail(who, "the context is not sharded");
+    if (!c->useVM) return fail(who, "the algorithm does not merge: nothing to exchange");
+    if (c->world > 256) return fail(who, "more than 256 shards: use the unsorted exchange");
+    if (strideRecords < 1 || strideRecords >= (1ll << 24)) return fail(who, "1 <= records per shard < 2^24 (the index shares a word with the path length): use the unsorted exchange");
+    *K = sorted_block_cells(c->world);
+    *nBlocks = (c->N + *K - 1) / *K;   /* nCells = pathCount (vertexcm.hxx:406) */
+    const long long w = strideRecords * VCM_SORTED_WORDS + (long long)*nBlocks + 1;
+    *slabWords = (w + 3) & ~3ll;
+    return 0;
+}
+extern "C" long long vcm_sorted_slab_words(vcm_ctx *c, long long strideRecords)
+{
+    int K, nBlocks; long long words;
+    if (sorted_shape(c, strideRecords, &K, &nBlocks, &words, "vcm_sorted_slab_words")) return -1;
+    return words;
+}
+static int vcm_sort_light_records_impl(vcm_ctx *c, void *dstDev, long long strideRecords)
+{
+    if (!c || !c->inIteration || !dstDev) return fail("vcm_sort_light_records", "call it between vcm_set_grid_bbox and vcm_build_grid");
+    if (!c->bboxPreset) return fail("vcm_sort_light_records", "call vcm_set_grid_bbox first: the cell of a vertex depends on the box of all ranks' vertices");
+    if (c->gridBuilt) return fail("vcm_sort_light_records", "the grid is built already");
+    int K, nBlocks; long long words;
+    if (sorted_shape(c, strideRecords, &K, &nBlocks, &words, "vcm_sort_light_records")) return -1;
+    if (use_device(c)) return -1;
+    /* HashGrid::Build (hashgrid.hxx:41-107) over THIS rank's vertices, with the box of all of them: the kernels of the
+       single-rank build, 1 / worldSize of its work; hdr->nRecords still is the local count here (k_set_counts) */
+    const int nCells = c->P.nCells;
+    const dim3 g(aux_blocks(c->nLocal)), b(256);
+    VertexSource recs; recs.records = c->recordsValid ? c->dRecordsLocal : NULL; recs.store = c->store; recs.slotOfVertex = c->dSlotOfVertex;
+    if (zero_ranges(c->stream, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
+    hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId, c->dSortedIndex, c->dCellCount,
+                       take_stamps(c, c->stream));
+    HIPCHK(hipGetLastError());
+    if (launch_scan<int>(c, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
+    hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId, (const int *)c->dSortedIndex,
+                       (const int *)c->dCellStart, recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
+    uint32_t *slab = (uint32_t *)dstDev;
+    hipLaunchKernelGGL(k_cell_rank_pack, g, b, 0, c->stream, (const DScene *)c->dScene, (const GridHeader *)c->dHdr, recs, (const int *)c->dCellStart,
+                       (const I4 *)c->dUnsorted, slab, (int *)(slab + (size_t)strideRecords * VCM_SORTED_WORDS), nCells, K, nBlocks);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int vcm_import_sorted_light_records_impl(vcm_ctx *c, const void *gathered, const long long *counts, int nSeg, long long strideRecords)
+{
+    if (!c || !c->inIteration || !gathered || !counts) return fail("vcm_import_sorted_light_records", "no iteration in progress");
+    if (nSeg != c->world) return fail("vcm_import_sorted_light_records", "one slab per rank");
+    if (nSeg > 64) return fail("vcm_import_sorted_light_records", "more than 64 shards: use the unsorted exchange");
+    int K, nBlocks; long long words;
+    if (sorted_shape(c, strideRecords, &K, &nBlocks, &words, "vcm_import_sorted_light_records")) return -1;
+    if (use_device(c)) return -1;
+    SortedSlabs &in = c->sortedIn;
+    in.base = (const uint32_t *)gathered; in.slabWords = words; in.strideRecords = strideRecords; in.S = nSeg; in.K = K; in.nBlocks = nBlocks;
+    long long total = 0;
+    for (int s = 0; s < nSeg; s++) {
+        if (counts[s] < 0 || counts[s] > strideRecords) return fail("vcm_import_sorted_light_records", "a count exceeds the slab");
+        in.rankBase[s] = (int)total;
+        total += counts[s];
+    }
+    in.rankBase[nSeg] = (int)total;
+    if (total > (long long)c->arena->capS * (long long)c->arena->capN) return fail("vcm_import_sorted_light_records", "too many records");
+    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, c->stream, c->dHdr, c->dLocalTotal, 0, (int)total, take_stamps(c, c->stream));
+    HIPCHK(hipGetLastError());
+    c->importedSorted = true;
+    c->importedRecords = false;
+    return 0;
+}
+extern "C" int vcm_sort_light_records(vcm_ctx *c, void *dstDev, long long strideRecords)
+{
+    g_hipFailed = false;
+    return abort_iteration(c, vcm_sort_light_records_impl(c, dstDev, strideRecords));
+}
+extern "C" int vcm_import_sorted_light_records(vcm_ctx *c, const void *gathered, const long long *counts, int nSeg, long long strideRecords)
+{
+    g_hipFailed = false;
+    return abort_iteration(c, vcm_import_sorted_light_records_impl(c, gathered, counts, nSeg, strideRecords));
+}
+
 /* the main stream continues only after the side stream's grid build */
 static int join_grid(vcm_ctx *c)
 {
@@ -1286,12 +1395,28 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         HIPCHK(hipEventRecord(c->evFork, c->stream));
         HIPCHK(hipStreamWaitEvent(q, c->evFork, 0));
         if (mark_on(c, EV_GRID_K0, q)) return -1;
+        if (c->importedSorted) {
+            /* every rank sorted its own vertices (vcm_sort_light_records); what is left of HashGrid::Build is ONE streaming
+               merge of the slabs, cell block by cell block: cellStart, the cell-sorted arrays, the index for the read-out */
+            if (!c->bboxPreset) return fail("vcm_build_grid", "sorted records without the box they were sorted with");
+            const int blocks = c->sortedIn.nBlocks < 8192 ? c->sortedIn.nBlocks : 8192;
+            hipLaunchKernelGGL(k_grid_merge_blocks, dim3(blocks), dim3(256), 0, q, c->P, (const GridHeader *)c->dHdr, c->sortedIn, c->dCellStart,
+                               c->dGx, c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex, take_stamps(c, q));
+            HIPCHK(hipGetLastError());
+            if (mark_on(c, EV_GRID, q)) return -1;
+            hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT, take_stamps(c, q));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->evGrid, q));
+            c->gridInFlight = true;
+            if (!c->P.wavefront && join_grid(c)) return -1;
+            return 0;
+        }
         VertexSource recs;
         recs.records = c->importedRecords ? c->dRecordsAll : (c->recordsValid ? c->dRecordsLocal : NULL);
         recs.store = c->store;
         recs.slotOfVertex = c->dSlotOfVertex;
         const int nCells = c->P.nCells;
-        const dim3 g(2048), b(256);
+        const dim3 g(aux_blocks(c->nLocal)), b(256);
         if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));   /* (q is the side stream itself unless the build runs in line) */
         else if (zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
         bool boxOnSide = false;
@@ -1396,7 +1521,18 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
-            if (c->countedInCamera && c->world == 1) {
+            /* Small frames (round 5): K3b and K3c are grid-stride kernels whose workgroups hold every wave slot of the chip
+               until they end, so a scan on another stream gets its workgroups only when K3b's are done and its second launch
+               when K3c's are: at 512^2 the two launches took 101 + 169 us (12 us alone), K4 started 200 us after K3b had ended
+               and the main stream idled for 16 % of the iteration (profiles/r06t_timeline512.txt).  Up to 1024^2 the scan
+               therefore runs IN LINE between K3 and K3b (nothing else is resident at that moment: its 12-25 us are all it
+               costs) and K3b scatters the sorted order as it goes.  At 2048^2 the in-line scan shared the memory system with the
+               tail of the grid build and took 0.9 ms (r06d): there it stays on the side stream.
+               SMALLVCM_AMD_SORT_INLINE=0/1 forces either. */
+            static int sortInline = -2;
+            if (sortInline == -2) { const char *e = getenv("SMALLVCM_AMD_SORT_INLINE"); sortInline = e ? (e[0] == '1' ? 1 : 0) : -1; }
+            const bool inlineSort = c->scatteredInDI && (sortInline == 1 || (sortInline == -1 && c->nLocal <= (1 << 20)));
+            if (c->countedInCamera && c->world == 1 && !inlineSort) {
                 /* The scan of the bucket table (16.8 M entries at 2048^2) and the scatter of the sorted order run on the SIDE
                    stream, behind the grid build and next to K3b: in line, between K3 and K3b, the scan took 0.9 ms -- 70 us
                    alone, but it shared the memory system with the tail of the grid build and the light splats while the VALU
@@ -1407,7 +1543,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                 HIPCHK(hipStreamWaitEvent(c->side, c->evSortFork, 0));
                 const StampArgs none = { { NULL, NULL, NULL, NULL } };
                 if (launch_scan_on<int>(c, 3, c->side, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1, none)) return -1;
-                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->side, c->vs, (const int *)c->dQueryKey,
+                hipLaunchKernelGGL(k_query_scatter, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->side, c->vs, (const int *)c->dQueryKey,
                                    (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
                 HIPCHK(hipEventRecord(c->evSorted, c->side));
                 c->sortInFlight = true;
@@ -1446,8 +1582,11 @@ static int vcm_merge_impl(vcm_ctx *c)
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
             const int nb = c->P.nBuckets;
             if (!c->countedInCamera) {
+                /* (camera pass before the grid build on a single rank: the side stream's zeroing of this very table, started
+                   next to K1, must be over before it is zeroed and counted into again here -- ADVICE r4) */
+                if (c->prezeroed) HIPCHK(hipStreamWaitEvent(c->stream, c->evZero, 0));
                 if (zero_ranges(c->stream, c->dQueryCount, ((size_t)nb + 1) * sizeof(int))) return -1;
-                hipLaunchKernelGGL(k_query_count, dim3(2048), dim3(256), 0, c->stream, c->P, c->vs,
+                hipLaunchKernelGGL(k_query_count, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, c->vs,
                                    (const GridHeader *)c->dHdr, c->dQueryKey, c->dQueryArrival, c->dQueryCount, take_stamps(c, c->stream));
             }
             if (c->sortInFlight) {   /* scan + scatter ran next to K3b */
@@ -1455,7 +1594,7 @@ static int vcm_merge_impl(vcm_ctx *c)
                 c->sortInFlight = false;
             } else if (!c->scatteredInDI) {
                 if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
-                hipLaunchKernelGGL(k_query_scatter, dim3(2048), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
+                hipLaunchKernelGGL(k_query_scatter, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->vs, (const int *)c->dQueryKey,
                                    (const int *)c->dQueryArrival, (const int *)c->dQueryStart, c->dSortedVertex);
             }
             if (mark(c, EV_SORT_K1)) return -1;
@@ -1518,7 +1657,7 @@ static int vcm_merge_impl(vcm_ctx *c)
         if (mark(c, EV_MERGE_K1)) return -1;
         /* K5: the first kernel since the light splats that touches the framebuffer */
         if (join_splats(c)) return -1;
-        hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
+        hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
     }

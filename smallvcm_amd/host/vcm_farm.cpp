@@ -302,15 +302,17 @@ struct Slot {
     hipStream_t stream;          // the renderer's kernels
     hipStream_t commStream;      // the RANK's communication stream (shared by its slots)
     hipEvent_t evRecords, evGathered;
-    float *local, *gathered;     // slabs: stride records / shards * stride records
-    size_t capRecords;
+    float *local, *gathered;     // slabs: one / shards of them, `slabWords` 4-byte words each
+    size_t capWords;             // words a slab can hold
+    long long slabWords;         // this iteration's slab
+    bool sorted;                 // this iteration uses the sorted exchange (every rank decides the same: same counts, same context shape)
     int first, count;            // iterations of this renderer
     std::vector<long long> counts;
     long long stride, nLocal;
     bool exchanging, live;
     Xchg mine;
     Slot() : ctx(NULL), group(NULL), stream(NULL), commStream(NULL), evRecords(NULL), evGathered(NULL), local(NULL), gathered(NULL),
-             capRecords(0), first(0), count(0), stride(0), nLocal(0), exchanging(false), live(false) {}
+             capWords(0), slabWords(0), sorted(false), first(0), count(0), stride(0), nLocal(0), exchanging(false), live(false) {}
 };
 
 struct RankArgs {
@@ -361,21 +363,30 @@ bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard
 {   // start of the all-gather; the part of the camera pass that does not need the other ranks' vertices
     if (!sl.group) return true;
     const int S = sl.group->size();
-    if ((size_t)sl.stride > sl.capRecords) {   // grow the slabs (rare: the counts vary by a fraction of a percent)
+    // Sorted exchange (round 5, the default): this rank sorts its OWN vertices by hash cell, the slabs travel, every rank
+    // merges them cell block by cell block -- the grid build is no longer replicated.  The unsorted exchange of rounds 1-4
+    // (records in the reference's order, the whole build on every rank) stays behind SMALLVCM_AMD_SORTED_EXCHANGE=0 and
+    // for shapes the sorted slabs do not cover (vcm_sorted_slab_words says so; every rank of the group gets the same answer).
+    static const bool allowSorted = [] { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE"); return !(e && e[0] == '0'); }();
+    const long long sortedWords = allowSorted ? vcm_sorted_slab_words(sl.ctx, sl.stride) : -1;
+    sl.sorted = sortedWords > 0;
+    sl.slabWords = sl.sorted ? sortedWords : sl.stride * VCM_MERGE_RECORD_FLOATS;
+    if ((size_t)sl.slabWords > sl.capWords) {   // grow the slabs (rare: the counts vary by a fraction of a percent)
         HIPOK(hipStreamSynchronize(sl.stream));
         HIPOK(hipStreamSynchronize(sl.commStream));
         if (sl.local) (void)hipFree(sl.local);
         if (sl.gathered) (void)hipFree(sl.gathered);
-        sl.capRecords = (size_t)sl.stride + (size_t)sl.stride / 16 + 1024;
-        HIPOK(hipMalloc((void **)&sl.local, sl.capRecords * VCM_MERGE_RECORD_FLOATS * sizeof(float)));
-        HIPOK(hipMalloc((void **)&sl.gathered, sl.capRecords * (size_t)S * VCM_MERGE_RECORD_FLOATS * sizeof(float)));
+        sl.capWords = (size_t)sl.slabWords + (size_t)sl.slabWords / 16 + 16384;
+        HIPOK(hipMalloc((void **)&sl.local, sl.capWords * sizeof(float)));
+        HIPOK(hipMalloc((void **)&sl.gathered, sl.capWords * (size_t)S * sizeof(float)));
     }
     if (!sl.group->sendBufferFree(sh, shard, sl.stream)) return false;
-    VCMOK(vcm_export_light_records(sl.ctx, sl.local, sl.nLocal));
+    if (sl.sorted) VCMOK(vcm_sort_light_records(sl.ctx, sl.local, sl.stride));
+    else VCMOK(vcm_export_light_records(sl.ctx, sl.local, sl.nLocal));
     // the all-gather runs on the communication stream, behind the export and next to the camera pass
     HIPOK(hipEventRecord(sl.evRecords, sl.stream));
     HIPOK(hipStreamWaitEvent(sl.commStream, sl.evRecords, 0));
-    if (!sl.group->allGather(sh, shard, sl.local, sl.gathered, (size_t)sl.stride * VCM_MERGE_RECORD_FLOATS, sl.commStream)) return false;
+    if (!sl.group->allGather(sh, shard, sl.local, sl.gathered, (size_t)sl.slabWords, sl.commStream)) return false;
     HIPOK(hipEventRecord(sl.evGathered, sl.commStream));
     sl.exchanging = true;
     if (vcm_is_wavefront(sl.ctx, cfg.maxLen)) VCMOK(vcm_trace_camera(sl.ctx));   // needs only the local light vertices
@@ -385,7 +396,8 @@ bool step_finish(Shared &sh, const FarmConfig &cfg, Slot &sl)
 {   // wait for the exchange, grid build, (camera pass,) merge, resolve
     if (sl.exchanging) {
         HIPOK(hipStreamWaitEvent(sl.stream, sl.evGathered, 0));
-        VCMOK(vcm_import_light_records(sl.ctx, sl.gathered, sl.counts.data(), (int)sl.counts.size(), sl.stride));
+        if (sl.sorted) VCMOK(vcm_import_sorted_light_records(sl.ctx, sl.gathered, sl.counts.data(), (int)sl.counts.size(), sl.stride));
+        else VCMOK(vcm_import_light_records(sl.ctx, sl.gathered, sl.counts.data(), (int)sl.counts.size(), sl.stride));
     }
     VCMOK(vcm_build_grid(sl.ctx));
     if (!(sl.exchanging && vcm_is_wavefront(sl.ctx, cfg.maxLen))) VCMOK(vcm_trace_camera(sl.ctx));

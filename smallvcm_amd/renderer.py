@@ -73,6 +73,10 @@ def load_library(require_gpu=True):
         L.vcm_export_light_records.argtypes = [vp, vp, C.c_longlong]
         L.vcm_export_framebuffer.argtypes = [vp, vp]
         L.vcm_import_light_records.argtypes = [vp, vp, llp, C.c_int, C.c_longlong]
+        L.vcm_sorted_slab_words.argtypes = [vp, C.c_longlong]
+        L.vcm_sorted_slab_words.restype = C.c_longlong
+        L.vcm_sort_light_records.argtypes = [vp, vp, C.c_longlong]
+        L.vcm_import_sorted_light_records.argtypes = [vp, vp, llp, C.c_int, C.c_longlong]
         L.vcm_read_framebuffer.argtypes = [vp, fp]
         L.vcm_framebuffer_device.argtypes = [vp, C.POINTER(vp)]
         L.vcm_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -237,6 +241,22 @@ class HipBackend:
         arr = (C.c_longlong * len(counts))(*[int(c) for c in counts])
         _check(self.L, self.L.vcm_import_light_records(self.ctx, gathered_tensor.data_ptr(), arr, len(counts),
                                                        stride_records), "vcm_import_light_records")
+
+    # the sorted exchange (include/smallvcm_amd.h): every rank sorts its own vertices by hash cell, the slabs travel,
+    # build_grid merges them -- SMALLVCM_AMD_SORTED_EXCHANGE=0 keeps the unsorted exchange above
+    def sorted_slab_words(self, stride_records):
+        """4-byte words of one rank's slab, or -1 when this context has to use the unsorted exchange"""
+        if os.environ.get("SMALLVCM_AMD_SORTED_EXCHANGE", "1") == "0":
+            return -1
+        return int(self.L.vcm_sorted_slab_words(self.ctx, int(stride_records)))
+
+    def sort_records(self, dst_tensor, stride_records):
+        _check(self.L, self.L.vcm_sort_light_records(self.ctx, dst_tensor.data_ptr(), int(stride_records)), "vcm_sort_light_records")
+
+    def import_sorted_records(self, gathered_tensor, counts, stride_records):
+        arr = (C.c_longlong * len(counts))(*[int(c) for c in counts])
+        _check(self.L, self.L.vcm_import_sorted_light_records(self.ctx, gathered_tensor.data_ptr(), arr, len(counts),
+                                                              int(stride_records)), "vcm_import_sorted_light_records")
 
     def export_framebuffer(self, dst_tensor):
         _check(self.L, self.L.vcm_export_framebuffer(self.ctx, dst_tensor.data_ptr()), "vcm_export_framebuffer")
@@ -415,28 +435,37 @@ class ShardedVertexCM:
                     b.set_grid_bbox([1e36] * 3, [-1e36] * 3)
             # 2) records, padded to the largest shard; asynchronous: the camera
             #    trace below does not need the other ranks' vertices
-            need = stride * VCM_MERGE_RECORD_FLOATS
+            #    (sorted exchange, when the backend offers it: the rank's records in CELL order + block starts, one slab)
+            words = b.sorted_slab_words(stride) if (boxed and hasattr(b, "sorted_slab_words")) else -1
+            sorted_x = words > 0
+            need = words if sorted_x else stride * VCM_MERGE_RECORD_FLOATS
             if self._local is None or self._local.numel() < need:
                 self._local = b.new_tensor(need)
                 self._gather = b.new_tensor(need * self.world)
             local = self._local[:need]
             gathered = self._gather[:need * self.world]
-            b.export_records(local, n_local)
+            if sorted_x:
+                b.sort_records(local, stride)
+            else:
+                b.export_records(local, n_local)
             overlap = getattr(b, "camera_before_grid", False)
             work = dist.all_gather_into_tensor(gathered, local, group=self.group, async_op=overlap)
         early = getattr(b, "camera_before_grid", False)
         if early:
             b.trace_camera()            # overlaps the all-gather
-        self._pending = (work, counts, stride, gathered, early)
+        self._pending = (work, counts, stride, gathered, early, self.world > 1 and sorted_x)
 
     def _finish(self):
         b = self.backend
-        work, counts, stride, gathered, early = self._pending
+        work, counts, stride, gathered, early, sorted_x = self._pending
         self._pending = None
         if work is not None and early:
             work.wait()
         if self.world > 1:
-            b.import_records(gathered, counts, stride)
+            if sorted_x:
+                b.import_sorted_records(gathered, counts, stride)
+            else:
+                b.import_records(gathered, counts, stride)
         b.build_grid()
         if not early:
             b.trace_camera()

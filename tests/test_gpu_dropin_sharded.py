@@ -563,19 +563,26 @@ def test_farm_over_rccl_with_shipped_ids():
 
 
 def test_bench_line_for_several_gpus_runs_as_typed():
-    """`python bench.py --gpus N` (no torch.distributed.run) drives the C++ farm in-process and prints ONE line with the
-    default and the strong decomposition; --collectives threads lets the two ranks share this box's one GPU"""
+    """`python bench.py --gpus N` (no torch.distributed.run) drives the C++ farm in-process and prints ONE short line: the
+    default is north_star's decomposition (one renderer sharded over all GPUs: "strong"), the replica hybrid beside it;
+    everything else is in bench_detail.json.  --collectives threads lets the two ranks share this box's one GPU"""
     import json
     import sys
+    detail = os.path.join(ROOT, "gpurun_out", "test_bench_detail.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) \
+        else os.path.join("/tmp", "test_bench_detail.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--collectives", "threads", "--res", "256",
-                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, SMALLVCM_AMD_BENCH_DETAIL=detail))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096          # the driver parses the LAST line of a tail of stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3 and d["scaling"] == "weak"
-    assert "C++" in d["config"]["host"] and d["config"]["rccl_ranks"] == 0
-    assert len(d["rank_iteration_ms"]) == 2 and min(d["rank_iteration_ms"]) > 0
-    assert d["strong_decomposition"]["scaling"] == "strong" and d["strong_decomposition"]["value"] > 0
-    assert d["config"]["paths_per_step"] == 2 * 256 * 256 * 2       # two renderers on the pair, two in flight
-    assert d["roofline"]["per_kernel"]["k_merge"]["ms"] > 0
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["paths_per_step"] == 2 * 256 * 256          # ONE renderer across both ranks
+    assert d["hybrid_decomposition"]["scaling"] == "weak" and d["hybrid_decomposition"]["value"] > 0
+    assert d["hybrid_decomposition"]["paths_per_step"] == 2 * 256 * 256 * 2    # two renderers on the pair, two in flight
+    assert d["roofline"]["frac"] is None or 0 < d["roofline"]["frac"] <= 1
+    full = json.load(open(detail))
+    assert "C++" in full["config"]["host"] and full["config"]["rccl_ranks"] == 0
+    assert len(full["rank_iteration_ms"]) == 2 and min(full["rank_iteration_ms"]) > 0
+    assert full["roofline"]["per_kernel"]["k_merge"]["ms"] > 0
