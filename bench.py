@@ -64,7 +64,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue roofline.  MI355X_MICROARCH.md "Wave scheduling": 4 SIMD-32 per CU, a wave64 instruction issues over 2 cycles
 # (157.3 TFLOP/s fp32 = 1024 SIMDs x 32 lanes x 2 x 2.4 GHz).  What a SIMD actually sustains was measured on this chip by
-# profiles/tools/valu_bench.hip (profiles/r02h_valu_bench.txt, >= 2 waves per SIMD, in cycles of the nominal clock): plain
+# profiles/tools/valu_bench.hip (profiles/archive/r02h_valu_bench.txt, >= 2 waves per SIMD, in cycles of the nominal clock): plain
 # fp32 / int32 2.7, binary64 add / mul / fma 5.2, transcendentals (rcp, sqrt, ...) 8.4.  The roof weighs the run's
 # instruction mix with THOSE costs (rounds 2-4 used a flat 4 cycles, which is no peak: kernels printed 1.04-1.12 of it):
 #   issue_ms = (plain x 2.7 + f64 x 5.2 + trans x 8.4) / (1024 SIMDs x 2.4 GHz);  frac = issue_ms / kernel_ms  (<= 1)
@@ -940,7 +940,7 @@ def main():
                 base["host_cores"] = cores
                 base["port"] = port
                 # BASELINE.md section 2 asks for all host cores.  At 2048^2 that is one 80-second iteration (1.2 GB of
-                # light vertices + grid) per core: recorded once (profiles/r01_cpu_reference_timing*.json: 1.89 Mpaths/s on
+                # light vertices + grid) per core: recorded once (profiles/archive/r01_cpu_reference_timing*.json: 1.89 Mpaths/s on
                 # 32 threads, 1.79 on 128 -- the host's memory system saturates), not repeated in every run.  What IS
                 # measured here on every core is the resolution the reference's own CLI renders (config.hxx:237).
                 if threads < cores and headline:
@@ -948,7 +948,7 @@ def main():
                         allc = cpu_reference(args.scene, args.algo, 512, args.warmup, args.steps, cores)
                         base["all_cores"] = {"value": allc["value"], "unit": "Mpaths/s", "cores": cores, "wall_s": allc["wall_s"],
                                              "res": 512, "sample": allc["sample"],
-                                             "recorded_2048": "profiles/r01_cpu_reference_timing.json, r01_cpu_reference_timing_128.json: "
+                                             "recorded_2048": "profiles/archive/r01_cpu_reference_timing.json, r01_cpu_reference_timing_128.json: "
                                                               "1.89 Mpaths/s on 32 threads, 1.79 on 128 threads at 2048^2 on this host type"}
                     except Exception as e:
                         base["all_cores"] = {"error": repr(e)}

@@ -16,7 +16,8 @@
 #   timeline<res>     profiles/tools/timeline.py of scene 1 vcm at <res>^2 (timeline1024s3: scene 3)
 #   ab<res>[:algo[:scene]]   profiles/quick_ab.sh (variants from $VARIANTS, switches from $ENVS, $REPS repetitions, $ITER iterations)
 #   farm:<ranks>:<shards>:<inflight>[:res]   vcm_render --gpus <ranks> --collectives threads on this one GPU
-#   dropin<res>       tests/dropin_rate (the reference's renderer interface over the drop-in, refresh included)
+#   dropin<res>       smallvcm_amd/dropin/dropin_rate[_addcolor]: the reference's renderer interface over the drop-in (host Framebuffer
+#                     refreshed after every RunIteration) against the C-ABI alone
 #   sh:<command>      anything else, verbatim
 set -u
 TAG=${1:-rXX}; shift
@@ -44,7 +45,7 @@ for step in "$@"; do
     farm:*)        IFS=: read -r _ n sh fl r <<< "$step"; r=${r:-2048}
                    ( cd smallvcm_amd/host && timeout 300 ./vcm_render -s 1 -a vcm -i ${ITER:-20} --warmup ${WARM:-5} --res $r $r --gpus $n --shards $sh --inflight $fl --collectives threads --same-window --json ) > ${O}_farm_${n}_${sh}_${fl}_${r}.txt 2>&1
                    tail -c 1500 ${O}_farm_${n}_${sh}_${fl}_${r}.txt ;;
-    dropin*)       r=${step#dropin}; timeout 600 tests/dropin_rate/dropin_rate $r ${ITER:-20} > ${O}_dropin${r}.txt 2>&1; cat ${O}_dropin${r}.txt ;;
+    dropin*)       r=${step#dropin}; ( timeout 300 smallvcm_amd/dropin/dropin_rate $r ${ITER:-20} ${WARM:-5}; timeout 300 smallvcm_amd/dropin/dropin_rate_addcolor $r ${ITER:-20} ${WARM:-5}; timeout 300 smallvcm_amd/dropin/dropin_rate $r ${ITER:-20} ${WARM:-5} 1 vcm 2; timeout 300 smallvcm_amd/dropin/dropin_rate $r ${ITER:-20} ${WARM:-5} 1 vcm 4 ) > ${O}_dropin${r}.txt 2>&1; cat ${O}_dropin${r}.txt ;;
     sh:*)          timeout 900 bash -c "${step#sh:}" > ${O}_sh.log 2>&1; tail -20 ${O}_sh.log ;;
     *)             echo "unknown step $step" ;;
   esac

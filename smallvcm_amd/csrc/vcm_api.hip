@@ -173,6 +173,7 @@ struct vcm_ctx : Scratch {
     bool bboxFromLight;               /* K1 of this iteration accumulated the vertices' box into dHdr (single rank) */
     bool bboxFinal;                   /* ... and k_compact_records has turned it into floats already */
     bool strictOrder;
+    bool relaxedOrder;                /* vcm_set_relaxed_order: additions to a pixel in any order (fp32 atomics); default false = the reference's order, bit for bit */
     int mergeKind;                    /* VCM_MERGE_* */
     bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
     bool sceneRects;                  /* ... and is an axis-aligned rectangle: the SceneRects kernels */
@@ -430,7 +431,7 @@ static int ensure_device(vcm_ctx *c)
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
         {   /* The helper streams at the lowest priority (SMALLVCM_AMD_STREAM_PRIO=1; default: equal priorities).  On a
                2048^2 frame the grid build and the light splats then fill what the main stream's long kernels leave free
-               instead of sharing the chip evenly with them: +0.5 to +0.9 % (profiles/r05k_prio.txt, r05s_ab.txt).  On small
+               instead of sharing the chip evenly with them: +0.5 to +0.9 % (profiles/archive/r05k_prio.txt, r05s_ab.txt).  On small
                frames the camera pass is one wave-round that holds the whole chip, a low-priority grid build starts when it
                ends, and the merge waits for the build: 512^2 407 -> 295 Mpaths/s, the BVH room at 1024^2 403 -> 379, two
                renderers in flight at 1024^2 1379 -> 810 (r05r_configs.txt) -- and contexts created LATER in the same
@@ -550,7 +551,7 @@ static __global__ void k_stamp_many(StampArgs st) { stamp_entry(st); }
 /* Zeroing up to four device ranges in ONE launch (16-byte stores plus a tail of 4-byte ones; every range starts
  * 16-byte aligned and is a whole number of 4-byte words, except byte tables, whose size is rounded up to 4: they are
  * allocated in larger units).  hipMemsetAsync reached 380 GB/s on the 16 MB tables and cost a launch per
- * range: nine of them were 0.43 ms of an 11 ms iteration (profiles/r02k_kernel_stats.csv). */
+ * range: nine of them were 0.43 ms of an 11 ms iteration (profiles/archive/r02k_kernel_stats.csv). */
 /* vcm_begin_iteration zeroes the first six words of the grid header: the order keys K1 accumulates the box into */
 static_assert(offsetof(GridHeader, bboxMinU) == 0 && offsetof(GridHeader, bboxMaxU) == 3 * sizeof(uint32_t), "GridHeader layout");
 struct ZeroArgs { void *p[4]; unsigned long long n16[4]; unsigned tail4[4]; };
@@ -657,9 +658,11 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPa
     /* 4096 = 16 waves per CU: measured best (fewer, longer-lived waves leave fewer partly used queue blocks) */
     int maxWaves = (tw && atoi(tw) > 0) ? atoi(tw) : 256 * 16;
     /* a 512^2 frame is exactly 4096 waves of one path per lane: every wave then lives as long as its longest path.  With
-       3072 waves a third of the lanes take a second path: K3 0.41 -> 0.36 ms (profiles/r05c_ab_summary.txt; at 1024^2
+       3072 waves a third of the lanes take a second path: K3 0.41 -> 0.36 ms (profiles/archive/r05c_ab_summary.txt; at 1024^2
        4096 is best) */
-    if (!(tw && atoi(tw) > 0) && nLocal <= (1 << 18)) maxWaves = 256 * 12;
+    /* ... and so does 1024^2 (round 5): 3072 waves and chunks of 128 -- a third of the chunks dealt dynamically -- K3 0.83 -> 0.72 ms
+       on scene 3, 1.02 -> 0.82 on scene 1 (1068 -> 1116 and 808 -> 896 Mpaths/s, profiles/r07g_ab_1024_*.txt); no effect at 2048^2 */
+    if (!(tw && atoi(tw) > 0) && nLocal <= (1 << 20)) maxWaves = 256 * 12;
     static const char *lw = getenv("SMALLVCM_AMD_LIGHT_WAVES");   /* K1 needs fewer registers than K3: 5 waves per SIMD fit */
     if (lightPass && lw && atoi(lw) > 0) maxWaves = atoi(lw);
     if (maxWaves > VCM_MAX_TRACE_WAVES) maxWaves = VCM_MAX_TRACE_WAVES;   /* the queue buffers hold one spare block per wave */
@@ -675,6 +678,14 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPa
     int ch = nLocal / totalWaves;
     static const char *ce = getenv("SMALLVCM_AMD_TRACE_CHUNK");
     if (ce && atoi(ce) > 0) ch = atoi(ce);
+    /* up to 1024^2 (round 5): chunks of 128.  At 1024^2 a third of the 8192 chunks is then dealt dynamically; at 512^2 it means
+       2048 waves with two paths per lane instead of 3072 with one and a third (584 -> 608 Mpaths/s, profiles/r07h_ab_512_vcm_s1.txt;
+       chunks of 64: 566) */
+    if (!(ce && atoi(ce) > 0) && !(tw && atoi(tw) > 0) && nLocal <= (1 << 20)) {
+        ch = 128;
+        const int need = (nLocal + ch - 1) / ch;   /* waves that get a first chunk at all */
+        if (totalWaves > need) *blocks = (need + wavesPerBlock - 1) / wavesPerBlock;
+    }
     *chunk = ch < 64 ? 64 : (ch > 256 && !(ce && atoi(ce) > 0) ? 256 : ch);
 }
 
@@ -753,6 +764,7 @@ static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor
     }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
+    { const char *e = getenv("SMALLVCM_AMD_RELAXED_ORDER"); c->relaxedOrder = (e && e[0] == '1') && !c->strictOrder && !c->renderer; }
     { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE");   /* 0: the host will use the unsorted exchange of rounds 1-4 */
       c->sortedExchange = worldSize > 1 && worldSize <= 256 && c->useVM && !(e && e[0] == '0'); }
     { const char *e = getenv("SMALLVCM_AMD_MERGE");
@@ -879,6 +891,17 @@ int vcm_set_strict_order(vcm_ctx *c, int on)
     if (!c) return fail("vcm_set_strict_order", "ctx is NULL");
     if (c->inIteration) return fail("vcm_set_strict_order", "iteration in progress");
     c->strictOrder = on != 0;
+    if (c->strictOrder) c->relaxedOrder = false;
+    return 0;
+}
+
+int vcm_set_relaxed_order(vcm_ctx *c, int on)
+{
+    if (!c) return fail("vcm_set_relaxed_order", "ctx is NULL");
+    if (c->inIteration) return fail("vcm_set_relaxed_order", "iteration in progress");
+    if (on && c->renderer) return fail("vcm_set_relaxed_order", "PathTracer / EyeLight have one addition per pixel and path: nothing to relax");
+    if (on && c->strictOrder) return fail("vcm_set_relaxed_order", "strict order is set");
+    c->relaxedOrder = on != 0;
     return 0;
 }
 
@@ -970,7 +993,12 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
        resolution (the cell count follows the radius, not the pixel count), 14 % of a 512^2 iteration; with few
        queries per cell anyway a bucket may as well span a few cells there. */
     {
-        long long nb = 16LL * c->nLocal;
+        static int perPath = 0;   /* SMALLVCM_AMD_BUCKETS_PER_PATH (measurement switch): buckets of the query sort per path */
+        if (!perPath) { const char *e = getenv("SMALLVCM_AMD_BUCKETS_PER_PATH"); perPath = (e && atoi(e) > 0) ? atoi(e) : 16; }
+        /* (round 5: 4 buckets per path up to 1024^2 -- the in-line scan of the table is on the critical path there: 1024^2 scene 3
+           1123 -> 1188 Mpaths/s, 512^2 588 -> 605, profiles/r07h_ab_*.txt; 16 from 2^21 paths, where it makes no difference) */
+        const int per = (getenv("SMALLVCM_AMD_BUCKETS_PER_PATH") || c->nLocal > (1 << 20)) ? perPath : 4;
+        long long nb = (long long)per * c->nLocal;
         if (nb < (1 << 18)) nb = 1 << 18;
         P.nBuckets = nb < VCM_QSORT_BUCKETS ? (int)nb : VCM_QSORT_BUCKETS;
     }
@@ -997,7 +1025,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
 /* workgroups of the dense task kernels (K1c, K3b, K3c: grid-stride loops over the tasks).  At 70-80 VGPRs 1536 of them
  * are resident (6 waves per SIMD); the 2048 of round 1 meant a second round that occupied a third of the chip.
  * Measured (1024 / 1536 / 1792 / 2048 / 3072 / 4608 / 8192): K3b+c 2.16 / 1.96 / 2.06 / 1.99 / 1.83 / 1.82 / 1.88 ms
- * next to the tail of the grid build (profiles/r03j_ab_summary.txt). */
+ * next to the tail of the grid build (profiles/archive/r03j_ab_summary.txt). */
 static int task_blocks(int nLocal)
 {
     static int n = -1;
@@ -1015,8 +1043,8 @@ static int task_blocks(int nLocal)
 /* workgroups of k_merge_walk (multiple of 8: they are dealt to the XCDs).  1024 are resident (126 VGPRs, 37 KB of
  * LDS); with 2048 every workgroup walked ~20 batches of 256 queries and the last ones to finish set the kernel's time,
  * with 16384 it is two or three batches each: 3.29 -> 3.15 ms; beyond that the launch itself shows (32768: 3.63 ms;
- * profiles/r03k, r03l). */
-static int merge_blocks(int nLocal)
+ * profiles/archive/r03k, r03l). */
+static int merge_blocks(int nLocal, int N)
 {
     static int n = -1;
     if (n < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_BLOCKS"); n = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 0; }
@@ -1026,8 +1054,12 @@ static int merge_blocks(int nLocal)
        8192: K4 0.40 / 0.42 / 0.52 / 0.86 ms (profiles/r07d_ab_*.txt) */
     if (n) return n;
     if (nLocal >= (1 << 21)) return 16384;
-    const int b = (nLocal / 1024) & ~7;
-    return b < 512 ? 512 : (b > 2048 ? 2048 : b);
+    int b = (nLocal / 1024) & ~7;
+    b = b < 512 ? 512 : (b > 2048 ? 2048 : b);
+    /* a SHARD of a large frame: its queries are as heavy as the whole frame's (the photon density follows the frame, 210
+       candidates per query at 2048^2 against 29 at 512^2), so it gets the whole frame's workgroups per query */
+    if (N >= (1 << 21) && nLocal < N) { const long long d = (16384ll * nLocal / N) & ~7ll; if (d > b) b = (int)d; }
+    return b;
 }
 /* workgroups of the streaming helper kernels (compaction, grid build, splat lists, query scatter, resolve: grid-stride loops over
  * paths, vertices or pixels).  2048 = 524 288 threads; a 512^2 frame has 262 144 paths and ~560 000 vertices: half the threads
@@ -1054,12 +1086,14 @@ static int flush_light_splats(vcm_ctx *c)
     {
         /* K1c / K1d only read the light-vertex store and add to the framebuffer; nothing of the camera pass touches the
            framebuffer before K5.  They run on a stream of their own next to the grid build and the camera pass and are
-           joined before K5: +4.5 % at 512^2, +7 % at 1024^2, +3 % at 2048^2 (profiles/r05c_ab_summary.txt; in round 1,
+           joined before K5: +4.5 % at 512^2, +7 % at 1024^2, +3 % at 2048^2 (profiles/archive/r05c_ab_summary.txt; in round 1,
            when they still shared their scratch with the grid build, the overlap had bought nothing).
            SMALLVCM_AMD_SPLAT_STREAM=0 puts them back in line. */
         static int force = -2;
         if (force == -2) { const char *e = getenv("SMALLVCM_AMD_SPLAT_STREAM"); force = e ? (e[0] == '1' ? 1 : 0) : -1; }
-        const bool overlap = (force != 0) && c->world == 1 && !c->strictOrder;
+        /* (round 5: sharded contexts too -- a rank's K1c / K1d then run beside its camera pass while its light vertices
+           travel, instead of in line in front of it) */
+        const bool overlap = (force != 0) && !c->strictOrder;
         hipStream_t q = overlap ? c->splat : c->stream;
         const StampArgs none = { { NULL, NULL, NULL, NULL } };
         if (overlap) {
@@ -1068,6 +1102,14 @@ static int flush_light_splats(vcm_ctx *c)
         }
         int *pixCount = c->dPixCount, *arrival = c->dSplatArrival, *pixStart = c->dPixStart;
         F4 *list = c->dSplatList;
+        if (c->relaxedOrder && c->P.wavefront) {
+            /* order-relaxed mode: K1c adds its splats with fp32 atomics; no pixel histogram, scan, scatter, ordered application */
+            LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, q, c->dScene, c->P, c->store,
+                               (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, (F4 *)NULL, (int *)NULL, (int *)NULL, c->dStats);
+            HIPCHK(hipGetLastError());
+            if (overlap) { HIPCHK(hipEventRecord(c->evSplatDone, q)); c->splatInFlight = true; }
+            return 0;
+        }
         if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));
         else if (zero_ranges(q, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
         LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, q, c->dScene, c->P, c->store,
@@ -1198,10 +1240,18 @@ static int vcm_local_light_bbox_impl(vcm_ctx *c, float *min3, float *max3, long 
 {
     if (!c || !c->inIteration || !min3 || !max3) return fail("vcm_local_light_bbox", "call it between vcm_trace_light and vcm_build_grid");
     if (use_device(c)) return -1;
-    VertexSource src; src.records = NULL; src.store = c->store; src.slotOfVertex = c->dSlotOfVertex;
-    hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr, take_stamps(c, c->stream));
-    hipLaunchKernelGGL(k_bbox, dim3(512), dim3(256), 0, c->stream, src, c->dHdr);
-    hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr, 0);
+    static int noK1Box = -1;
+    if (noK1Box < 0) { const char *e = getenv("SMALLVCM_AMD_NO_K1_BBOX"); noK1Box = (e && e[0] == '1') ? 1 : 0; }
+    if (!noK1Box && !c->renderer && !c->bboxFinal) {
+        /* K1 kept the box of what it stored in the header's key words (minimum inverted), as on a single rank: one tiny
+           launch turns them into floats -- rounds 2-4 gathered every local vertex's position once more for this (k_bbox) */
+        hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr, 1);
+    } else if (!c->bboxFinal) {
+        VertexSource src; src.records = NULL; src.store = c->store; src.slotOfVertex = c->dSlotOfVertex;
+        hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, c->stream, c->dHdr, take_stamps(c, c->stream));
+        hipLaunchKernelGGL(k_bbox, dim3(512), dim3(256), 0, c->stream, src, c->dHdr);
+        hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr, 0);
+    }
     HIPCHK(hipGetLastError());
     GridHeader h;
     HIPCHK(hipMemcpyAsync(&h, c->dHdr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -1495,6 +1545,8 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
+        c->vs.relaxedFb = c->relaxedOrder ? c->dFb : NULL;
+        c->vs.relaxedTarget = c->dCamOut;
         if (c->countedInCamera) {
             if (c->prezeroed) HIPCHK(hipStreamWaitEvent(c->stream, c->evZero, 0));
             else if (zero_ranges(c->stream, c->dQueryCount, ((size_t)c->P.nBuckets + 1) * sizeof(int))) return -1;
@@ -1504,20 +1556,12 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
             /* K3c reads what K3 appended and the light store, and only K5 reads what it writes: it runs on the splat
-               stream, next to K3b and K4, joined before K5: +2 % at 512^2, +6 % at 1024^2 (profiles/r05d_ab_summary.txt);
+               stream, next to K3b and K4, joined before K5: +2 % at 512^2, +6 % at 1024^2 (profiles/archive/r05d_ab_summary.txt);
                at 2048^2, where K4 is issue-bound, it neither gains nor loses with equal stream priorities (r05f) and gained
                1.4 % with the helper streams at low priority (r05l).  SMALLVCM_AMD_VC_STREAM=0: in line. */
             static int vcForce = -2;
             if (vcForce == -2) { const char *e = getenv("SMALLVCM_AMD_VC_STREAM"); vcForce = e ? (e[0] == '1' ? 1 : 0) : -1; }
-            const bool vcAside = (vcForce != 0) && c->world == 1;
-            if (vcAside) {
-                HIPCHK(hipEventRecord(c->evSplatFork, c->stream));   /* behind K3 */
-                HIPCHK(hipStreamWaitEvent(c->splat, c->evSplatFork, 0));
-                LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->splat, c->dScene, c->P, c->vs,
-                                   c->store, c->dStats);
-                HIPCHK(hipEventRecord(c->evSplatDone, c->splat));   /* also behind the light splats: same stream */
-                c->splatInFlight = true;
-            }
+            const bool vcAside = (vcForce != 0);
             /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
@@ -1550,6 +1594,17 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                 c->scatteredInDI = false;
             }
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
+            if (vcAside) {
+                /* behind K3 -- and behind the in-line scan of the bucket table: launched at the same moment as K3c, the scan's
+                   8192 workgroups shared the chip with K3c's resident ones and took 93 + 127 us instead of ~25 at 1024^2, on the
+                   critical path (profiles/r07f_timeline1024.txt) */
+                HIPCHK(hipEventRecord(c->evSplatFork, c->stream));
+                HIPCHK(hipStreamWaitEvent(c->splat, c->evSplatFork, 0));
+                LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->splat, c->dScene, c->P, c->vs,
+                                   c->store, c->dStats);
+                HIPCHK(hipEventRecord(c->evSplatDone, c->splat));   /* also behind the light splats: same stream */
+                c->splatInFlight = true;
+            }
             LAUNCH_SC(c, k_connect_di, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
                                c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
@@ -1607,9 +1662,9 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
             /* Three kernels, same bits (vcm_set_merge_kernel).  k_merge_walk (default): every lane walks its own
                non-empty runs back to back -- 3.51 ms against 3.93 for k_merge_lane, which visits the 8 cells in
-               lockstep (profiles/r02j_ab_summary.txt).  k_merge_staged: the workgroup stages the cell lists of its
+               lockstep (profiles/archive/r02j_ab_summary.txt).  k_merge_staged: the workgroup stages the cell lists of its
                queries through LDS -- 27 % less HBM traffic than k_merge_lane (13.7 -> 9.9 GB per launch,
-               profiles/r02c_ab_summary.txt) but slower: the kernel is not bound by the candidate loads, and the
+               profiles/archive/r02c_ab_summary.txt) but slower: the kernel is not bound by the candidate loads, and the
                staging adds instructions and barriers. */
             const int mergeStaged = c->mergeKind;
             if (mergeStaged == 2) {
@@ -1617,8 +1672,8 @@ static int vcm_merge_impl(vcm_ctx *c)
                    from eight counters (vs.count[24..31], zeroed with the queue counts), with stealing; as many workgroups
                    as are resident (4 per CU).  Measured against the static dealing (default) on the Cornell scenes: K4's
                    HBM traffic 6.89 -> 5.58 GB per launch, 3.155 -> 3.11 ms at 2048^2, 0.260 -> 0.229 ms at 512^2
-                   (profiles/r05e_ab_summary.txt) -- and on the 10 380-triangle room, whose caustic puts thousands of
-                   photons into a few cells, 1.06 -> 1.48 ms (profiles/r05f_ab_summary.txt): the queries of the hot cells
+                   (profiles/archive/r05e_ab_summary.txt) -- and on the 10 380-triangle room, whose caustic puts thousands of
+                   photons into a few cells, 1.06 -> 1.48 ms (profiles/archive/r05f_ab_summary.txt): the queries of the hot cells
                    are neighbours in the sorted order, i.e. ONE slab, and one XCD's L2 then serves the reads that the
                    round-robin chunks spread over all eight.  Not the default. */
                 static int slab = -1;
@@ -1626,11 +1681,11 @@ static int vcm_merge_impl(vcm_ctx *c)
                 static int slabBlocks = 0;
                 if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
                 if (c->intPhong)
-                    hipLaunchKernelGGL(k_merge_walk<true>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                    hipLaunchKernelGGL(k_merge_walk<true>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
                                        c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
                                        slab ? c->vs.count + 24 : (int *)NULL);
                 else
-                    hipLaunchKernelGGL(k_merge_walk<false>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                    hipLaunchKernelGGL(k_merge_walk<false>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
                                        c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
                                        slab ? c->vs.count + 24 : (int *)NULL);
             }
@@ -1655,11 +1710,15 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (mark(c, EV_SORT_K1)) return -1;
         }
         if (mark(c, EV_MERGE_K1)) return -1;
-        /* K5: the first kernel since the light splats that touches the framebuffer */
+        /* K5: the first kernel since the light splats that touches the framebuffer.  (Order-relaxed mode: K3 and the task
+           kernels have added everything to the pixels themselves; there is nothing to replay.) */
+        if (c->relaxedOrder && c->P.wavefront && !c->renderer) { if (flush_stamps(c, c->stream)) return -1; }
+        else {
         if (join_splats(c)) return -1;
         hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
+        }
     }
     if (join_splats(c)) return -1;               /* light tracing alone: nothing else waited for them */
     if (mark(c, EV_CAMERA)) return -1;
@@ -1767,6 +1826,20 @@ int vcm_read_framebuffer(vcm_ctx *c, float *rgbHost)
     if (join_splats(c)) return -1;   /* K1c / K1d of an open iteration add to dFb on the splat stream */
     HIPCHK(hipMemcpyAsync(rgbHost, c->dFb, (size_t)c->N * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vcm_pin_host_memory(void *hostPtr, unsigned long long bytes)
+{
+    if (!hostPtr || !bytes) return fail("vcm_pin_host_memory", "NULL argument");
+    if (vcm_device_count() <= 0) return fail("vcm_pin_host_memory", "no HIP device available");
+    HIPCHK(hipHostRegister(hostPtr, (size_t)bytes, hipHostRegisterPortable));
+    return 0;
+}
+int vcm_unpin_host_memory(void *hostPtr)
+{
+    if (!hostPtr) return fail("vcm_unpin_host_memory", "NULL argument");
+    HIPCHK(hipHostUnregister(hostPtr));
     return 0;
 }
 

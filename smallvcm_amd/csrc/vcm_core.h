@@ -58,11 +58,11 @@ struct GridHeader {
  * kernels that wait for memory, against 0.14 GB less written by K1 and ~3 GB less gathered per 2048^2 iteration.
  * History: the record was five 16-byte fields (80 B).  K1 writes slot-major, so a wave (64 consecutive paths at the same bounce) fills one
  * contiguous 5 KB region; the consumers GATHER a vertex (vertex connection K3c, the camera connection K1c, the
- * cell-sorted copy of the grid build) and a gather moves whole 128-byte lines (profiles/r05a_fetch_calib.json): an
+ * cell-sorted copy of the grid build) and a gather moves whole 128-byte lines (profiles/archive/r05a_fetch_calib.json): an
  * 80-byte record lies in 1.5 of them on average.  Round 3 measured the alternative -- the four fields the connections
  * read as a 64-byte aligned record (one line), the fifth in an array of its own: the connections
  * gain, the grid build (which wants fields 0, 1, 3 AND 4: two lines) loses and slows the camera pass it runs next to:
- * 868 against 875 Mpaths/s (profiles/r05h_ab_summary.txt).  The camera-vertex records, below, ARE split.
+ * 868 against 875 Mpaths/s (profiles/archive/r05h_ab_summary.txt).  The camera-vertex records, below, ARE split.
  * (Five separate arrays were measured in round 1: five lines per gather, k_cell_rank_gather 1.16 ms instead of 0.6.)
  * Replaces the AoS std::vector<LightVertex> (vertexcm.hxx:79-101, 120 B/vertex). */
 #define VCM_LV_FIELDS 4
@@ -105,9 +105,9 @@ struct VertexStore {
     /* the record of camera vertex i: four 16-byte fields, contiguous and 64-byte aligned (q[i * 4 + k]) = what the merge
        (K4, which GATHERS the vertices in cell order: one 128-byte line each) and the connections read, plus a fifth
        in an array of its own (q4[i]) that only K3b / K3c want.  As one 80-byte record (round 2) a vertex
-       straddled two lines half of the time: 864 -> 875 Mpaths/s with the split (profiles/r05h_ab_summary.txt); as five
+       straddled two lines half of the time: 864 -> 875 Mpaths/s with the split (profiles/archive/r05h_ab_summary.txt); as five
        separate arrays (round 1) a wave's append was five partly written lines per step and every gather touched five
-       (K4 3.55 -> 3.39 ms when they were joined, profiles/r02r_ab_summary.txt)
+       (K4 3.55 -> 3.39 ms when they were joined, profiles/archive/r02r_ab_summary.txt)
          k=0 hitpoint.xyz | local path index
          k=1 isect.normal.xyz | pathLength (bits 0-7), matID (8-15)
          k=2 localDirFix.xyz | dVCM
@@ -138,11 +138,30 @@ struct VertexStore {
        the vertex takes its bucket key and its place in the bucket the moment it is appended; NULL otherwise */
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
+    /* ORDER-RELAXED mode (vcm_set_relaxed_order, round 5): non-NULL = the framebuffer; every addend of a camera path goes
+       straight to the path's pixel with fp32 atomics instead of to its slot for k_resolve's ordered replay.  relaxedTarget =
+       camOut (its .w is the pixel of the path's jittered sample, written when K3 ends the path) */
+    float *relaxedFb;
+    const F4 *relaxedTarget;
 };
 VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 4 + (size_t)k] : vs.q4[i]; }
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
+}
+/* order-relaxed mode: colour += v at the pixel camera path `lp` belongs to (Framebuffer::AddColor, framebuffer.hxx:43-57, as an
+   fp32 atomic: the additions of a pixel then happen in whatever order the hardware serves them) */
+VCM_HD void relaxed_add_to_path_pixel(const VertexStore &vs, uint32_t lp, V3 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (v.x == 0.f && v.y == 0.f && v.z == 0.f) return;   /* an occluded connection: nothing to add */
+    const int target = (int)f2u(vs.relaxedTarget[lp].w);
+    if (target < 0) return;                                /* the jittered sample left the frame (AddColor's bounds check) */
+    float *px = vs.relaxedFb + (size_t)target * 3;
+    atomicAdd(px + 0, v.x); atomicAdd(px + 1, v.y); atomicAdd(px + 2, v.z);
+#else
+    (void)vs; (void)lp; (void)v;
+#endif
 }
 
 struct LaneStats {
@@ -383,7 +402,7 @@ struct DScene {
 /* Which of the two a scene carries, as a TYPE: every kernel that casts rays exists once per kind (the launch picks by
  * nNodes), so the brute-force kernels hold no traversal code and the BVH kernels no list loop.  Compiled together the
  * two paths cost the headline kernels 11-27 VGPRs, i.e. a wave per SIMD (K3 122 -> 133 registers: 713 -> 576
- * Mpaths/s on the same box, profiles/r02g_*).  Functions that cast rays take `const SC &`, the rest `const DScene &`. */
+ * Mpaths/s on the same box, profiles/archive/r02g_*).  Functions that cast rays take `const SC &`, the rest `const DScene &`. */
 /* kIntPhong: the host found every Phong exponent in use to be an integer in [1, 65536] (the reference's scenes: 90), so
  * pow(x, n) of the lobe is detmath.h's binary exponentiation and nothing else -- the kernels of such a kind hold no call
  * of the general powf where a lobe is only EVALUATED (the call's register constraints cost k_merge_walk its fourth wave
@@ -405,7 +424,7 @@ struct SceneRects : DScene { static constexpr bool kBvh = false; static constexp
  * primitives, material -> light, lights: the reference's scenes have at most 10 / 26 / 10 / 2 entries) into LDS when it
  * starts (stage_scene_tables: all threads of the block, one barrier) and scene_material() / scene_prim() /
  * scene_mat2light() / scene_light() read them from there; a table with more entries than its room keeps the global path
- * (a scalar branch on the count).  Materials alone: 887 / 893 -> 924 / 917 Mpaths/s, same box (profiles/r05s_ab.txt).
+ * (a scalar branch on the count).  Materials alone: 887 / 893 -> 924 / 917 Mpaths/s, same box (profiles/archive/r05s_ab.txt).
  * RULE: a kernel that can reach one of the accessors calls stage_scene_tables() first -- nothing else initialises the
  * copy (the merge kernels do not, and pass lds = false where they read a material). */
 #define VCM_LDS_MATERIALS 32
@@ -1156,7 +1175,7 @@ VCM_HD void fast_classify(float w0, float w1, float w2, float tau, FastHit &h)
     /* geometry.hxx:141-142 with certain signs: all three below -tau or all three above tau = certainly inside; one below
        -tau and one above tau = certainly outside.  Taken on the smallest and the largest of the three (v_min3 / v_max3,
        four comparisons, two mask operations -- six comparisons and ten mask operations when written per edge, and the
-       scalar unit issues no faster than a SIMD: profiles/r05o_ab.txt, +1.3 %).  min / max skip a NaN operand, so a
+       scalar unit issues no faster than a SIMD: profiles/archive/r05o_ab.txt, +1.3 %).  min / max skip a NaN operand, so a
        caller whose operands can be NaN makes tau infinite instead (fast_rect_edges; Pluecker edges are finite). */
     const float lo = fminf(fminf(w0, w1), w2), hi = fmaxf(fmaxf(w0, w1), w2);
     h.certIn = (bool)((int)(hi < -tau) | (int)(lo > tau));
@@ -2608,7 +2627,7 @@ struct CameraPath {
  * ds_read / ds_write that the compiler neither caches in a register nor hoists out of the loop.  (They were a
  * `volatile int *` first: a GENERIC pointer, so every access was a flat_load / flat_store with system scope followed
  * by s_waitcnt vmcnt(0) -- twelve of them per vertex K3 appended, each also waiting for every record store in flight:
- * 28 % of K3's wave time, profiles/r05z_region_clock.txt.) */
+ * 28 % of K3's wave time, profiles/archive/r05z_region_clock.txt.) */
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) int *WaveQueueWords;
 #else
@@ -2872,7 +2891,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
                 wqs.pendingVertex = -1;
                 if (k >= 0) { wqs.pendingVertex = vi; wqs.pendingArrival = atomicAdd(&vs.bucketCount[k], 1); }
 #endif
-                else vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
+                else if (!vs.relaxedFb) vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
             }
 #endif
             if (hasDI) vs.diTask[di] = vi;

@@ -90,7 +90,7 @@ __device__ __forceinline__ float float_from_order_key(uint32_t k)
  * chunk cannot serve every dead lane the rest comes out of the next one in the same step.  The first version gave
  * every wave ONE fixed range: the waves of K3 that start late -- the grid build on the side stream holds part of the
  * chip when K3 is launched -- then finish late by the whole length of their range: K3 took 2.35 ms next to the build
- * against 1.71 ms alone (profiles/r03d_ab_summary.txt).  Which wave traces which path does not matter: every path has
+ * against 1.71 ms alone (profiles/archive/r03d_ab_summary.txt).  Which wave traces which path does not matter: every path has
  * its own random stream and its own slots in the stores. */
 struct WaveWork { int next, end, dynBase; bool exhausted; };
 /* the FIRST chunk of every wave is fixed (chunk number = wave number): 4096 waves asking one counter word at the same
@@ -236,6 +236,10 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
+                if (MODE == 1 && vs.relaxedFb && target >= 0 && (path.color.x != 0.f || path.color.y != 0.f || path.color.z != 0.f)) {
+                    float *px = vs.relaxedFb + (size_t)target * 3;   /* order-relaxed mode: the emission terms of the path, now */
+                    atomicAdd(px + 0, path.color.x); atomicAdd(px + 1, path.color.y); atomicAdd(px + 2, path.color.z);
+                }
                 if (MODE == 1) camMask[path.lp] = path.queryMask;
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
@@ -313,7 +317,7 @@ k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned c
 /* One lane per task; every lane of a wave runs the same code path (a BSDF
  * evaluation or two and ONE shadow ray), which is what the fused path could
  * not offer: there the connection loop ran at the trip count of the busiest
- * lane and at 23 % lane utilisation (profiles/r01b_pmc_*). */
+ * lane and at 23 % lane utilisation (profiles/archive/r01b_pmc_*). */
 #define VCM_TASK_BLOCK 256
 /* (Round 4 dealt the tasks of K3b / K3c out by (cell of the ray's origin, cell of its end point) for scenes behind a BVH --
  * a counting sort with chunk histograms in LDS.  The host replay had promised half the wave-instructions per ray
@@ -341,7 +345,8 @@ k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsig
         if (vi < 0) continue;   /* hole */
         size_t ps;
         const V3 v = eval_di_task(sc, P, vs, vi, ls, ps);
-        vs.diOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+        if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(vq(vs, 0, vi).w), v);
+        else vs.diOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         if (sortedVertex) {   /* K4a's scatter pass, here: this kernel visits every camera vertex once */
             const int k = vs.sortKey[vi];
             if (k >= 0) sortedVertex[bucketStart[k] + vs.sortArrival[vi]] = vi;
@@ -363,7 +368,8 @@ k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, Light
         const int vi = vs.vcTask[2 * t];
         if (vi < 0) continue;   /* hole */
         const V3 v = eval_vc_task(sc, P, vs, store, vi, vs.vcTask[2 * t + 1], ls);
-        vs.vcOut[t] = mk4(v.x, v.y, v.z, 0.f);
+        if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(vq(vs, 0, vi).w), v);
+        else vs.vcOut[t] = mk4(v.x, v.y, v.z, 0.f);
     }
     flush_stats(ls, gstats);
 }
@@ -391,7 +397,7 @@ __global__ void __launch_bounds__(256) k_query_count(IterParams P, VertexStore v
         int k = -1;
         if (f2u(r0.w) != 0xffffffffu) {
             k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
-            if (k < 0)   /* empty query: contrib = 0 */
+            if (k < 0 && !vs.relaxedFb)   /* empty query: contrib = 0 */
                 vs.mergeOut[path_slot(P, f2u(vq(vs, 1, q).w) & 0xffu, f2u(r0.w))] = mk4(0.f, 0.f, 0.f, 0.f);
         }
         key[q] = k;
@@ -451,7 +457,8 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             const int vi = sortedVertex[q];
             size_t ps;
             const V3 v = eval_merge_task<IP>(sc, P, vs, g, vi, ls, ms, ps, false);   /* this kernel stages no material table */
-            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+            if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(vq(vs, 0, vi).w), v);
+            else vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -460,7 +467,7 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 /* ---------------- K4 (walk): every lane walks ITS candidate runs without waiting for the others ---------------- */
 /* merge_query (k_merge_lane) visits the 8 cells in lockstep: in step j every lane scans its j-th cell and the wave
  * iterates until the LONGEST of the 64 runs is done -- measured 40 % of the candidate slots of a step hold a candidate
- * (48.6 M ds_write per launch = 12.1 M wave steps x 256 slots for 1.25 G candidates, profiles/r01u_pmc_sq.json), and
+ * (48.6 M ds_write per launch = 12.1 M wave steps x 256 slots for 1.25 G candidates, profiles/archive/r01u_pmc_sq.json), and
  * both halves of the scan, the per-lane loads (TA-bound) and the distance arithmetic, pay for the empty ones.
  * Here a lane first writes the (at most 8) NON-EMPTY runs of its query to LDS -- all 8 hashes and 16 range words in
  * flight together -- and then walks them back to back: when its run ends it takes its next one in the same step,
@@ -475,7 +482,7 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #endif
 #ifndef VCM_WALK_Q
 #define VCM_WALK_Q 20   /* accepted-index queue per lane: 21 rows + 8 run rows of 8 bytes = 37 KB per block, four blocks per CU
-                           (12 / 16 / 20 entries: 3.51 / 3.40 / 3.35 ms, profiles/r03a_ab_summary.txt) */
+                           (12 / 16 / 20 entries: 3.51 / 3.40 / 3.35 ms, profiles/archive/r03a_ab_summary.txt) */
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 struct alignas(8) WalkRun { int lo, hi; };
@@ -500,7 +507,7 @@ __device__ __forceinline__ int merge_walk_runs(const IterParams &P, const GridSt
     /* (Round 3 tried to leave out the edge / corner probes that cannot hold a photon within the radius -- 21 % of the
        edge probes, 48 % of the corner probes for evenly spread queries, decided from the query's position in its
        cell with a 1 % margin and only when no other probe shares the bucket: bit-exact, 14 % fewer candidates, and
-       2 % SLOWER, profiles/r05b_ab_summary.txt: the wave walks until the lane with the MOST candidates is done,
+       2 % SLOWER, profiles/archive/r05b_ab_summary.txt: the wave walks until the lane with the MOST candidates is done,
        and that is a lane near a cell corner, which skips nothing.) */
     int lo[8], hi[8];
 #pragma unroll
@@ -566,7 +573,7 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
             nxt.lo = 0; nxt.hi = 0;
             if (k + 1 < n) nxt = runs[(k + 1) * stride];
         } else cur.lo = stepEnd;
-        /* (draining only when K lanes are full was measured in round 3, K = 4 .. 24: no gain, profiles/r05zz_k4full_*.txt) */
+        /* (draining only when K lanes are full was measured in round 3, K = 4 .. 24: no gain, profiles/archive/r05zz_k4full_*.txt) */
         if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
             ls.mergeAccepted += (uint32_t)qn;
             RC_MARK(15);
@@ -647,7 +654,8 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             ls.mergeCandidates += (uint32_t)total;
             const V3 contrib = merge_query_walk<IP>(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK, n);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
-            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+            if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(a.w), v);
+            else vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -895,7 +903,8 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
             st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
             const V3 contrib = merge_query_staged<IP>(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
-            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+            if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(a.w), v);
+            else vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
         __syncthreads();
     }
@@ -937,9 +946,9 @@ __global__ void __launch_bounds__(256) k_resolve(IterParams P, const F4 *__restr
  * a workgroup adds up the sums of ALL tiles before its own -- its 256 threads take them in strides, at most 8192 tile
  * sums = 32 KB out of L2 -- and scans its tile from there.  No workgroup waits for another: the first version put a
  * single 256-thread block between the two (40 us per scan at 512^2, four scans per iteration: 0.31 of 1.54 ms,
- * profiles/r02n_trace512_summary.txt), and a single-pass scan with decoupled look-back (one launch; tried in round 3)
+ * profiles/archive/r02n_trace512_summary.txt), and a single-pass scan with decoupled look-back (one launch; tried in round 3)
  * is bound by the latency of its look-back chain on this chip -- 64 tiles per ~4 us step: 1.2 ms for the 16.8 M-entry
- * bucket table of a 2048^2 frame against 70 us here (profiles/r05b_ab_summary.txt).  Wave scans are shuffles
+ * bucket table of a 2048^2 frame against 70 us here (profiles/archive/r05b_ab_summary.txt).  Wave scans are shuffles
  * (6 steps), the four wave totals cross LDS once. */
 #define VCM_SCAN_BLOCK 256
 #define VCM_SCAN_ITEMS 8
@@ -1081,6 +1090,10 @@ k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         F4 sp;
         connect_stored_vertex_to_camera(sc, P, store, (size_t)slotOfVertex[i], fb, ls, &sp);
+        if (!splat) {   /* order-relaxed mode: Framebuffer::AddColor (vertexcm.hxx:931) as fp32 atomics, no ordered lists */
+            if (f2u(sp.w) != 0xffffffffu) { float *px = fb + (size_t)f2u(sp.w) * 3; atomicAdd(px + 0, sp.x); atomicAdd(px + 1, sp.y); atomicAdd(px + 2, sp.z); }
+            continue;
+        }
         if (pendI >= 0) arrival[pendI] = pendArrival;
         pendI = -1;
         splat[i] = sp;
@@ -1112,7 +1125,7 @@ __global__ void __launch_bounds__(256) k_splat_scatter(const F4 *__restrict__ sp
  * and more splats -- go to k_splat_apply_long, one WAVE per pixel (sending every list above 8 there cost 0.7 ms at
  * 2048^2, r02y: a wave per pixel and a fence per pixel for lists of a dozen).
  * (They used to take a per-lane selection loop here, quadratic in the list length on ONE lane: 5.2 of the 11.5 ms of an
- * iteration of the 10 380-triangle room, profiles/r02w.) */
+ * iteration of the 10 380-triangle room, profiles/archive/r02w.) */
 #define VCM_SPLAT_REG 8
 #define VCM_SPLAT_LONG 48   /* up to here a lane orders its list by selection (k^2 / 2 loads that hit the cache) */
 __global__ void __launch_bounds__(256) k_splat_apply(int N, const int *__restrict__ pixStart, const F4 *__restrict__ list, float *fb,

@@ -21,6 +21,21 @@
 
 namespace smallvcm_amd {
 
+// Framebuffer keeps its pixels private and has no bulk setter (src/framebuffer.hxx:253-258); AbstractRenderer::GetFramebuffer
+// is not virtual and copies the protected mFramebuffer (src/renderer.hxx:49-55).  So after EVERY RunIteration the host
+// Framebuffer has to hold the running sum.  Round 2 did that through the public interface alone -- Clear() + one AddColor per
+// pixel behind a 50 MB read into pageable memory: at 2048^2 that is 4.2 M calls and more host time than the GPU needs for
+// the iteration itself.  The storage is a std::vector<Vec3f> of 12-byte texels in pixel order -- exactly the layout of the
+// device framebuffer -- so the refresh below copies device -> mColor DIRECTLY, the vector's memory page-locked once
+// (vcm_pin_host_memory).  Reaching the private member needs no edit of framebuffer.hxx: a pointer to member may be named in an
+// EXPLICIT template instantiation whatever its access (C++ [temp.spec]: "the usual access checking rules do not apply
+// to names used to specify explicit instantiations").  -DSMALLVCM_AMD_DROPIN_ADDCOLOR keeps the public-interface refresh.
+#if !defined(SMALLVCM_AMD_DROPIN_ADDCOLOR)
+template <typename Tag, typename Tag::type Member> struct MemberDoor { friend typename Tag::type member_of(Tag) { return Member; } };
+struct FramebufferColors { typedef std::vector<Vec3f> Framebuffer::*type; friend type member_of(FramebufferColors); };
+template struct MemberDoor<FramebufferColors, &Framebuffer::mColor>;
+#endif
+
 class GpuRenderer : public AbstractRenderer
 {
 public:
@@ -34,7 +49,7 @@ public:
         int           aSeed
     ) :
         AbstractRenderer(aScene),
-        mCtx(NULL)
+        mCtx(NULL), mPixels(NULL), mPixelBytes(0), mPinned(false)
     {
         vcm_scene_desc desc;
         const int rc = FlattenScene(aScene, desc);
@@ -66,11 +81,31 @@ public:
 
         mResX = int(aScene.mCamera.mResolution.x);
         mResY = int(aScene.mCamera.mResolution.y);
+#if !defined(SMALLVCM_AMD_DROPIN_ADDCOLOR)
+        // AbstractRenderer's constructor has sized the pixels (renderer.hxx:41 -> framebuffer.hxx:62-69); nothing resizes them later
+        static_assert(sizeof(Vec3f) == 3 * sizeof(float), "Vec3f is three packed floats (math.hxx:87-128)");
+        std::vector<Vec3f> &pixels = mFramebuffer.*member_of(FramebufferColors());
+        mPixels = pixels.empty() ? NULL : &pixels[0].x;
+        mPixelBytes = pixels.size() * sizeof(Vec3f);
+        mPinned = mPixels != NULL && pixels.size() == size_t(mResX) * size_t(mResY) && vcm_pin_host_memory(mPixels, mPixelBytes) == 0;
+#endif
     }
 
     virtual ~GpuRenderer()
     {
+#if !defined(SMALLVCM_AMD_DROPIN_ADDCOLOR)
+        if(mPinned) vcm_unpin_host_memory(mPixels);
+#endif
         vcm_destroy(mCtx);
+    }
+
+    static const char* RefreshKind()
+    {
+#if defined(SMALLVCM_AMD_DROPIN_ADDCOLOR)
+        return "Clear + AddColor per pixel (public interface only)";
+#else
+        return "device -> Framebuffer::mColor, page-locked";
+#endif
     }
 
     // src/vertexcm.hxx:284-548, src/pathtracer.hxx:45-215, src/eyelight.hxx:46-77.
@@ -84,10 +119,22 @@ public:
             exit(2);
         }
 
-        // AbstractRenderer::GetFramebuffer (src/renderer.hxx:49-55) is not
-        // virtual and reads the protected host mFramebuffer, which must hold
-        // the running SUM over iterations.  Framebuffer has no bulk setter
-        // (src/framebuffer.hxx:253-258): refresh it with Clear + one AddColor
+        // AbstractRenderer::GetFramebuffer (src/renderer.hxx:49-55) is not virtual and reads the protected host
+        // mFramebuffer, which must hold the running SUM over iterations when it is called -- and nothing tells this
+        // class when that is: the refresh happens here, after every iteration.
+#if !defined(SMALLVCM_AMD_DROPIN_ADDCOLOR)
+        if(mPixels != NULL && mPixelBytes == size_t(mResX) * size_t(mResY) * sizeof(Vec3f))
+        {
+            if(vcm_read_framebuffer(mCtx, mPixels) != 0)   // one DMA into the Framebuffer's own texels (12 bytes, pixel order)
+            {
+                fprintf(stderr, "smallvcm_amd: %s\n", vcm_last_error());
+                exit(2);
+            }
+            mIterations++;   // vertexcm.hxx:547, pathtracer.hxx:216, eyelight.hxx:79
+            return;
+        }
+#endif
+        // public interface only: Framebuffer has no bulk setter (src/framebuffer.hxx:253-258): Clear + one AddColor
         // per pixel (0 + c == c, so the copy is exact).
         mHost.resize(size_t(mResX) * mResY * 3);
         if(vcm_read_framebuffer(mCtx, &mHost[0]) != 0)
@@ -116,6 +163,9 @@ private:
     vcm_ctx            *mCtx;
     int                 mResX, mResY;
     std::vector<float>  mHost;
+    float              *mPixels;      // the Framebuffer's own texels (NULL: public-interface refresh)
+    size_t              mPixelBytes;
+    bool                mPinned;
 };
 
 } // namespace smallvcm_amd

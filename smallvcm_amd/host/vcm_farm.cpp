@@ -54,6 +54,19 @@ struct Shared {   // one per farm_render call
 #define NCCLOK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { sh.fail(std::string(#expr) + ": " + ncclGetErrorString(r_)); return false; } } while (0)
 #define VCMOK(expr) do { if ((expr) != 0) { sh.fail(std::string(#expr) + ": " + vcm_last_error()); return false; } } while (0)
 
+// MEASUREMENT MODE for boxes with ONE GPU (SMALLVCM_AMD_FARM_SERIALIZE=1, stand-in collectives only): the rank threads take
+// turns on the device -- a rank enqueues a phase, waits until the device has finished it and only then lets the next rank
+// enqueue -- so that the kernels of one rank never share the chip with another rank's.  A kernel trace of such a run holds
+// the kernel times ONE rank of an S-GPU node would see (its shard of the paths, the merge over everybody's vertices); with
+// the ranks running concurrently on one chip they would be each other's contention.  profiles/tools/scaling_model.py reads it.
+struct GpuTurn {
+    static std::mutex &token() { static std::mutex m; return m; }
+    static bool enabled() { static const bool on = [] { const char *e = getenv("SMALLVCM_AMD_FARM_SERIALIZE"); return e && e[0] == '1'; }(); return on; }
+    explicit GpuTurn(hipStream_t a, hipStream_t b) : mA(a), mB(b), mHeld(enabled()) { if (mHeld) token().lock(); }
+    ~GpuTurn() { if (mHeld) { (void)hipStreamSynchronize(mA); if (mB) (void)hipStreamSynchronize(mB); (void)hipDeviceSynchronize(); token().unlock(); } }
+    hipStream_t mA, mB; bool mHeld;
+};
+
 // what the ranks of a group tell each other before the vertices travel: 7 numbers (hashgrid.hxx:47-61)
 struct Xchg { long long n; float mn[3], mx[3]; };
 
@@ -332,6 +345,7 @@ struct RankArgs {
 // exchanges never queue behind a large all-gather of the same step. ----
 bool step_light(Shared &sh, const FarmConfig &cfg, Slot &sl, int iteration)
 {   // light pass (vertexcm.hxx:321-396)
+    GpuTurn turn(sl.stream, NULL);
     VCMOK(vcm_begin_iteration(sl.ctx, iteration, cfg.minLen, cfg.maxLen));
     VCMOK(vcm_trace_light(sl.ctx));
     sl.exchanging = false;
@@ -343,7 +357,7 @@ bool step_counts(Shared &sh, Slot &sl, int shard)
     const int S = sl.group->size();
     if (S > VCM_FARM_MAX_RANKS) { sh.fail("too many shards"); return false; }
     long long n = 0;
-    VCMOK(vcm_local_light_bbox(sl.ctx, sl.mine.mn, sl.mine.mx, &n));
+    { GpuTurn turn(sl.stream, NULL); VCMOK(vcm_local_light_bbox(sl.ctx, sl.mine.mn, sl.mine.mx, &n)); }
     sl.mine.n = n; sl.nLocal = n;
     Xchg all[VCM_FARM_MAX_RANKS];
     if (!sl.group->exchange(sh, shard, sl.mine, all, sl.commStream)) return false;
@@ -356,7 +370,7 @@ bool step_counts(Shared &sh, Slot &sl, int shard)
         if (all[r].n > 0)
             for (int k = 0; k < 3; k++) { gmn[k] = std::min(gmn[k], all[r].mn[k]); gmx[k] = std::max(gmx[k], all[r].mx[k]); }
     }
-    VCMOK(vcm_set_grid_bbox(sl.ctx, gmn, gmx));
+    { GpuTurn turn(sl.stream, NULL); VCMOK(vcm_set_grid_bbox(sl.ctx, gmn, gmx)); }
     return true;
 }
 bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard)
@@ -367,6 +381,8 @@ bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard
     // merges them cell block by cell block -- the grid build is no longer replicated.  The unsorted exchange of rounds 1-4
     // (records in the reference's order, the whole build on every rank) stays behind SMALLVCM_AMD_SORTED_EXCHANGE=0 and
     // for shapes the sorted slabs do not cover (vcm_sorted_slab_words says so; every rank of the group gets the same answer).
+    GpuTurn *turn = new GpuTurn(sl.stream, NULL);
+    struct Release { GpuTurn *&t; ~Release() { delete t; t = NULL; } } release = { turn };
     static const bool allowSorted = [] { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE"); return !(e && e[0] == '0'); }();
     const long long sortedWords = allowSorted ? vcm_sorted_slab_words(sl.ctx, sl.stride) : -1;
     sl.sorted = sortedWords > 0;
@@ -386,14 +402,17 @@ bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard
     // the all-gather runs on the communication stream, behind the export and next to the camera pass
     HIPOK(hipEventRecord(sl.evRecords, sl.stream));
     HIPOK(hipStreamWaitEvent(sl.commStream, sl.evRecords, 0));
+    delete turn; turn = NULL;   // (measurement mode: the collective below meets the other ranks -- nobody holds the device across it)
     if (!sl.group->allGather(sh, shard, sl.local, sl.gathered, (size_t)sl.slabWords, sl.commStream)) return false;
     HIPOK(hipEventRecord(sl.evGathered, sl.commStream));
     sl.exchanging = true;
+    turn = new GpuTurn(sl.stream, sl.commStream);
     if (vcm_is_wavefront(sl.ctx, cfg.maxLen)) VCMOK(vcm_trace_camera(sl.ctx));   // needs only the local light vertices
     return true;
 }
 bool step_finish(Shared &sh, const FarmConfig &cfg, Slot &sl)
 {   // wait for the exchange, grid build, (camera pass,) merge, resolve
+    GpuTurn turn(sl.stream, sl.commStream);
     if (sl.exchanging) {
         HIPOK(hipStreamWaitEvent(sl.stream, sl.evGathered, 0));
         if (sl.sorted) VCMOK(vcm_import_sorted_light_records(sl.ctx, sl.gathered, sl.counts.data(), (int)sl.counts.size(), sl.stride));

@@ -120,8 +120,8 @@ int main(int argc, char **argv)
         FarmConfig fc;
         fc.scene = scene; fc.algorithm = algorithm; fc.radiusFactor = radiusFactor; fc.radiusAlpha = radiusAlpha;
         fc.baseSeed = seed; fc.minLen = minLen; fc.maxLen = maxLen; fc.iterations = iterations; fc.ranks = gpus;
-        fc.shards = shards > 0 ? shards : ((gpus % 2 == 0) ? 2 : gpus);
-        fc.inflight = inflight > 0 ? inflight : (fc.shards > 1 ? 2 : 1);
+        fc.shards = shards > 0 ? shards : gpus;        // default: north_star's decomposition, one renderer across all GPUs
+        fc.inflight = inflight > 0 ? inflight : 1;
         fc.rccl = rccl != 0; fc.warmup = warmup;
         fc.firstRank = 0; fc.localRanks = gpus;   // every rank is a thread of this process
         fc.sameWindow = sameWindow != 0;

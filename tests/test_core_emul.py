@@ -33,7 +33,7 @@ def test_device_functions_equal_oracle(sid, algo, res, nit, mn, mx):
 def test_certified_filters_against_the_reference_loop_on_every_ray():
     """tests/filter_check.py at a small size: the host build with -DVCM_FILTER_CHECK runs the filter AND the reference's
     brute-force loop on every ray (rectangles, Pluecker quads, the general list) and prints a line for every certified
-    answer the loop does not give.  (The full-size run is profiles/r05w_filter_check.txt.)"""
+    answer the loop does not give.  (The full-size run is profiles/archive/r05w_filter_check.txt.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -44,6 +44,13 @@ SWITCHES = [
     "SMALLVCM_AMD_NO_STAMPS=1",
     "SMALLVCM_AMD_TIMING=events",
     "SMALLVCM_AMD_STRICT_ORDER=1 SMALLVCM_AMD_ARENAS=1",
+    # round 5
+    "SMALLVCM_AMD_SORT_INLINE=0",              # the query sort's scan + scatter on the side stream whatever the frame size
+    "SMALLVCM_AMD_SORT_INLINE=1",
+    "SMALLVCM_AMD_BUCKETS_PER_PATH=16",
+    "SMALLVCM_AMD_BUCKETS_PER_PATH=1",
+    "SMALLVCM_AMD_AUX_BLOCKS=64",
+    "SMALLVCM_AMD_MERGE_BLOCKS=16384 SMALLVCM_AMD_TASK_BLOCKS=3072 SMALLVCM_AMD_TRACE_WAVES=4096",   # the launch shapes of a 2048^2 frame
 ]
 
 _oracle_cache = {}
