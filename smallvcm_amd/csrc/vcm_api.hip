@@ -173,6 +173,7 @@ struct vcm_ctx : Scratch {
     bool bboxFromLight;               /* K1 of this iteration accumulated the vertices' box into dHdr (single rank) */
     bool bboxFinal;                   /* ... and k_compact_records has turned it into floats already */
     bool strictOrder;
+    int relaxedSplatsOnly;            /* measurement (SMALLVCM_AMD_RELAXED_ORDER=2): only the light splats are atomics; addends + k_resolve stay */
     bool relaxedOrder;                /* vcm_set_relaxed_order: additions to a pixel in any order (fp32 atomics); default false = the reference's order, bit for bit */
     int mergeKind;                    /* VCM_MERGE_* */
     bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
@@ -764,7 +765,8 @@ static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor
     }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
-    { const char *e = getenv("SMALLVCM_AMD_RELAXED_ORDER"); c->relaxedOrder = (e && e[0] == '1') && !c->strictOrder && !c->renderer; }
+    { const char *e = getenv("SMALLVCM_AMD_RELAXED_ORDER"); c->relaxedOrder = (e && (e[0] == '1' || e[0] == '2')) && !c->strictOrder && !c->renderer;
+      c->relaxedSplatsOnly = (e && e[0] == '2') ? 1 : 0; }
     { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE");   /* 0: the host will use the unsorted exchange of rounds 1-4 */
       c->sortedExchange = worldSize > 1 && worldSize <= 256 && c->useVM && !(e && e[0] == '0'); }
     { const char *e = getenv("SMALLVCM_AMD_MERGE");
@@ -1545,7 +1547,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
-        c->vs.relaxedFb = c->relaxedOrder ? c->dFb : NULL;
+        c->vs.relaxedFb = (c->relaxedOrder && !c->relaxedSplatsOnly) ? c->dFb : NULL;
         c->vs.relaxedTarget = c->dCamOut;
         if (c->countedInCamera) {
             if (c->prezeroed) HIPCHK(hipStreamWaitEvent(c->stream, c->evZero, 0));
@@ -1712,7 +1714,7 @@ static int vcm_merge_impl(vcm_ctx *c)
         if (mark(c, EV_MERGE_K1)) return -1;
         /* K5: the first kernel since the light splats that touches the framebuffer.  (Order-relaxed mode: K3 and the task
            kernels have added everything to the pixels themselves; there is nothing to replay.) */
-        if (c->relaxedOrder && c->P.wavefront && !c->renderer) { if (flush_stamps(c, c->stream)) return -1; }
+        if (c->relaxedOrder && !c->relaxedSplatsOnly && c->P.wavefront && !c->renderer) { if (flush_stamps(c, c->stream)) return -1; }
         else {
         if (join_splats(c)) return -1;
         hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,

@@ -24,13 +24,18 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 40, 2), (2, 1, 2, 40, 2), (3, 3, 4, 33, 1), (2, 0, 3, 32, 1),
-                                                      (8, 1, 4, 40, 1)])   # the node's size: eight shards of one renderer
-def test_sharded_equals_unsharded(tmp_path, world, sid, algo, res, iters):
+@pytest.mark.parametrize("world,sid,algo,res,iters,sorted_exchange", [
+    (2, 1, 4, 40, 2, 0), (2, 1, 2, 40, 2, 0), (3, 3, 4, 33, 1, 0), (2, 0, 3, 32, 1, 0),
+    (8, 1, 4, 40, 1, 0),    # the node's size: eight shards of one renderer
+    # the sorted exchange of round 5 (every rank sorts its own vertices by cell, slabs travel, placement by cell):
+    # ShardedVertexCM's path for it and the slab layout, restated in numpy by the worker's backend
+    (2, 1, 4, 40, 2, 1), (3, 3, 4, 33, 1, 1), (2, 1, 2, 40, 2, 1), (8, 1, 4, 40, 1, 1)])
+def test_sharded_equals_unsharded(tmp_path, world, sid, algo, res, iters, sorted_exchange):
     port = _free_port()
     out = str(tmp_path / "fb.npy")
+    env = dict(os.environ, SHARDED_WORKER_SORTED=str(sorted_exchange))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(port),
-                               str(sid), str(algo), str(res), str(iters), out]) for r in range(world)]
+                               str(sid), str(algo), str(res), str(iters), out], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     fb = np.load(out)
