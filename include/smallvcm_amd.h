@@ -218,15 +218,6 @@ void vcm_destroy(vcm_ctx *ctx);
  * the reference does (about 2x slower; light splats are fp32 atomics there).
  * The environment variable SMALLVCM_AMD_STRICT_ORDER=1 sets the default. */
 int vcm_set_strict_order(vcm_ctx *ctx, int on);
-/* ORDER-RELAXED mode (round 5; default off; SMALLVCM_AMD_RELAXED_ORDER=1 sets it at creation).  The default mode adds
- * everything a pixel receives in the order of the reference's serial loops (vertexcm.hxx:321-396 light splats in vertex
- * order :931, then :415-545 per path: DI, VC in increasing j, merge, per vertex; emission last; paths in index order
- * :544), which makes the frame bit-identical to the reference's and costs ordered splat lists, per-slot addends and
- * k_resolve.  With `on` every addend goes to its pixel as an fp32 atomic the moment it is computed: the SAME addends,
- * summed in the order the hardware serves them -- the frame differs from the default's by rounding only (RMSE against the
- * reference at the BASELINE configurations: tests/test_gpu_relaxed.py, bound 1e-6; north_star's bar is 1e-4) and is not
- * reproducible bit for bit from run to run.  Not available for PathTracer / EyeLight or together with strict order. */
-int vcm_set_relaxed_order(vcm_ctx *ctx, int on);
 /* 1 if an iteration with this maxPathLength will run in wavefront mode, 0 if it falls back to / was set to the
  * strict order (vcm_set_strict_order, or maxPathLength > 31: the per-path vertex masks are 32 bits).  A sharded
  * host asks this to know whether vcm_trace_camera may run before vcm_build_grid. */

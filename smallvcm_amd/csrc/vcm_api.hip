@@ -173,8 +173,6 @@ struct vcm_ctx : Scratch {
     bool bboxFromLight;               /* K1 of this iteration accumulated the vertices' box into dHdr (single rank) */
     bool bboxFinal;                   /* ... and k_compact_records has turned it into floats already */
     bool strictOrder;
-    int relaxedSplatsOnly;            /* measurement (SMALLVCM_AMD_RELAXED_ORDER=2): only the light splats are atomics; addends + k_resolve stay */
-    bool relaxedOrder;                /* vcm_set_relaxed_order: additions to a pixel in any order (fp32 atomics); default false = the reference's order, bit for bit */
     int mergeKind;                    /* VCM_MERGE_* */
     bool sceneQuads;                  /* every triangle pair of the list shares its plane part: the SceneQuads kernels */
     bool sceneRects;                  /* ... and is an axis-aligned rectangle: the SceneRects kernels */
@@ -765,8 +763,6 @@ static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor
     }
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
-    { const char *e = getenv("SMALLVCM_AMD_RELAXED_ORDER"); c->relaxedOrder = (e && (e[0] == '1' || e[0] == '2')) && !c->strictOrder && !c->renderer;
-      c->relaxedSplatsOnly = (e && e[0] == '2') ? 1 : 0; }
     { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE");   /* 0: the host will use the unsorted exchange of rounds 1-4 */
       c->sortedExchange = worldSize > 1 && worldSize <= 256 && c->useVM && !(e && e[0] == '0'); }
     { const char *e = getenv("SMALLVCM_AMD_MERGE");
@@ -893,17 +889,6 @@ int vcm_set_strict_order(vcm_ctx *c, int on)
     if (!c) return fail("vcm_set_strict_order", "ctx is NULL");
     if (c->inIteration) return fail("vcm_set_strict_order", "iteration in progress");
     c->strictOrder = on != 0;
-    if (c->strictOrder) c->relaxedOrder = false;
-    return 0;
-}
-
-int vcm_set_relaxed_order(vcm_ctx *c, int on)
-{
-    if (!c) return fail("vcm_set_relaxed_order", "ctx is NULL");
-    if (c->inIteration) return fail("vcm_set_relaxed_order", "iteration in progress");
-    if (on && c->renderer) return fail("vcm_set_relaxed_order", "PathTracer / EyeLight have one addition per pixel and path: nothing to relax");
-    if (on && c->strictOrder) return fail("vcm_set_relaxed_order", "strict order is set");
-    c->relaxedOrder = on != 0;
     return 0;
 }
 
@@ -1104,14 +1089,6 @@ static int flush_light_splats(vcm_ctx *c)
         }
         int *pixCount = c->dPixCount, *arrival = c->dSplatArrival, *pixStart = c->dPixStart;
         F4 *list = c->dSplatList;
-        if (c->relaxedOrder && c->P.wavefront) {
-            /* order-relaxed mode: K1c adds its splats with fp32 atomics; no pixel histogram, scan, scatter, ordered application */
-            LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, q, c->dScene, c->P, c->store,
-                               (const int *)c->dSlotOfVertex, (const int *)c->dLocalTotal, c->dFb, (F4 *)NULL, (int *)NULL, (int *)NULL, c->dStats);
-            HIPCHK(hipGetLastError());
-            if (overlap) { HIPCHK(hipEventRecord(c->evSplatDone, q)); c->splatInFlight = true; }
-            return 0;
-        }
         if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));
         else if (zero_ranges(q, pixCount, ((size_t)c->N + 1) * sizeof(int))) return -1;
         LAUNCH_SC(c, k_connect_camera, dim3(task_blocks(c->nLocal)), dim3(256), 0, q, c->dScene, c->P, c->store,
@@ -1547,8 +1524,6 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         c->vs.sortKey = c->countedInCamera ? c->dQueryKey : NULL;
         c->vs.sortArrival = c->countedInCamera ? c->dQueryArrival : NULL;
         c->vs.bucketCount = c->countedInCamera ? c->dQueryCount : NULL;
-        c->vs.relaxedFb = (c->relaxedOrder && !c->relaxedSplatsOnly) ? c->dFb : NULL;
-        c->vs.relaxedTarget = c->dCamOut;
         if (c->countedInCamera) {
             if (c->prezeroed) HIPCHK(hipStreamWaitEvent(c->stream, c->evZero, 0));
             else if (zero_ranges(c->stream, c->dQueryCount, ((size_t)c->P.nBuckets + 1) * sizeof(int))) return -1;
@@ -1712,15 +1687,11 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (mark(c, EV_SORT_K1)) return -1;
         }
         if (mark(c, EV_MERGE_K1)) return -1;
-        /* K5: the first kernel since the light splats that touches the framebuffer.  (Order-relaxed mode: K3 and the task
-           kernels have added everything to the pixels themselves; there is nothing to replay.) */
-        if (c->relaxedOrder && !c->relaxedSplatsOnly && c->P.wavefront && !c->renderer) { if (flush_stamps(c, c->stream)) return -1; }
-        else {
+        /* K5: the first kernel since the light splats that touches the framebuffer */
         if (join_splats(c)) return -1;
         hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
-        }
     }
     if (join_splats(c)) return -1;               /* light tracing alone: nothing else waited for them */
     if (mark(c, EV_CAMERA)) return -1;

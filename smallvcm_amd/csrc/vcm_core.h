@@ -138,30 +138,11 @@ struct VertexStore {
        the vertex takes its bucket key and its place in the bucket the moment it is appended; NULL otherwise */
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
-    /* ORDER-RELAXED mode (vcm_set_relaxed_order, round 5): non-NULL = the framebuffer; every addend of a camera path goes
-       straight to the path's pixel with fp32 atomics instead of to its slot for k_resolve's ordered replay.  relaxedTarget =
-       camOut (its .w is the pixel of the path's jittered sample, written when K3 ends the path) */
-    float *relaxedFb;
-    const F4 *relaxedTarget;
 };
 VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 4 + (size_t)k] : vs.q4[i]; }
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
-}
-/* order-relaxed mode: colour += v at the pixel camera path `lp` belongs to (Framebuffer::AddColor, framebuffer.hxx:43-57, as an
-   fp32 atomic: the additions of a pixel then happen in whatever order the hardware serves them) */
-VCM_HD void relaxed_add_to_path_pixel(const VertexStore &vs, uint32_t lp, V3 v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (v.x == 0.f && v.y == 0.f && v.z == 0.f) return;   /* an occluded connection: nothing to add */
-    const int target = (int)f2u(vs.relaxedTarget[lp].w);
-    if (target < 0) return;                                /* the jittered sample left the frame (AddColor's bounds check) */
-    float *px = vs.relaxedFb + (size_t)target * 3;
-    atomicAdd(px + 0, v.x); atomicAdd(px + 1, v.y); atomicAdd(px + 2, v.z);
-#else
-    (void)vs; (void)lp; (void)v;
-#endif
 }
 
 struct LaneStats {
@@ -2891,7 +2872,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
                 wqs.pendingVertex = -1;
                 if (k >= 0) { wqs.pendingVertex = vi; wqs.pendingArrival = atomicAdd(&vs.bucketCount[k], 1); }
 #endif
-                else if (!vs.relaxedFb) vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
+                else vs.mergeOut[path_slot(P, st.pathLength, (uint32_t)cp.lp)] = mk4(0.f, 0.f, 0.f, 0.f);   /* empty query */
             }
 #endif
             if (hasDI) vs.diTask[di] = vi;

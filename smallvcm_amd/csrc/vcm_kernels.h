@@ -236,10 +236,6 @@ k_camera_trace(const DScene *__restrict__ scp, IterParams P, LightStore store, G
             if (!alive) {
                 const int target = camera_path_target(P, path);
                 camOut[path.lp] = mk4(path.color.x, path.color.y, path.color.z, u2f((uint32_t)target));
-                if (MODE == 1 && vs.relaxedFb && target >= 0 && (path.color.x != 0.f || path.color.y != 0.f || path.color.z != 0.f)) {
-                    float *px = vs.relaxedFb + (size_t)target * 3;   /* order-relaxed mode: the emission terms of the path, now */
-                    atomicAdd(px + 0, path.color.x); atomicAdd(px + 1, path.color.y); atomicAdd(px + 2, path.color.z);
-                }
                 if (MODE == 1) camMask[path.lp] = path.queryMask;
                 rngCount[path.lp] = (unsigned char)path.rng.k;
             }
@@ -345,8 +341,7 @@ k_connect_di(const DScene *__restrict__ scp, IterParams P, VertexStore vs, unsig
         if (vi < 0) continue;   /* hole */
         size_t ps;
         const V3 v = eval_di_task(sc, P, vs, vi, ls, ps);
-        if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(vq(vs, 0, vi).w), v);
-        else vs.diOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+        vs.diOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         if (sortedVertex) {   /* K4a's scatter pass, here: this kernel visits every camera vertex once */
             const int k = vs.sortKey[vi];
             if (k >= 0) sortedVertex[bucketStart[k] + vs.sortArrival[vi]] = vi;
@@ -368,8 +363,7 @@ k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, Light
         const int vi = vs.vcTask[2 * t];
         if (vi < 0) continue;   /* hole */
         const V3 v = eval_vc_task(sc, P, vs, store, vi, vs.vcTask[2 * t + 1], ls);
-        if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(vq(vs, 0, vi).w), v);
-        else vs.vcOut[t] = mk4(v.x, v.y, v.z, 0.f);
+        vs.vcOut[t] = mk4(v.x, v.y, v.z, 0.f);
     }
     flush_stats(ls, gstats);
 }
@@ -397,7 +391,7 @@ __global__ void __launch_bounds__(256) k_query_count(IterParams P, VertexStore v
         int k = -1;
         if (f2u(r0.w) != 0xffffffffu) {
             k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
-            if (k < 0 && !vs.relaxedFb)   /* empty query: contrib = 0 */
+            if (k < 0)   /* empty query: contrib = 0 */
                 vs.mergeOut[path_slot(P, f2u(vq(vs, 1, q).w) & 0xffu, f2u(r0.w))] = mk4(0.f, 0.f, 0.f, 0.f);
         }
         key[q] = k;
@@ -457,8 +451,7 @@ k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             const int vi = sortedVertex[q];
             size_t ps;
             const V3 v = eval_merge_task<IP>(sc, P, vs, g, vi, ls, ms, ps, false);   /* this kernel stages no material table */
-            if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(vq(vs, 0, vi).w), v);
-            else vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -654,8 +647,7 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
             ls.mergeCandidates += (uint32_t)total;
             const V3 contrib = merge_query_walk<IP>(sc, P, g, bsdf, sps, mk3(a.x, a.y, a.z), ls, ms, runs + threadIdx.x, VCM_MERGE_BLOCK, n);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
-            if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(a.w), v);
-            else vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
     }
     flush_stats(ls, gstats);
@@ -903,8 +895,7 @@ k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, Vertex
             st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
             const V3 contrib = merge_query_staged<IP>(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
             const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
-            if (vs.relaxedFb) relaxed_add_to_path_pixel(vs, f2u(a.w), v);
-            else vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
         __syncthreads();
     }
@@ -1090,10 +1081,6 @@ k_connect_camera(const DScene *__restrict__ scp, IterParams P, LightStore store,
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         F4 sp;
         connect_stored_vertex_to_camera(sc, P, store, (size_t)slotOfVertex[i], fb, ls, &sp);
-        if (!splat) {   /* order-relaxed mode: Framebuffer::AddColor (vertexcm.hxx:931) as fp32 atomics, no ordered lists */
-            if (f2u(sp.w) != 0xffffffffu) { float *px = fb + (size_t)f2u(sp.w) * 3; atomicAdd(px + 0, sp.x); atomicAdd(px + 1, sp.y); atomicAdd(px + 2, sp.z); }
-            continue;
-        }
         if (pendI >= 0) arrival[pendI] = pendArrival;
         pendI = -1;
         splat[i] = sp;

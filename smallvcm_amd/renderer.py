@@ -61,7 +61,6 @@ def load_library(require_gpu=True):
         L.vcm_destroy.restype = None
         L.vcm_set_stream.argtypes = [vp, vp]
         L.vcm_set_strict_order.argtypes = [vp, C.c_int]
-        L.vcm_set_relaxed_order.argtypes = [vp, C.c_int]
         L.vcm_pin_host_memory.argtypes = [vp, C.c_ulonglong]
         L.vcm_unpin_host_memory.argtypes = [vp]
         L.vcm_set_merge_kernel.argtypes = [vp, C.c_int]
@@ -174,10 +173,6 @@ class HipBackend:
         _check(self.L, self.L.vcm_set_strict_order(self.ctx, 1 if on else 0), "vcm_set_strict_order")
 
     MERGE_KERNELS = {"lane": 0, "staged": 1, "walk": 2}
-
-    def set_relaxed_order(self, on):
-        """additions to a pixel in any order (fp32 atomics) instead of the reference's: same addends, rounding differs"""
-        _check(self.L, self.L.vcm_set_relaxed_order(self.ctx, 1 if on else 0), "vcm_set_relaxed_order")
 
     def set_merge_kernel(self, kind):
         """which kernel evaluates the range merges: 'lane', 'staged' or 'walk' (same bits; include/smallvcm_amd.h)"""
