@@ -304,7 +304,7 @@ VCM_HD float dm_powf(float xf, float yf, bool lds = false)
  * wave holds the same integer exponent, the binary exponentiation is driven by SCALAR control flow -- only the
  * ~log2(n) + popcount(n) binary64 multiplies remain as vector work, instead of a per-lane loop with selects.  Same
  * multiplication sequence as dm_pow_int, hence the same bits; any other case falls back to dm_powf. */
-VCM_HD float dm_powf_wave(float xf, float yf, bool lds = true, bool intOnly = false)
+VCM_HD float dm_powf_wave(float xf, float yf, bool lds = false /* true only in kernels that call stage_scene_tables() */, bool intOnly = false)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yf)));

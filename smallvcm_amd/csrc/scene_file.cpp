@@ -103,13 +103,14 @@ struct Loader {
        the middle of an index and read the tail as an unknown key) */
     static bool read_line(FILE *f, std::string &line)
     {
+        /* character by character (getc is buffered): a NUL byte inside a line is data like any other -- fgets + strlen lost
+           everything between it and the end of the chunk and then glued the next physical line onto this one */
         line.clear();
-        char buf[1024];
         bool any = false;
-        while (fgets(buf, sizeof(buf), f)) {
+        for (int ch; (ch = getc(f)) != EOF;) {
             any = true;
-            line += buf;
-            if (!line.empty() && line[line.size() - 1] == '\n') break;
+            line += (char)ch;
+            if (ch == '\n') break;
         }
         return any;
     }
@@ -313,9 +314,10 @@ vcm_scene_file *vcm_scene_load(const char *path, int resX, int resY)
         const std::string p(path);
         ok = (Loader::ends_with(p, ".obj") ? ld.load_obj(p) : ld.load_scene(p)) && ld.finish(resX, resY);
     } catch (const std::exception &e) {
-        try { g_sceneError = std::string("vcm_scene_load: ") + e.what(); } catch (...) {}
+        try { g_sceneError = std::string("vcm_scene_load: ") + e.what(); } catch (...) { try { g_sceneError.assign("vcm_scene_load: exception"); } catch (...) {} }
         ok = false;
     } catch (...) {
+        try { g_sceneError = "vcm_scene_load: exception"; } catch (...) {}   /* never a stale message from an earlier call */
         ok = false;
     }
     if (!ok) { delete s; return NULL; }

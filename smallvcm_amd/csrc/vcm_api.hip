@@ -441,7 +441,16 @@ static int ensure_device(vcm_ctx *c)
             const bool low = prio == 1;
             int lo = 0, hi = 0;
             if (low) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   /* lo = the numerically largest = least urgent */
-            if (low) {
+            /* SMALLVCM_AMD_HELPER_CUS=n (measurement switch): the helper streams may only use n of every 8 CUs (a mask spread
+               evenly over the chip), so that the main stream's kernels keep the rest to themselves */
+            static int helperCus = -1;
+            if (helperCus < 0) { const char *e = getenv("SMALLVCM_AMD_HELPER_CUS"); helperCus = (e && atoi(e) > 0 && atoi(e) < 8) ? atoi(e) : 0; }
+            if (helperCus) {
+                uint32_t mask[8];
+                for (int w = 0; w < 8; w++) { mask[w] = 0u; for (int b = 0; b < 32; b++) if (((w * 32 + b) % 8) < helperCus) mask[w] |= 1u << b; }
+                HIPCHK(hipExtStreamCreateWithCUMask(&c->side, 8, mask));
+                HIPCHK(hipExtStreamCreateWithCUMask(&c->splat, 8, mask));
+            } else if (low) {
                 HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo));
                 HIPCHK(hipStreamCreateWithPriority(&c->splat, hipStreamNonBlocking, lo));
             } else {
@@ -940,6 +949,10 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     if (!c) return fail("vcm_begin_iteration", "ctx is NULL");
     if (c->inIteration) return fail("vcm_begin_iteration", "previous iteration not ended");
     if (maxLen > 255) return fail("vcm_begin_iteration", "maxPathLength > 255 unsupported (8-bit vertex counts)");
+    /* the two-launch scans (launch_scan_on) take at most 16384 tiles of 2048 entries: say so here, not in the middle of an
+       iteration -- 33.5 M paths per rank, a 5792^2 frame */
+    if ((long long)c->N / VCM_SCAN_TILE + 2 > 16384 || (long long)c->nLocal / VCM_SCAN_TILE + 2 > 16384)
+        return fail("vcm_begin_iteration", "more than 33.5 M paths: the scans of the iteration are two-level (16384 tiles of 2048); shard the frame over more ranks");
     /* light-vertex slots per path / camera vertices per path; PathTracer and EyeLight store neither */
     const int S = c->renderer ? 1 : ((maxLen >= 2) ? (int)maxLen - 1 : 1);
     const int L = c->renderer ? 1 : ((maxLen >= 1) ? (int)maxLen : 1);
@@ -1177,7 +1190,8 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     }
     if (wf && (c->useVC || c->lightTraceOnly)) {
         c->splatsPending = true;
-        if (c->world == 1 && flush_light_splats(c)) return -1;
+        { const char *e = getenv("SMALLVCM_AMD_SPLATS_AFTER_K3");
+          if (c->world == 1 && !(e && e[0] == '1' && !c->lightTraceOnly) && flush_light_splats(c)) return -1; }
     }
     if (mark(c, EV_LIGHT)) return -1;   /* written by the next kernel of the stream as it starts */
     if (!countsSet) {
@@ -1411,7 +1425,8 @@ static int vcm_build_grid_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:403-408 -> HashGrid::Build hashgrid.hxx:41-107 */
     if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
     if (use_device(c)) return -1;
-    if (flush_light_splats(c)) return -1;
+    { const char *e = getenv("SMALLVCM_AMD_SPLATS_AFTER_K3");
+      if (!(e && e[0] == '1' && c->P.wavefront && !c->lightTraceOnly && !c->cameraTraced) && flush_light_splats(c)) return -1; }
     c->gridBuilt = true;
     if (c->useVM) {
         /* The grid build is atomic- and gather-bound, the camera pass that follows in the single-rank order
@@ -1498,7 +1513,11 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:415-545 without the merge (:530-538) in wavefront mode */
     if (!c || !c->inIteration) return fail("vcm_trace_camera", "no iteration in progress");
     if (use_device(c)) return -1;
-    if (flush_light_splats(c)) return -1;
+    /* SMALLVCM_AMD_SPLATS_AFTER_K3=1 (measurement switch): K1c / K1d start when K3 has ENDED -- beside K3b / K4 instead of beside K3 */
+    static int splatsAfterK3 = -1;
+    if (splatsAfterK3 < 0) { const char *e = getenv("SMALLVCM_AMD_SPLATS_AFTER_K3"); splatsAfterK3 = (e && e[0] == '1') ? 1 : 0; }
+    const bool deferSplats = splatsAfterK3 && c->P.wavefront && !c->lightTraceOnly && !c->renderer;
+    if (!deferSplats && flush_light_splats(c)) return -1;
     c->cameraTraced = true;
     if (c->lightTraceOnly) return 0;
     int blocks, chunk;
@@ -1530,6 +1549,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         }
         LAUNCH_SC_MODE(c, k_camera_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
+        if (deferSplats && flush_light_splats(c)) return -1;
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
             /* K3c reads what K3 appended and the light store, and only K5 reads what it writes: it runs on the splat

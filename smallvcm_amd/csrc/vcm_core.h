@@ -139,6 +139,7 @@ struct VertexStore {
     const GridHeader *sortHdr;
     int *sortKey, *sortArrival, *bucketCount;
 };
+struct alignas(8) VcTaskPair { int vertex, j; };   /* one entry of VertexStore::vcTask */
 VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 4 + (size_t)k] : vs.q4[i]; }
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
@@ -2880,8 +2881,8 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
             while (jmask) {
                 const int j = __builtin_ctz(jmask);
                 jmask &= jmask - 1u;
-                vs.vcTask[2 * t] = vi;
-                vs.vcTask[2 * t + 1] = j;
+                VcTaskPair pr; pr.vertex = vi; pr.j = j;
+                reinterpret_cast<VcTaskPair *>(vs.vcTask)[t] = pr;   /* one 8-byte store (the array is 256-byte aligned) */
                 t++;
             }
             cp.queryMask |= 1u << st.pathLength;

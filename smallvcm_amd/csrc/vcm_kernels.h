@@ -360,9 +360,10 @@ k_connect_vc(const DScene *__restrict__ scp, IterParams P, VertexStore vs, Light
     const int n = vs.count[2];
     LaneStats ls; lane_stats_zero(ls);
     for (int t = blockIdx.x * VCM_TASK_BLOCK + threadIdx.x; t < n; t += gridDim.x * VCM_TASK_BLOCK) {
-        const int vi = vs.vcTask[2 * t];
+        const VcTaskPair pr = reinterpret_cast<const VcTaskPair *>(vs.vcTask)[t];
+        const int vi = pr.vertex;
         if (vi < 0) continue;   /* hole */
-        const V3 v = eval_vc_task(sc, P, vs, store, vi, vs.vcTask[2 * t + 1], ls);
+        const V3 v = eval_vc_task(sc, P, vs, store, vi, pr.j, ls);
         vs.vcOut[t] = mk4(v.x, v.y, v.z, 0.f);
     }
     flush_stats(ls, gstats);

@@ -279,3 +279,23 @@ def ref_render_stock(mask, resx, resy, algo, iterations=1, threads=1, seed=1234,
     ref_stock().ref_render_stock_iters(mask, resx, resy, config_algo, algo, iterations, idx, threads, seed, min_len, max_len,
                                        radius_factor, radius_alpha, _fptr(fb), C.byref(wall))
     return fb, wall.value
+
+
+def host_libm_is_the_restated_one():
+    """detmath restates ONE libm bit for bit: glibc 2.35's sinf / cosf / powf in their FMA multiarch variants (x86-64 with
+    FMA3: what the reference's image runs on).  Comparisons against the AMBIENT libm.so.6 are only meaningful there; on
+    another glibc, or a CPU without FMA (glibc's ifunc then picks the non-fused variant), they would fail with no product bug
+     -- the tests that call libm.so.6 directly ask here first and skip that part otherwise."""
+    try:
+        libc = C.CDLL("libc.so.6")
+        libc.gnu_get_libc_version.restype = C.c_char_p
+        if libc.gnu_get_libc_version().decode() != "2.35":
+            return False
+        flags = ""
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = line
+                break
+        return " fma " in (flags + " ") or flags.rstrip().endswith(" fma")
+    except Exception:
+        return False

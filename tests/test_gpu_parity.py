@@ -69,7 +69,8 @@ def test_numeric_spec_on_device():
     for op, of, mf in ((0, O.oracle_sinf, M.sinf), (1, O.oracle_cosf, M.cosf)):
         d = dev(op, wide, b)
         assert same(d, np.array([of(float(x)) for x in wide], np.float32))
-        assert same(d, np.array([mf(float(x)) for x in wide], np.float32))
+        if oracle_lib.host_libm_is_the_restated_one():   # the ambient libm is glibc 2.35 / FMA: the one detmath restates
+            assert same(d, np.array([mf(float(x)) for x in wide], np.float32))
     u = rng.random(n).astype(np.float32)
     y = np.where(rng.random(n) < 0.5, 90.0, 1.0 / 91.0).astype(np.float32)
     assert np.array_equal(dev(2, u, y), np.array([O.oracle_powf(float(p), float(q)) for p, q in zip(u, y)], np.float32))
