@@ -149,7 +149,8 @@ class _ThreadCollectives:
         g.bar.wait()
 
 
-@pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 128, 2), (4, 1, 2, 96, 2), (3, 3, 4, 100, 1)])
+@pytest.mark.parametrize("world,sid,algo,res,iters", [(2, 1, 4, 128, 2), (4, 1, 2, 96, 2), (3, 3, 4, 100, 1),
+                                                      (8, 1, 4, 64, 1), (5, 2, 2, 50, 2)])   # eight shards; a point light, five shards
 def test_sharded_contexts_equal_single_context(world, sid, algo, res, iters):
     sc = cornell_scene(sid, res, res)
     coll = _ThreadCollectives(world)
@@ -523,6 +524,26 @@ def test_cpp_farm_thread_ranks_equal_single_gpu_renderers(tmp_path, ranks, shard
     ref, _ = _farm(tmp_path, "r", "--renderers", str(renderers), iters=iters, algo=algo)
     assert np.allclose(img, ref, rtol=3e-6, atol=2e-7)
     assert img.max() > 0
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="vcm_render not built")
+@pytest.mark.parametrize("ranks,algo,scene,res", [(8, "vcm", 1, (64, 48)), (5, "bpm", 3, (50, 50)), (2, "vcm", 2, (96, 80)), (3, "ppm", 0, (40, 56))])
+def test_sorted_and_unsorted_exchange_render_the_same_bits(tmp_path, ranks, algo, scene, res):
+    """ONE renderer on `ranks` shards, twice: with the sorted exchange of round 5 (every rank sorts its own light vertices by
+    hash cell, k_grid_merge_blocks places the slabs: the default) and with the unsorted exchange of rounds 1-4
+    (SMALLVCM_AMD_SORTED_EXCHANGE=0: records in the reference's order, the whole grid build on every rank).  Both build
+    HashGrid::Build's grid (hashgrid.hxx:41-107) -- same cells, same in-cell order -- so the frames are the same bits, and
+    serialising the ranks (the scaling model's measurement mode) changes nothing either.  Shard counts that do not divide
+    the frame, more shards than cell blocks, a point light whose photons crowd a few cells, an environment light."""
+    args = ("--gpus", str(ranks), "--shards", str(ranks), "--inflight", "1", "--collectives", "threads")
+    a, info = _farm(tmp_path, "sorted", *args, iters=3, res=res, algo=algo, scene=scene)
+    b, _ = _farm(tmp_path, "unsorted", *args, iters=3, res=res, algo=algo, scene=scene, env={"SMALLVCM_AMD_SORTED_EXCHANGE": "0"})
+    c, _ = _farm(tmp_path, "turns", *args, iters=3, res=res, algo=algo, scene=scene, env={"SMALLVCM_AMD_FARM_SERIALIZE": "1"})
+    assert info["renderers"] == 1 and a.max() > 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    one, _ = _farm(tmp_path, "one", "--renderers", "1", iters=3, res=res, algo=algo, scene=scene)
+    assert np.allclose(a, one, rtol=3e-6, atol=2e-7)   # the shards' partial sums meet in the all-reduce: another order of the final sum
 
 
 # ---- the same host behind its C-ABI (include/smallvcm_amd_farm.h), as bench.py --gpus N drives it ---------------------
