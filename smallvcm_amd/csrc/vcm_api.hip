@@ -149,6 +149,8 @@ struct vcm_ctx : Scratch {
     hipEvent_t evZero;                /* the iteration's tables are zero (side stream, next to K1) */
     bool prezeroed, sortInFlight;
     bool splatInFlight;
+    bool resolveInFlight;             /* K5 of the LAST iteration runs on the splat stream (beside the next iteration's K1): survives vcm_end_iteration */
+    hipEvent_t evMergeDone, evSplatWork, evResolved;
     bool deviceReady;
     ArenaPool *pool;                  /* the device's shared arenas (NULL: sharded context with a private one) */
     Arena *arena; bool holdsArena;    /* the arena of the current / last iteration */
@@ -378,7 +380,8 @@ static void arena_release(vcm_ctx *c, bool recordEvent)
 {
     if (!c->holdsArena) return;
     Arena *a = c->arena;
-    const bool recorded = recordEvent && a->eventReady && hipEventRecord(a->lastUse, c->stream) == hipSuccess;
+    /* (K5 on the splat stream: the iteration's LAST kernel is there, behind everything of the main stream) */
+    const bool recorded = recordEvent && a->eventReady && hipEventRecord(a->lastUse, c->resolveInFlight ? c->splat : c->stream) == hipSuccess;
     c->holdsArena = false;
     {
         std::lock_guard<std::mutex> g(*a->mtx);
@@ -399,6 +402,7 @@ static int abort_iteration(vcm_ctx *c, int rc)
         if (c->deviceReady) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->splat); }
         c->gridInFlight = false;
         c->splatInFlight = false;
+        c->resolveInFlight = false;
         c->sortInFlight = false;
         c->inIteration = false;
         arena_release(c, false);
@@ -463,6 +467,9 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipEventCreateWithFlags(&c->evZero, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSplatFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSplatDone, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evMergeDone, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evSplatWork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evResolved, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evBbox, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
@@ -850,6 +857,7 @@ void vcm_destroy(vcm_ctx *c)
     if (c->deviceReady) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->splat);   /* K5 of the last iteration */
     }
     arena_release(c, false);
     if (c->pool) {
@@ -886,6 +894,7 @@ void vcm_destroy(vcm_ctx *c)
         (void)hipEventDestroy(c->evSortFork); (void)hipEventDestroy(c->evSorted); (void)hipEventDestroy(c->evZero);
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
         (void)hipEventDestroy(c->evSplatFork); (void)hipEventDestroy(c->evSplatDone);
+        (void)hipEventDestroy(c->evMergeDone); (void)hipEventDestroy(c->evSplatWork); (void)hipEventDestroy(c->evResolved);
         (void)hipStreamDestroy(c->side);
         (void)hipStreamDestroy(c->splat);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
@@ -923,6 +932,7 @@ int vcm_set_stream(vcm_ctx *c, void *hipStream)
     if (c->deviceReady) {
         if (use_device(c)) return -1;
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->resolveInFlight) { HIPCHK(hipStreamSynchronize(c->splat)); c->resolveInFlight = false; c->splatInFlight = false; }
         if (c->ownStream) { (void)hipStreamDestroy(c->stream); }
     }
     if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
@@ -1013,6 +1023,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     c->importedRecords = false;
     c->importedSorted = false;
     c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->splatInFlight = c->bboxPreset = c->bboxFromLight = c->bboxFinal = c->prezeroed = c->sortInFlight = false;
+    c->splatInFlight = c->resolveInFlight;   /* whoever reads the framebuffer still has the last iteration's K5 to wait for */
     c->inIteration = true;
     c->evValid = false;
     return 0;
@@ -1077,6 +1088,7 @@ static int join_splats(vcm_ctx *c)
     if (!c->splatInFlight) return 0;
     HIPCHK(hipStreamWaitEvent(c->stream, c->evSplatDone, 0));
     c->splatInFlight = false;
+    c->resolveInFlight = false;   /* (evSplatDone is recorded behind K5 as well) */
     return 0;
 }
 static int flush_light_splats(vcm_ctx *c)
@@ -1522,6 +1534,9 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     if (c->lightTraceOnly) return 0;
     int blocks, chunk;
     trace_launch_shape(c->nLocal, &blocks, &chunk);
+    /* the camera pass overwrites what K5 of the LAST iteration replays (path colours, masks, per-slot addends): if that K5 runs
+       on the splat stream, beside this iteration's K1, it has to be over now */
+    if (c->resolveInFlight) HIPCHK(hipStreamWaitEvent(c->stream, c->evResolved, 0));
     if (mark(c, EV_CAMERA_K0)) return -1;
     if (c->renderer) {   /* PathTracer / EyeLight: colour + jittered pixel per path; K5 adds them in path order */
         if (c->renderer == 1)
@@ -1707,7 +1722,37 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (mark(c, EV_SORT_K1)) return -1;
         }
         if (mark(c, EV_MERGE_K1)) return -1;
-        /* K5: the first kernel since the light splats that touches the framebuffer */
+        /* K5: the first kernel since the light splats that touches the framebuffer.
+           Round 5: on the SPLAT stream, behind K1c / K1d / K3c (what join_splats enforced) and behind K4 (an event) -- the main
+           stream is free the moment K4 ends, so the NEXT iteration's K1 (VALU-bound, touches neither the framebuffer nor
+           anything K5 reads) runs beside K5 (bound by its fetches) instead of behind it.  The next camera pass waits for
+           evResolved, the next light splats follow K5 on its stream, every reader of the framebuffer joins the splat stream as
+           before.  SMALLVCM_AMD_RESOLVE_ASIDE=0: in line, as in rounds 1-4. */
+        static int asideEnv = -2;
+        if (asideEnv == -2) { const char *e = getenv("SMALLVCM_AMD_RESOLVE_ASIDE"); asideEnv = e ? (e[0] == '1' ? 1 : 0) : -1; }
+        const bool aside = asideEnv != 0 && c->world == 1 && !c->strictOrder;
+        if (aside) {
+            HIPCHK(hipEventRecord(c->evMergeDone, c->stream));
+            HIPCHK(hipEventRecord(c->evSplatWork, c->splat));    /* K1c, K1d, K3c of this iteration: the light store is dead behind it */
+            HIPCHK(hipStreamWaitEvent(c->splat, c->evMergeDone, 0));
+            hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->splat, c->P, (const F4 *)c->dCamOut,
+                               (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
+            HIPCHK(hipGetLastError());
+            if (mark(c, EV_CAMERA)) return -1;
+            if (c->nPend[0] > 0) {   /* the end mark: a one-lane launch behind K5, on its stream */
+                hipLaunchKernelGGL(k_stamp_many, dim3(1), dim3(1), 0, c->splat, take_stamps(c, c->stream));
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipEventRecord(c->evResolved, c->splat));
+            HIPCHK(hipEventRecord(c->evSplatDone, c->splat));
+            /* the next iteration's K1 overwrites the light store: K1c / K3c of THIS iteration (splat stream) must be over --
+               they are, long before K4 ends, but the main stream has to know */
+            HIPCHK(hipStreamWaitEvent(c->stream, c->evSplatWork, 0));
+            c->splatInFlight = true;
+            c->resolveInFlight = true;
+            c->merged = true;
+            return 0;
+        }
         if (join_splats(c)) return -1;
         hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
@@ -1771,7 +1816,8 @@ int vcm_merge(vcm_ctx *c) { g_hipFailed = false; return abort_iteration(c, vcm_m
 static int vcm_end_iteration_impl(vcm_ctx *c)
 {
     if (use_device(c)) return -1;
-    if (join_grid(c) || join_splats(c)) return -1;   /* (a merge-free algorithm never waited) */
+    if (join_grid(c)) return -1;
+    if (!c->resolveInFlight && join_splats(c)) return -1;   /* (a merge-free algorithm never waited; K5 aside: the next camera pass waits) */
     if (flush_stamps(c, c->stream) || (c->deviceReady && flush_stamps(c, c->side))) return -1;
     c->iterations++;   /* :547 */
     c->inIteration = false;
@@ -1808,6 +1854,7 @@ int vcm_synchronize(vcm_ctx *c)
     if (!c->deviceReady) return 0;
     if (use_device(c)) return -1;
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->resolveInFlight) HIPCHK(hipStreamSynchronize(c->splat));   /* the last iteration's K5 */
     return 0;
 }
 
@@ -1890,6 +1937,7 @@ int vcm_get_stats_at(vcm_ctx *c, int ago, vcm_stats *out)
     if (newest < 0) return 0;
     if (newest - ago < 0) return fail("vcm_get_stats_at", "no such iteration");
     const int slot = (newest - ago) % VCM_STAMP_RING;
+    if (c->resolveInFlight) HIPCHK(hipStreamSynchronize(c->splat));   /* the end mark of the last iteration is written behind its K5 */
     unsigned long long h[VCM_STAT_SLOTS];
     HIPCHK(hipMemcpyAsync(h, c->dStatsRing + (size_t)slot * VCM_STAT_SLOTS, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

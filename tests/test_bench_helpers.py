@@ -193,3 +193,17 @@ def test_recorded_counters_need_the_same_kernel_sources_and_configuration(tmp_pa
     assert bench.recorded_counters("C3") == (None, None)
     monkeypatch.setattr(bench, "kernel_source_hash", lambda: "bbbb")
     assert bench.recorded_counters("C1") == (None, None)
+
+
+def test_the_line_of_a_multi_gpu_run_carries_both_decompositions():
+    """N > 1: the default is north_star's decomposition ("strong"), the replica hybrid beside it; both fit the line"""
+    full = _full_from_fixture()
+    full.update({"n_gpus": 8, "scaling": "strong", "rank_iteration_ms": [1.1] * 8,
+                 "hybrid_decomposition": {"value": 7000.0, "unit": "Mpaths/s", "scaling": "weak", "shards": 2, "inflight": 2, "ms_per_step": 9.5,
+                                          "paths_per_step": 8 * 8388608, "parallelism": "x" * 400, "rccl_ranks": 8, "rank_iteration_ms": [9.0] * 8}})
+    full.pop("cpu_baseline")
+    full.pop("configs")
+    line = bench.short_line(full, "bench_detail.json")
+    text = json.dumps(line, allow_nan=False)
+    assert len(text) < bench.LINE_LIMIT and line["scaling"] == "strong" and line["n_gpus"] == 8
+    assert line["hybrid_decomposition"] == {"value": 7000.0, "ms_per_step": 9.5, "scaling": "weak", "paths_per_step": 8 * 8388608, "shards": 2, "inflight": 2}
