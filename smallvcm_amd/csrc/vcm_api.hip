@@ -151,6 +151,8 @@ struct vcm_ctx : Scratch {
     bool splatInFlight;
     bool resolveInFlight;             /* K5 of the LAST iteration runs on the splat stream (beside the next iteration's K1): survives vcm_end_iteration */
     hipEvent_t evMergeDone, evSplatWork, evResolved;
+    hipEvent_t evPreMerge;            /* K4 runs on the SIDE stream (round 5), so that the main stream can start the NEXT iteration's K1 beside it */
+    bool mergeInFlight;               /* K4 of the last iteration may still run: what it reads (grid header floats, cell ranges, camera vertices) must not be rewritten yet */
     bool deviceReady;
     ArenaPool *pool;                  /* the device's shared arenas (NULL: sharded context with a private one) */
     Arena *arena; bool holdsArena;    /* the arena of the current / last iteration */
@@ -400,6 +402,7 @@ static int abort_iteration(vcm_ctx *c, int rc)
         const std::string keep = g_err;   /* the message of the failure, not of the clean-up */
         (void)hipStreamSynchronize(c->stream);
         if (c->deviceReady) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->splat); }
+        c->mergeInFlight = false;
         c->gridInFlight = false;
         c->splatInFlight = false;
         c->resolveInFlight = false;
@@ -470,6 +473,7 @@ static int ensure_device(vcm_ctx *c)
         HIPCHK(hipEventCreateWithFlags(&c->evMergeDone, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSplatWork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evResolved, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evPreMerge, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evBbox, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evGrid, hipEventDisableTiming));
@@ -895,6 +899,7 @@ void vcm_destroy(vcm_ctx *c)
         (void)hipEventDestroy(c->evFork); (void)hipEventDestroy(c->evBbox); (void)hipEventDestroy(c->evGrid);
         (void)hipEventDestroy(c->evSplatFork); (void)hipEventDestroy(c->evSplatDone);
         (void)hipEventDestroy(c->evMergeDone); (void)hipEventDestroy(c->evSplatWork); (void)hipEventDestroy(c->evResolved);
+        (void)hipEventDestroy(c->evPreMerge);
         (void)hipStreamDestroy(c->side);
         (void)hipStreamDestroy(c->splat);
         if (c->ownStream) (void)hipStreamDestroy(c->stream);
@@ -1186,6 +1191,10 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
        record array in the reference's vertex order */
     if (launch_scan<unsigned char>(c, c->store.count, c->nLocal, c->dPathStart, c->dLocalTotal, 0)) return -1;
+    /* K4 of the LAST iteration (merge stream) reads the grid header's box and counts, the cell ranges and the camera vertices:
+       everything from here on rewrites them (compaction first: the header), so the main stream waits for it now -- K1 above ran
+       beside it */
+    if (c->mergeInFlight) { HIPCHK(hipStreamWaitEvent(c->stream, c->evMergeDone, 0)); c->mergeInFlight = false; }
     bool countsSet = false;
     if (c->useVM || wf) {
         /* a sharded renderer ships the records to the other ranks; a single-rank one builds its grid straight
@@ -1643,6 +1652,7 @@ static int vcm_merge_impl(vcm_ctx *c)
     if (!c->cameraTraced) return fail("vcm_merge", "call vcm_trace_camera first");
     if (use_device(c)) return -1;
     if (!c->lightTraceOnly) {
+        bool mergeAside = false;
         if (mark(c, EV_MERGE_K0)) return -1;
         if (c->P.wavefront && c->useVM) {
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
@@ -1670,6 +1680,31 @@ static int vcm_merge_impl(vcm_ctx *c)
                stream, the pending marks are written first (they must not absorb the wait). */
             if (c->gridInFlight && hipEventQuery(c->evGrid) != hipSuccess) { (void)hipGetLastError(); if (flush_stamps(c, c->stream)) return -1; }
             if (join_grid(c)) return -1;
+            /* Round 5: K4 on the SIDE stream, behind the grid build and the query sort it needs anyway.  It is the iteration's
+               longest kernel, bound by its cache-line requests (VALU 0.42); the main stream is free when K3b has ended, so the
+               NEXT iteration's K1 (VALU-bound) runs beside it and waits for it only when compaction is about to rewrite the grid
+               header (vcm_trace_light); the next grid build and table zeroing queue behind it on the side stream, which they have
+               to.  K5 follows K4 through an event (it runs on the splat stream, see below).  Same conditions as for K5; not with
+               the slab dealing, whose counters the next vcm_begin_iteration zeroes.  (A stream of its own was the first attempt: HIP
+               gave it the splat stream's hardware queue and K4 waited for K3c, profiles/r09b_timeline2048.txt.)
+               SMALLVCM_AMD_MERGE_ASIDE=0: on the main stream as in rounds 1-4. */
+            static int mergeAsideEnv = -2, slabEnv = -1;
+            if (mergeAsideEnv == -2) { const char *e = getenv("SMALLVCM_AMD_MERGE_ASIDE"); mergeAsideEnv = e ? (e[0] == '1' ? 1 : 0) : -1; }
+            if (slabEnv < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slabEnv = (e && !strcmp(e, "slab")) ? 1 : 0; }
+            /* Measured (profiles/r09c_ab_*.txt, pairs of 40-400 iteration runs, bit-exact): 1024^2 scene 3 1206 -> 1344 Mpaths/s
+               (+11 %), 1024^2 scene 1 962 -> 1049 (+9 %), 2048^2 BPM 1240 -> 1264 (+2 %), 512^2 equal -- and 2048^2 VCM 1012 -> 989
+               (-2 %): there K4 already shares the chip with K3c, and K1 beside both costs more than it hides.  So: by default up to
+               1024^2, and at any size for the algorithms without vertex connection; SMALLVCM_AMD_MERGE_ASIDE=1 forces it. */
+            { const char *e = getenv("SMALLVCM_AMD_RESOLVE_ASIDE");
+              const bool pays = mergeAsideEnv == 1 || c->nLocal <= (1 << 20) || !c->useVC;
+              mergeAside = mergeAsideEnv != 0 && pays && !(e && e[0] == '0') && c->world == 1 && !c->strictOrder && !slabEnv; }
+            hipStream_t ks = c->stream;
+            if (mergeAside) {
+                if (flush_stamps(c, c->stream)) return -1;   /* the marks so far belong to what ran on the main stream */
+                HIPCHK(hipEventRecord(c->evPreMerge, c->stream));
+                HIPCHK(hipStreamWaitEvent(c->side, c->evPreMerge, 0));
+                ks = c->side;
+            }
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
             /* Three kernels, same bits (vcm_set_merge_kernel).  k_merge_walk (default): every lane walks its own
@@ -1693,11 +1728,11 @@ static int vcm_merge_impl(vcm_ctx *c)
                 static int slabBlocks = 0;
                 if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
                 if (c->intPhong)
-                    hipLaunchKernelGGL(k_merge_walk<true>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                    hipLaunchKernelGGL(k_merge_walk<true>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
                                        c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
                                        slab ? c->vs.count + 24 : (int *)NULL);
                 else
-                    hipLaunchKernelGGL(k_merge_walk<false>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                    hipLaunchKernelGGL(k_merge_walk<false>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
                                        c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
                                        slab ? c->vs.count + 24 : (int *)NULL);
             }
@@ -1706,20 +1741,25 @@ static int vcm_merge_impl(vcm_ctx *c)
                 if (ch < 1) ch = 1;
                 if (c->intPhong)
                     hipLaunchKernelGGL(k_merge_staged<true>, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
-                                       c->stream, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
+                                       ks, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
                                        (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
                 else
                     hipLaunchKernelGGL(k_merge_staged<false>, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
-                                       c->stream, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
+                                       ks, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
                                        (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
             } else if (c->intPhong)
-                hipLaunchKernelGGL(k_merge_lane<true>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                hipLaunchKernelGGL(k_merge_lane<true>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
                                    c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
             else
-                hipLaunchKernelGGL(k_merge_lane<false>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, c->P, grid_of(c),
+                hipLaunchKernelGGL(k_merge_lane<false>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
                                    c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
         } else {
             if (mark(c, EV_SORT_K1)) return -1;
+        }
+        if (mergeAside) {
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->evMergeDone, c->side));
+            c->mergeInFlight = true;
         }
         if (mark(c, EV_MERGE_K1)) return -1;
         /* K5: the first kernel since the light splats that touches the framebuffer.
@@ -1732,7 +1772,7 @@ static int vcm_merge_impl(vcm_ctx *c)
         if (asideEnv == -2) { const char *e = getenv("SMALLVCM_AMD_RESOLVE_ASIDE"); asideEnv = e ? (e[0] == '1' ? 1 : 0) : -1; }
         const bool aside = asideEnv != 0 && c->world == 1 && !c->strictOrder;
         if (aside) {
-            HIPCHK(hipEventRecord(c->evMergeDone, c->stream));
+            if (!mergeAside) HIPCHK(hipEventRecord(c->evMergeDone, c->stream));   /* (else: recorded behind K4 on its own stream) */
             HIPCHK(hipEventRecord(c->evSplatWork, c->splat));    /* K1c, K1d, K3c of this iteration: the light store is dead behind it */
             HIPCHK(hipStreamWaitEvent(c->splat, c->evMergeDone, 0));
             hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->splat, c->P, (const F4 *)c->dCamOut,

@@ -51,6 +51,8 @@ SWITCHES = [
     "SMALLVCM_AMD_BUCKETS_PER_PATH=1",
     "SMALLVCM_AMD_AUX_BLOCKS=64",
     "SMALLVCM_AMD_MERGE_BLOCKS=16384 SMALLVCM_AMD_TASK_BLOCKS=3072 SMALLVCM_AMD_TRACE_WAVES=4096",   # the launch shapes of a 2048^2 frame
+    "SMALLVCM_AMD_MERGE_ASIDE=0",              # K4 on the main stream (rounds 1-4) instead of on the side stream beside the next K1
+    "SMALLVCM_AMD_MERGE_ASIDE=1",              # ... forced (the default decides by frame size and algorithm)
     "SMALLVCM_AMD_RESOLVE_ASIDE=0",            # K5 in line on the main stream (rounds 1-4) instead of on the splat stream beside the next K1
     "SMALLVCM_AMD_SPLATS_AFTER_K3=1",          # measurement: K1c / K1d start when K3 has ended
     "SMALLVCM_AMD_HELPER_CUS=4",               # measurement: the helper streams on half of the CUs (hipExtStreamCreateWithCUMask)
