@@ -546,6 +546,53 @@ def test_sorted_and_unsorted_exchange_render_the_same_bits(tmp_path, ranks, algo
     assert np.allclose(a, one, rtol=3e-6, atol=2e-7)   # the shards' partial sums meet in the all-reduce: another order of the final sum
 
 
+def test_sorted_exchange_and_pinning_entry_points_say_what_they_refuse():
+    """vcm_sorted_slab_words / vcm_sort_light_records / vcm_import_sorted_light_records (include/smallvcm_amd.h): the slab size
+    is records x 13 words + one block-start word per block of cells (+ padding to 16 bytes); contexts that cannot use the
+    sorted exchange get -1 and a reason; sorting before the box of ALL ranks is known is refused (the cell of a vertex depends
+    on it, hashgrid.hxx:47-61, :189-201) and ends the iteration like every failed phase call.  vcm_pin_host_memory: a
+    page-locked destination reads the same framebuffer."""
+    import ctypes as C
+    from smallvcm_amd.renderer import load_library
+    L = load_library()
+    sc = cornell_scene(1, 64, 64)
+
+    def err():
+        return (L.vcm_last_error() or b"").decode()
+    one = HipBackend(sc, 4, 0.003, 0.75, 1234, device=0, rank=0, world=1)
+    assert L.vcm_sorted_slab_words(one.ctx, 100) == -1 and "not sharded" in err()
+    two = HipBackend(sc, 4, 0.003, 0.75, 1234, device=0, rank=0, world=2)
+    n_blocks = (64 * 64 + 1023) // 1024                      # K = 1024 cells per block for 2 shards, nCells = pathCount (vertexcm.hxx:406)
+    assert L.vcm_sorted_slab_words(two.ctx, 100) == (100 * 13 + n_blocks + 1 + 3) // 4 * 4
+    assert L.vcm_sorted_slab_words(two.ctx, 1 << 24) == -1 and "2^24" in err()
+    assert L.vcm_sorted_slab_words(two.ctx, 0) == -1
+    bpt = HipBackend(sc, 3, 0.003, 0.75, 1234, device=0, rank=0, world=2)
+    assert L.vcm_sorted_slab_words(bpt.ctx, 100) == -1 and "does not merge" in err()
+    bpt.close()
+    two.begin(0, 0, 10)
+    two.trace_light()
+    buf = two.new_tensor(L.vcm_sorted_slab_words(two.ctx, 20000))
+    assert L.vcm_sort_light_records(two.ctx, C.c_void_p(buf.data_ptr()), 20000) == -1 and "vcm_set_grid_bbox" in err()
+    two.begin(1, 0, 10)                                       # the failed call ended the iteration: a new one opens
+    two.trace_light()
+    mn, mx, n = two.local_bbox()
+    two.set_grid_bbox(mn, mx)
+    assert n > 0 and L.vcm_sort_light_records(two.ctx, C.c_void_p(buf.data_ptr()), 20000) == 0
+    arr = (C.c_longlong * 1)(n)
+    assert L.vcm_import_sorted_light_records(two.ctx, C.c_void_p(buf.data_ptr()), arr, 1, 20000) == -1 and "one slab per rank" in err()
+    two.close()
+    # page-locked read-out
+    assert L.vcm_pin_host_memory(None, 0) == -1
+    one.run_iteration(0, 0, 10)
+    a = one.framebuffer_sum()
+    b = np.zeros_like(a)
+    assert L.vcm_pin_host_memory(C.c_void_p(b.ctypes.data), b.nbytes) == 0
+    assert L.vcm_read_framebuffer(one.ctx, b.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert L.vcm_unpin_host_memory(C.c_void_p(b.ctypes.data)) == 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.max() > 0
+    one.close()
+
+
 # ---- the same host behind its C-ABI (include/smallvcm_amd_farm.h), as bench.py --gpus N drives it ---------------------
 def test_farm_binding_equals_the_command_line_host(tmp_path):
     """smallvcm_amd.farm (ctypes onto libsmallvcm_amd_farm.so) and vcm_render --gpus run the same C++ farm: same image,
