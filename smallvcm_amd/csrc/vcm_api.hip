@@ -50,6 +50,7 @@ enum { EV_START = 0, EV_LIGHT_K0, EV_LIGHT_K1, EV_LIGHT, EV_GRID_K0, EV_GRID, EV
  * its memory, at most 8; vcm_set_arena_limit): iterations of different renderers then overlap on the GPU -- one
  * renderer's tails and latency-bound helper kernels run next to another's wide kernels, which is what fills the
  * chip at 512^2, where a single iteration is too small to do it. */
+#define VCM_RSORT_MAX_BLOCKS 4096   /* workgroups of K2's radix sort (sort_cells_radix) */
 struct Scratch {
     LightStore store;                 /* S*nLocal slots (+ count[nLocal]) */
     int *dPathStart;                  /* nLocal+1 */
@@ -64,7 +65,8 @@ struct Scratch {
     float *dRecordsAll;               /* S*N records (multi-rank only) */
     int *dCellCount, *dCellStart;     /* N+2 each */
     int *dCellId;                     /* per record */
-    I4 *dUnsorted;                    /* per record: {index, slot, cell} list entries, grouped by cell (also K1d scratch) */
+    I4 *dUnsorted;                    /* per record: {index, slot, cell} list entries, grouped by cell; the radix sort's two {vertex, slot} lists */
+    int *dRadixHist;                  /* 2 x 256 x VCM_RSORT_MAX_BLOCKS: digit histogram per workgroup, raw and scanned */
     float *dGx, *dGy, *dGz; F4 *dG1, *dG2; F2 *dG3;
     int *dSortedIndex;                /* parity: grid position -> record index */
     F4 *dCamOut;                      /* nLocal */
@@ -241,7 +243,7 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.dPathStart); DFREE(s.dLocalTotal); DFREE(s.dTileSums[0]); DFREE(s.dTileSums[1]); DFREE(s.dTileSums[2]); DFREE(s.dTileSums[3]);
     DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
-    DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted);
+    DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted); DFREE(s.dRadixHist);
     DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
     DFREE(s.vs.q); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
@@ -279,7 +281,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dPixCount, cn + 2) || dalloc(&s.dPixStart, cn + 2) || dalloc(&s.dSplatArrival, slots) || dalloc(&s.dSplatList, slots)) return -1;
     if (sh && dalloc(&s.dRecordsAll, allRecs * VCM_MERGE_RECORD_FLOATS)) return -1;
     if (dalloc(&s.dCellCount, cn + 2) || dalloc(&s.dCellStart, cn + 2)) return -1;
-    if (dalloc(&s.dCellId, allRecs) || dalloc(&s.dUnsorted, allRecs)) return -1;
+    if (dalloc(&s.dCellId, allRecs) || dalloc(&s.dUnsorted, allRecs) || dalloc(&s.dRadixHist, (size_t)2 * 256 * VCM_RSORT_MAX_BLOCKS)) return -1;
     if (dalloc(&s.dGx, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dGy, allRecs + VCM_MERGE_UNROLL) ||
         dalloc(&s.dGz, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
         dalloc(&s.dG3, allRecs) || dalloc(&s.dSortedIndex, allRecs)) return -1;
@@ -1087,6 +1089,32 @@ static int aux_blocks(int nLocal)
     if (n) return n;
     return 2048;
 }
+static int env_blocks(const char *name, int *cache, int fallback)
+{
+    if (*cache < 0) { const char *e = getenv(name); *cache = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    return *cache ? *cache : fallback;
+}
+/* K5; `heavy` = beside the next iteration's K1 (SMALLVCM_AMD_RESOLVE_ASIDE) with the addends of a VC algorithm to replay: with 2048
+   workgroups its 8192 waves took the wave slots K1's persistent waves were about to claim.  At 2048^2 VCM (K5 replays 41 M addends, 2.3 GB) 2048 / 1024 / 768 / 512 / 256 workgroups:
+   1014 / 1035 / 1058 / 1062 / 1044 Mpaths/s (5 pairs of 40 iterations, profiles/r11l_ab_summary.txt); BPM at 2048^2, 1024^2 and
+   512^2 do not care down to 512 and lose below (r11m). */
+static int resolve_blocks(int nLocal, bool heavy) { static int n = -1; return env_blocks("SMALLVCM_AMD_RESOLVE_BLOCKS", &n, (heavy && nLocal >= (1 << 21)) ? 512 : aux_blocks(nLocal)); }
+/* K2's sort (vcm_kernels.h, "K2 as a radix sort"): SMALLVCM_AMD_GRID_SORT=count keeps the reference's counting sort with one
+   atomic per vertex (rounds 1-5); the default is the radix sort. */
+static bool grid_sort_is_radix(const vcm_ctx *c)
+{
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("SMALLVCM_AMD_GRID_SORT"); mode = !e ? -1 : (!strcmp(e, "radix") ? 1 : (!strcmp(e, "count") ? 0 : -1)); }
+    return mode != 0;
+}
+static int radix_sort_blocks(int nLocal)
+{
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("SMALLVCM_AMD_GRID_SORT_BLOCKS"); forced = (e && atoi(e) > 0) ? (atoi(e) < VCM_RSORT_MAX_BLOCKS ? atoi(e) : VCM_RSORT_MAX_BLOCKS) : 0; }
+    if (forced) return forced;
+    int v = nLocal / 2048;   /* ~2200 vertices per workgroup at the reference's path lengths (4096 / 2048 / 1024 / 512 workgroups at 2048^2: 1000-1009 / 1006-1016 / 1001-1022 / 1008-1019 Mpaths/s, profiles/r11h) */
+    return v < 64 ? 64 : (v > VCM_RSORT_MAX_BLOCKS ? VCM_RSORT_MAX_BLOCKS : v);
+}
 /* the main stream continues only after the splat stream's K1c / K1d (before anything else touches the framebuffer) */
 static int join_splats(vcm_ctx *c)
 {
@@ -1168,7 +1196,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         HIPCHK(hipEventRecord(c->evFork, c->stream));   /* behind the previous users of the arena */
         HIPCHK(hipStreamWaitEvent(c->side, c->evFork, 0));
         if (zero_ranges(c->side, c->useVM ? c->dQueryCount : NULL, c->useVM ? ((size_t)c->P.nBuckets + 1) * sizeof(int) : 0,
-                        c->useVM ? c->dCellCount : NULL, c->useVM ? ((size_t)c->P.nCells + 1) * sizeof(int) : 0,
+                        (c->useVM && !grid_sort_is_radix(c)) ? c->dCellCount : NULL, c->useVM ? ((size_t)c->P.nCells + 1) * sizeof(int) : 0,
                         (c->useVC || c->lightTraceOnly) ? c->dPixCount : NULL, ((size_t)c->N + 1) * sizeof(int))) return -1;
         HIPCHK(hipEventRecord(c->evZero, c->side));
         c->prezeroed = true;
@@ -1352,6 +1380,33 @@ static int vcm_import_light_records_impl(vcm_ctx *c, const void *devPtr, const l
     return 0;
 }
 
+/* the vertices of `recs` sorted by cell, stable: cellStart and the list {vertex, slot} in the grid's order (returned) */
+static const I2 *sort_cells_radix(vcm_ctx *c, hipStream_t q, int scanSlot, const VertexSource &recs)
+{
+    const int nCells = c->P.nCells;
+    int bits = 1;
+    while (bits < 31 && (1ll << bits) < (long long)nCells) bits++;
+    const int passes = (bits + 7) / 8;
+    const int V = radix_sort_blocks(c->nLocal);
+    const StampArgs none = { { NULL, NULL, NULL, NULL } };
+    uint32_t *key[2] = { (uint32_t *)c->dCellId, (uint32_t *)c->dSortedIndex };   /* (the index is written by the gather, after the keys are dead) */
+    I2 *pay[2] = { (I2 *)c->dUnsorted, (I2 *)c->dUnsorted + (size_t)c->arena->capS * c->arena->capN };   /* an I4 per record = two lists of I2 */
+    int *hist = c->dRadixHist, *scanned = c->dRadixHist + 256 * VCM_RSORT_MAX_BLOCKS;
+    hipLaunchKernelGGL(k_cell_keys, dim3(V), dim3(256), 0, q, c->P, recs, (const GridHeader *)c->dHdr, key[0], pay[0], hist, take_stamps(c, q));
+    int cur = 0;
+    for (int p = 0; p < passes; p++) {
+        if (p > 0) hipLaunchKernelGGL(k_radix_hist, dim3(V), dim3(256), 0, q, (const uint32_t *)key[cur], (const GridHeader *)c->dHdr, 8 * p, hist);
+        if (hipGetLastError() != hipSuccess) { fail("vcm_build_grid", "radix histogram launch"); return NULL; }
+        if (launch_scan_on<int>(c, scanSlot, q, hist, 256 * V, scanned, NULL, 0, none)) return NULL;
+        hipLaunchKernelGGL(k_radix_scatter, dim3(V), dim3(256), 0, q, (const uint32_t *)key[cur], (const I2 *)pay[cur], key[cur ^ 1], pay[cur ^ 1],
+                           (const GridHeader *)c->dHdr, 8 * p, (const int *)scanned);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_cell_starts, dim3(aux_blocks(c->nLocal)), dim3(256), 0, q, (const uint32_t *)key[cur], (const GridHeader *)c->dHdr, nCells, c->dCellStart);
+    if (hipGetLastError() != hipSuccess) { fail("vcm_build_grid", "radix sort launch"); return NULL; }
+    return pay[cur];
+}
+
 /* ---- the sorted exchange of a sharded renderer (include/smallvcm_amd.h; kernels: vcm_kernels.h "K2 of a SHARDED renderer") ---- */
 static int sorted_shape(vcm_ctx *c, long long strideRecords, int *K, int *nBlocks, long long *slabWords, const char *who)
 {
@@ -1385,16 +1440,21 @@ static int vcm_sort_light_records_impl(vcm_ctx *c, void *dstDev, long long strid
     const int nCells = c->P.nCells;
     const dim3 g(aux_blocks(c->nLocal)), b(256);
     VertexSource recs; recs.records = c->recordsValid ? c->dRecordsLocal : NULL; recs.store = c->store; recs.slotOfVertex = c->dSlotOfVertex;
-    if (zero_ranges(c->stream, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
-    hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId, c->dSortedIndex, c->dCellCount,
-                       take_stamps(c, c->stream));
-    HIPCHK(hipGetLastError());
-    if (launch_scan<int>(c, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
-    hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId, (const int *)c->dSortedIndex,
-                       (const int *)c->dCellStart, recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
+    const I2 *sorted = NULL;
+    if (grid_sort_is_radix(c)) {
+        if (!(sorted = sort_cells_radix(c, c->stream, 0, recs))) return -1;
+    } else {
+        if (zero_ranges(c->stream, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
+        hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId, c->dSortedIndex, c->dCellCount,
+                           take_stamps(c, c->stream));
+        HIPCHK(hipGetLastError());
+        if (launch_scan<int>(c, c->dCellCount, nCells, c->dCellStart, NULL, 1)) return -1;
+        hipLaunchKernelGGL(k_cell_scatter, g, b, 0, c->stream, (const GridHeader *)c->dHdr, (const int *)c->dCellId, (const int *)c->dSortedIndex,
+                           (const int *)c->dCellStart, recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
+    }
     uint32_t *slab = (uint32_t *)dstDev;
     hipLaunchKernelGGL(k_cell_rank_pack, g, b, 0, c->stream, (const DScene *)c->dScene, (const GridHeader *)c->dHdr, recs, (const int *)c->dCellStart,
-                       (const I4 *)c->dUnsorted, slab, (int *)(slab + (size_t)strideRecords * VCM_SORTED_WORDS), nCells, K, nBlocks);
+                       (const I4 *)c->dUnsorted, sorted, slab, (int *)(slab + (size_t)strideRecords * VCM_SORTED_WORDS), nCells, K, nBlocks);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1482,8 +1542,9 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         recs.slotOfVertex = c->dSlotOfVertex;
         const int nCells = c->P.nCells;
         const dim3 g(aux_blocks(c->nLocal)), b(256);
+        const bool radix = grid_sort_is_radix(c);
         if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));   /* (q is the side stream itself unless the build runs in line) */
-        else if (zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
+        else if (!radix && zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
         bool boxOnSide = false;
         if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
             if (c->bboxFromLight && !recs.records) {   /* K1 left the box of what it stored in the header's key words */
@@ -1496,15 +1557,20 @@ static int vcm_build_grid_impl(vcm_ctx *c)
             }
         }
         HIPCHK(hipEventRecord(c->evBbox, q));
-        hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
-                           c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount, take_stamps(c, q));
-        HIPCHK(hipGetLastError());
-        if (launch_scan_on<int>(c, noSide ? 0 : 1, q, c->dCellCount, nCells, c->dCellStart, NULL, 1, take_stamps(c, q))) return -1;
-        hipLaunchKernelGGL(k_cell_scatter, g, b, 0, q, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
-                           (const int *)c->dSortedIndex, (const int *)c->dCellStart,
-                           recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
+        const I2 *sorted = NULL;
+        if (radix) {
+            if (!(sorted = sort_cells_radix(c, q, noSide ? 0 : 1, recs))) return -1;
+        } else {
+            hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
+                               c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount, take_stamps(c, q));
+            HIPCHK(hipGetLastError());
+            if (launch_scan_on<int>(c, noSide ? 0 : 1, q, c->dCellCount, nCells, c->dCellStart, NULL, 1, take_stamps(c, q))) return -1;
+            hipLaunchKernelGGL(k_cell_scatter, g, b, 0, q, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
+                               (const int *)c->dSortedIndex, (const int *)c->dCellStart,
+                               recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
+        }
         hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, q, (const DScene *)c->dScene, (const GridHeader *)c->dHdr, recs,
-                           (const int *)c->dCellStart, (const I4 *)c->dUnsorted, c->dGx,
+                           (const int *)c->dCellStart, (const I4 *)c->dUnsorted, sorted, c->dGx,
                            c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
         if (mark_on(c, EV_GRID, q)) return -1;
         hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT, take_stamps(c, q));
@@ -1592,11 +1658,12 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                and the main stream idled for 16 % of the iteration (profiles/r06t_timeline512.txt).  Up to 1024^2 the scan
                therefore runs IN LINE between K3 and K3b (nothing else is resident at that moment: its 12-25 us are all it
                costs) and K3b scatters the sorted order as it goes.  At 2048^2 the in-line scan shared the memory system with the
-               tail of the grid build and took 0.9 ms (r06d): there it stays on the side stream.
-               SMALLVCM_AMD_SORT_INLINE=0/1 forces either. */
+               tail of the counting-sort grid build and took 0.9 ms (r06d); beside the radix-sort build it takes 0.1-0.2 ms and
+               frees the side stream, whose scan + k_query_scatter (0.42 ms behind the build) were what K4 waited for: in line
+               there too, +1.7 % (profiles/r11l_ab_summary.txt).  SMALLVCM_AMD_SORT_INLINE=0/1 forces either. */
             static int sortInline = -2;
             if (sortInline == -2) { const char *e = getenv("SMALLVCM_AMD_SORT_INLINE"); sortInline = e ? (e[0] == '1' ? 1 : 0) : -1; }
-            const bool inlineSort = c->scatteredInDI && (sortInline == 1 || (sortInline == -1 && c->nLocal <= (1 << 20)));
+            const bool inlineSort = c->scatteredInDI && (sortInline == 1 || (sortInline == -1 && (c->nLocal <= (1 << 20) || grid_sort_is_radix(c))));
             if (c->countedInCamera && c->world == 1 && !inlineSort) {
                 /* The scan of the bucket table (16.8 M entries at 2048^2) and the scatter of the sorted order run on the SIDE
                    stream, behind the grid build and next to K3b: in line, between K3 and K3b, the scan took 0.9 ms -- 70 us
@@ -1775,7 +1842,7 @@ static int vcm_merge_impl(vcm_ctx *c)
             if (!mergeAside) HIPCHK(hipEventRecord(c->evMergeDone, c->stream));   /* (else: recorded behind K4 on its own stream) */
             HIPCHK(hipEventRecord(c->evSplatWork, c->splat));    /* K1c, K1d, K3c of this iteration: the light store is dead behind it */
             HIPCHK(hipStreamWaitEvent(c->splat, c->evMergeDone, 0));
-            hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->splat, c->P, (const F4 *)c->dCamOut,
+            hipLaunchKernelGGL(k_resolve, dim3(resolve_blocks(c->nLocal, c->useVC)), dim3(256), 0, c->splat, c->P, (const F4 *)c->dCamOut,
                                (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
             HIPCHK(hipGetLastError());
             if (mark(c, EV_CAMERA)) return -1;
@@ -1794,7 +1861,7 @@ static int vcm_merge_impl(vcm_ctx *c)
             return 0;
         }
         if (join_splats(c)) return -1;
-        hipLaunchKernelGGL(k_resolve, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
+        hipLaunchKernelGGL(k_resolve, dim3(resolve_blocks(c->nLocal, false)), dim3(256), 0, c->stream, c->P, (const F4 *)c->dCamOut,
                            (const uint32_t *)c->dCamMask, c->vs, c->dFb, take_stamps(c, c->stream));
         HIPCHK(hipGetLastError());
     }

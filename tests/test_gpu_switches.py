@@ -56,6 +56,12 @@ SWITCHES = [
     "SMALLVCM_AMD_RESOLVE_ASIDE=0",            # K5 in line on the main stream (rounds 1-4) instead of on the splat stream beside the next K1
     "SMALLVCM_AMD_SPLATS_AFTER_K3=1",          # measurement: K1c / K1d start when K3 has ended
     "SMALLVCM_AMD_HELPER_CUS=4",               # measurement: the helper streams on half of the CUs (hipExtStreamCreateWithCUMask)
+    "SMALLVCM_AMD_GRID_SORT=count",            # HashGrid::Build as rounds 1-5 did it: a counter per cell, one atomic per vertex, a ranking pass
+    "SMALLVCM_AMD_GRID_SORT_BLOCKS=1",         # the radix sort with ONE workgroup: ~70 000 vertices = 35 tiles in a row
+    "SMALLVCM_AMD_GRID_SORT_BLOCKS=7",         # chunks that are not a multiple of the tile
+    "SMALLVCM_AMD_GRID_SORT_BLOCKS=4096",      # more workgroups than 256-vertex chunks: most of them have nothing to do
+    "SMALLVCM_AMD_GRID_SORT=count SMALLVCM_AMD_SORT_INLINE=0 SMALLVCM_AMD_RESOLVE_BLOCKS=2048",   # the launch plan of the round-4 build
+    "SMALLVCM_AMD_RESOLVE_BLOCKS=3",
 ]
 
 _oracle_cache = {}
