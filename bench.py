@@ -333,7 +333,7 @@ def add_counters(roof, dom, counters, note, st, n_local):
     dsg = design_bytes(st, n_local)
     groups = dict(KERNEL_KEYS)
     groups.update({"k_resolve": ["vcm::k_resolve"], "k_connect_camera": ["vcm::k_connect_camera"],
-                   "grid_build": ["vcm::k_cell_", "vcm::k_grid_", "vcm::k_bbox"], "splat": ["vcm::k_splat_"]})
+                   "grid_build": ["vcm::k_cell_", "vcm::k_radix_", "vcm::k_grid_", "vcm::k_bbox"], "splat": ["vcm::k_splat_"]})
     for name, prefixes in groups.items():
         pk = roof["per_kernel"].setdefault(name, {"design_bytes": int(dsg.get(name, 0))})
         fetch = _sum_over(counters, prefixes, "FETCH_SIZE")
