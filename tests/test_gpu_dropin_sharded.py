@@ -207,7 +207,9 @@ def test_reference_driver_time_mode_uses_every_host_core(tmp_path):
     """`-t` makes render() run one renderer per host core concurrently (smallvcm.cxx:66, :82-108): on the GPU
     box that is 256 contexts on one device, which only fit because the iteration scratch is shared."""
     out = str(tmp_path / "img_t.hdr")
-    r = subprocess.run([DROPIN, "-s", "1", "-a", "vcm", "-t", "2", "-o", out], capture_output=True, text=True, timeout=900)
+    # (-t counts the CPU time of the process, smallvcm.cxx:74-83: 8 "seconds" on 256 threads are 31 ms of wall time -- enough for
+    # the OpenMP team to wake up before the limit has passed; with 2 the margin was 8 ms)
+    r = subprocess.run([DROPIN, "-s", "1", "-a", "vcm", "-t", "8", "-o", out], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "done in" in r.stdout
     img = _read_hdr(out).astype(np.int32)
@@ -453,11 +455,17 @@ def _read_bmp_mean(path):
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs a SmallVCM checkout)")
 def test_reference_driver_full_report_over_dropin(tmp_path):
-    """`smallvcm --report -t 1` (FullReport, smallvcm.cxx:156-263; html_writer.hxx) of the UNCHANGED driver over the
-    drop-in: every scene x algorithm combination renders on the GPU (7 algorithms x 4 scenes, one renderer per host
-    core each), index.html and the 28 images are written, and the images of one scene agree: the unbiased / consistent
+    """`smallvcm --report -t 2` (FullReport, smallvcm.cxx:156-263; html_writer.hxx) of the UNCHANGED driver over the
+    drop-in: every scene x algorithm combination renders on the GPU (7 algorithms x 4 scenes, one renderer per core the
+    process may use each), index.html and the 28 images are written, and the images of one scene agree: the unbiased / consistent
     estimators (pt, bpt, bpm, vcm) have the same mean up to Monte-Carlo error and 8-bit gamma quantisation."""
-    r = subprocess.run([DROPIN, "--report", "-t", "1"], cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
+    # The driver's time limit is clock() -- the CPU time of the PROCESS (smallvcm.cxx:74-83) -- so with one renderer per host core
+    # "1 second" on a 256-thread host is 4 ms of wall time from `startT = clock()` to every thread's first look at the clock; when
+    # waking the OpenMP team takes longer than that, no renderer runs an iteration and the reference writes a 0 x 0 image (seen
+    # once in round 5).  32 cores and 2 seconds: 60 ms, and 32 instead of 256 renderers to create per combination.
+    cores = sorted(os.sched_getaffinity(0))[:32]
+    r = subprocess.run(["taskset", "-c", ",".join(str(c) for c in cores), DROPIN, "--report", "-t", "2"], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Whole run took" in r.stdout
     html = open(os.path.join(str(tmp_path), "index.html")).read()
