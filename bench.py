@@ -240,8 +240,18 @@ def live_counters(args):
                     "= the timed window" % (warm, warm + steps - 1))
 
 
+def _launches_per_iteration(counters, v, name):
+    """a counter value is the mean per DISPATCH; a kernel launched k times per iteration (the radix sort's passes) counts k times.
+    k = its dispatches / the dispatches of a kernel that runs once per iteration (K5, else the rarest kernel of the run)"""
+    grp = "_n_fetch" if name == "FETCH_SIZE" else "_n_write" if name == "WRITE_SIZE" else "_n_valu"
+    n = v.get(grp)
+    ref = counters.get("vcm::k_resolve", {}).get(grp) or min((x[grp] for x in counters.values() if x.get(grp)), default=None)
+    return max(1, int(round(n / float(ref)))) if n and ref else 1
+
+
 def _sum_over(counters, prefixes, name):
-    vals = [v[name] for k, v in counters.items() if _is_kernel(k, [p.split("<")[0] for p in prefixes]) and name in v]
+    vals = [v[name] * _launches_per_iteration(counters, v, name) for k, v in counters.items()
+            if _is_kernel(k, [p.split("<")[0] for p in prefixes]) and name in v]
     return sum(vals) if vals else None
 
 

@@ -1388,6 +1388,7 @@ static const I2 *sort_cells_radix(vcm_ctx *c, hipStream_t q, int scanSlot, const
     while (bits < 31 && (1ll << bits) < (long long)nCells) bits++;
     const int passes = (bits + 7) / 8;
     const int V = radix_sort_blocks(c->nLocal);
+    static_assert(256 * VCM_RSORT_MAX_BLOCKS <= VCM_QSORT_BUCKETS, "the scan scratch (dTileSums) is sized for the bucket table: the digit matrix must not be larger");
     const StampArgs none = { { NULL, NULL, NULL, NULL } };
     uint32_t *key[2] = { (uint32_t *)c->dCellId, (uint32_t *)c->dSortedIndex };   /* (the index is written by the gather, after the keys are dead) */
     I2 *pay[2] = { (I2 *)c->dUnsorted, (I2 *)c->dUnsorted + (size_t)c->arena->capS * c->arena->capN };   /* an I4 per record = two lists of I2 */

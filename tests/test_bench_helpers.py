@@ -207,3 +207,24 @@ def test_the_line_of_a_multi_gpu_run_carries_both_decompositions():
     text = json.dumps(line, allow_nan=False)
     assert len(text) < bench.LINE_LIMIT and line["scaling"] == "strong" and line["n_gpus"] == 8
     assert line["hybrid_decomposition"] == {"value": 7000.0, "ms_per_step": 9.5, "scaling": "weak", "paths_per_step": 8 * 8388608, "shards": 2, "inflight": 2}
+
+
+def test_a_kernel_launched_three_times_per_iteration_counts_three_times():
+    """the counter files hold means per DISPATCH; the radix sort's scatter runs once per digit (bench._sum_over)"""
+    c = {"vcm::k_resolve": {"FETCH_SIZE": 10.0, "_n_fetch": 25, "SQ_INSTS_VALU": 5.0, "_us_valu": 1.0, "_n_valu": 25},
+         "vcm::k_radix_scatter": {"FETCH_SIZE": 2.0, "_n_fetch": 75, "SQ_INSTS_VALU": 7.0, "_us_valu": 3.0, "_n_valu": 75},
+         "vcm::k_radix_hist": {"FETCH_SIZE": 1.0, "_n_fetch": 50, "SQ_INSTS_VALU": 1.0, "_us_valu": 0.5, "_n_valu": 50},
+         "vcm::k_cell_keys": {"FETCH_SIZE": 4.0, "_n_fetch": 25, "SQ_INSTS_VALU": 2.0, "_us_valu": 2.0, "_n_valu": 25}}
+    pre = ["vcm::k_cell_", "vcm::k_radix_"]
+    assert bench._sum_over(c, pre, "FETCH_SIZE") == 4.0 + 3 * 2.0 + 2 * 1.0
+    assert bench._sum_over(c, pre, "SQ_INSTS_VALU") == 2.0 + 3 * 7.0 + 2 * 1.0
+    assert bench._sum_over(c, pre, "_us_valu") == 2.0 + 3 * 3.0 + 2 * 0.5
+    assert bench._sum_over(c, ["vcm::k_resolve"], "FETCH_SIZE") == 10.0
+    assert bench._sum_over(c, ["vcm::k_absent"], "FETCH_SIZE") is None
+    # the recorded set of the final sources: K2 = keys + 3 scatter passes + 2 histograms + starts + gather
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r12_counters_C4.json")
+    if os.path.exists(path):
+        k = json.load(open(path))["kernels"]
+        grid = ["vcm::k_cell_", "vcm::k_radix_", "vcm::k_grid_", "vcm::k_bbox"]
+        gb = (2 * bench._sum_over(k, grid, "FETCH_SIZE") + bench._sum_over(k, grid, "WRITE_SIZE")) * 1024 / 1e9
+        assert 3.0 < gb < 4.6, gb
