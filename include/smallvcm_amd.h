@@ -223,12 +223,14 @@ int vcm_set_strict_order(vcm_ctx *ctx, int on);
  * host asks this to know whether vcm_trace_camera may run before vcm_build_grid. */
 int vcm_is_wavefront(vcm_ctx *ctx, unsigned maxPathLength);
 
-/* Which kernel evaluates the range merges (HashGrid::Process, hashgrid.hxx:110-169) in wavefront mode: all three
+/* Which kernel evaluates the range merges (HashGrid::Process, hashgrid.hxx:110-169) in wavefront mode: all four
  * produce the same bits, they differ in how a wave walks the cell lists (vcm_kernels.h; measured in DESIGN.md 5).
- * The environment variable SMALLVCM_AMD_MERGE=lane|staged|walk sets the default. */
+ * The environment variable SMALLVCM_AMD_MERGE=lane|staged|walk|pairs sets the default. */
 #define VCM_MERGE_LANE   0   /* the 8 cells in lockstep, per-lane global loads */
 #define VCM_MERGE_STAGED 1   /* a workgroup stages the cell lists of its queries through LDS */
 #define VCM_MERGE_WALK   2   /* every lane walks its own non-empty runs back to back */
+#define VCM_MERGE_PAIRS  3   /* the scan per lane as in WALK; the accepted (query, photon) pairs of a wave evaluated 64 at a time
+                                by whichever lane gets them (scenes with more than 32 materials: WALK) */
 int vcm_set_merge_kernel(vcm_ctx *ctx, int kind);
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all
@@ -301,7 +303,7 @@ int vcm_import_light_records(vcm_ctx *ctx, const void *devPtr,
  *   vcm_sorted_slab_words    4-byte words one rank's slab takes for `strideRecords` records: the records (13 words each,
  *                            cell order) + one block-start word per block of cells (+ padding to 16 bytes); -1 with
  *                            vcm_last_error() when the context cannot use the sorted exchange (not sharded, no merging
- *                            algorithm, more than 256 shards, 2^24 or more records in a shard): use the calls above.
+ *                            algorithm, more than 64 shards, 2^24 or more records in a shard): use the calls above.
  *   vcm_sort_light_records   after vcm_set_grid_bbox (the cell of a vertex depends on the box of ALL vertices): sorts the
  *                            local vertices and writes the slab to dstDev (device memory of the caller, e.g. the send
  *                            buffer of ncclAllGather).  Asynchronous on the context's stream.

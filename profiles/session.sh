@@ -13,6 +13,7 @@
 #   bench_record      ... --cpu-baseline none --record-counters <tag>  (keeps profiles/<tag>_counters_<config>.json)
 #   collect           profiles/collect.sh <tag> on the headline (kernel stats, FETCH / WRITE, SQ passes)
 #   collect:<cfg>     ... on C1 | C2 | C3
+#   mem[:<args>]      profiles/collect_mem.sh: TA / TD / TCP / TCC counter passes (default C4; args = vcm_render arguments)
 #   timeline<res>     profiles/tools/timeline.py of scene 1 vcm at <res>^2 (timeline1024s3: scene 3)
 #   ab<res>[:algo[:scene]]   profiles/quick_ab.sh (variants from $VARIANTS, switches from $ENVS, $REPS repetitions, $ITER iterations)
 #   farm:<ranks>:<shards>:<inflight>[:res]   vcm_render --gpus <ranks> --collectives threads on this one GPU
@@ -37,6 +38,8 @@ for step in "$@"; do
     collect:C1)    BENCH_ARGS="--steps 20 --warmup 5 --scene 1 --algo vcm --res 512" timeout 600 bash profiles/collect.sh ${TAG}_C1 > ${O}_collect_C1.log 2>&1; tail -2 ${O}_collect_C1.log ;;
     collect:C2)    BENCH_ARGS="--steps 20 --warmup 5 --scene 3 --algo vcm --res 1024" timeout 600 bash profiles/collect.sh ${TAG}_C2 > ${O}_collect_C2.log 2>&1; tail -2 ${O}_collect_C2.log ;;
     collect:C3)    BENCH_ARGS="--steps 20 --warmup 5 --scene 1 --algo bpm --res 2048" timeout 600 bash profiles/collect.sh ${TAG}_C3 > ${O}_collect_C3.log 2>&1; tail -2 ${O}_collect_C3.log ;;
+    mem)           timeout 1500 bash profiles/collect_mem.sh ${TAG} > ${O}_mem.log 2>&1; tail -150 ${O}_mem.log ;;
+    mem:*)         timeout 1500 bash profiles/collect_mem.sh ${TAG} ${step#mem:} > ${O}_mem.log 2>&1; tail -150 ${O}_mem.log ;;
     timeline1024s3) timeout 300 python profiles/tools/timeline.py ${TAG} --res 1024 --scene 3 > /dev/null 2>&1; head -60 ${O}_timeline1024.txt ;;
     timeline*)     r=${step#timeline}; timeout 300 python profiles/tools/timeline.py ${TAG} --res $r > /dev/null 2>&1; head -60 ${O}_timeline${r}.txt ;;
     ab*)           spec=${step#ab}; IFS=: read -r r a s <<< "$spec"

@@ -786,9 +786,9 @@ static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor
     const char *so = getenv("SMALLVCM_AMD_STRICT_ORDER");
     c->strictOrder = (so && so[0] == '1');
     { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE");   /* 0: the host will use the unsorted exchange of rounds 1-4 */
-      c->sortedExchange = worldSize > 1 && worldSize <= 256 && c->useVM && !(e && e[0] == '0'); }
+      c->sortedExchange = worldSize > 1 && worldSize <= VCM_SORTED_MAX_SHARDS && c->useVM && !(e && e[0] == '0'); }
     { const char *e = getenv("SMALLVCM_AMD_MERGE");
-      c->mergeKind = (e && !strcmp(e, "staged")) ? VCM_MERGE_STAGED : (e && !strcmp(e, "walk")) ? VCM_MERGE_WALK : (e && !strcmp(e, "lane")) ? VCM_MERGE_LANE : VCM_MERGE_DEFAULT; }
+      c->mergeKind = (e && !strcmp(e, "staged")) ? VCM_MERGE_STAGED : (e && !strcmp(e, "walk")) ? VCM_MERGE_WALK : (e && !strcmp(e, "lane")) ? VCM_MERGE_LANE : (e && !strcmp(e, "pairs")) ? VCM_MERGE_PAIRS : VCM_MERGE_DEFAULT; }
     return c;
 }
 
@@ -921,7 +921,7 @@ int vcm_set_merge_kernel(vcm_ctx *c, int kind)
 {
     if (!c) return fail("vcm_set_merge_kernel", "ctx is NULL");
     if (c->inIteration) return fail("vcm_set_merge_kernel", "iteration in progress");
-    if (kind != VCM_MERGE_LANE && kind != VCM_MERGE_STAGED && kind != VCM_MERGE_WALK) return fail("vcm_set_merge_kernel", "unknown kernel");
+    if (kind != VCM_MERGE_LANE && kind != VCM_MERGE_STAGED && kind != VCM_MERGE_WALK && kind != VCM_MERGE_PAIRS) return fail("vcm_set_merge_kernel", "unknown kernel");
     c->mergeKind = kind;
     return 0;
 }
@@ -1144,7 +1144,7 @@ static int flush_light_splats(vcm_ctx *c)
         if (overlap) {
             HIPCHK(hipEventRecord(c->evSplatFork, c->stream));
             HIPCHK(hipStreamWaitEvent(q, c->evSplatFork, 0));
-        }
+        } else if (join_splats(c)) return -1;   /* in line: K5 of the LAST iteration may still be adding to dFb on the splat stream */
         int *pixCount = c->dPixCount, *arrival = c->dSplatArrival, *pixStart = c->dPixStart;
         F4 *list = c->dSplatList;
         if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));
@@ -1203,6 +1203,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     }
     if (mark(c, EV_LIGHT_K0)) return -1;
     const bool wf = !c->strictOrder;
+    if (!wf && join_splats(c)) return -1;   /* the fused K1 splats straight into dFb: behind a K5 the last (aside) iteration left in flight */
     if (wf)
         LAUNCH_SC_MODE(c, k_light_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
                            c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16, c->dHdr);
@@ -1414,7 +1415,7 @@ static int sorted_shape(vcm_ctx *c, long long strideRecords, int *K, int *nBlock
     if (!c) return fail(who, "ctx is NULL");
     if (c->world <= 1) return fail(who, "the context is not sharded");
     if (!c->useVM) return fail(who, "the algorithm does not merge: nothing to exchange");
-    if (c->world > 256) return fail(who, "more than 256 shards: use the unsorted exchange");
+    if (c->world > VCM_SORTED_MAX_SHARDS) return fail(who, "more than 64 shards: use the unsorted exchange");
     if (strideRecords < 1 || strideRecords >= (1ll << 24)) return fail(who, "1 <= records per shard < 2^24 (the index shares a word with the path length): use the unsorted exchange");
     *K = sorted_block_cells(c->world);
     *nBlocks = (c->N + *K - 1) / *K;   /* nCells = pathCount (vertexcm.hxx:406) */
@@ -1445,6 +1446,7 @@ static int vcm_sort_light_records_impl(vcm_ctx *c, void *dstDev, long long strid
     if (grid_sort_is_radix(c)) {
         if (!(sorted = sort_cells_radix(c, c->stream, 0, recs))) return -1;
     } else {
+        if (c->prezeroed) HIPCHK(hipStreamWaitEvent(c->stream, c->evZero, 0));   /* the side stream's zeroing must not overtake the counts */
         if (zero_ranges(c->stream, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
         hipLaunchKernelGGL(k_cell_count, g, b, 0, c->stream, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId, c->dSortedIndex, c->dCellCount,
                            take_stamps(c, c->stream));
@@ -1463,7 +1465,7 @@ static int vcm_import_sorted_light_records_impl(vcm_ctx *c, const void *gathered
 {
     if (!c || !c->inIteration || !gathered || !counts) return fail("vcm_import_sorted_light_records", "no iteration in progress");
     if (nSeg != c->world) return fail("vcm_import_sorted_light_records", "one slab per rank");
-    if (nSeg > 64) return fail("vcm_import_sorted_light_records", "more than 64 shards: use the unsorted exchange");
+    if (nSeg > VCM_SORTED_MAX_SHARDS) return fail("vcm_import_sorted_light_records", "more than 64 shards: use the unsorted exchange");
     int K, nBlocks; long long words;
     if (sorted_shape(c, strideRecords, &K, &nBlocks, &words, "vcm_import_sorted_light_records")) return -1;
     if (use_device(c)) return -1;
@@ -1765,7 +1767,7 @@ static int vcm_merge_impl(vcm_ctx *c)
                1024^2, and at any size for the algorithms without vertex connection; SMALLVCM_AMD_MERGE_ASIDE=1 forces it. */
             { const char *e = getenv("SMALLVCM_AMD_RESOLVE_ASIDE");
               const bool pays = mergeAsideEnv == 1 || c->nLocal <= (1 << 20) || !c->useVC;
-              mergeAside = mergeAsideEnv != 0 && pays && !(e && e[0] == '0') && c->world == 1 && !c->strictOrder && !slabEnv; }
+              mergeAside = mergeAsideEnv != 0 && pays && !(e && e[0] != '1') /* = `aside` below: K5 follows K4 through evMergeDone only there */ && c->world == 1 && !c->strictOrder && !slabEnv; }
             hipStream_t ks = c->stream;
             if (mergeAside) {
                 if (flush_stamps(c, c->stream)) return -1;   /* the marks so far belong to what ran on the main stream */
@@ -1781,8 +1783,18 @@ static int vcm_merge_impl(vcm_ctx *c)
                queries through LDS -- 27 % less HBM traffic than k_merge_lane (13.7 -> 9.9 GB per launch,
                profiles/archive/r02c_ab_summary.txt) but slower: the kernel is not bound by the candidate loads, and the
                staging adds instructions and barriers. */
-            const int mergeStaged = c->mergeKind;
-            if (mergeStaged == 2) {
+            int mergeStaged = c->mergeKind;
+            /* k_merge_pairs keeps a material table of VCM_PAIR_MATERIALS rows in LDS */
+            if (mergeStaged == VCM_MERGE_PAIRS && (int)c->scene->materials.size() > VCM_PAIR_MATERIALS) mergeStaged = VCM_MERGE_WALK;
+            if (mergeStaged == VCM_MERGE_PAIRS) {
+                if (c->intPhong)
+                    hipLaunchKernelGGL(k_merge_pairs<true>, dim3(merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
+                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
+                else
+                    hipLaunchKernelGGL(k_merge_pairs<false>, dim3(merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
+                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
+            }
+            else if (mergeStaged == 2) {
                 /* SMALLVCM_AMD_MERGE_DEAL=slab: one contiguous eighth of the sorted queries per XCD, drawn batch by batch
                    from eight counters (vs.count[24..31], zeroed with the queue counts), with stealing; as many workgroups
                    as are resident (4 per CU).  Measured against the static dealing (default) on the Cornell scenes: K4's

@@ -656,6 +656,334 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #endif
 }
 
+/* ---------------- K4 (pairs): the scan per lane, RangeQuery::Process per PAIR ---------------- */
+/* Round 6 (profiles/r13a_pmc_mem.json): k_merge_walk is bound by the texture path -- TD busy 97 % of the kernel's cycles, TA
+ * 83 %, 46 % of the cycles moving data at the full 64 bytes per clock, the rest stalled behind L1 misses -- and that path is
+ * charged per LANE of a load whether or not the lane's data is wanted: the drain of k_merge_walk evaluates the queued photons
+ * of a wave's 64 queries in lockstep, the wave drains when ONE lane's queue is full, and on average 38 % of the lanes then
+ * hold an entry -- 2.6 gathers of 40 bytes x 64 lanes (and 2.6 evaluations of ~75 instructions) per useful one.
+ * Here the accepted (query lane, photon) PAIRS of a wave go to ONE ring in LDS (ballot + prefix popcount, in the order the
+ * lanes meet them) and are evaluated 64 at a time by whichever lane gets them: every gather and every evaluation is a
+ * wanted one.  What a pair's lane needs of ITS query -- the frame, mLocalDirFix, the component probabilities, the MIS terms:
+ * 20 words -- the query's lane wrote to an LDS row when the batch started (the 12 words a diffuse surface needs first, the 8
+ * only a Phong lobe reads behind them); the material constants come from a table staged at kernel start.
+ * ORDER, and why the sum is still the reference's (vertexcm.hxx:168): a query's pairs enter the ring in the order its lane
+ * walks its candidates (cells in the reference's order, hashgrid.hxx:142-155, vertices in index order) and leave it first
+ * in, first out.  Every entry carries how many pairs of ITS query precede it in its batch of 64 (`occ`, counted by the
+ * query's lane as it pushes); the terms are added to the queries' accumulators in rounds -- round r: the lanes whose entry
+ * has occ = r, which are pairs of DIFFERENT queries, each a plain read-add-write on its query's three words.  (ds_add_f32
+ * would do the same in one instruction -- the LDS serialises it by lane -- at 195 cycles per wave-instruction against 4-5 for
+ * a read or a write: profiles/r13d_lds_bench.txt; the first version of this kernel spent its time there.)
+ * The gathers of a batch are issued when it is full and its evaluation waits until the NEXT batch is full (or the scan has
+ * ended): the scan steps in between hide their latency. */
+#define VCM_PAIR_RING 128          /* entries per wave: 63 pending + the 64 one candidate column can add */
+#define VCM_PAIR_MATERIALS 32      /* material rows in LDS; a scene with more keeps k_merge_walk (vcm_api.hip) */
+#define VCM_PAIR_ROW 5             /* 16-byte words of a query's row */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float vcm_f4 __attribute__((ext_vector_type(4)));
+struct alignas(8) PairEntry { uint32_t idx, meta; };   /* photon | query lane (bits 0-5), occ (bits 8-14) */
+struct PairLds {
+    int runLo[8 * VCM_MERGE_BLOCK];
+    unsigned short runLen[8 * VCM_MERGE_BLOCK];   /* saturates at 65535: the lane then re-reads the cell's end (merge_pairs_run_end) */
+    vcm_f4 row[VCM_MERGE_BLOCK * VCM_PAIR_ROW];   /* {mZ | ldf.z}, {diffProb, phongProb, contProb, code}, {camTerm, camdVM, revPdfDiffuse, -}; Phong only: {mX | ldf.x}, {mY | ldf.y} */
+    float acc[3 * VCM_MERGE_BLOCK];
+    PairEntry ring[(VCM_MERGE_BLOCK / 64) * VCM_PAIR_RING];
+    vcm_f4 mat[VCM_PAIR_MATERIALS * 2];           /* {diffuse / pi, phongExp}, {rho, -} */
+};
+static_assert(sizeof(PairLds) <= 40960, "four workgroups per CU");
+struct PairRun { int lo, hi; bool sat; };
+struct PairBatch { uint32_t meta; MergePhoton ph; bool valid; };
+
+/* the end of probe j's cell, for a run whose 16-bit length saturated (a cell with 65535 photons or more: a caustic, a point
+   light next to a wall).  Cold: recomputes the probe's cell from the query position exactly as merge_pairs_runs did. */
+__device__ __noinline__ int merge_pairs_run_end(const IterParams &P, const GridStore &g, V3 queryPos, int probe)
+{
+    const V3 bmin = ld3(g.hdr->bboxMin);
+    const V3 cellPt = P.invCellSize * (queryPos - bmin);
+    const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+    const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
+    const V3 fractCoord = cellPt - coordF;
+    const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+    const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+    const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+    const int cell = grid_cell_hash((probe & 4) ? pxo : px, (probe & 2) ? pyo : py, (probe & 1) ? pzo : pz, P.nCells);
+    return g.cellStart[cell + 1];
+}
+
+/* hashgrid.hxx:116-155 as in merge_walk_runs, the runs as {lo, 16-bit length}; `probes` = which of the 8 probes they are */
+__device__ __forceinline__ int merge_pairs_runs(const IterParams &P, const GridStore &g, V3 queryPos, PairLds &L, int tid, int &total, uint32_t &probes)
+{
+    int n = 0;
+    total = 0; probes = 0u;
+    const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
+    const V3 distMin = queryPos - bmin, distMax = bmax - queryPos;
+    const bool inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
+                          distMin.z < 0.f || distMax.z < 0.f);
+    const V3 cellPt = P.invCellSize * distMin;
+    const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
+    const int px = int(coordF.x), py = int(coordF.y), pz = int(coordF.z);
+    const V3 fractCoord = cellPt - coordF;
+    const int pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
+    const int pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
+    const int pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
+    int lo[8], hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        lo[j] = 0; hi[j] = 0;
+        if (inside) {
+            const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
+            lo[j] = g.cellStart[cell];
+            hi[j] = g.cellStart[cell + 1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int len = hi[j] - lo[j];
+        total += len;   /* one distance test per entry (:162-165) */
+        if (len > 0) {
+            L.runLo[n * VCM_MERGE_BLOCK + tid] = lo[j];
+            L.runLen[n * VCM_MERGE_BLOCK + tid] = (unsigned short)(len < 65535 ? len : 65535);
+            probes |= (uint32_t)j << (3 * n);
+            n++;
+        }
+    }
+    return n;
+}
+__device__ __forceinline__ PairRun merge_pairs_read_run(const PairLds &L, int tid, int k, int n)
+{
+    PairRun r; r.lo = 0; r.hi = 0; r.sat = false;
+    if (k < n) {
+        const int len = L.runLen[k * VCM_MERGE_BLOCK + tid];
+        r.lo = L.runLo[k * VCM_MERGE_BLOCK + tid];
+        r.hi = r.lo + len;
+        r.sat = len == 65535;
+    }
+    return r;
+}
+
+/* a batch leaves the ring: its (at most 64) entries, the gathers of their photons */
+__device__ __forceinline__ void merge_pairs_issue(const GridStore &g, const PairEntry *ring, int lane, int &head, int &cnt, PairBatch &b)
+{
+    const int n = cnt < 64 ? cnt : 64;
+    b.valid = lane < n;
+    __builtin_amdgcn_wave_barrier();   /* the entries are other lanes' stores: LDS operations of a wave complete in order */
+    const PairEntry e = ring[(head + lane) & (VCM_PAIR_RING - 1)];
+    b.meta = e.meta;
+    /* lanes without an entry read photon 0 (always allocated); the value is not used */
+    const uint32_t idx = b.valid ? e.idx : 0u;
+    const F2 t = g.g3[idx];
+    b.ph.lenBits = t.y;
+    b.ph.b = g.g1[idx];
+    b.ph.c = g.g2[idx];
+    b.ph.dVM = t.x;
+    head = (head + n) & (VCM_PAIR_RING - 1);
+    cnt -= n;
+}
+/* RangeQuery::Process (vertexcm.hxx:130-169) for the pair of every lane: merge_eval_setup + merge_eval_photon (vcm_core.h)
+   statement by statement, the query's side out of its LDS row; then the terms to the accumulators, round by round */
+template <bool IP>
+__device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L, int waveBase, const PairBatch &b)
+{
+    V3 term = sp3(0.f);
+    const int ql = waveBase + (int)(b.meta & 63u);
+    const uint32_t occ = b.valid ? ((b.meta >> 8) & 127u) : 0u;
+    if (b.valid) {
+        const vcm_f4 *row = L.row + ql * VCM_PAIR_ROW;
+        const vcm_f4 h0 = row[0], h1 = row[1], h2 = row[2];
+        const float codeBits = h1.w;   /* (by value: __builtin_bit_cast of the vector ELEMENT h1.w read element 0, ROCm 7.2) */
+        const uint32_t code = f2u(codeBits);
+        const vcm_f4 m0 = L.mat[(code >> 8) * 2];
+        const V3 lightDirection = mk3(b.ph.b.x, b.ph.b.y, b.ph.b.z);
+        const float ldfz = h0.w, diffProb = h1.x, phongProb = h1.y;
+        const uint32_t lvLen = f2u(b.ph.lenBits), pathLength = code & 0xffu;
+        const float genz = dot(lightDirection, mk3(h0.x, h0.y, h0.z));                        /* bsdf.hxx:140 (ToLocal's z) */
+        const bool valid = !((lvLen + pathLength > P.maxLen) || (lvLen + pathLength < P.minLen))   /* :133-135 */
+                           && !(genz * ldfz < 0.f);                                          /* bsdf.hxx:142 */
+        const bool ok = !(ldfz < VCM_EPS_COSINE) && !(genz < VCM_EPS_COSINE);                /* :402, :423 */
+        const bool dOn = valid && ok && (diffProb != 0.f);
+        float dirPdf = dOn ? diffProb * smax(0.f, genz * VCM_INV_PI_F) : 0.f;
+        float revPdf = dOn ? h2.z : 0.f;
+        V3 result = sp3(0.f) + (dOn ? mk3(m0.x, m0.y, m0.z) : sp3(0.f));
+        V3 ph = sp3(0.f);
+        if (valid && ok && (phongProb != 0.f)) {   /* EvaluatePhong: the other two axes of the frame, mLocalDirFix.xy, rho */
+            const vcm_f4 c0 = row[3], c1 = row[4];
+            const vcm_f4 m1 = L.mat[(code >> 8) * 2 + 1];
+            const V3 gen = mk3(dot(lightDirection, mk3(c0.x, c0.y, c0.z)), dot(lightDirection, mk3(c1.x, c1.y, c1.z)), genz);
+            const float dot_R_Wi = dot(reflect_local(mk3(c0.w, c1.w, ldfz)), gen);
+            if (!(dot_R_Wi <= VCM_EPS_PHONG)) {
+                const float pw = dm_powf_wave(dot_R_Wi, m0.w, false, IP);
+                const float pdfW = phongProb * ((m0.w + 1.f) * pw * (VCM_INV_PI_F * 0.5f));
+                dirPdf += pdfW;
+                revPdf += pdfW;
+                ph = mk3(m1.x, m1.y, m1.z) * pw;
+            }
+        }
+        result = result + ph;
+        if (valid && !iszero(result)) {                                                     /* :145-146 */
+            dirPdf *= h1.z;                                                                 /* :148 */
+            revPdf *= b.ph.b.w;                                                             /* :153 */
+            const float wLight = b.ph.c.w * P.misVcWeightFactor + b.ph.dVM * mis(dirPdf);   /* :156-157 */
+            const float wCamera = h2.x + h2.y * mis(revPdf);                                /* :160-161 */
+            const float misWeight = P.ppm ? 1.f : 1.f / (wLight + 1.f + wCamera);           /* :164-166 */
+            term = term + misWeight * result * mk3(b.ph.c.x, b.ph.c.y, b.ph.c.z);           /* :168: 0 + x is x */
+        }
+    }
+    /* contrib += term, a query's terms in the order of its pairs: round r = the entries with r pairs of their query before them */
+    const bool live = b.valid && (term.x != 0.f || term.y != 0.f || term.z != 0.f);
+    for (uint32_t r = 0;; r++) {
+        if (live && occ == r) {
+            const float ax = L.acc[ql], ay = L.acc[VCM_MERGE_BLOCK + ql], az = L.acc[2 * VCM_MERGE_BLOCK + ql];
+            L.acc[ql] = ax + term.x; L.acc[VCM_MERGE_BLOCK + ql] = ay + term.y; L.acc[2 * VCM_MERGE_BLOCK + ql] = az + term.z;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!wave_any(live && occ > r)) break;
+    }
+}
+#endif
+
+template <bool IP>
+__global__ void __launch_bounds__(VCM_MERGE_BLOCK) VCM_K4_ATTR
+k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
+              const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
+{
+    stamp_entry(st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const DScene &sc = *scp;
+    const int nQ = *nSorted;
+    __shared__ __attribute__((aligned(16))) PairLds L;
+    const int tid = (int)threadIdx.x, lane = tid & 63, waveBase = tid & ~63;
+    PairEntry *ring = L.ring + (tid >> 6) * VCM_PAIR_RING;
+    for (int m = tid; m < sc.nMaterials && m < VCM_PAIR_MATERIALS; m += VCM_MERGE_BLOCK) {
+        const vcm_material mm = scene_material(sc, m, false);
+        const V3 dv = ld3(mm.diffuse) * VCM_INV_PI_F;                                    /* bsdf.hxx:411 */
+        const V3 rho = ld3(mm.phong) * (mm.phongExp + 2.f) * 0.5f * VCM_INV_PI_F;       /* :442-443 */
+        vcm_f4 a, b;
+        a.x = dv.x; a.y = dv.y; a.z = dv.z; a.w = mm.phongExp;
+        b.x = rho.x; b.y = rho.y; b.z = rho.z; b.w = 0.f;
+        L.mat[m * 2] = a; L.mat[m * 2 + 1] = b;
+    }
+    __syncthreads();   /* the only barrier: from here on a wave touches its own quarter of the LDS */
+    LaneStats ls; lane_stats_zero(ls);
+    uint32_t waveAccepted = 0;   /* wave-uniform */
+    const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
+    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
+    for (int t = wgOfXcd;; t += wgPerXcd) {   /* k_merge_walk's static dealing: chunks of batches round-robin over the XCDs */
+        const int bt = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
+        if ((t / chunk) * 8 * chunk >= nBatches) break;
+        if (bt >= nBatches) continue;
+        const int q = bt * VCM_MERGE_BLOCK + tid;
+        V3 qp = sp3(0.f), thr = sp3(0.f);
+        size_t ps = 0;
+        int n = 0;
+        uint32_t probes = 0u;
+        if (q < nQ) {
+            const int vi = sortedVertex[q];
+            const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
+            ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
+            Bsdf bsdf;
+            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
+            vcm_f4 r;
+            vcm_f4 *row = L.row + tid * VCM_PAIR_ROW;
+            r.x = bsdf.frame.mZ.x; r.y = bsdf.frame.mZ.y; r.z = bsdf.frame.mZ.z; r.w = bsdf.localDirFix.z; row[0] = r;
+            r.x = bsdf.diffProb; r.y = bsdf.phongProb; r.z = bsdf.contProb; r.w = bq.w; row[1] = r;   /* bq.w: pathLength | matID << 8 */
+            r.x = c.w * P.misVcWeightFactor;                                              /* vertexcm.hxx:160 */
+            r.y = d.w;
+            r.z = bsdf.diffProb * smax(0.f, bsdf.localDirFix.z * VCM_INV_PI_F);           /* bsdf.hxx:408 */
+            r.w = 0.f; row[2] = r;
+            if (bsdf.phongProb != 0.f) {
+                r.x = bsdf.frame.mX.x; r.y = bsdf.frame.mX.y; r.z = bsdf.frame.mX.z; r.w = bsdf.localDirFix.x; row[3] = r;
+                r.x = bsdf.frame.mY.x; r.y = bsdf.frame.mY.y; r.z = bsdf.frame.mY.z; r.w = bsdf.localDirFix.y; row[4] = r;
+            }
+            qp = mk3(a.x, a.y, a.z); thr = mk3(d.x, d.y, d.z);
+            int total;
+            n = merge_pairs_runs(P, g, qp, L, tid, total, probes);
+            ls.mergeCandidates += (uint32_t)total;
+        }
+        L.acc[tid] = 0.f; L.acc[VCM_MERGE_BLOCK + tid] = 0.f; L.acc[2 * VCM_MERGE_BLOCK + tid] = 0.f;
+        /* ---- scan (merge_query_walk's) with the accepted pairs to the wave's ring */
+        const f2 qx = f2_sp(qp.x), qy = f2_sp(qp.y), qz = f2_sp(qp.z);
+        int k = 0, head = 0, cnt = 0;
+        uint32_t occ = 0u;   /* this lane's pairs in the batch that is filling */
+        bool inflight = false;
+        PairBatch pb;
+        pb.valid = false; pb.meta = 0u;
+        PairRun cur = merge_pairs_read_run(L, tid, 0, n), nxt = merge_pairs_read_run(L, tid, 1, n);
+        f4u X = *(const f4u *)(g.gx + cur.lo), Y = *(const f4u *)(g.gy + cur.lo), Z = *(const f4u *)(g.gz + cur.lo);
+        while (wave_any(cur.lo < cur.hi)) {
+            const int stepEnd = cur.lo + VCM_MERGE_UNROLL;
+            const bool last = stepEnd >= cur.hi;
+            int aNext = last ? nxt.lo : stepEnd;
+            if (last && cur.sat) aNext = cur.hi;   /* a saturated run goes on where this piece ends */
+            const f4u Xn = *(const f4u *)(g.gx + aNext), Yn = *(const f4u *)(g.gy + aNext), Zn = *(const f4u *)(g.gz + aNext);
+            float distSqr[VCM_MERGE_UNROLL];
+            {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */
+                const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
+                const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
+                const f2 da = dxa * dxa + dya * dya + dza * dza;
+                const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
+                distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
+            }
+            X = Xn; Y = Yn; Z = Zn;
+#pragma unroll
+            for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
+                const int idx = cur.lo + u;
+                const bool acc = (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(acc);
+                if (m) {   /* scalar branch */
+                    const int rel = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (acc) {
+                        PairEntry e; e.idx = (uint32_t)idx; e.meta = (uint32_t)lane | (occ << 8);
+                        ring[(head + rel) & (VCM_PAIR_RING - 1)] = e;
+                        occ++;
+                    }
+                    const int add = __popcll(m);
+                    cnt += add;
+                    waveAccepted += (uint32_t)add;
+                    if (cnt >= 64) {
+                        if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
+                        const int headWas = head;
+                        merge_pairs_issue(g, ring, lane, head, cnt, pb);
+                        inflight = true;
+                        /* the entries of this column that did not fit open the next batch */
+                        const bool left = acc && rel >= 64;
+                        if (left) ring[(headWas + rel) & (VCM_PAIR_RING - 1)].meta = (uint32_t)lane;
+                        occ = left ? 1u : 0u;
+                    }
+                }
+            }
+            if (last) {
+                if (cur.sat) {   /* cold: 65535 candidates done, the cell has more */
+                    const int end = merge_pairs_run_end(P, g, qp, (int)((probes >> (3 * k)) & 7u));
+                    const int rest = end - cur.hi;
+                    cur.lo = cur.hi;
+                    cur.hi = cur.lo + (rest < 65535 ? rest : 65535);
+                    cur.sat = rest >= 65535;
+                    if (rest == 0) { cur = nxt; k++; nxt = merge_pairs_read_run(L, tid, k + 1, n); }
+                    X = *(const f4u *)(g.gx + cur.lo); Y = *(const f4u *)(g.gy + cur.lo); Z = *(const f4u *)(g.gz + cur.lo);
+                } else {
+                    cur = nxt;
+                    k++;
+                    nxt = merge_pairs_read_run(L, tid, k + 1, n);
+                }
+            } else cur.lo = stepEnd;
+        }
+        if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
+        while (cnt > 0) {
+            merge_pairs_issue(g, ring, lane, head, cnt, pb);
+            merge_pairs_eval<IP>(P, L, waveBase, pb);
+        }
+        if (q < nQ) {
+            const V3 contrib = mk3(L.acc[tid], L.acc[VCM_MERGE_BLOCK + tid], L.acc[2 * VCM_MERGE_BLOCK + tid]);
+            const V3 v = thr * P.vmNormalization * contrib;
+            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
+        }
+    }
+    if (lane == 0) ls.mergeAccepted = waveAccepted;
+    flush_stats(ls, gstats);
+#endif
+}
+
 /* ---------------- K4 (selectable): range-merge with the cell lists staged through LDS ---------------- */
 /* HashGrid::Process walks 8 hashed cells per query (hashgrid.hxx:142-167).  k_merge_lane reads the candidates of
  * those cells with per-lane global loads: three 16-byte loads per lane and step, each touching as many cache lines
@@ -1391,6 +1719,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t *__restric
     const long long lo64 = (long long)blockIdx.x * chunk;
     const int lo = lo64 < n ? (int)lo64 : n, hi = (n - lo < chunk) ? n : lo + chunk;
     sGlobal[tid] = histScanned[tid * V + (int)blockIdx.x];
+    static_assert(VCM_WAVE == 64, "the ballots and `below` are 64-bit lane masks");
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int t0 = lo; t0 < hi; t0 += VCM_RSORT_TILE) {
         const int m = (hi - t0 < VCM_RSORT_TILE) ? hi - t0 : VCM_RSORT_TILE;
@@ -1419,6 +1748,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t *__restric
                 const int run = sRun[w][d];
                 r[round] = run + before;
                 if (valid && before == 0) sRun[w][d] = run + __popcll(peers);   /* the first lane of the group */
+                __builtin_amdgcn_wave_barrier();   /* the next round's loads of sRun[w][*] stay behind this store */
                 validBits |= valid ? (1u << round) : 0u;
             }
         }
@@ -1557,6 +1887,7 @@ __global__ void __launch_bounds__(256) k_cell_rank_gather(const DScene *__restri
  * the parity read-out wants sortedIndex (grid position -> vertex index); a shard of 2^24 vertices or more keeps the
  * unsorted exchange (vcm_sort_light_records refuses). */
 #define VCM_SORTED_WORDS 13
+#define VCM_SORTED_MAX_SHARDS 64   /* SortedSlabs::rankBase, k_grid_merge_blocks' sSeg; more shards: the unsorted exchange */
 #define VCM_SORTED_MAX_TABLE 4096   /* K * S entries per LDS table */
 inline __host__ __device__ int sorted_block_cells(int S)
 {   /* K: the largest power of two <= 4096 / S, within [16, 1024] */
@@ -1615,7 +1946,7 @@ struct SortedSlabs {
     const uint32_t *base;        /* S slabs of slabWords words: [stride records of 13 words][nBlocks + 1 block starts] */
     long long slabWords, strideRecords;
     int S, K, nBlocks;
-    int rankBase[65];            /* vertices of the ranks before r (r = 0 .. S): global index of rank r's first vertex */
+    int rankBase[VCM_SORTED_MAX_SHARDS + 1];            /* vertices of the ranks before r (r = 0 .. S): global index of rank r's first vertex */
 };
 
 __global__ void __launch_bounds__(256) k_grid_merge_blocks(IterParams P, const GridHeader *__restrict__ hdr, SortedSlabs in,
@@ -1625,7 +1956,7 @@ __global__ void __launch_bounds__(256) k_grid_merge_blocks(IterParams P, const G
     stamp_entry(st);
     __shared__ int sCnt[VCM_SORTED_MAX_TABLE];     /* [cell][rank]: run length, then (scanned in place) the run's offset in the block's output */
     __shared__ int sFirst[VCM_SORTED_MAX_TABLE];   /* [cell][rank]: slab index of the run's first record */
-    __shared__ int sSeg[2 * 64 + 2];               /* per rank: segment start, end; [128] = output start of the block, [129] = records */
+    __shared__ int sSeg[2 * VCM_SORTED_MAX_SHARDS + 2];               /* per rank: segment start, end; [128] = output start of the block, [129] = records */
     __shared__ int sPart[256];
     const int tid = (int)threadIdx.x, S = in.S, K = in.K;
     const V3 bmin = ld3(hdr->bboxMin);

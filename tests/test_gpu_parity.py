@@ -174,7 +174,7 @@ def test_long_splat_lists_one_wave_per_pixel():
     assert got.max() > 0
 
 
-@pytest.mark.parametrize("kind", ["lane", "staged", "walk"])
+@pytest.mark.parametrize("kind", ["lane", "staged", "walk", "pairs"])
 @pytest.mark.parametrize("sid,algo,res,nit,mx", [(1, 4, 256, 3, 10), (3, 2, 192, 2, 10), (0, 1, 128, 2, 6), (2, 4, 64, 1, 10), (1, 4, 40, 1, 10)])
 def test_merge_kernels_equal_oracle(sid, algo, res, nit, mx, kind):
     """The three range-merge kernels (vcm_set_merge_kernel) walk the cell lists differently and give the same bits."""
