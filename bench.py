@@ -71,12 +71,16 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 # binary64 fma has no counter in the group collected here and is priced as plain: issue_ms is a lower bound, frac errs low.
 VALU_SIMDS, VALU_CLK_HZ = 1024, 2.4e9
 VALU_CYCLES = {"plain": 2.7, "f64": 5.2, "trans": 8.4}
+# The same mix at the costs MI355X_MICROARCH.md's SIMD-32 model gives (a wave64 fp32 / int32 instruction over 2 cycles, "Per-instruction
+# cycle constants": v_fma_f32 2 cyc; binary64 at half that rate, transcendentals at a quarter): `valu_frac_guide` beside `valu_frac`
+# (the measured 2.7 is this builder's own number, the guide's 2 is the hardware's)
+VALU_CYCLES_GUIDE = {"plain": 2.0, "f64": 4.0, "trans": 8.0}
 LINE_LIMIT = 4096        # the driver keeps a tail of stdout: the JSON line must fit it with room to spare
 # kernel-name PREFIXES as rocprofv3 prints them (the ray-casting kernels are templates over the kind of scene:
 # "vcm::k_camera_trace<1, vcm::SceneList>")
 KERNEL_KEYS = {"k_light_trace": ["vcm::k_light_trace<1"], "k_camera_trace": ["vcm::k_camera_trace<1"],
                "k_connect_di+vc": ["vcm::k_connect_di", "vcm::k_connect_vc"],
-               "k_merge": ["vcm::k_merge_walk", "vcm::k_merge_staged", "vcm::k_merge_lane"]}
+               "k_merge": ["vcm::k_merge_pairs", "vcm::k_merge_walk"]}
 # How a kernel reads memory decides what FETCH_SIZE means for it (profiles/tools/fetch_calib.hip measures the factor
 # per pattern on the GPU box; profiles/fetch_calib.json holds the result).  Until a class is calibrated the guide's
 # factor for wide streaming reads (2) is used and the figure is marked "uncalibrated".
@@ -268,6 +272,7 @@ def valu_block(counters, prefixes, kernel_ms):
     plain = max(insts - f64 - trans, 0)
     cycles = plain * VALU_CYCLES["plain"] + f64 * VALU_CYCLES["f64"] + trans * VALU_CYCLES["trans"]
     t_min = cycles / (VALU_SIMDS * VALU_CLK_HZ)
+    t_guide = (plain * VALU_CYCLES_GUIDE["plain"] + f64 * VALU_CYCLES_GUIDE["f64"] + trans * VALU_CYCLES_GUIDE["trans"]) / (VALU_SIMDS * VALU_CLK_HZ)
     lane = thr / (active * 64.0)
     frac = t_min / (kernel_ms / 1e3)
     wc, wa = _sum_over(counters, prefixes, "SQ_WAVE_CYCLES"), _sum_over(counters, prefixes, "SQ_WAIT_ANY")
@@ -275,6 +280,7 @@ def valu_block(counters, prefixes, kernel_ms):
             "class_costs": VALU_CYCLES if classes else "classes not collected: every instruction at %.1f cycles" % VALU_CYCLES["plain"],
             "simds": VALU_SIMDS, "clk_GHz": VALU_CLK_HZ / 1e9,
             "issue_ms": round(t_min * 1e3, 3), "lane_util": round(lane, 3), "frac": round(frac, 4),
+            "frac_guide": round(t_guide / (kernel_ms / 1e3), 4), "guide_costs": VALU_CYCLES_GUIDE,
             "frac_useful_lanes": round(frac * lane, 4), "wait_share_of_wave_cycles": round(wa / wc, 3) if wc and wa else None}
 
 
@@ -403,7 +409,8 @@ def finalize_roofline(roof):
             v = roof["valu"]
             peak = VALU_SIMDS * VALU_CLK_HZ / v["cycles_per_inst"] / 1e9
             head.update({"bound": "valu", "achieved": round(v["insts"] / (roof["kernel_ms"] / 1e3) / 1e9, 2), "peak": round(peak, 1),
-                         "unit": "G wave-instr/s (1024 SIMDs x 2.4 GHz / %.2f cyc)" % v["cycles_per_inst"], "frac": vf})
+                         "unit": "G wave-instr/s (1024 SIMDs x 2.4 GHz / %.2f cyc; the cost per instruction is MEASURED on this chip, "
+                                 "profiles/tools/valu_bench.hip -- at the guide's 2 / 4 / 8 cycles: valu_frac_guide)" % v["cycles_per_inst"], "frac": vf})
         else:
             head.update({"bound": "hbm", "achieved": roof["achieved_traffic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (measured HBM traffic)",
                          "frac": ft})
@@ -420,6 +427,7 @@ def finalize_roofline(roof):
     head["limiter"] = roof.get("limiter")
     if roof.get("valu"):
         head["valu_frac"] = roof["valu"]["frac"]
+        head["valu_frac_guide"] = roof["valu"].get("frac_guide")
         head["valu_lane_util"] = roof["valu"]["lane_util"]
     head["traffic"] = roof.get("traffic")
     head["frac_traffic"] = ft
@@ -466,7 +474,7 @@ def write_detail(full):
 
 
 ROOF_LINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "frac_algorithmic",
-                  "valu_frac", "valu_lane_util", "kernel_ms", "iteration_frac", "iteration_ms", "traffic_source", "frac_note")
+                  "valu_frac", "valu_frac_guide", "valu_lane_util", "kernel_ms", "iteration_frac", "iteration_ms", "traffic_source", "frac_note")
 
 
 def short_line(full, detail_path):
@@ -492,6 +500,10 @@ def short_line(full, detail_path):
         c = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "wall_s", "host_cores") if k in cb}
         if cb.get("sample"):
             c["sample"] = _short(cb["sample"], 160)
+        if cb.get("host_ram_GB") is not None:
+            c["host_ram_GB"] = cb["host_ram_GB"]
+        if isinstance(cb.get("all_cores_at_this_res"), dict):
+            c["all_cores_at_this_res"] = {k: cb["all_cores_at_this_res"].get(k) for k in ("needed_GB", "fits", "value", "cores", "wall_s") if cb["all_cores_at_this_res"].get(k) is not None}
         if isinstance(cb.get("all_cores"), dict) and "value" in cb["all_cores"]:
             c["all_cores"] = {k: cb["all_cores"].get(k) for k in ("value", "cores", "wall_s", "res")}
         port = cb.get("port") if cb.get("kind") == "reference" else None
@@ -510,11 +522,16 @@ def short_line(full, detail_path):
             line["configs"].append({"name": c["name"], "value": c["value"], "ms_per_step": c["ms_per_step"],
                                     "iteration_frac": cr.get("iteration_frac"), "frac": cr.get("frac"), "bound": cr.get("bound"),
                                     "kernel": cr.get("kernel")})
+    if full.get("dropin"):
+        line["dropin"] = {k: ({kk: v.get(kk) for kk in ("value", "ratio", "error") if v.get(kk) is not None} if isinstance(v, dict) else v)
+                          for k, v in full["dropin"].items() if k.startswith("renderers_") or k == "error"}
     if full.get("host_cross_check"):
         line["host_cross_check"] = {"value": full["host_cross_check"]["value"], "host": "python/ctypes"}
     if full.get("strong_decomposition"):
         sd = full["strong_decomposition"]
         line["strong_decomposition"] = {k: sd.get(k) for k in ("value", "ms_per_step", "scaling", "paths_per_step")}
+    if full.get("selftest"):
+        line["selftest"] = {k: full["selftest"].get(k) for k in ("ran", "ok", "why", "ranks", "direct_equals_allgather_bitwise", "error") if full["selftest"].get(k) is not None}
     if full.get("hybrid_decomposition"):
         sd = full["hybrid_decomposition"]
         line["hybrid_decomposition"] = {k: sd.get(k) for k in ("value", "ms_per_step", "scaling", "paths_per_step", "shards", "inflight")}
@@ -522,7 +539,7 @@ def short_line(full, detail_path):
         line["image_mean"] = full["image_mean"]
     line["detail"] = detail_path
     line = _clean(line)
-    for drop in (None, "image_mean", "host_cross_check", "configs", "cpu_baseline.sample", "config.parallelism"):
+    for drop in (None, "image_mean", "host_cross_check", "cpu_baseline.sample", "configs", "dropin", "config.parallelism"):
         if drop:
             a, _, b = drop.partition(".")
             if b:
@@ -593,6 +610,96 @@ def cpu_port(scene, algo, res, iteration, budget_rows=8):
             "sample": "oracle/vcm_oracle.cpp, path-parallel, radius index %d: all %d light paths + grid build, camera paths of "
                       "every %dth pixel row, camera time scaled by %.2f; %.1f s light, %.1f s grid, %.1f s camera sample"
                       % (iteration, n, budget_rows, res / rows, t1 - t0, t2 - t1, t3 - t2)}
+
+
+def host_memory_GB():
+    """(total, available) of the host in GB, from /proc/meminfo; (None, None) if unreadable"""
+    try:
+        kv = {}
+        for ln in open("/proc/meminfo"):
+            k, _, v = ln.partition(":")
+            kv[k.strip()] = float(v.split()[0]) / 1048576.0
+        return round(kv["MemTotal"], 1), round(kv.get("MemAvailable", kv["MemFree"]), 1)
+    except Exception:
+        return None, None
+
+
+REF_GB_PER_RENDERER_2048 = 1.3   # one VertexCM of the reference at 2048^2: mLightVertices 8.9 M x 120 B + the hash grid + the framebuffer
+
+
+def dropin_leg(res, steps, warmup):
+    """The north_star surface -- AbstractRenderer::RunIteration + GetFramebuffer (renderer.hxx:49-55) over the drop-in, the host
+    Framebuffer refreshed after EVERY iteration -- timed by dropin/dropin_rate with one renderer and with two on two host
+    threads (the unchanged render() creates one per core, smallvcm.cxx:61-72), next to the C-ABI alone in the same process."""
+    exe = os.path.join(ROOT, "smallvcm_amd", "dropin", "dropin_rate")
+    if not os.path.exists(exe):
+        return {"error": "smallvcm_amd/dropin/dropin_rate not built (needs the reference checkout at build time)"}
+    out = {}
+    for n in (1, 2):
+        cmd = [exe, str(res), str(steps), str(warmup)] + (["1", "vcm", str(n)] if n > 1 else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out["renderers_%d" % n] = {"value": d["dropin_Mpaths_s"], "cabi": d["cabi_Mpaths_s"], "ratio": d["dropin_over_cabi"],
+                                       "pixels_that_differ": d.get("pixels_that_differ")}
+        except Exception as e:
+            out["renderers_%d" % n] = {"error": repr(e)[:200]}
+    out["unit"] = "Mpaths/s"
+    out["what"] = ("reference's Scene / VertexCM interface over dropin/vertexcm.hxx at %d^2, host Framebuffer refreshed after every "
+                   "RunIteration; cabi = vcm_run_iteration alone in the same process" % res)
+    return out
+
+
+def rccl_selftest(n_ranks=2, res=256, iters=3):
+    """The FIRST execution of the RCCL path with more than one rank should not be the timed run: wherever two GPUs
+    are visible, render scene 1 VCM at 256^2 for three iterations with ONE renderer on `n_ranks` shards over real RCCL -- once with
+    ncclAllGather, once with the direct exchange (grouped ncclSend / ncclRecv) -- and compare both frames with one renderer on
+    one GPU (equal up to the order of the final framebuffer sum; the two exchanges bit for bit).  A few seconds."""
+    import numpy as np
+    exe = os.path.join(ROOT, "smallvcm_amd", "host", "vcm_render")
+    if not os.path.exists(exe):
+        return {"ran": False, "why": "smallvcm_amd/host/vcm_render not built"}
+    sys.path.insert(0, ROOT)
+    from smallvcm_amd.renderer import load_library
+    visible = load_library(require_gpu=False).vcm_device_count()
+    if visible < n_ranks:
+        return {"ran": False, "why": "%d GPU(s) visible, %d needed" % (visible, n_ranks), "gpus_visible": visible}
+
+    def pfm(path):
+        with open(path, "rb") as f:
+            assert f.readline().strip() == b"PF"
+            w, h = (int(x) for x in f.readline().split())
+            f.readline()
+            return np.frombuffer(f.read(w * h * 12), dtype="<f4").copy()
+
+    tmp = tempfile.mkdtemp(prefix="vcm_selftest_")
+    frames, info = {}, {"ran": True, "ranks": n_ranks, "res": res, "iterations": iters, "gpus_visible": visible}
+    try:
+        runs = (("one_gpu", ["--renderers", "1"], {}),
+                ("allgather", ["--gpus", str(n_ranks), "--shards", str(n_ranks), "--inflight", "1"], {"SMALLVCM_AMD_FARM_EXCHANGE": "allgather"}),
+                ("direct", ["--gpus", str(n_ranks), "--shards", str(n_ranks), "--inflight", "1"], {"SMALLVCM_AMD_FARM_EXCHANGE": "direct"}))
+        for name, extra, env in runs:
+            out = os.path.join(tmp, name + ".pfm")
+            e = dict(os.environ, **env)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):   # a plain one-process run, whatever launched us
+                e.pop(k, None)
+            r = subprocess.run([exe, "-s", "1", "-a", "vcm", "-i", str(iters), "--res", str(res), str(res), "-o", out, "--json"] + extra,
+                               capture_output=True, text=True, timeout=300, env=e)
+            if r.returncode != 0:
+                info["ok"] = False
+                info["error"] = "%s: rc %d %s" % (name, r.returncode, (r.stderr or r.stdout)[-300:])
+                return info
+            frames[name] = pfm(out)
+        a, g, d = frames["one_gpu"], frames["allgather"], frames["direct"]
+        info["allgather_vs_one_gpu_max_rel"] = float(np.max(np.abs(g - a) / np.maximum(np.abs(a), 1e-6)))
+        info["direct_equals_allgather_bitwise"] = bool(np.array_equal(g.view(np.uint32), d.view(np.uint32)))
+        info["ok"] = bool(np.allclose(g, a, rtol=3e-6, atol=2e-7) and info["direct_equals_allgather_bitwise"] and a.max() > 0)
+    except Exception as ex:
+        info["ok"] = False
+        info["error"] = repr(ex)[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return info
 
 
 def timed_run(farm, steps, warmup, sync):
@@ -675,6 +782,8 @@ def multi_gpu(args):
     # smallvcm.cxx:61-72, "weak") is timed beside it and reported as hybrid_decomposition.
     shards = args.shards if args.shards > 0 else N
     inflight = args.inflight if args.inflight > 0 else 1
+    # two real RCCL ranks against one GPU, both exchanges, before anything is timed (a few seconds; rank 0's subprocesses)
+    selftest = rccl_selftest() if (rank == 0 and args.collectives == "rccl") else None
     main_run = run(shards, inflight)
     strong = None
     hybrid = run(2, 2) if (args.shards <= 0 and args.inflight <= 0 and N % 2 == 0 and not args.no_hybrid) else None
@@ -710,6 +819,8 @@ def multi_gpu(args):
         }
         roof["scope"] = "world rank 0 (1 of %d shards of renderer 0), mean over its timed iterations" % shards
         out["roofline"] = finalize_roofline(roof)
+        if selftest is not None:
+            out["selftest"] = selftest
         if hybrid is not None:
             out["hybrid_decomposition"] = {
                 "value": round(hybrid["value"], 3), "unit": "Mpaths/s", "scaling": "weak", "shards": 2, "inflight": 2,
@@ -745,6 +856,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the reference leg (default min(32, cores): "
                                                                "it saturates the host's memory system there)")
+    ap.add_argument("--cpu-all-cores-2048", action="store_true",
+                    help="also time the reference on EVERY host thread at the headline resolution (one 2048^2 iteration per thread: "
+                         "~1.3 GB each and about ten minutes; refused when the host's memory does not hold it)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="only run the multi-rank RCCL self-check (2 real ranks, 256^2, 3 iterations, both exchanges against one GPU) and print its result")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (dropin/dropin_rate: the reference's renderer interface)")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's other single-GPU configs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 child runs (HBM traffic, VALU counters)")
     ap.add_argument("--no-cross-check", action="store_true", help="skip the second timing of the headline through the Python host")
@@ -757,6 +874,9 @@ def main():
     if args.scene_file:   # a scene the reference cannot load: no CPU leg, no per-kernel child runs by scene id
         args.scene = "file:" + args.scene_file
         args.cpu_baseline, args.no_traffic = "none", True
+    if args.selftest:
+        print(json.dumps({"selftest": rccl_selftest(max(2, min(args.gpus, 8)) if args.gpus > 1 else 2)}, allow_nan=False), flush=True)
+        return
     if args.gpus > 1:
         return multi_gpu(args)
 
@@ -846,7 +966,9 @@ def main():
         "metric": "Mpaths/sec (light+camera), %s scene %s at %d^2" % (args.algo.upper(), args.scene, res),
         "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak",
+        # the N = 1 point of the curve --gpus N continues: ONE renderer, a step = one iteration of the whole frame whatever N
+        # (the N > 1 default shards that iteration: "strong"); several renderers in flight (--inflight) are replicas: "weak"
+        "scaling": "strong" if replicas == 1 else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (reference's built-in Cornell box scene %s)" % args.scene,
         "config": {"workload": workload_name(args.scene, args.algo, res, replicas, args.warmup, args.warmup + args.steps - 1)
                                + (" by every renderer" if replicas > 1 else ""),
@@ -855,7 +977,7 @@ def main():
                    "parallelism": "%d renderer(s) (iteration-parallel, smallvcm.cxx:61-108) on one GPU, %d in flight"
                                   % (replicas, inflight_used),
                    "host": host,
-                   "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "walk")},
+                   "merge_kernel": os.environ.get("SMALLVCM_AMD_MERGE", "pairs")},
         "roofline": roof,
         "counters": {k: int(st[k]) for k in ("lightVertices", "gridVertices", "mergeQueries", "mergeCandidates",
                                              "mergeAccepted", "connections", "lightSplats", "lightRays", "cameraRays",
@@ -936,6 +1058,11 @@ def main():
             except Exception as e:
                 cfgs.append({"name": name, "error": repr(e)})
         out["configs"] = cfgs
+    if headline and not args.no_dropin and not args.child:
+        try:
+            out["dropin"] = dropin_leg(res, args.steps, args.warmup)
+        except Exception as e:
+            out["dropin"] = {"error": repr(e)}
     if args.cpu_baseline != "none":
         base = None
         try:
@@ -949,6 +1076,20 @@ def main():
                 base = cpu_reference(args.scene, args.algo, res, args.warmup, args.steps, threads)
                 base["host_cores"] = cores
                 base["port"] = port
+                ram_total, ram_avail = host_memory_GB()
+                need = round(REF_GB_PER_RENDERER_2048 * cores * (res / 2048.0) ** 2, 1)
+                base["host_ram_GB"] = ram_total
+                base["all_cores_at_this_res"] = {"needed_GB": need, "present_GB": ram_total, "available_GB": ram_avail,
+                                                 "fits": bool(ram_avail is not None and need < 0.8 * ram_avail)}
+                if threads < cores and args.cpu_all_cores_2048:
+                    if base["all_cores_at_this_res"]["fits"]:
+                        try:
+                            full = cpu_reference(args.scene, args.algo, res, args.warmup, args.steps, cores)
+                            base["all_cores_at_this_res"].update({"value": full["value"], "cores": cores, "wall_s": full["wall_s"], "sample": full["sample"]})
+                        except Exception as e:
+                            base["all_cores_at_this_res"]["error"] = repr(e)
+                    else:
+                        base["all_cores_at_this_res"]["refused"] = "%s GB needed, %s GB available" % (need, ram_avail)
                 # BASELINE.md section 2 asks for all host cores.  At 2048^2 that is one 80-second iteration (1.2 GB of
                 # light vertices + grid) per core: recorded once (profiles/archive/r01_cpu_reference_timing*.json: 1.89 Mpaths/s on
                 # 32 threads, 1.79 on 128 -- the host's memory system saturates), not repeated in every run.  What IS

@@ -223,12 +223,12 @@ int vcm_set_strict_order(vcm_ctx *ctx, int on);
  * host asks this to know whether vcm_trace_camera may run before vcm_build_grid. */
 int vcm_is_wavefront(vcm_ctx *ctx, unsigned maxPathLength);
 
-/* Which kernel evaluates the range merges (HashGrid::Process, hashgrid.hxx:110-169) in wavefront mode: all four
- * produce the same bits, they differ in how a wave walks the cell lists (vcm_kernels.h; measured in DESIGN.md 5).
- * The environment variable SMALLVCM_AMD_MERGE=lane|staged|walk|pairs sets the default. */
-#define VCM_MERGE_LANE   0   /* the 8 cells in lockstep, per-lane global loads */
-#define VCM_MERGE_STAGED 1   /* a workgroup stages the cell lists of its queries through LDS */
-#define VCM_MERGE_WALK   2   /* every lane walks its own non-empty runs back to back */
+/* Which kernel evaluates the range merges (HashGrid::Process, hashgrid.hxx:110-169) in wavefront mode: both produce the
+ * same bits, they differ in who evaluates an accepted photon (vcm_kernels.h; measured in DESIGN.md 5).
+ * The environment variable SMALLVCM_AMD_MERGE=walk|pairs sets the default (pairs). */
+#define VCM_MERGE_LANE   0   /* retired in round 6 (the 8 cells in lockstep): vcm_set_merge_kernel refuses it */
+#define VCM_MERGE_STAGED 1   /* retired in round 6 (cell lists staged through LDS by a workgroup): refused */
+#define VCM_MERGE_WALK   2   /* every lane walks its own non-empty runs back to back and evaluates its own accepted photons */
 #define VCM_MERGE_PAIRS  3   /* the scan per lane as in WALK; the accepted (query, photon) pairs of a wave evaluated 64 at a time
                                 by whichever lane gets them (scenes with more than 32 materials: WALK) */
 int vcm_set_merge_kernel(vcm_ctx *ctx, int kind);

@@ -41,7 +41,7 @@ typedef struct vcm_farm_result {
     int    renderers;                /* (ranks / shards) * inflight */
     int    rcclRanks;                /* ranks that took part in RCCL collectives (0 with the stand-in) */
     float  rankIterationMs[VCM_FARM_MAX_RANKS]; /* per world rank: mean device time of one iteration of its first renderer */
-    vcm_stats meanStats;             /* world rank 0, first renderer: mean over its timed iterations */
+    vcm_stats meanStats;             /* first renderer, mean over its timed iterations: times = world rank 0's; work counters = the sum over its shards in this process */
 } vcm_farm_result;
 
 /* Runs the farm; blocks until every local rank is done.  imageOut (W*H*3 floats, may be NULL) receives the averaged

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-rXX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-CMD="python bench.py --no-cpu-baseline --no-configs --no-traffic --no-cross-check ${BENCH_ARGS:-}"
+CMD="python bench.py --no-cpu-baseline --no-configs --no-traffic --no-cross-check --no-dropin ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- $CMD > gpurun_out/${TAG}_profiled_run.log 2>&1
 # counters in their own runs, never combined with trace domains other than --kernel-trace
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_fetch -- $CMD > /dev/null 2>&1

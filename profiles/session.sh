@@ -13,6 +13,7 @@
 #   bench_record      ... --cpu-baseline none --record-counters <tag>  (keeps profiles/<tag>_counters_<config>.json)
 #   collect           profiles/collect.sh <tag> on the headline (kernel stats, FETCH / WRITE, SQ passes)
 #   collect:<cfg>     ... on C1 | C2 | C3
+#   kstats[:res[:algo[:scene]]]   profiles/kstats.sh: average us per launch of the big kernels under --kernel-trace (VARIANTS, ENVS as for ab)
 #   mem[:<args>]      profiles/collect_mem.sh: TA / TD / TCP / TCC counter passes (default C4; args = vcm_render arguments)
 #   timeline<res>     profiles/tools/timeline.py of scene 1 vcm at <res>^2 (timeline1024s3: scene 3)
 #   ab<res>[:algo[:scene]]   profiles/quick_ab.sh (variants from $VARIANTS, switches from $ENVS, $REPS repetitions, $ITER iterations)
@@ -38,6 +39,8 @@ for step in "$@"; do
     collect:C1)    BENCH_ARGS="--steps 20 --warmup 5 --scene 1 --algo vcm --res 512" timeout 600 bash profiles/collect.sh ${TAG}_C1 > ${O}_collect_C1.log 2>&1; tail -2 ${O}_collect_C1.log ;;
     collect:C2)    BENCH_ARGS="--steps 20 --warmup 5 --scene 3 --algo vcm --res 1024" timeout 600 bash profiles/collect.sh ${TAG}_C2 > ${O}_collect_C2.log 2>&1; tail -2 ${O}_collect_C2.log ;;
     collect:C3)    BENCH_ARGS="--steps 20 --warmup 5 --scene 1 --algo bpm --res 2048" timeout 600 bash profiles/collect.sh ${TAG}_C3 > ${O}_collect_C3.log 2>&1; tail -2 ${O}_collect_C3.log ;;
+    kstats*)       spec=${step#kstats}; spec=${spec#:}; IFS=: read -r r a sc <<< "$spec"
+                   RES=${r:-2048} ALGO=${a:-vcm} SCENE=${sc:-1} timeout 900 bash profiles/kstats.sh > ${O}_kstats_${r:-2048}_${a:-vcm}.txt 2>&1; cat ${O}_kstats_${r:-2048}_${a:-vcm}.txt ;;
     mem)           timeout 1500 bash profiles/collect_mem.sh ${TAG} > ${O}_mem.log 2>&1; tail -150 ${O}_mem.log ;;
     mem:*)         timeout 1500 bash profiles/collect_mem.sh ${TAG} ${step#mem:} > ${O}_mem.log 2>&1; tail -150 ${O}_mem.log ;;
     timeline1024s3) timeout 300 python profiles/tools/timeline.py ${TAG} --res 1024 --scene 3 > /dev/null 2>&1; head -60 ${O}_timeline1024.txt ;;

@@ -28,7 +28,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 MAIN = ["k_light_trace", "k_scan_tile_sums", "k_scan_apply", "k_compact_records", "k_bbox_finalize", "k_bbox", "k_grid_init", "k_cell_count",
         "k_cell_scatter", "k_cell_rank_pack", "k_cell_rank_gather", "k_camera_trace", "k_connect_di", "k_query_scatter", "k_query_count",
-        "k_merge_walk", "k_resolve", "k_zero_ranges", "k_set_counts", "k_stamp_many", "k_set_bbox"]
+        "k_merge_walk", "k_merge_pairs", "k_resolve", "k_zero_ranges", "k_set_counts", "k_stamp_many", "k_set_bbox"]
 BESIDE = ["k_connect_camera", "k_splat_scatter", "k_splat_apply", "k_splat_apply_long", "k_connect_vc", "k_note_grid_vertices"]
 GRID_MERGE = ["k_grid_merge_blocks"]
 OVERLAP_WINDOW = ["k_camera_trace", "k_connect_di"]   # what the exchange hides behind

@@ -67,7 +67,7 @@ struct Scratch {
     int *dCellId;                     /* per record */
     I4 *dUnsorted;                    /* per record: {index, slot, cell} list entries, grouped by cell; the radix sort's two {vertex, slot} lists */
     int *dRadixHist;                  /* 2 x 256 x VCM_RSORT_MAX_BLOCKS: digit histogram per workgroup, raw and scanned */
-    float *dGx, *dGy, *dGz; F4 *dG1, *dG2; F2 *dG3;
+    float *dGx, *dGy, *dGz, *dGb; F4 *dG1, *dG2; F2 *dG3;
     int *dSortedIndex;                /* parity: grid position -> record index */
     F4 *dCamOut;                      /* nLocal */
     uint32_t *dCamMask;               /* nLocal: path lengths at which a vertex record was appended */
@@ -129,7 +129,7 @@ static unsigned long long this_thread_id() { if (!g_threadId) g_threadId = ++g_t
                                           else hipLaunchKernelGGL((K<M, SceneList>), __VA_ARGS__); } while (0)
 
 #ifndef VCM_MERGE_DEFAULT
-#define VCM_MERGE_DEFAULT VCM_MERGE_WALK
+#define VCM_MERGE_DEFAULT VCM_MERGE_PAIRS
 #endif
 struct vcm_ctx : Scratch {
     SceneHost *scene;                 /* host copy of the scene + the structure the intersection code walks */
@@ -244,7 +244,7 @@ static void arena_free_buffers(Arena *a)
     DFREE(s.dPixCount); DFREE(s.dPixStart); DFREE(s.dSplatArrival); DFREE(s.dSplatList);
     DFREE(s.dRecordsLocal); DFREE(s.dRecordsAll); DFREE(s.dSlotOfVertex); DFREE(s.dSplat);
     DFREE(s.dCellCount); DFREE(s.dCellStart); DFREE(s.dCellId); DFREE(s.dUnsorted); DFREE(s.dRadixHist);
-    DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
+    DFREE(s.dGx); DFREE(s.dGy); DFREE(s.dGz); DFREE(s.dGb); DFREE(s.dG1); DFREE(s.dG2); DFREE(s.dG3); DFREE(s.dSortedIndex);
     DFREE(s.dCamOut); DFREE(s.dCamMask);
     DFREE(s.vs.q); DFREE(s.vs.q4); DFREE(s.vs.meta); DFREE(s.vs.count);
     DFREE(s.vs.diTask); DFREE(s.vs.vcTask); DFREE(s.vs.diOut); DFREE(s.vs.vcOut); DFREE(s.vs.mergeOut);
@@ -283,7 +283,7 @@ static int arena_ensure(Arena *a, size_t nLocal, size_t N, int S, int L, bool sh
     if (dalloc(&s.dCellCount, cn + 2) || dalloc(&s.dCellStart, cn + 2)) return -1;
     if (dalloc(&s.dCellId, allRecs) || dalloc(&s.dUnsorted, allRecs) || dalloc(&s.dRadixHist, (size_t)2 * 256 * VCM_RSORT_MAX_BLOCKS)) return -1;
     if (dalloc(&s.dGx, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dGy, allRecs + VCM_MERGE_UNROLL) ||
-        dalloc(&s.dGz, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
+        dalloc(&s.dGz, allRecs + VCM_MERGE_UNROLL) || dalloc(&s.dGb, 3 * (allRecs + 2 * VCM_MERGE_UNROLL)) || dalloc(&s.dG1, allRecs) || dalloc(&s.dG2, allRecs) ||
         dalloc(&s.dG3, allRecs) || dalloc(&s.dSortedIndex, allRecs)) return -1;
     if (dalloc(&s.dCamOut, cl) || dalloc(&s.dCamMask, cl) || dalloc(&s.vs.count, 32)) return -1;
     /* wavefront buffers, worst case: <= L vertices per path; a vertex at path length l connects to
@@ -788,7 +788,7 @@ static vcm_ctx *create_from_host(SceneHost *h, int algorithm, float radiusFactor
     { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE");   /* 0: the host will use the unsorted exchange of rounds 1-4 */
       c->sortedExchange = worldSize > 1 && worldSize <= VCM_SORTED_MAX_SHARDS && c->useVM && !(e && e[0] == '0'); }
     { const char *e = getenv("SMALLVCM_AMD_MERGE");
-      c->mergeKind = (e && !strcmp(e, "staged")) ? VCM_MERGE_STAGED : (e && !strcmp(e, "walk")) ? VCM_MERGE_WALK : (e && !strcmp(e, "lane")) ? VCM_MERGE_LANE : (e && !strcmp(e, "pairs")) ? VCM_MERGE_PAIRS : VCM_MERGE_DEFAULT; }
+      c->mergeKind = (e && !strcmp(e, "walk")) ? VCM_MERGE_WALK : (e && !strcmp(e, "pairs")) ? VCM_MERGE_PAIRS : VCM_MERGE_DEFAULT; }
     return c;
 }
 
@@ -921,7 +921,8 @@ int vcm_set_merge_kernel(vcm_ctx *c, int kind)
 {
     if (!c) return fail("vcm_set_merge_kernel", "ctx is NULL");
     if (c->inIteration) return fail("vcm_set_merge_kernel", "iteration in progress");
-    if (kind != VCM_MERGE_LANE && kind != VCM_MERGE_STAGED && kind != VCM_MERGE_WALK && kind != VCM_MERGE_PAIRS) return fail("vcm_set_merge_kernel", "unknown kernel");
+    if (kind == VCM_MERGE_LANE || kind == VCM_MERGE_STAGED) return fail("vcm_set_merge_kernel", "k_merge_lane / k_merge_staged were retired in round 6: VCM_MERGE_WALK or VCM_MERGE_PAIRS");
+    if (kind != VCM_MERGE_WALK && kind != VCM_MERGE_PAIRS) return fail("vcm_set_merge_kernel", "unknown kernel");
     c->mergeKind = kind;
     return 0;
 }
@@ -1529,7 +1530,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
             if (!c->bboxPreset) return fail("vcm_build_grid", "sorted records without the box they were sorted with");
             const int blocks = c->sortedIn.nBlocks < 8192 ? c->sortedIn.nBlocks : 8192;
             hipLaunchKernelGGL(k_grid_merge_blocks, dim3(blocks), dim3(256), 0, q, c->P, (const GridHeader *)c->dHdr, c->sortedIn, c->dCellStart,
-                               c->dGx, c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex, take_stamps(c, q));
+                               c->dGx, c->dGy, c->dGz, c->dGb, c->dG1, c->dG2, c->dG3, c->dSortedIndex, take_stamps(c, q));
             HIPCHK(hipGetLastError());
             if (mark_on(c, EV_GRID, q)) return -1;
             hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT, take_stamps(c, q));
@@ -1574,7 +1575,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         }
         hipLaunchKernelGGL(k_cell_rank_gather, g, b, 0, q, (const DScene *)c->dScene, (const GridHeader *)c->dHdr, recs,
                            (const int *)c->dCellStart, (const I4 *)c->dUnsorted, sorted, c->dGx,
-                           c->dGy, c->dGz, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
+                           c->dGy, c->dGz, c->dGb, c->dG1, c->dG2, c->dG3, c->dSortedIndex);
         if (mark_on(c, EV_GRID, q)) return -1;
         hipLaunchKernelGGL(k_note_grid_vertices, dim3(1), dim3(1), 0, q, (const GridHeader *)c->dHdr, c->dStats + STAT_COUNT, take_stamps(c, q));
         HIPCHK(hipGetLastError());
@@ -1594,7 +1595,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
 static GridStore grid_of(vcm_ctx *c)
 {
     GridStore grid;
-    grid.cellStart = c->dCellStart; grid.gx = c->dGx; grid.gy = c->dGy; grid.gz = c->dGz; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
+    grid.cellStart = c->dCellStart; grid.gx = c->dGx; grid.gy = c->dGy; grid.gz = c->dGz; grid.gb = c->dGb; grid.g1 = c->dG1; grid.g2 = c->dG2; grid.g3 = c->dG3;
     grid.hdr = c->dHdr;
     return grid;
 }
@@ -1777,12 +1778,9 @@ static int vcm_merge_impl(vcm_ctx *c)
             }
             static int mergeChunk = 0;
             if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
-            /* Three kernels, same bits (vcm_set_merge_kernel).  k_merge_walk (default): every lane walks its own
-               non-empty runs back to back -- 3.51 ms against 3.93 for k_merge_lane, which visits the 8 cells in
-               lockstep (profiles/archive/r02j_ab_summary.txt).  k_merge_staged: the workgroup stages the cell lists of its
-               queries through LDS -- 27 % less HBM traffic than k_merge_lane (13.7 -> 9.9 GB per launch,
-               profiles/archive/r02c_ab_summary.txt) but slower: the kernel is not bound by the candidate loads, and the
-               staging adds instructions and barriers. */
+            /* Two kernels, same bits (vcm_set_merge_kernel).  k_merge_pairs (default since round 6): every lane walks its own non-empty
+               runs back to back, the accepted (query, photon) pairs of a wave are evaluated 64 at a time -- 2.73 ms against 3.23 for
+               k_merge_walk, whose lanes evaluate their own queues at 38 % occupancy (profiles/r13m_kstats_2048_vcm.txt). */
             int mergeStaged = c->mergeKind;
             /* k_merge_pairs keeps a material table of VCM_PAIR_MATERIALS rows in LDS */
             if (mergeStaged == VCM_MERGE_PAIRS && (int)c->scene->materials.size() > VCM_PAIR_MATERIALS) mergeStaged = VCM_MERGE_WALK;
@@ -1794,7 +1792,7 @@ static int vcm_merge_impl(vcm_ctx *c)
                     hipLaunchKernelGGL(k_merge_pairs<false>, dim3(merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
                                        c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
             }
-            else if (mergeStaged == 2) {
+            else {
                 /* SMALLVCM_AMD_MERGE_DEAL=slab: one contiguous eighth of the sorted queries per XCD, drawn batch by batch
                    from eight counters (vs.count[24..31], zeroed with the queue counts), with stealing; as many workgroups
                    as are resident (4 per CU).  Measured against the static dealing (default) on the Cornell scenes: K4's
@@ -1816,23 +1814,6 @@ static int vcm_merge_impl(vcm_ctx *c)
                                        c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
                                        slab ? c->vs.count + 24 : (int *)NULL);
             }
-            else if (mergeStaged) {
-                int ch = mergeChunk * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK;
-                if (ch < 1) ch = 1;
-                if (c->intPhong)
-                    hipLaunchKernelGGL(k_merge_staged<true>, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
-                                       ks, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
-                                       (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
-                else
-                    hipLaunchKernelGGL(k_merge_staged<false>, dim3(256 * 8 * VCM_MERGE_BLOCK / VCM_STAGE_BLOCK), dim3(VCM_STAGE_BLOCK), 0,
-                                       ks, c->dScene, c->P, grid_of(c), c->vs, (const int *)c->dSortedVertex,
-                                       (const int *)(c->dQueryStart + nb), c->dStats, ch, take_stamps(c, c->stream));
-            } else if (c->intPhong)
-                hipLaunchKernelGGL(k_merge_lane<true>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
-                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
-            else
-                hipLaunchKernelGGL(k_merge_lane<false>, dim3(256 * 8), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
-                                   c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
         } else {
             if (mark(c, EV_SORT_K1)) return -1;
         }

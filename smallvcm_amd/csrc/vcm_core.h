@@ -86,6 +86,9 @@ struct GridStore {
     const float *gx, *gy, *gz;   /* position, one array per axis (padded by VCM_MERGE_UNROLL): the distance
                                     test reads nothing else, and consecutive candidates of a cell arrive as the
                                     two halves of a packed fp32 operand */
+    const float *gb;        /* the positions once more, BLOCKED: photons 4b .. 4b+3 as x0..x3 y0..y3 z0..z3 (48 bytes, 16-byte aligned):
+                               the three loads of a step of k_merge_pairs fall into ONE line (or two) instead of three arrays'
+                               (grid_blocked_index) */
     const F4 *g1;           /* WorldDirFix.xyz | light ContinuationProb */
     const F4 *g2;           /* throughput.xyz | dVCM */
     const F2 *g3;           /* dVM | pathLength bits */
@@ -93,6 +96,8 @@ struct GridStore {
        measured in round 4: K4 itself 3.0 -> 2.7 ms, the grid build's strided writes slower by as much: profiles/r06i_ab.txt) */
     const GridHeader *hdr;
 };
+
+VCM_HD size_t grid_blocked_index(int i, int axis) { return (size_t)(i >> 2) * 12u + (size_t)(axis * 4 + (i & 3)); }
 
 /* Camera vertices of one iteration (wavefront mode).  Direct illumination,
  * vertex connection and merging only ADD to the pixel colour, they never steer

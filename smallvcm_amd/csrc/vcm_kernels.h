@@ -14,7 +14,7 @@
 //   K3b k_connect_di      direct illumination tasks (dense, one lane each)
 //   K3c k_connect_vc      vertex connection tasks (dense, one lane each)
 //   K4a k_query_count/scatter  counting sort of the camera vertices by the cell they lie in
-//   K4  k_merge_lane      range-merge, one lane per camera vertex
+//   K4  k_merge_pairs / k_merge_walk   range-merge: one lane per camera vertex scans, the accepted pairs evaluated 64 at a time
 //   K5  k_resolve         replays every path's additions in the reference's order,
 //                         Framebuffer::AddColor
 //   PathTracer / EyeLight: k_path_trace, k_eye_light (+ K5)
@@ -422,42 +422,8 @@ __global__ void __launch_bounds__(256) k_query_scatter(VertexStore vs, const int
  * (A wave-per-query mapping was measured too: 17 ms vs 6 ms for this one at
  * 2048^2 -- one query per wave exposes its 4 dependent memory round trips.) */
 #define VCM_MERGE_BLOCK 256
-/* 104 VGPRs = 4 waves/SIMD.  Forcing 5 / 6 / 8 waves (amdgpu_waves_per_eu) was measured: 5.66 / 6.9 / 10.8 ms
- * against 5.4 ms on the same box -- the spills cost more than the occupancy buys. */
-template <bool IP>
-__global__ void __launch_bounds__(VCM_MERGE_BLOCK)
-k_merge_lane(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
-             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
-{
-    stamp_entry(st);
-    const DScene &sc = *scp;
-    const int nQ = *nSorted;
-    __shared__ uint32_t accQ[(VCM_MERGE_Q + 1) * VCM_MERGE_BLOCK];
-    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK; ms.cap = VCM_MERGE_Q;
-    LaneStats ls; lane_stats_zero(ls);
-    /* XCD-aware dealing of the sorted queries.  A batch = 256 consecutive queries of the Morton order, a chunk =
-       `chunk` consecutive batches = one compact region of the scene.  Workgroup i runs on XCD i mod 8 (round-robin
-       dispatch), and each XCD has its own L2: chunk c goes to XCD c mod 8 and is shared out among that XCD's
-       workgroups, so the photons of a region are fetched into ONE L2 and reused by the neighbouring queries, while
-       dense regions (many photons per cell), which span many chunks, are still spread over all XCDs.  (Measured
-       alternatives: batches round-robin over all workgroups -- every L2 streams the whole photon set; one
-       contiguous range per XCD -- a long tail from the XCDs that own the dense regions, 6.8 ms.) */
-    const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
-    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
-    for (int t = wgOfXcd;; t += wgPerXcd) {
-        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
-        if ((t / chunk) * 8 * chunk >= nBatches) break;   /* every chunk row of this XCD is past the end */
-        if (b >= nBatches) continue;
-        const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
-        if (q < nQ) {
-            const int vi = sortedVertex[q];
-            size_t ps;
-            const V3 v = eval_merge_task<IP>(sc, P, vs, g, vi, ls, ms, ps, false);   /* this kernel stages no material table */
-            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
-        }
-    }
-    flush_stats(ls, gstats);
-}
+/* (k_merge_lane, the lockstep kernel of round 1 -- merge_query of vcm_core.h as a task kernel, 3.93 ms at 2048^2 -- was retired in
+   round 6; merge_query itself stays: the fused in-path variant k_camera_trace<0> and the host emulation run it) */
 
 /* ---------------- K4 (walk): every lane walks ITS candidate runs without waiting for the others ---------------- */
 /* merge_query (k_merge_lane) visits the 8 cells in lockstep: in step j every lane scans its j-th cell and the wave
@@ -689,9 +655,13 @@ struct PairLds {
     float acc[3 * VCM_MERGE_BLOCK];
     PairEntry ring[(VCM_MERGE_BLOCK / 64) * VCM_PAIR_RING];
     vcm_f4 mat[VCM_PAIR_MATERIALS * 2];           /* {diffuse / pi, phongExp}, {rho, -} */
+#if defined(VCM_PAIRS_PAD_LDS)
+    char pad[VCM_PAIRS_PAD_LDS];                  /* measurement build: fewer workgroups per CU */
+#else
+#define VCM_PAIRS_PAD_LDS 0
+#endif
 };
-static_assert(sizeof(PairLds) <= 40960, "four workgroups per CU");
-struct PairRun { int lo, hi; bool sat; };
+static_assert(sizeof(PairLds) <= 40960 + VCM_PAIRS_PAD_LDS, "four workgroups per CU");
 struct PairBatch { uint32_t meta; MergePhoton ph; bool valid; };
 
 /* the end of probe j's cell, for a run whose 16-bit length saturated (a cell with 65535 photons or more: a caustic, a point
@@ -749,9 +719,12 @@ __device__ __forceinline__ int merge_pairs_runs(const IterParams &P, const GridS
     }
     return n;
 }
-__device__ __forceinline__ PairRun merge_pairs_read_run(const PairLds &L, int tid, int k, int n)
+/* where a step of a lane's walk stands: candidates [lo, min((lo & ~3) + 4, hi)) of its run k -- the rest of lo's block of four
+   (GridStore::gb) -- (lo = hi = 0: the lane is done) */
+struct PairPos { int lo, hi, k; bool sat; };
+__device__ __forceinline__ PairPos merge_pairs_run_pos(const PairLds &L, int tid, int k, int n)
 {
-    PairRun r; r.lo = 0; r.hi = 0; r.sat = false;
+    PairPos r; r.lo = 0; r.hi = 0; r.k = k; r.sat = false;
     if (k < n) {
         const int len = L.runLen[k * VCM_MERGE_BLOCK + tid];
         r.lo = L.runLo[k * VCM_MERGE_BLOCK + tid];
@@ -759,6 +732,19 @@ __device__ __forceinline__ PairRun merge_pairs_read_run(const PairLds &L, int ti
         r.sat = len == 65535;
     }
     return r;
+}
+__device__ __forceinline__ PairPos merge_pairs_first(const PairLds &L, int tid, int n) { return merge_pairs_run_pos(L, tid, 0, n); }
+/* the step after p: the next four candidates of its run, or the first of the lane's next run */
+__device__ __forceinline__ PairPos merge_pairs_next(const IterParams &P, const GridStore &g, const PairLds &L, int tid, int n, V3 queryPos,
+                                                     uint32_t probes, PairPos p)
+{
+    if ((p.lo & ~3) + VCM_MERGE_UNROLL < p.hi) { p.lo = (p.lo & ~3) + VCM_MERGE_UNROLL; return p; }   /* the steps after a run's first are aligned blocks */
+    if (p.sat) {   /* cold: 65535 candidates of this cell done, it has more (hi is where the next piece starts) */
+        const int end = merge_pairs_run_end(P, g, queryPos, (int)((probes >> (3 * p.k)) & 7u));
+        const int rest = end - p.hi;
+        if (rest > 0) { p.lo = p.hi; p.hi = p.lo + (rest < 65535 ? rest : 65535); p.sat = rest >= 65535; return p; }
+    }
+    return merge_pairs_run_pos(L, tid, p.lo < p.hi ? p.k + 1 : p.k, n);
 }
 
 /* a batch leaves the ring: its (at most 64) entries, the gathers of their photons */
@@ -839,6 +825,49 @@ __device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L
         if (!wave_any(live && occ > r)) break;
     }
 }
+/* the four candidates of a step: the accepted ones to the ring, one candidate column at a time as a REAL loop (the drain
+   exists once per call site; unrolled, four copies of it cost a register shuffle of the batch in flight at every step) */
+template <bool IP>
+__device__ __forceinline__ void merge_pairs_push(const IterParams &P, const GridStore &g, PairLds &L, PairEntry *ring, int lane, int waveBase,
+                                                 int lo, int hi, float d0, float d1, float d2, float d3,
+                                                 int &head, int &cnt, uint32_t &occ, bool &inflight, PairBatch &pb, uint32_t &waveAccepted)
+{
+    int idx = lo & ~3;   /* the step's block of four; its candidates are those of [lo, hi) */
+    const uint32_t len = (uint32_t)(hi - lo);
+#pragma unroll 1
+    for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
+        const bool acc = ((uint32_t)(idx - lo) < len) & (d0 <= P.radiusSqr);   /* :165 */
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(acc);
+        if (m) {   /* scalar branch */
+            const int rel = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (acc) {
+                PairEntry e; e.idx = (uint32_t)idx; e.meta = (uint32_t)lane | (occ << 8);
+                ring[(head + rel) & (VCM_PAIR_RING - 1)] = e;
+                occ++;
+            }
+            const int add = __popcll(m);
+            cnt += add;
+            waveAccepted += (uint32_t)add;
+            if (cnt >= 64) {
+#if !defined(VCM_PAIRS_ABLATE)
+                if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
+#endif
+                const int headWas = head;
+#if defined(VCM_PAIRS_ABLATE) && VCM_PAIRS_ABLATE >= 2
+                head = (head + 64) & (VCM_PAIR_RING - 1); cnt -= 64;   /* measurement build: pairs dropped */
+#else
+                merge_pairs_issue(g, ring, lane, head, cnt, pb);
+#endif
+                inflight = true;
+                /* the entries of this column that did not fit open the next batch */
+                const bool left = acc && rel >= 64;
+                if (left) ring[(headWas + rel) & (VCM_PAIR_RING - 1)].meta = (uint32_t)lane;
+                occ = left ? 1u : 0u;
+            }
+        }
+        d0 = d1; d1 = d2; d2 = d3; idx++;
+    }
+}
 #endif
 
 template <bool IP>
@@ -848,7 +877,6 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
 {
     stamp_entry(st);
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const DScene &sc = *scp;
     const int nQ = *nSorted;
     __shared__ __attribute__((aligned(16))) PairLds L;
@@ -901,78 +929,69 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
             ls.mergeCandidates += (uint32_t)total;
         }
         L.acc[tid] = 0.f; L.acc[VCM_MERGE_BLOCK + tid] = 0.f; L.acc[2 * VCM_MERGE_BLOCK + tid] = 0.f;
-        /* ---- scan (merge_query_walk's) with the accepted pairs to the wave's ring */
+        /* ---- scan (merge_query_walk's) with the accepted pairs to the wave's ring.  The candidates of a step are loaded TWO
+           steps ahead (k_merge_walk: one): the kernel waits for memory, not for issue slots -- three workgroups per CU instead
+           of four cost it 16 % (profiles/r13i) -- and the two register sets that hold a step's candidates serve: a set is
+           free the moment its distances are formed, and takes the candidates of the step after next. */
         const f2 qx = f2_sp(qp.x), qy = f2_sp(qp.y), qz = f2_sp(qp.z);
-        int k = 0, head = 0, cnt = 0;
+        int head = 0, cnt = 0;
         uint32_t occ = 0u;   /* this lane's pairs in the batch that is filling */
         bool inflight = false;
         PairBatch pb;
         pb.valid = false; pb.meta = 0u;
-        PairRun cur = merge_pairs_read_run(L, tid, 0, n), nxt = merge_pairs_read_run(L, tid, 1, n);
-        f4u X = *(const f4u *)(g.gx + cur.lo), Y = *(const f4u *)(g.gy + cur.lo), Z = *(const f4u *)(g.gz + cur.lo);
-        while (wave_any(cur.lo < cur.hi)) {
-            const int stepEnd = cur.lo + VCM_MERGE_UNROLL;
-            const bool last = stepEnd >= cur.hi;
-            int aNext = last ? nxt.lo : stepEnd;
-            if (last && cur.sat) aNext = cur.hi;   /* a saturated run goes on where this piece ends */
-            const f4u Xn = *(const f4u *)(g.gx + aNext), Yn = *(const f4u *)(g.gy + aNext), Zn = *(const f4u *)(g.gz + aNext);
-            float distSqr[VCM_MERGE_UNROLL];
-            {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */
-                const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
-                const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
-                const f2 da = dxa * dxa + dya * dya + dza * dza;
-                const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
-                distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
-            }
-            X = Xn; Y = Yn; Z = Zn;
-#pragma unroll
-            for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
-                const int idx = cur.lo + u;
-                const bool acc = (idx < cur.hi) & (distSqr[u] <= P.radiusSqr);   /* :165 */
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(acc);
-                if (m) {   /* scalar branch */
-                    const int rel = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (acc) {
-                        PairEntry e; e.idx = (uint32_t)idx; e.meta = (uint32_t)lane | (occ << 8);
-                        ring[(head + rel) & (VCM_PAIR_RING - 1)] = e;
-                        occ++;
-                    }
-                    const int add = __popcll(m);
-                    cnt += add;
-                    waveAccepted += (uint32_t)add;
-                    if (cnt >= 64) {
-                        if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
-                        const int headWas = head;
-                        merge_pairs_issue(g, ring, lane, head, cnt, pb);
-                        inflight = true;
-                        /* the entries of this column that did not fit open the next batch */
-                        const bool left = acc && rel >= 64;
-                        if (left) ring[(headWas + rel) & (VCM_PAIR_RING - 1)].meta = (uint32_t)lane;
-                        occ = left ? 1u : 0u;
-                    }
-                }
-            }
-            if (last) {
-                if (cur.sat) {   /* cold: 65535 candidates done, the cell has more */
-                    const int end = merge_pairs_run_end(P, g, qp, (int)((probes >> (3 * k)) & 7u));
-                    const int rest = end - cur.hi;
-                    cur.lo = cur.hi;
-                    cur.hi = cur.lo + (rest < 65535 ? rest : 65535);
-                    cur.sat = rest >= 65535;
-                    if (rest == 0) { cur = nxt; k++; nxt = merge_pairs_read_run(L, tid, k + 1, n); }
-                    X = *(const f4u *)(g.gx + cur.lo); Y = *(const f4u *)(g.gy + cur.lo); Z = *(const f4u *)(g.gz + cur.lo);
-                } else {
-                    cur = nxt;
-                    k++;
-                    nxt = merge_pairs_read_run(L, tid, k + 1, n);
-                }
-            } else cur.lo = stepEnd;
+        PairPos it0 = merge_pairs_first(L, tid, n), it1 = merge_pairs_next(P, g, L, tid, n, qp, probes, it0), it2 = merge_pairs_next(P, g, L, tid, n, qp, probes, it1);
+#define VCM_PAIR_LOAD(SX, SY, SZ, at) { const vcm_f4 *blk = (const vcm_f4 *)(g.gb + (size_t)((at) >> 2) * 12u); SX = blk[0]; SY = blk[1]; SZ = blk[2]; }
+        vcm_f4 AX, AY, AZ, BX, BY, BZ;
+        VCM_PAIR_LOAD(AX, AY, AZ, it0.lo)
+        VCM_PAIR_LOAD(BX, BY, BZ, it1.lo)
+#if defined(VCM_PAIRS_DEPTH3)
+        vcm_f4 CX, CY, CZ;
+        VCM_PAIR_LOAD(CX, CY, CZ, it2.lo)
+        PairPos it3 = merge_pairs_next(P, g, L, tid, n, qp, probes, it2);
+#define VCM_PAIR_AHEAD it3
+#define VCM_PAIR_SHIFT it0 = it1; it1 = it2; it2 = it3; it3 = merge_pairs_next(P, g, L, tid, n, qp, probes, it3);
+#else
+#define VCM_PAIR_AHEAD it2
+#define VCM_PAIR_SHIFT it0 = it1; it1 = it2; it2 = merge_pairs_next(P, g, L, tid, n, qp, probes, it2);
+#endif
+#define VCM_PAIR_STEP(SX, SY, SZ)                                                                                              \
+        {                                                                                                                      \
+            float d0, d1, d2, d3;                                                                                              \
+            {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */          \
+                const f2 dxa = qx - SX.xy, dya = qy - SY.xy, dza = qz - SZ.xy;                                                 \
+                const f2 dxb = qx - SX.zw, dyb = qy - SY.zw, dzb = qz - SZ.zw;                                                 \
+                const f2 da = dxa * dxa + dya * dya + dza * dza;                                                               \
+                const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;                                                               \
+                d0 = da.x; d1 = da.y; d2 = db.x; d3 = db.y;                                                                    \
+            }                                                                                                                  \
+            VCM_PAIR_LOAD(SX, SY, SZ, VCM_PAIR_AHEAD.lo)                                                                       \
+            merge_pairs_push<IP>(P, g, L, ring, lane, waveBase, it0.lo, it0.hi, d0, d1, d2, d3, head, cnt, occ, inflight, pb, waveAccepted); \
+            VCM_PAIR_SHIFT                                                                                                     \
         }
+        for (;;) {
+            if (!wave_any(it0.lo < it0.hi)) break;
+            VCM_PAIR_STEP(AX, AY, AZ)
+            if (!wave_any(it0.lo < it0.hi)) break;
+            VCM_PAIR_STEP(BX, BY, BZ)
+#if defined(VCM_PAIRS_DEPTH3)
+            if (!wave_any(it0.lo < it0.hi)) break;
+            VCM_PAIR_STEP(CX, CY, CZ)
+#endif
+        }
+#undef VCM_PAIR_STEP
+#undef VCM_PAIR_LOAD
+#undef VCM_PAIR_AHEAD
+#undef VCM_PAIR_SHIFT
+#if defined(VCM_PAIRS_ABLATE)
+        if (inflight) L.acc[tid] = pb.ph.b.x + pb.ph.c.x + pb.ph.dVM;   /* measurement build: the gathers stay live */
+        cnt = 0;
+#else
         if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
         while (cnt > 0) {
             merge_pairs_issue(g, ring, lane, head, cnt, pb);
             merge_pairs_eval<IP>(P, L, waveBase, pb);
         }
+#endif
         if (q < nQ) {
             const V3 contrib = mk3(L.acc[tid], L.acc[VCM_MERGE_BLOCK + tid], L.acc[2 * VCM_MERGE_BLOCK + tid]);
             const V3 v = thr * P.vmNormalization * contrib;
@@ -984,254 +1003,9 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
 #endif
 }
 
-/* ---------------- K4 (selectable): range-merge with the cell lists staged through LDS ---------------- */
-/* HashGrid::Process walks 8 hashed cells per query (hashgrid.hxx:142-167).  k_merge_lane reads the candidates of
- * those cells with per-lane global loads: three 16-byte loads per lane and step, each touching as many cache lines
- * as the wave has distinct cells (~13) -- the L1/TA path, not HBM and not the VALU, bounds its scan half (2.1 of
- * 4.1 ms at 2048^2; its measured HBM traffic is still 30x the photon set because every XCD streams the positions
- * again and again).  Here a WORKGROUP handles a batch of VCM_STAGE_BLOCK consecutive queries of the cell-sorted
- * order -- neighbours in space, so their 8-cell neighbourhoods overlap almost completely -- in four steps:
- *   A  every lane hashes its 8 cells, fetches their ranges (cellStart) and enters them into a small open-addressed
- *      table in LDS (key = hashed cell); the lane that creates an entry (the CAS winner) reserves the space for the
- *      cell's run in the staging area; duplicates -- the same cell wanted by hundreds of lanes -- cost one CAS;
- *   B  the distinct runs are copied global -> LDS cooperatively: contiguous, coalesced reads of gx / gy / gz,
- *      once per workgroup instead of once per query (16 lanes per run, 4 runs per wave at a time);
- *   C  every lane scans ITS 8 cells in the reference's order out of LDS (ds_read_b128: lanes of the same cell
- *      broadcast), tests 4 candidates per step with packed fp32, queues accepted photon indices per lane and
- *      drains the queue through the BSDF evaluation exactly as k_merge_lane does -- same operations, same order,
- *      same bits;
- *   D  barrier, table reset, next batch.
- * A run that does not fit (staging area or table full: caustic hot spots, or late iterations where the cells are
- * tiny and every query has its own neighbourhood) is simply read from global memory by the lanes that need it,
- * so the staging is a cache, never a limit.  Only positions are staged (12 of the 52 bytes): the distance test
- * is 1.27 G candidates per iteration, the 40 bytes of an ACCEPTED photon (0.2 G) stay per-lane gathers. */
-#ifndef VCM_STAGE_BLOCK
-#define VCM_STAGE_BLOCK 512
-#endif
-#define VCM_STAGE_Q 16   /* accepted-index queue per lane: the staging area needs the LDS a deeper queue would take */
-#define VCM_STAGE_HT (VCM_STAGE_BLOCK)                 /* table slots, power of two */
-#define VCM_STAGE_CAP (5 * VCM_STAGE_BLOCK)            /* staged photons per workgroup */
-#define VCM_STAGE_NOSLOT 1023u
-#if defined(__HIP_DEVICE_COMPILE__)
-struct StageLds {
-    float sx[VCM_STAGE_CAP], sy[VCM_STAGE_CAP], sz[VCM_STAGE_CAP];   /* 16-byte aligned runs (every run starts at a multiple of 4) */
-    int key[VCM_STAGE_HT];                   /* hashed cell, -1 = free */
-    int lo[VCM_STAGE_HT], len[VCM_STAGE_HT], off[VCM_STAGE_HT];   /* run in the grid arrays; where it is staged (-1: not) */
-    unsigned short list[VCM_STAGE_HT];       /* slots in use, dense: the copy phase walks this */
-    int count, used;
-};
-
-/* 16-byte aligned LDS read through an explicitly LOCAL pointer (ds_read_b128).  Written through the generic
- * reference alone, the compiler merges "staged ? LDS : global" into one flat_load of a selected generic pointer,
- * which sends every candidate read through the vector-memory path again -- the thing this kernel exists to avoid. */
-typedef float vcm_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ vcm_f4 lds_read4(const float *p)
-{
-    return *(const __attribute__((address_space(3))) vcm_f4 *)p;
-}
-
-/* step A for one cell: returns the table slot that holds `cell`, VCM_STAGE_NOSLOT if the table is full */
-__device__ __forceinline__ uint32_t stage_insert(StageLds &L, int cell, int lo, int hi)
-{
-    uint32_t slot = ((uint32_t)cell * 2654435761u) >> (32 - __builtin_ctz(VCM_STAGE_HT));
-#pragma unroll 1
-    for (int probe = 0; probe < 8; probe++) {
-        const int prev = atomicCAS(&L.key[slot], -1, cell);
-        if (prev == -1) {   /* this lane creates the entry */
-            const int len = hi - lo, padded = (len + 3) & ~3;
-            int off = -1;
-            if (len > 0) {
-                const int o = atomicAdd(&L.used, padded);
-                if (o + padded <= VCM_STAGE_CAP) off = o;
-            }
-            L.lo[slot] = lo; L.len[slot] = len; L.off[slot] = off;
-            L.list[atomicAdd(&L.count, 1)] = (unsigned short)slot;
-            return slot;
-        }
-        if (prev == cell) return slot;
-        slot = (slot + 1u) & (uint32_t)(VCM_STAGE_HT - 1);
-    }
-    return VCM_STAGE_NOSLOT;
-}
-
-/* HashGrid::Process + RangeQuery::Process for one camera vertex, candidates out of LDS where staged.
- * Mirrors merge_query (vcm_core.h) statement by statement; `slots` = the 8 table slots of step A, 10 bits each. */
-template <bool IP>
-__device__ __forceinline__ V3 merge_query_staged(const DScene &sc, const IterParams &P, const GridStore &g,
-                                                 const Bsdf &cameraBsdf, const SubPathState &st, V3 queryPos, bool inside,
-                                                 int px, int py, int pz, int pxo, int pyo, int pzo,
-                                                 uint32_t s0, uint32_t s1, uint32_t s2, const StageLds &L, LaneStats &ls,
-                                                 const MergeScratch &ms)
-{
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    V3 contrib = sp3(0.f);
-    MergeEval ev;
-    merge_eval_setup(ev, sc, P, cameraBsdf, st, false);
-    const f2 qx = f2_sp(queryPos.x), qy = f2_sp(queryPos.y), qz = f2_sp(queryPos.z);
-    int qn = 0;
-    for (int j = 0; j < 8; j++) {
-        int lo = 0, len = 0, off = -1;
-        if (inside) {
-            const uint32_t w = (j < 3) ? s0 : ((j < 6) ? s1 : s2);
-            const uint32_t slot = (w >> (10 * (j % 3))) & 1023u;
-            if (slot != VCM_STAGE_NOSLOT) {
-                lo = L.lo[slot]; len = L.len[slot]; off = L.off[slot];
-            } else {   /* table full: the lane fetches the range itself */
-                const int cell = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
-                lo = g.cellStart[cell];
-                len = g.cellStart[cell + 1] - lo;
-            }
-        }
-        ls.mergeCandidates += (uint32_t)len;   /* one distance test per entry (:162-165) */
-        const bool staged = off >= 0;
-        /* software-pipelined like merge_query: the candidates of step s+1 are in flight while step s is tested.
-           Staged runs are read 16-byte aligned (LDS offset and step are multiples of 4; the read past a run's end
-           stays inside its padding or falls back to its first quad); global runs as in merge_query. */
-        f4u X, Y, Z;
-        if (staged) { X = lds_read4(L.sx + off); Y = lds_read4(L.sy + off); Z = lds_read4(L.sz + off); }
-        else { X = *(const f4u *)(g.gx + lo); Y = *(const f4u *)(g.gy + lo); Z = *(const f4u *)(g.gz + lo); }
-        int i = 0;
-        while (wave_any(i < len)) {
-            const int ni = i + VCM_MERGE_UNROLL;
-            f4u Xn, Yn, Zn;
-            if (staged) {
-                const int a = off + ((ni < len) ? ni : 0);
-                Xn = lds_read4(L.sx + a); Yn = lds_read4(L.sy + a); Zn = lds_read4(L.sz + a);
-            } else {
-                const int a = lo + ((ni < len) ? ni : len);
-                Xn = *(const f4u *)(g.gx + a); Yn = *(const f4u *)(g.gy + a); Zn = *(const f4u *)(g.gz + a);
-            }
-            float distSqr[VCM_MERGE_UNROLL];
-            {   /* LenSqr(query - position), hashgrid.hxx:162, math.hxx:107: two candidates per packed operation */
-                const f2 dxa = qx - X.xy, dya = qy - Y.xy, dza = qz - Z.xy;
-                const f2 dxb = qx - X.zw, dyb = qy - Y.zw, dzb = qz - Z.zw;
-                const f2 da = dxa * dxa + dya * dya + dza * dza;
-                const f2 db = dxb * dxb + dyb * dyb + dzb * dzb;
-                distSqr[0] = da.x; distSqr[1] = da.y; distSqr[2] = db.x; distSqr[3] = db.y;
-            }
-            X = Xn; Y = Yn; Z = Zn;
-#pragma unroll
-            for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
-                const bool acc = (i + u < len) & (distSqr[u] <= P.radiusSqr);   /* :165 */
-                ms.q[qn * ms.stride] = (uint32_t)(lo + i + u);
-                qn += acc ? 1 : 0;
-            }
-            i = (ni < len) ? ni : len;
-            if (wave_any(qn > ms.cap - VCM_MERGE_UNROLL)) {
-                ls.mergeAccepted += (uint32_t)qn;
-                merge_drain<IP>(P, g, ev, ms, qn, contrib);
-                qn = 0;
-            }
-        }
-    }
-    ls.mergeAccepted += (uint32_t)qn;
-    merge_drain<IP>(P, g, ev, ms, qn, contrib);
-    return contrib;
-}
-#endif
-
-/* 4 waves per SIMD = two 512-thread workgroups per CU: at 129 registers (one too many) only ONE fitted, 6.4 instead of
- * 4.2 ms (r02j-r03o) */
-template <bool IP>
-__global__ void __launch_bounds__(VCM_STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_merge_staged(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
-               const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
-{
-    stamp_entry(st);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const DScene &sc = *scp;
-    const int nQ = *nSorted;
-    __shared__ uint32_t accQ[(VCM_STAGE_Q + 1) * VCM_STAGE_BLOCK];
-    __shared__ __attribute__((aligned(16))) StageLds L;
-    MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_STAGE_BLOCK; ms.cap = VCM_STAGE_Q;
-    LaneStats ls; lane_stats_zero(ls);
-    const int tid = (int)threadIdx.x;
-    const V3 bmin = ld3(g.hdr->bboxMin), bmax = ld3(g.hdr->bboxMax);
-    /* batches are dealt to the XCDs in chunks, as in k_merge_lane: a region's photons stay in one L2 */
-    const int nBatches = (nQ + VCM_STAGE_BLOCK - 1) / VCM_STAGE_BLOCK;
-    const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
-    for (int t = wgOfXcd;; t += wgPerXcd) {
-        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
-        if ((t / chunk) * 8 * chunk >= nBatches) break;   /* block-uniform */
-        if (b >= nBatches) continue;
-        /* ---- reset the table (the previous batch's readers are past the barrier at the end of the loop body) */
-        for (int i = tid; i < VCM_STAGE_HT; i += VCM_STAGE_BLOCK) L.key[i] = -1;
-        if (tid == 0) { L.count = 0; L.used = 0; }
-        __syncthreads();
-        /* ---- A: this lane's query, its 8 cells, their ranges -> table */
-        const int q = b * VCM_STAGE_BLOCK + tid;
-        const bool active = q < nQ;
-        int vi = 0;
-        V3 pos = sp3(0.f);
-        bool inside = false;
-        int px = 0, py = 0, pz = 0, pxo = 0, pyo = 0, pzo = 0;
-        uint32_t s0 = 0u, s1 = 0u, s2 = 0u;
-        if (active) {
-            vi = sortedVertex[q];
-            const F4 a = vq(vs, 0, vi);
-            pos = mk3(a.x, a.y, a.z);
-            const V3 distMin = pos - bmin, distMax = bmax - pos;
-            inside = !(distMin.x < 0.f || distMax.x < 0.f || distMin.y < 0.f || distMax.y < 0.f ||
-                       distMin.z < 0.f || distMax.z < 0.f);   /* hashgrid.hxx:116-122 */
-            const V3 cellPt = P.invCellSize * distMin;          /* :124-138 */
-            const V3 coordF = mk3(floorf(cellPt.x), floorf(cellPt.y), floorf(cellPt.z));
-            px = int(coordF.x); py = int(coordF.y); pz = int(coordF.z);
-            const V3 fractCoord = cellPt - coordF;
-            pxo = px + (fractCoord.x < 0.5f ? -1 : +1);
-            pyo = py + (fractCoord.y < 0.5f ? -1 : +1);
-            pzo = pz + (fractCoord.z < 0.5f ? -1 : +1);
-            if (inside) {
-                int cell[8], lo[8], hi[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {   /* :142-155, all 16 range words in flight together */
-                    cell[j] = grid_cell_hash((j & 4) ? pxo : px, (j & 2) ? pyo : py, (j & 1) ? pzo : pz, P.nCells);
-                    lo[j] = g.cellStart[cell[j]];
-                    hi[j] = g.cellStart[cell[j] + 1];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t slot = stage_insert(L, cell[j], lo[j], hi[j]);
-                    if (j < 3) s0 |= slot << (10 * j);
-                    else if (j < 6) s1 |= slot << (10 * (j - 3));
-                    else s2 |= slot << (10 * (j - 6));
-                }
-            }
-        }
-        __syncthreads();
-        /* ---- B: copy the distinct runs, 16 lanes per run */
-        {
-            const int n = L.count;
-            const int sub = tid >> 4, lane16 = tid & 15;
-            for (int e = sub; e < n; e += VCM_STAGE_BLOCK / 16) {
-                const int slot = L.list[e];
-                const int off = L.off[slot];
-                if (off < 0) continue;
-                const int lo = L.lo[slot], len = L.len[slot];
-                for (int i = lane16; i < len; i += 16) {
-                    L.sx[off + i] = g.gx[lo + i];
-                    L.sy[off + i] = g.gy[lo + i];
-                    L.sz[off + i] = g.gz[lo + i];
-                }
-            }
-        }
-        __syncthreads();
-        /* ---- C: scan + evaluate (eval_merge_task with the staged scan) */
-        if (active) {
-            const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
-            const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
-            Bsdf bsdf;
-            bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
-            SubPathState st;
-            st.pathLength = f2u(bq.w) & 0xffu; st.dVCM = c.w; st.dVM = d.w;
-            const V3 contrib = merge_query_staged<IP>(sc, P, g, bsdf, st, pos, inside, px, py, pz, pxo, pyo, pzo, s0, s1, s2, L, ls, ms);
-            const V3 v = mk3(d.x, d.y, d.z) * P.vmNormalization * contrib;
-            vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
-        }
-        __syncthreads();
-    }
-    flush_stats(ls, gstats);
-#endif
-}
+/* (k_merge_staged -- a workgroup of 512 staging the cell lists of its queries through LDS behind an open-addressed table, 27 % less
+   HBM traffic than the lockstep kernel and slower than it: 4.2 ms, barriers and a lockstep scan -- was retired in round 6 with the
+   kernel it was measured against; the record is HISTORY.md and profiles/archive/r02c_ab_summary.txt.) */
 
 /* ---------------- K5: Framebuffer::AddColor of camera colours ----------- */
 /* vertexcm.hxx:544 adds colour p to the pixel of its jittered sample, in path
@@ -1830,7 +1604,7 @@ __global__ void __launch_bounds__(256) k_cell_starts(const uint32_t *__restrict_
  * mIndices indirection. */
 __global__ void __launch_bounds__(256) k_cell_rank_gather(const DScene *__restrict__ scp, const GridHeader *__restrict__ hdr, VertexSource src,
                                    const int *__restrict__ cellStart, const I4 *__restrict__ unsorted, const I2 *__restrict__ sorted,
-                                   float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3, int *sortedIndex)
+                                   float *gx, float *gy, float *gz, float *gb, F4 *g1, F4 *g2, F2 *g3, int *sortedIndex)
 {
     const int n = hdr->nRecords;
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
@@ -1852,6 +1626,7 @@ __global__ void __launch_bounds__(256) k_cell_rank_gather(const DScene *__restri
         if (src.records) {
             const float *r = src.records + (size_t)i * VCM_MERGE_RECORD_FLOATS;
             gx[dst] = r[0]; gy[dst] = r[1]; gz[dst] = r[2];
+            gb[grid_blocked_index(dst, 0)] = r[0]; gb[grid_blocked_index(dst, 1)] = r[1]; gb[grid_blocked_index(dst, 2)] = r[2];
             g1[dst] = mk4(r[3], r[4], r[5], r[11]);
             g2[dst] = mk4(r[6], r[7], r[8], r[9]);
             t.x = r[10]; t.y = r[12];
@@ -1860,6 +1635,7 @@ __global__ void __launch_bounds__(256) k_cell_rank_gather(const DScene *__restri
             const F4 a = lv(src.store, slot, 0), b = lv(src.store, slot, 1), d = lv(src.store, slot, 3);
             const F4 e = light_vertex_wdir_contprob(*scp, a, lv(src.store, slot, 2), d, false);   /* (one 64-byte record: one line) */
             gx[dst] = a.x; gy[dst] = a.y; gz[dst] = a.z;
+            gb[grid_blocked_index(dst, 0)] = a.x; gb[grid_blocked_index(dst, 1)] = a.y; gb[grid_blocked_index(dst, 2)] = a.z;
             g1[dst] = e;
             g2[dst] = b;
             t.x = d.w; t.y = u2f(f2u(a.w) & 0xffu);
@@ -1950,7 +1726,7 @@ struct SortedSlabs {
 };
 
 __global__ void __launch_bounds__(256) k_grid_merge_blocks(IterParams P, const GridHeader *__restrict__ hdr, SortedSlabs in,
-                                    int *cellStart, float *gx, float *gy, float *gz, F4 *g1, F4 *g2, F2 *g3, int *sortedIndex, StampArgs st)
+                                    int *cellStart, float *gx, float *gy, float *gz, float *gb, F4 *g1, F4 *g2, F2 *g3, int *sortedIndex, StampArgs st)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     stamp_entry(st);
@@ -2021,6 +1797,7 @@ __global__ void __launch_bounds__(256) k_grid_merge_blocks(IterParams P, const G
                 const int k = (cell - c0) * S + r;
                 const int dst = g0 + sCnt[k] + (i - sFirst[k]);
                 gx[dst] = u2f(w[0]); gy[dst] = u2f(w[1]); gz[dst] = u2f(w[2]);
+                gb[grid_blocked_index(dst, 0)] = u2f(w[0]); gb[grid_blocked_index(dst, 1)] = u2f(w[1]); gb[grid_blocked_index(dst, 2)] = u2f(w[2]);
                 g1[dst] = mk4(u2f(w[3]), u2f(w[4]), u2f(w[5]), u2f(w[11]));
                 g2[dst] = mk4(u2f(w[6]), u2f(w[7]), u2f(w[8]), u2f(w[9]));
                 F2 t; t.x = u2f(w[10]); t.y = u2f(w[12] & 0xffu);

@@ -67,6 +67,18 @@ struct GpuTurn {
     hipStream_t mA, mB; bool mHeld;
 };
 
+// How the slabs of light vertices travel.  SMALLVCM_AMD_FARM_EXCHANGE =
+//   allgather  (default) ONE ncclAllGather per iteration: RCCL's ring / tree schedules over the xGMI links
+//   direct     every rank SENDS its slab to each of its S - 1 peers and receives theirs, all 2 (S - 1) transfers in one RCCL
+//              group: point-to-point over the seven links of a GPU at once instead of a ring's neighbour hops
+// Same bytes in the same places either way; which is faster is a question for an 8-GPU node (bench.py --gpus N --selftest
+// runs both for correctness wherever two GPUs exist).
+static bool exchange_is_direct()
+{
+    static const bool on = [] { const char *e = getenv("SMALLVCM_AMD_FARM_EXCHANGE"); return e && !strcmp(e, "direct"); }();
+    return on;
+}
+
 // what the ranks of a group tell each other before the vertices travel: 7 numbers (hashgrid.hxx:47-61)
 struct Xchg { long long n; float mn[3], mx[3]; };
 
@@ -166,7 +178,20 @@ public:
     bool allGather(Shared &sh, int rank, const float *send, float *recv, size_t n, hipStream_t s) override
     {
         if (mComms.empty()) return false;
-        NCCLOK(ncclAllGather(send, recv, n, ncclFloat, mComms[(size_t)(rank - mFirst)], s));
+        ncclComm_t comm = mComms[(size_t)(rank - mFirst)];
+        if (exchange_is_direct() && mRanks > 1) {
+            /* own slab in place; then every peer at once: RCCL runs the sends and receives of a group concurrently */
+            if (recv + (size_t)rank * n != send) HIPOK(hipMemcpyAsync(recv + (size_t)rank * n, send, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            NCCLOK(ncclGroupStart());
+            for (int d = 1; d < mRanks; d++) {   /* staggered: rank r starts with r + 1, so no peer is everybody's first target */
+                const int to = (rank + d) % mRanks, from = (rank - d + mRanks) % mRanks;
+                NCCLOK(ncclSend(send, n, ncclFloat, to, comm, s));
+                NCCLOK(ncclRecv(recv + (size_t)from * n, n, ncclFloat, from, comm, s));
+            }
+            NCCLOK(ncclGroupEnd());
+            return true;
+        }
+        NCCLOK(ncclAllGather(send, recv, n, ncclFloat, comm, s));
         return true;
     }
     bool allReduceSum(Shared &sh, int rank, float *buf, size_t n, hipStream_t s) override
@@ -235,7 +260,7 @@ private:
 // moves with device-to-device copies ordered by events.  Same interface, same call pattern as the RCCL class.
 class ThreadCollectives : public Collectives {
 public:
-    ThreadCollectives(Shared &sh, int ranks) : Collectives(sh, ranks, ranks), mSend((size_t)ranks, NULL), mReady((size_t)ranks),
+    ThreadCollectives(Shared &sh, int ranks) : Collectives(sh, ranks, ranks), mSend((size_t)ranks, NULL), mRecv((size_t)ranks, NULL), mFree((size_t)ranks, (hipEvent_t)NULL), mReady((size_t)ranks),
                                                mDone((size_t)ranks), mHave((size_t)ranks, 0), mHost((size_t)ranks)
     {
         for (int r = 0; r < ranks; r++) { mReady[(size_t)r] = NULL; mDone[(size_t)r] = NULL; }
@@ -244,10 +269,29 @@ public:
     {
         for (hipEvent_t e : mReady) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : mDone) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : mFree) if (e) (void)hipEventDestroy(e);
     }
     bool allGather(Shared &sh, int rank, const float *send, float *recv, size_t n, hipStream_t s) override
     {
         if (!events(sh, rank)) return false;
+        if (exchange_is_direct()) {
+            /* the direct exchange as the stand-in can show it: every rank WRITES its slab into each peer's receive buffer on
+               its own stream (the peers published where), the receivers wait for all writers' events */
+            mRecv[(size_t)rank] = recv;
+            HIPOK(hipEventRecord(mFree[(size_t)rank], s));   // my stream is here: whatever read my receive buffer last has been ordered before it
+            if (!mBar.wait()) return false;   // every receive buffer is known
+            for (int d = 0; d < mRanks; d++) {
+                const int to = (rank + d) % mRanks;
+                HIPOK(hipStreamWaitEvent(s, mFree[(size_t)to], 0));   // (ncclRecv gives the real exchange the same guarantee: it is posted in the receiver's stream order)
+                HIPOK(hipMemcpyAsync(mRecv[(size_t)to] + (size_t)rank * n, send, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
+            HIPOK(hipEventRecord(mReady[(size_t)rank], s));   // "my slab has landed everywhere"
+            if (!mBar.wait()) return false;
+            for (int r = 0; r < mRanks; r++) HIPOK(hipStreamWaitEvent(s, mReady[(size_t)r], 0));
+            HIPOK(hipEventRecord(mDone[(size_t)rank], s));
+            mHave[(size_t)rank] = 1;
+            return mBar.wait();
+        }
         mSend[(size_t)rank] = send;
         HIPOK(hipEventRecord(mReady[(size_t)rank], s));
         if (!mBar.wait()) return false;
@@ -285,10 +329,13 @@ private:
         if (!mReady[(size_t)rank]) {
             HIPOK(hipEventCreateWithFlags(&mReady[(size_t)rank], hipEventDisableTiming));
             HIPOK(hipEventCreateWithFlags(&mDone[(size_t)rank], hipEventDisableTiming));
+            HIPOK(hipEventCreateWithFlags(&mFree[(size_t)rank], hipEventDisableTiming));
         }
         return true;
     }
     std::vector<const float *> mSend;
+    std::vector<float *> mRecv;
+    std::vector<hipEvent_t> mFree;
     std::vector<hipEvent_t> mReady, mDone;
     std::vector<char> mHave;   // one byte per rank: the rank threads write their own element concurrently
     std::vector<std::vector<float>> mHost;
@@ -509,7 +556,22 @@ bool rank_main(RankArgs &a)
         for (int ago = 0; ago < n; ago++) { vcm_stats st; VCMOK(vcm_get_stats_at(slots[0].ctx, ago, &st)); stats_accumulate(acc, st); }
         stats_scale(acc, n);
         iterMs = acc.msTotal;
-        if (a.rank == 0) { std::lock_guard<std::mutex> g(*a.resultMutex); a.result->meanStats = acc; }
+        {   /* times, radius, the grid's vertex count: world rank 0's; the WORK counters: summed over the shards of the first
+               renderer that this process hosts (rank < shards), so that a sharded renderer reports what a single one would */
+            std::lock_guard<std::mutex> g(*a.resultMutex);
+            vcm_stats &m = a.result->meanStats;
+            if (a.rank == 0) {
+                const vcm_stats work = m;   /* what other shards have added already */
+                m = acc;
+                m.lightVertices += work.lightVertices; m.lightRays += work.lightRays; m.cameraRays += work.cameraRays; m.shadowRays += work.shadowRays;
+                m.mergeQueries += work.mergeQueries; m.mergeCandidates += work.mergeCandidates; m.mergeAccepted += work.mergeAccepted;
+                m.connections += work.connections; m.lightSplats += work.lightSplats;
+            } else if (a.rank < cfg.shards) {
+                m.lightVertices += acc.lightVertices; m.lightRays += acc.lightRays; m.cameraRays += acc.cameraRays; m.shadowRays += acc.shadowRays;
+                m.mergeQueries += acc.mergeQueries; m.mergeCandidates += acc.mergeCandidates; m.mergeAccepted += acc.mergeAccepted;
+                m.connections += acc.connections; m.lightSplats += acc.lightSplats;
+            }
+        }
     }
     {   // wall = max over ranks, iteration ms per rank: one small all-reduce of a table every rank fills its row of
         const size_t n = 2 * (size_t)cfg.ranks;

@@ -71,7 +71,7 @@ struct FarmResult {
     int renderers;
     int rcclRanks;             // ranks that took part in RCCL collectives (0 with the stand-in)
     std::vector<float> rankIterationMs;   // per world rank: mean device time of an iteration of its first renderer
-    vcm_stats meanStats;       // world rank 0, first renderer: counters and kernel times, mean over its timed iterations
+    vcm_stats meanStats;       // first renderer, mean over its timed iterations: kernel times of world rank 0; work counters summed over the renderer's shards hosted by this process
     std::string error;         // empty on success
 };
 

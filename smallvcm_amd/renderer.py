@@ -172,10 +172,10 @@ class HipBackend:
         """True: DI / VC / merge inside the camera path as the reference does (slower, same bits)."""
         _check(self.L, self.L.vcm_set_strict_order(self.ctx, 1 if on else 0), "vcm_set_strict_order")
 
-    MERGE_KERNELS = {"lane": 0, "staged": 1, "walk": 2, "pairs": 3}
+    MERGE_KERNELS = {"walk": 2, "pairs": 3}
 
     def set_merge_kernel(self, kind):
-        """which kernel evaluates the range merges: 'lane', 'staged', 'walk' or 'pairs' (same bits; include/smallvcm_amd.h)"""
+        """which kernel evaluates the range merges: 'walk' or 'pairs' (same bits; include/smallvcm_amd.h)"""
         _check(self.L, self.L.vcm_set_merge_kernel(self.ctx, self.MERGE_KERNELS[kind]), "vcm_set_merge_kernel")
 
     def set_stream(self, stream_handle):

@@ -22,8 +22,7 @@ CONFIGS = [(1, "vcm", 4, 256, 2), (3, "bpm", 2, 192, 2)]
 SWITCHES = [
     "SMALLVCM_AMD_MERGE_DEAL=slab",            # k_merge_walk: one slab of the sorted queries per XCD, with stealing
     "SMALLVCM_AMD_MERGE_DEAL=slab SMALLVCM_AMD_MERGE_SLAB_BLOCKS=64",
-    "SMALLVCM_AMD_MERGE=lane",                 # k_merge_lane
-    "SMALLVCM_AMD_MERGE=staged",               # k_merge_staged
+    "SMALLVCM_AMD_MERGE=walk",                 # k_merge_walk (the default is k_merge_pairs)
     "SMALLVCM_AMD_MERGE_CHUNK=3",
     "SMALLVCM_AMD_MERGE_BLOCKS=64",
     "SMALLVCM_AMD_NO_RECTS=1",                 # the Pluecker filter (SceneQuads kernels) instead of the rectangles
