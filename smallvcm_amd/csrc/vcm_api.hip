@@ -437,36 +437,10 @@ static int ensure_device(vcm_ctx *c)
     if (!c->deviceReady) {
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-        {   /* The helper streams at the lowest priority (SMALLVCM_AMD_STREAM_PRIO=1; default: equal priorities).  On a
-               2048^2 frame the grid build and the light splats then fill what the main stream's long kernels leave free
-               instead of sharing the chip evenly with them: +0.5 to +0.9 % (profiles/archive/r05k_prio.txt, r05s_ab.txt).  On small
-               frames the camera pass is one wave-round that holds the whole chip, a low-priority grid build starts when it
-               ends, and the merge waits for the build: 512^2 407 -> 295 Mpaths/s, the BVH room at 1024^2 403 -> 379, two
-               renderers in flight at 1024^2 1379 -> 810 (r05r_configs.txt) -- and contexts created LATER in the same
-               process with equal priorities were slowed too (r05s: the runtime seems to hand their streams the hardware
-               queues of the low-priority ones).  Half a percent does not pay for that: off. */
-            static int prio = -1;
-            if (prio < 0) { const char *e = getenv("SMALLVCM_AMD_STREAM_PRIO"); prio = (e && e[0] == '1') ? 1 : 0; }
-            const bool low = prio == 1;
-            int lo = 0, hi = 0;
-            if (low) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   /* lo = the numerically largest = least urgent */
-            /* SMALLVCM_AMD_HELPER_CUS=n (measurement switch): the helper streams may only use n of every 8 CUs (a mask spread
-               evenly over the chip), so that the main stream's kernels keep the rest to themselves */
-            static int helperCus = -1;
-            if (helperCus < 0) { const char *e = getenv("SMALLVCM_AMD_HELPER_CUS"); helperCus = (e && atoi(e) > 0 && atoi(e) < 8) ? atoi(e) : 0; }
-            if (helperCus) {
-                uint32_t mask[8];
-                for (int w = 0; w < 8; w++) { mask[w] = 0u; for (int b = 0; b < 32; b++) if (((w * 32 + b) % 8) < helperCus) mask[w] |= 1u << b; }
-                HIPCHK(hipExtStreamCreateWithCUMask(&c->side, 8, mask));
-                HIPCHK(hipExtStreamCreateWithCUMask(&c->splat, 8, mask));
-            } else if (low) {
-                HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo));
-                HIPCHK(hipStreamCreateWithPriority(&c->splat, hipStreamNonBlocking, lo));
-            } else {
-                HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-                HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
-            }
-        }
+        /* the helper streams: equal priorities (lowest priority for them bought 0.5-0.9 % at 2048^2 and cost 28 % at 512^2, a CU mask
+           for them cost 7-12 %: profiles/archive/r05k_prio.txt, r05r_configs.txt, profiles/r07l_ab_2048_vcm_s1.txt; both switches retired in round 6) */
+        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->evSortFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evSorted, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evZero, hipEventDisableTiming));
@@ -625,15 +599,12 @@ static int flush_stamps(vcm_ctx *c, hipStream_t stream)
     return 0;
 }
 /* mark a phase boundary on `stream`: the NEXT kernel launched there writes the device clock into the mark's slot when
- * it starts (take_stamps / stamp_entry) -- the boundary costs no launch of its own.  SMALLVCM_AMD_NO_STAMPS=1: no
- * marks at all (vcm_get_stats then reports counters only); SMALLVCM_AMD_TIMING=events additionally records a HIP
- * event per mark (the two agree; the events only remember the last iteration). */
+ * it starts (take_stamps / stamp_entry) -- the boundary costs no launch of its own.  SMALLVCM_AMD_TIMING=events additionally
+ * records a HIP event per mark (the two agree; the events only remember the last iteration). */
 static int mark_on(vcm_ctx *c, int ev, hipStream_t stream)
 {
-    static int off = -1, events = -1;
-    if (off < 0) { const char *e = getenv("SMALLVCM_AMD_NO_STAMPS"); off = (e && e[0] == '1') ? 1 : 0; }
+    static int events = -1;
     if (events < 0) { const char *e = getenv("SMALLVCM_AMD_TIMING"); events = (e && !strcmp(e, "events")) ? 1 : 0; }
-    if (off) return 0;
     if (events) HIPCHK(hipEventRecord(c->ev[ev], stream));
     const int w = (stream == c->side) ? 1 : 0;
     if (c->nPend[w] == 4 && flush_stamps(c, stream)) return -1;
@@ -670,22 +641,40 @@ static int launch_scan(vcm_ctx *c, const T *in, int n, int *out, int *totalOut, 
     return launch_scan_on<T>(c, 0, c->stream, in, n, out, totalOut, writeTotalAtN, take_stamps(c, c->stream));
 }
 
+/* Launch shapes are chosen per frame size below ("Launch shapes follow the frame"); ONE switch overrides any of them
+   for sweeps and tests: SMALLVCM_AMD_SHAPE="key=value,key=value", keys: trace_waves, light_waves, trace_chunk (persistent waves of
+   K3 / of K1, paths per chunk), task_blocks (K1c, K3b, K3c), merge_blocks, merge_chunk (K4), aux_blocks (streaming helpers),
+   resolve_blocks (K5), grid_sort_blocks (K2's radix sort), buckets_per_path (the query sort).  0 / absent: the default.
+   (Rounds 2-5 had one environment variable per knob: ten of them.) */
+static int shape_knob(const char *key)
+{
+    static const char *spec = getenv("SMALLVCM_AMD_SHAPE");
+    if (!spec) return 0;
+    const size_t n = strlen(key);
+    for (const char *p = spec; *p;) {
+        if (!strncmp(p, key, n) && p[n] == '=') { const int v = atoi(p + n + 1); return v > 0 ? v : 0; }
+        const char *q = strchr(p, ',');
+        if (!q) break;
+        p = q + 1;
+    }
+    return 0;
+}
 static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPass = false)
 {
     /* persistent waves: enough to fill 256 CUs several times over, each wave
        owning a contiguous chunk of paths (>= 64) */
     int waves = (nLocal + VCM_WAVE - 1) / VCM_WAVE;
-    static const char *tw = getenv("SMALLVCM_AMD_TRACE_WAVES");
+    const int tw = shape_knob("trace_waves");
     /* 4096 = 16 waves per CU: measured best (fewer, longer-lived waves leave fewer partly used queue blocks) */
-    int maxWaves = (tw && atoi(tw) > 0) ? atoi(tw) : 256 * 16;
+    int maxWaves = tw ? tw : 256 * 16;
     /* a 512^2 frame is exactly 4096 waves of one path per lane: every wave then lives as long as its longest path.  With
        3072 waves a third of the lanes take a second path: K3 0.41 -> 0.36 ms (profiles/archive/r05c_ab_summary.txt; at 1024^2
        4096 is best) */
     /* ... and so does 1024^2 (round 5): 3072 waves and chunks of 128 -- a third of the chunks dealt dynamically -- K3 0.83 -> 0.72 ms
        on scene 3, 1.02 -> 0.82 on scene 1 (1068 -> 1116 and 808 -> 896 Mpaths/s, profiles/r07g_ab_1024_*.txt); no effect at 2048^2 */
-    if (!(tw && atoi(tw) > 0) && nLocal <= (1 << 20)) maxWaves = 256 * 12;
-    static const char *lw = getenv("SMALLVCM_AMD_LIGHT_WAVES");   /* K1 needs fewer registers than K3: 5 waves per SIMD fit */
-    if (lightPass && lw && atoi(lw) > 0) maxWaves = atoi(lw);
+    if (!tw && nLocal <= (1 << 20)) maxWaves = 256 * 12;
+    const int lw = shape_knob("light_waves");   /* K1 needs fewer registers than K3: 5 waves per SIMD fit */
+    if (lightPass && lw) maxWaves = lw;
     if (maxWaves > VCM_MAX_TRACE_WAVES) maxWaves = VCM_MAX_TRACE_WAVES;   /* the queue buffers hold one spare block per wave */
     if (waves > maxWaves) waves = maxWaves;
     if (waves < 1) waves = 1;
@@ -697,17 +686,17 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPa
        before); above, chunks of 256 -- four per wave at 2048^2.  Smaller chunks balance no better and cost a grab
        every step where paths are short (environment light: K1 0.24 -> 0.34 ms at 1024^2 with 64-path chunks, r03f) */
     int ch = nLocal / totalWaves;
-    static const char *ce = getenv("SMALLVCM_AMD_TRACE_CHUNK");
-    if (ce && atoi(ce) > 0) ch = atoi(ce);
+    const int ce = shape_knob("trace_chunk");
+    if (ce) ch = ce;
     /* up to 1024^2 (round 5): chunks of 128.  At 1024^2 a third of the 8192 chunks is then dealt dynamically; at 512^2 it means
        2048 waves with two paths per lane instead of 3072 with one and a third (584 -> 608 Mpaths/s, profiles/r07h_ab_512_vcm_s1.txt;
        chunks of 64: 566) */
-    if (!(ce && atoi(ce) > 0) && !(tw && atoi(tw) > 0) && nLocal <= (1 << 20)) {
+    if (!ce && !tw && nLocal <= (1 << 20)) {
         ch = 128;
         const int need = (nLocal + ch - 1) / ch;   /* waves that get a first chunk at all */
         if (totalWaves > need) *blocks = (need + wavesPerBlock - 1) / wavesPerBlock;
     }
-    *chunk = ch < 64 ? 64 : (ch > 256 && !(ce && atoi(ce) > 0) ? 256 : ch);
+    *chunk = ch < 64 ? 64 : (ch > 256 && !ce ? 256 : ch);
 }
 
 extern "C" {
@@ -1011,11 +1000,10 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
        resolution (the cell count follows the radius, not the pixel count), 14 % of a 512^2 iteration; with few
        queries per cell anyway a bucket may as well span a few cells there. */
     {
-        static int perPath = 0;   /* SMALLVCM_AMD_BUCKETS_PER_PATH (measurement switch): buckets of the query sort per path */
-        if (!perPath) { const char *e = getenv("SMALLVCM_AMD_BUCKETS_PER_PATH"); perPath = (e && atoi(e) > 0) ? atoi(e) : 16; }
+        const int perPath = shape_knob("buckets_per_path");   /* buckets of the query sort per path */
         /* (round 5: 4 buckets per path up to 1024^2 -- the in-line scan of the table is on the critical path there: 1024^2 scene 3
            1123 -> 1188 Mpaths/s, 512^2 588 -> 605, profiles/r07h_ab_*.txt; 16 from 2^21 paths, where it makes no difference) */
-        const int per = (getenv("SMALLVCM_AMD_BUCKETS_PER_PATH") || c->nLocal > (1 << 20)) ? perPath : 4;
+        const int per = perPath ? perPath : (c->nLocal > (1 << 20) ? 16 : 4);
         long long nb = (long long)per * c->nLocal;
         if (nb < (1 << 18)) nb = 1 << 18;
         P.nBuckets = nb < VCM_QSORT_BUCKETS ? (int)nb : VCM_QSORT_BUCKETS;
@@ -1047,8 +1035,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
  * next to the tail of the grid build (profiles/archive/r03j_ab_summary.txt). */
 static int task_blocks(int nLocal)
 {
-    static int n = -1;
-    if (n < 0) { const char *e = getenv("SMALLVCM_AMD_TASK_BLOCKS"); n = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    const int n = shape_knob("task_blocks");
     /* Small frames (round 5, profiles/r07c_ab_*.txt, r07d_ab_*.txt; 400-iteration runs): rounds 1-4 kept 2048 workgroups up to
        1024^2 -- 8192 waves where ~6144 are resident, for one or two tasks per thread, next to K3c / K4 which want wave slots at
        the same time.  512 workgroups at 512^2 (five tasks per thread; 256 / 384 / 512 / 768 / 1024 / 1536 / 2048: 531 / 534 /
@@ -1065,8 +1052,7 @@ static int task_blocks(int nLocal)
  * profiles/archive/r03k, r03l). */
 static int merge_blocks(int nLocal, int N)
 {
-    static int n = -1;
-    if (n < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_BLOCKS"); n = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 0; }
+    const int n = shape_knob("merge_blocks") >= 8 ? (shape_knob("merge_blocks") & ~7) : 0;
     /* smaller frames have fewer batches than that.  2048 until round 4 (16384 at 1024^2: 0.40 -> 1.08 ms, r03m); round 5
        measured the small end: 512^2 with 512 / 768 / 1024 / 1536 / 2048 / 4096 workgroups: K4 0.18 / 0.19 / 0.21 / 0.24 / 0.27 /
        0.31 ms (571 / 559 / 543 / 529 / 497 / 475 Mpaths/s with 512 task workgroups); 1024^2 scene 3 with 1024 / 2048 / 4096 /
@@ -1082,24 +1068,17 @@ static int merge_blocks(int nLocal, int N)
 }
 /* workgroups of the streaming helper kernels (compaction, grid build, splat lists, query scatter, resolve: grid-stride loops over
  * paths, vertices or pixels).  2048 = 524 288 threads; a 512^2 frame has 262 144 paths and ~560 000 vertices: half the threads
- * found nothing to do.  SMALLVCM_AMD_AUX_BLOCKS overrides. */
+ * found nothing to do. */
 static int aux_blocks(int nLocal)
 {
-    static int n = -1;
-    if (n < 0) { const char *e = getenv("SMALLVCM_AMD_AUX_BLOCKS"); n = (e && atoi(e) > 0) ? atoi(e) : 0; }
-    if (n) return n;
-    return 2048;
+    const int n = shape_knob("aux_blocks");
+    return n ? n : 2048;
 }
-static int env_blocks(const char *name, int *cache, int fallback)
-{
-    if (*cache < 0) { const char *e = getenv(name); *cache = (e && atoi(e) > 0) ? atoi(e) : 0; }
-    return *cache ? *cache : fallback;
-}
-/* K5; `heavy` = beside the next iteration's K1 (SMALLVCM_AMD_RESOLVE_ASIDE) with the addends of a VC algorithm to replay: with 2048
+/* K5; `heavy` = beside the next iteration's K1 with the addends of a VC algorithm to replay: with 2048
    workgroups its 8192 waves took the wave slots K1's persistent waves were about to claim.  At 2048^2 VCM (K5 replays 41 M addends, 2.3 GB) 2048 / 1024 / 768 / 512 / 256 workgroups:
    1014 / 1035 / 1058 / 1062 / 1044 Mpaths/s (5 pairs of 40 iterations, profiles/r11l_ab_summary.txt); BPM at 2048^2, 1024^2 and
    512^2 do not care down to 512 and lose below (r11m). */
-static int resolve_blocks(int nLocal, bool heavy) { static int n = -1; return env_blocks("SMALLVCM_AMD_RESOLVE_BLOCKS", &n, (heavy && nLocal >= (1 << 21)) ? 512 : aux_blocks(nLocal)); }
+static int resolve_blocks(int nLocal, bool heavy) { const int n = shape_knob("resolve_blocks"); return n ? n : ((heavy && nLocal >= (1 << 21)) ? 512 : aux_blocks(nLocal)); }
 /* K2's sort (vcm_kernels.h, "K2 as a radix sort"): SMALLVCM_AMD_GRID_SORT=count keeps the reference's counting sort with one
    atomic per vertex (rounds 1-5); the default is the radix sort. */
 static bool grid_sort_is_radix(const vcm_ctx *c)
@@ -1110,9 +1089,8 @@ static bool grid_sort_is_radix(const vcm_ctx *c)
 }
 static int radix_sort_blocks(int nLocal)
 {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("SMALLVCM_AMD_GRID_SORT_BLOCKS"); forced = (e && atoi(e) > 0) ? (atoi(e) < VCM_RSORT_MAX_BLOCKS ? atoi(e) : VCM_RSORT_MAX_BLOCKS) : 0; }
-    if (forced) return forced;
+    const int forced = shape_knob("grid_sort_blocks");
+    if (forced) return forced < VCM_RSORT_MAX_BLOCKS ? forced : VCM_RSORT_MAX_BLOCKS;
     int v = nLocal / 2048;   /* ~2200 vertices per workgroup at the reference's path lengths (4096 / 2048 / 1024 / 512 workgroups at 2048^2: 1000-1009 / 1006-1016 / 1001-1022 / 1008-1019 Mpaths/s, profiles/r11h) */
     return v < 64 ? 64 : (v > VCM_RSORT_MAX_BLOCKS ? VCM_RSORT_MAX_BLOCKS : v);
 }
@@ -1133,13 +1111,10 @@ static int flush_light_splats(vcm_ctx *c)
         /* K1c / K1d only read the light-vertex store and add to the framebuffer; nothing of the camera pass touches the
            framebuffer before K5.  They run on a stream of their own next to the grid build and the camera pass and are
            joined before K5: +4.5 % at 512^2, +7 % at 1024^2, +3 % at 2048^2 (profiles/archive/r05c_ab_summary.txt; in round 1,
-           when they still shared their scratch with the grid build, the overlap had bought nothing).
-           SMALLVCM_AMD_SPLAT_STREAM=0 puts them back in line. */
-        static int force = -2;
-        if (force == -2) { const char *e = getenv("SMALLVCM_AMD_SPLAT_STREAM"); force = e ? (e[0] == '1' ? 1 : 0) : -1; }
+           when they still shared their scratch with the grid build, the overlap had bought nothing).  Strict order keeps them in line. */
         /* (round 5: sharded contexts too -- a rank's K1c / K1d then run beside its camera pass while its light vertices
            travel, instead of in line in front of it) */
-        const bool overlap = (force != 0) && !c->strictOrder;
+        const bool overlap = !c->strictOrder;
         hipStream_t q = overlap ? c->splat : c->stream;
         const StampArgs none = { { NULL, NULL, NULL, NULL } };
         if (overlap) {
@@ -1212,11 +1187,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         LAUNCH_SC_MODE(c, k_light_trace, 0, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P, c->store,
                            c->dFb, c->dRngLight, c->dStats, chunk, take_stamps(c, c->stream), c->vs.count + 16, c->dHdr);
     HIPCHK(hipGetLastError());
-    {   /* SMALLVCM_AMD_NO_K1_BBOX=1 (measurement switch): the grid build computes the box itself, as in round 1 */
-        static int noK1Box = -1;
-        if (noK1Box < 0) { const char *e = getenv("SMALLVCM_AMD_NO_K1_BBOX"); noK1Box = (e && e[0] == '1') ? 1 : 0; }
-        c->bboxFromLight = (c->world == 1) && !noK1Box;
-    }
+    c->bboxFromLight = c->world == 1;   /* K1 keeps the box of what it stores (k_bbox, a pass of its own over the vertices, serves imported records) */
     if (mark(c, EV_LIGHT_K1)) return -1;
     /* mPathEnds (:395) = scan of the per-path counts, then the contiguous
        record array in the reference's vertex order */
@@ -1241,8 +1212,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
     }
     if (wf && (c->useVC || c->lightTraceOnly)) {
         c->splatsPending = true;
-        { const char *e = getenv("SMALLVCM_AMD_SPLATS_AFTER_K3");
-          if (c->world == 1 && !(e && e[0] == '1' && !c->lightTraceOnly) && flush_light_splats(c)) return -1; }
+        if (c->world == 1 && flush_light_splats(c)) return -1;
     }
     if (mark(c, EV_LIGHT)) return -1;   /* written by the next kernel of the stream as it starts */
     if (!countsSet) {
@@ -1284,9 +1254,7 @@ static int vcm_local_light_bbox_impl(vcm_ctx *c, float *min3, float *max3, long 
 {
     if (!c || !c->inIteration || !min3 || !max3) return fail("vcm_local_light_bbox", "call it between vcm_trace_light and vcm_build_grid");
     if (use_device(c)) return -1;
-    static int noK1Box = -1;
-    if (noK1Box < 0) { const char *e = getenv("SMALLVCM_AMD_NO_K1_BBOX"); noK1Box = (e && e[0] == '1') ? 1 : 0; }
-    if (!noK1Box && !c->renderer && !c->bboxFinal) {
+    if (!c->renderer && !c->bboxFinal) {
         /* K1 kept the box of what it stored in the header's key words (minimum inverted), as on a single rank: one tiny
            launch turns them into floats -- rounds 2-4 gathered every local vertex's position once more for this (k_bbox) */
         hipLaunchKernelGGL(k_bbox_finalize, dim3(1), dim3(64), 0, c->stream, c->dHdr, 1);
@@ -1510,17 +1478,14 @@ static int vcm_build_grid_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:403-408 -> HashGrid::Build hashgrid.hxx:41-107 */
     if (!c || !c->inIteration) return fail("vcm_build_grid", "no iteration in progress");
     if (use_device(c)) return -1;
-    { const char *e = getenv("SMALLVCM_AMD_SPLATS_AFTER_K3");
-      if (!(e && e[0] == '1' && c->P.wavefront && !c->lightTraceOnly && !c->cameraTraced) && flush_light_splats(c)) return -1; }
+    if (flush_light_splats(c)) return -1;
     c->gridBuilt = true;
     if (c->useVM) {
         /* The grid build is atomic- and gather-bound, the camera pass that follows in the single-rank order
            (K3, K3b, K3c) is VALU-bound and does not read the grid: the build runs on a side stream next to it.
            Main waits for the bounding box only (K3 derives the query-sort keys from it); vcm_merge waits for the
            rest.  Strict mode merges inside K3 and waits at once. */
-        static int noSide = -1;   /* SMALLVCM_AMD_NO_SIDE=1 (measurement switch): the build in line on the main stream */
-        if (noSide < 0) { const char *e = getenv("SMALLVCM_AMD_NO_SIDE"); noSide = (e && e[0] == '1') ? 1 : 0; }
-        hipStream_t q = noSide ? c->stream : c->side;
+        hipStream_t q = c->side;
         HIPCHK(hipEventRecord(c->evFork, c->stream));
         HIPCHK(hipStreamWaitEvent(q, c->evFork, 0));
         if (mark_on(c, EV_GRID_K0, q)) return -1;
@@ -1547,7 +1512,7 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         const int nCells = c->P.nCells;
         const dim3 g(aux_blocks(c->nLocal)), b(256);
         const bool radix = grid_sort_is_radix(c);
-        if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));   /* (q is the side stream itself unless the build runs in line) */
+        if (c->prezeroed) HIPCHK(hipStreamWaitEvent(q, c->evZero, 0));   /* (q is the side stream itself) */
         else if (!radix && zero_ranges(q, c->dCellCount, ((size_t)nCells + 1) * sizeof(int))) return -1;
         bool boxOnSide = false;
         if (!c->bboxPreset) {   /* a sharded host has exchanged the ranks' boxes already (vcm_set_grid_bbox) */
@@ -1563,12 +1528,12 @@ static int vcm_build_grid_impl(vcm_ctx *c)
         HIPCHK(hipEventRecord(c->evBbox, q));
         const I2 *sorted = NULL;
         if (radix) {
-            if (!(sorted = sort_cells_radix(c, q, noSide ? 0 : 1, recs))) return -1;
+            if (!(sorted = sort_cells_radix(c, q, 1, recs))) return -1;
         } else {
             hipLaunchKernelGGL(k_cell_count, g, b, 0, q, c->P, recs, (const GridHeader *)c->dHdr, c->dCellId,
                                c->dSortedIndex /* arrival: dead before k_cell_rank_gather writes the index */, c->dCellCount, take_stamps(c, q));
             HIPCHK(hipGetLastError());
-            if (launch_scan_on<int>(c, noSide ? 0 : 1, q, c->dCellCount, nCells, c->dCellStart, NULL, 1, take_stamps(c, q))) return -1;
+            if (launch_scan_on<int>(c, 1, q, c->dCellCount, nCells, c->dCellStart, NULL, 1, take_stamps(c, q))) return -1;
             hipLaunchKernelGGL(k_cell_scatter, g, b, 0, q, (const GridHeader *)c->dHdr, (const int *)c->dCellId,
                                (const int *)c->dSortedIndex, (const int *)c->dCellStart,
                                recs.records ? (const int *)NULL : (const int *)c->dSlotOfVertex, c->dUnsorted);
@@ -1604,11 +1569,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:415-545 without the merge (:530-538) in wavefront mode */
     if (!c || !c->inIteration) return fail("vcm_trace_camera", "no iteration in progress");
     if (use_device(c)) return -1;
-    /* SMALLVCM_AMD_SPLATS_AFTER_K3=1 (measurement switch): K1c / K1d start when K3 has ENDED -- beside K3b / K4 instead of beside K3 */
-    static int splatsAfterK3 = -1;
-    if (splatsAfterK3 < 0) { const char *e = getenv("SMALLVCM_AMD_SPLATS_AFTER_K3"); splatsAfterK3 = (e && e[0] == '1') ? 1 : 0; }
-    const bool deferSplats = splatsAfterK3 && c->P.wavefront && !c->lightTraceOnly && !c->renderer;
-    if (!deferSplats && flush_light_splats(c)) return -1;
+    if (flush_light_splats(c)) return -1;
     c->cameraTraced = true;
     if (c->lightTraceOnly) return 0;
     int blocks, chunk;
@@ -1643,16 +1604,12 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
         }
         LAUNCH_SC_MODE(c, k_camera_trace, 1, dim3(blocks), dim3(VCM_TRACE_BLOCK), 0, c->stream, c->dScene, c->P,
                            c->store, grid_of(c), c->vs, c->dCamOut, c->dCamMask, c->dRngCam, c->dStats, chunk, take_stamps(c, c->stream));
-        if (deferSplats && flush_light_splats(c)) return -1;
         if (mark(c, EV_CAMERA_K1)) return -1;
         if (c->useVC) {   /* K3b, K3c: dense DI / VC tasks */
             /* K3c reads what K3 appended and the light store, and only K5 reads what it writes: it runs on the splat
                stream, next to K3b and K4, joined before K5: +2 % at 512^2, +6 % at 1024^2 (profiles/archive/r05d_ab_summary.txt);
                at 2048^2, where K4 is issue-bound, it neither gains nor loses with equal stream priorities (r05f) and gained
-               1.4 % with the helper streams at low priority (r05l).  SMALLVCM_AMD_VC_STREAM=0: in line. */
-            static int vcForce = -2;
-            if (vcForce == -2) { const char *e = getenv("SMALLVCM_AMD_VC_STREAM"); vcForce = e ? (e[0] == '1' ? 1 : 0) : -1; }
-            const bool vcAside = (vcForce != 0);
+               1.4 % with the helper streams at low priority (r05l). */
             /* with the histogram done in K3 (countedInCamera) and one DI task per camera vertex (every vertex of a
                VC algorithm has one unless minPathLength cuts it off), K3b also does the scatter of the query sort */
             c->scatteredInDI = c->countedInCamera && c->P.minLen <= 2;
@@ -1664,10 +1621,9 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                costs) and K3b scatters the sorted order as it goes.  At 2048^2 the in-line scan shared the memory system with the
                tail of the counting-sort grid build and took 0.9 ms (r06d); beside the radix-sort build it takes 0.1-0.2 ms and
                frees the side stream, whose scan + k_query_scatter (0.42 ms behind the build) were what K4 waited for: in line
-               there too, +1.7 % (profiles/r11l_ab_summary.txt).  SMALLVCM_AMD_SORT_INLINE=0/1 forces either. */
-            static int sortInline = -2;
-            if (sortInline == -2) { const char *e = getenv("SMALLVCM_AMD_SORT_INLINE"); sortInline = e ? (e[0] == '1' ? 1 : 0) : -1; }
-            const bool inlineSort = c->scatteredInDI && (sortInline == 1 || (sortInline == -1 && (c->nLocal <= (1 << 20) || grid_sort_is_radix(c))));
+               there too, +1.7 % (profiles/r11l_ab_summary.txt); the side-stream form stays for large frames with the counting-sort build
+               (SMALLVCM_AMD_GRID_SORT=count). */
+            const bool inlineSort = c->scatteredInDI && (c->nLocal <= (1 << 20) || grid_sort_is_radix(c));
             if (c->countedInCamera && c->world == 1 && !inlineSort) {
                 /* The scan of the bucket table (16.8 M entries at 2048^2) and the scatter of the sorted order run on the SIDE
                    stream, behind the grid build and next to K3b: in line, between K3 and K3b, the scan took 0.9 ms -- 70 us
@@ -1686,7 +1642,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
                 c->scatteredInDI = false;
             }
             if (c->scatteredInDI && launch_scan<int>(c, c->dQueryCount, c->P.nBuckets, c->dQueryStart, NULL, 1)) return -1;
-            if (vcAside) {
+            {
                 /* behind K3 -- and behind the in-line scan of the bucket table: launched at the same moment as K3c, the scan's
                    8192 workgroups shared the chip with K3c's resident ones and took 93 + 127 us instead of ~25 at 1024^2, on the
                    critical path (profiles/r07f_timeline1024.txt) */
@@ -1700,9 +1656,6 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             LAUNCH_SC(c, k_connect_di, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
                                c->dStats, c->scatteredInDI ? (const int *)c->dQueryStart : (const int *)NULL,
                                c->scatteredInDI ? c->dSortedVertex : (int *)NULL, take_stamps(c, c->stream));
-            if (!vcAside)
-                LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->stream, c->dScene, c->P, c->vs,
-                                   c->store, c->dStats);
         }
         if (mark(c, EV_CONNECT_K1)) return -1;
     } else {
@@ -1755,20 +1708,15 @@ static int vcm_merge_impl(vcm_ctx *c)
                longest kernel, bound by its cache-line requests (VALU 0.42); the main stream is free when K3b has ended, so the
                NEXT iteration's K1 (VALU-bound) runs beside it and waits for it only when compaction is about to rewrite the grid
                header (vcm_trace_light); the next grid build and table zeroing queue behind it on the side stream, which they have
-               to.  K5 follows K4 through an event (it runs on the splat stream, see below).  Same conditions as for K5; not with
-               the slab dealing, whose counters the next vcm_begin_iteration zeroes.  (A stream of its own was the first attempt: HIP
-               gave it the splat stream's hardware queue and K4 waited for K3c, profiles/r09b_timeline2048.txt.)
-               SMALLVCM_AMD_MERGE_ASIDE=0: on the main stream as in rounds 1-4. */
-            static int mergeAsideEnv = -2, slabEnv = -1;
-            if (mergeAsideEnv == -2) { const char *e = getenv("SMALLVCM_AMD_MERGE_ASIDE"); mergeAsideEnv = e ? (e[0] == '1' ? 1 : 0) : -1; }
-            if (slabEnv < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slabEnv = (e && !strcmp(e, "slab")) ? 1 : 0; }
+               to.  K5 follows K4 through an event (it runs on the splat stream, see below).  Same conditions as for K5.  (A stream of
+               its own was the first attempt: HIP gave it the splat stream's hardware queue and K4 waited for K3c,
+               profiles/r09b_timeline2048.txt.) */
             /* Measured (profiles/r09c_ab_*.txt, pairs of 40-400 iteration runs, bit-exact): 1024^2 scene 3 1206 -> 1344 Mpaths/s
                (+11 %), 1024^2 scene 1 962 -> 1049 (+9 %), 2048^2 BPM 1240 -> 1264 (+2 %), 512^2 equal -- and 2048^2 VCM 1012 -> 989
                (-2 %): there K4 already shares the chip with K3c, and K1 beside both costs more than it hides.  So: by default up to
-               1024^2, and at any size for the algorithms without vertex connection; SMALLVCM_AMD_MERGE_ASIDE=1 forces it. */
-            { const char *e = getenv("SMALLVCM_AMD_RESOLVE_ASIDE");
-              const bool pays = mergeAsideEnv == 1 || c->nLocal <= (1 << 20) || !c->useVC;
-              mergeAside = mergeAsideEnv != 0 && pays && !(e && e[0] != '1') /* = `aside` below: K5 follows K4 through evMergeDone only there */ && c->world == 1 && !c->strictOrder && !slabEnv; }
+               1024^2, and at any size for the algorithms without vertex connection (re-measured with k_merge_pairs in round 6: forced at
+               2048^2 VCM 1129 -> 1057, profiles/r13l). */
+            mergeAside = (c->nLocal <= (1 << 20) || !c->useVC) && c->world == 1 && !c->strictOrder;   /* (the conditions of `aside` below: K5 follows K4 through evMergeDone only there) */
             hipStream_t ks = c->stream;
             if (mergeAside) {
                 if (flush_stamps(c, c->stream)) return -1;   /* the marks so far belong to what ran on the main stream */
@@ -1777,7 +1725,7 @@ static int vcm_merge_impl(vcm_ctx *c)
                 ks = c->side;
             }
             static int mergeChunk = 0;
-            if (!mergeChunk) { const char *e = getenv("SMALLVCM_AMD_MERGE_CHUNK"); mergeChunk = (e && atoi(e) > 0) ? atoi(e) : 16; }
+            if (!mergeChunk) mergeChunk = shape_knob("merge_chunk") ? shape_knob("merge_chunk") : 16;
             /* Two kernels, same bits (vcm_set_merge_kernel).  k_merge_pairs (default since round 6): every lane walks its own non-empty
                runs back to back, the accepted (query, photon) pairs of a wave are evaluated 64 at a time -- 2.73 ms against 3.23 for
                k_merge_walk, whose lanes evaluate their own queues at 38 % occupancy (profiles/r13m_kstats_2048_vcm.txt). */
@@ -1793,26 +1741,12 @@ static int vcm_merge_impl(vcm_ctx *c)
                                        c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
             }
             else {
-                /* SMALLVCM_AMD_MERGE_DEAL=slab: one contiguous eighth of the sorted queries per XCD, drawn batch by batch
-                   from eight counters (vs.count[24..31], zeroed with the queue counts), with stealing; as many workgroups
-                   as are resident (4 per CU).  Measured against the static dealing (default) on the Cornell scenes: K4's
-                   HBM traffic 6.89 -> 5.58 GB per launch, 3.155 -> 3.11 ms at 2048^2, 0.260 -> 0.229 ms at 512^2
-                   (profiles/archive/r05e_ab_summary.txt) -- and on the 10 380-triangle room, whose caustic puts thousands of
-                   photons into a few cells, 1.06 -> 1.48 ms (profiles/archive/r05f_ab_summary.txt): the queries of the hot cells
-                   are neighbours in the sorted order, i.e. ONE slab, and one XCD's L2 then serves the reads that the
-                   round-robin chunks spread over all eight.  Not the default. */
-                static int slab = -1;
-                if (slab < 0) { const char *e = getenv("SMALLVCM_AMD_MERGE_DEAL"); slab = (e && !strcmp(e, "slab")) ? 1 : 0; }
-                static int slabBlocks = 0;
-                if (!slabBlocks) { const char *e = getenv("SMALLVCM_AMD_MERGE_SLAB_BLOCKS"); slabBlocks = (e && atoi(e) >= 8) ? (atoi(e) & ~7) : 1024; }
                 if (c->intPhong)
-                    hipLaunchKernelGGL(k_merge_walk<true>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
-                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
-                                       slab ? c->vs.count + 24 : (int *)NULL);
+                    hipLaunchKernelGGL(k_merge_walk<true>, dim3(merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
+                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
                 else
-                    hipLaunchKernelGGL(k_merge_walk<false>, dim3(slab ? slabBlocks : merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
-                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream),
-                                       slab ? c->vs.count + 24 : (int *)NULL);
+                    hipLaunchKernelGGL(k_merge_walk<false>, dim3(merge_blocks(c->nLocal, c->N)), dim3(VCM_MERGE_BLOCK), 0, ks, c->dScene, c->P, grid_of(c),
+                                       c->vs, (const int *)c->dSortedVertex, (const int *)(c->dQueryStart + nb), c->dStats, mergeChunk, take_stamps(c, c->stream));
             }
         } else {
             if (mark(c, EV_SORT_K1)) return -1;
@@ -1828,10 +1762,8 @@ static int vcm_merge_impl(vcm_ctx *c)
            stream is free the moment K4 ends, so the NEXT iteration's K1 (VALU-bound, touches neither the framebuffer nor
            anything K5 reads) runs beside K5 (bound by its fetches) instead of behind it.  The next camera pass waits for
            evResolved, the next light splats follow K5 on its stream, every reader of the framebuffer joins the splat stream as
-           before.  SMALLVCM_AMD_RESOLVE_ASIDE=0: in line, as in rounds 1-4. */
-        static int asideEnv = -2;
-        if (asideEnv == -2) { const char *e = getenv("SMALLVCM_AMD_RESOLVE_ASIDE"); asideEnv = e ? (e[0] == '1' ? 1 : 0) : -1; }
-        const bool aside = asideEnv != 0 && c->world == 1 && !c->strictOrder;
+           before (sharded and strict-order contexts keep it in line). */
+        const bool aside = c->world == 1 && !c->strictOrder;
         if (aside) {
             if (!mergeAside) HIPCHK(hipEventRecord(c->evMergeDone, c->stream));   /* (else: recorded behind K4 on its own stream) */
             HIPCHK(hipEventRecord(c->evSplatWork, c->splat));    /* K1c, K1d, K3c of this iteration: the light store is dead behind it */

@@ -551,20 +551,16 @@ __device__ __forceinline__ V3 merge_query_walk(const DScene &sc, const IterParam
 }
 #endif
 
-/* How the batches (256 consecutive queries of the cell-sorted order) reach the workgroups:
- *   slabCtr == NULL  static: chunks of `chunk` batches dealt round-robin to the XCDs (k_merge_lane's scheme, rounds 1-2);
- *   slabCtr != NULL  every XCD owns one contiguous EIGHTH of the sorted queries -- a slab of space -- and its workgroups
- *                    (blockIdx & 7 = the XCD, round-robin dispatch) draw batch after batch from the slab's counter, so
- *                    the ~128 workgroups resident on an XCD always work on ~128 consecutive batches and find each
- *                    other's photons in that XCD's L2; a workgroup whose slab is exhausted STEALS from the next slabs
- *                    (the contiguous ranges of round 1 had no stealing: the XCDs that owned the dense regions formed a
- *                    long tail, 6.8 ms).  Which workgroup evaluates a query does not matter: every query has its own
- *                    output slot. */
+/* The batches (256 consecutive queries of the cell-sorted order) reach the workgroups in chunks of `chunk` batches dealt round-robin to
+ * the XCDs (workgroup i runs on XCD i mod 8, and each XCD has its own L2: a region's photons are fetched into ONE L2 and reused by the
+ * neighbouring queries, while dense regions, which span many chunks, are still spread over all XCDs).  (One contiguous eighth of the
+ * sorted queries per XCD drawn from eight counters with stealing -- SMALLVCM_AMD_MERGE_DEAL=slab, rounds 3-5 -- moved 19 % less HBM
+ * traffic and was 1.5 % faster on the Cornell scenes and 40 % slower on a mesh with a caustic: retired in round 6,
+ * profiles/archive/r05e_ab_summary.txt, r05f_ab_summary.txt.) */
 template <bool IP>
 __global__ void __launch_bounds__(VCM_MERGE_BLOCK) VCM_K4_ATTR
 k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexStore vs,
-             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st,
-             int *slabCtr)
+             const int *__restrict__ sortedVertex, const int *__restrict__ nSorted, unsigned long long *gstats, int chunk, StampArgs st)
 {
     stamp_entry(st);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -572,35 +568,14 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
     const int nQ = *nSorted;
     __shared__ uint32_t accQ[(VCM_WALK_Q + 1) * VCM_MERGE_BLOCK];
     __shared__ WalkRun runs[8 * VCM_MERGE_BLOCK];
-    __shared__ int sBatch;
     MergeScratch ms; ms.q = accQ + threadIdx.x; ms.stride = VCM_MERGE_BLOCK; ms.cap = VCM_WALK_Q;
     LaneStats ls; lane_stats_zero(ls);
     const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
     const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
-    const int perSlab = (nBatches + 7) / 8;
     for (int t = wgOfXcd;; t += wgPerXcd) {
-        int b;
-        if (slabCtr) {
-            if (threadIdx.x == 0) {
-                int got = -1;
-                for (int v = 0; v < 8 && got < 0; v++) {   /* own slab first, then the others in turn */
-                    const int s2 = (xcd + v) & 7;
-                    const int lo = s2 * perSlab, hi = min(nBatches, lo + perSlab);
-                    if (lo >= hi) continue;
-                    const int k = atomicAdd(&slabCtr[s2], 1);
-                    if (lo + k < hi) got = lo + k;
-                }
-                sBatch = got;
-            }
-            __syncthreads();
-            b = sBatch;
-            __syncthreads();   /* everybody has read it before thread 0 draws again */
-            if (b < 0) break;
-        } else {
-            b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
-            if ((t / chunk) * 8 * chunk >= nBatches) break;
-            if (b >= nBatches) continue;
-        }
+        const int b = ((t / chunk) * 8 + xcd) * chunk + (t % chunk);
+        if ((t / chunk) * 8 * chunk >= nBatches) break;
+        if (b >= nBatches) continue;
         const int q = b * VCM_MERGE_BLOCK + (int)threadIdx.x;
         if (q < nQ) {   /* the runs of a lane are private to it: no barrier */
             const int vi = sortedVertex[q];
@@ -655,13 +630,8 @@ struct PairLds {
     float acc[3 * VCM_MERGE_BLOCK];
     PairEntry ring[(VCM_MERGE_BLOCK / 64) * VCM_PAIR_RING];
     vcm_f4 mat[VCM_PAIR_MATERIALS * 2];           /* {diffuse / pi, phongExp}, {rho, -} */
-#if defined(VCM_PAIRS_PAD_LDS)
-    char pad[VCM_PAIRS_PAD_LDS];                  /* measurement build: fewer workgroups per CU */
-#else
-#define VCM_PAIRS_PAD_LDS 0
-#endif
 };
-static_assert(sizeof(PairLds) <= 40960 + VCM_PAIRS_PAD_LDS, "four workgroups per CU");
+static_assert(sizeof(PairLds) <= 40960, "four workgroups per CU");
 struct PairBatch { uint32_t meta; MergePhoton ph; bool valid; };
 
 /* the end of probe j's cell, for a run whose 16-bit length saturated (a cell with 65535 photons or more: a caustic, a point
@@ -849,15 +819,9 @@ __device__ __forceinline__ void merge_pairs_push(const IterParams &P, const Grid
             cnt += add;
             waveAccepted += (uint32_t)add;
             if (cnt >= 64) {
-#if !defined(VCM_PAIRS_ABLATE)
                 if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
-#endif
                 const int headWas = head;
-#if defined(VCM_PAIRS_ABLATE) && VCM_PAIRS_ABLATE >= 2
-                head = (head + 64) & (VCM_PAIR_RING - 1); cnt -= 64;   /* measurement build: pairs dropped */
-#else
                 merge_pairs_issue(g, ring, lane, head, cnt, pb);
-#endif
                 inflight = true;
                 /* the entries of this column that did not fit open the next batch */
                 const bool left = acc && rel >= 64;
@@ -944,16 +908,8 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
         vcm_f4 AX, AY, AZ, BX, BY, BZ;
         VCM_PAIR_LOAD(AX, AY, AZ, it0.lo)
         VCM_PAIR_LOAD(BX, BY, BZ, it1.lo)
-#if defined(VCM_PAIRS_DEPTH3)
-        vcm_f4 CX, CY, CZ;
-        VCM_PAIR_LOAD(CX, CY, CZ, it2.lo)
-        PairPos it3 = merge_pairs_next(P, g, L, tid, n, qp, probes, it2);
-#define VCM_PAIR_AHEAD it3
-#define VCM_PAIR_SHIFT it0 = it1; it1 = it2; it2 = it3; it3 = merge_pairs_next(P, g, L, tid, n, qp, probes, it3);
-#else
 #define VCM_PAIR_AHEAD it2
 #define VCM_PAIR_SHIFT it0 = it1; it1 = it2; it2 = merge_pairs_next(P, g, L, tid, n, qp, probes, it2);
-#endif
 #define VCM_PAIR_STEP(SX, SY, SZ)                                                                                              \
         {                                                                                                                      \
             float d0, d1, d2, d3;                                                                                              \
@@ -973,25 +929,16 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
             VCM_PAIR_STEP(AX, AY, AZ)
             if (!wave_any(it0.lo < it0.hi)) break;
             VCM_PAIR_STEP(BX, BY, BZ)
-#if defined(VCM_PAIRS_DEPTH3)
-            if (!wave_any(it0.lo < it0.hi)) break;
-            VCM_PAIR_STEP(CX, CY, CZ)
-#endif
         }
 #undef VCM_PAIR_STEP
 #undef VCM_PAIR_LOAD
 #undef VCM_PAIR_AHEAD
 #undef VCM_PAIR_SHIFT
-#if defined(VCM_PAIRS_ABLATE)
-        if (inflight) L.acc[tid] = pb.ph.b.x + pb.ph.c.x + pb.ph.dVM;   /* measurement build: the gathers stay live */
-        cnt = 0;
-#else
         if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
         while (cnt > 0) {
             merge_pairs_issue(g, ring, lane, head, cnt, pb);
             merge_pairs_eval<IP>(P, L, waveBase, pb);
         }
-#endif
         if (q < nQ) {
             const V3 contrib = mk3(L.acc[tid], L.acc[VCM_MERGE_BLOCK + tid], L.acc[2 * VCM_MERGE_BLOCK + tid]);
             const V3 v = thr * P.vmNormalization * contrib;

@@ -20,47 +20,25 @@ HOST = os.path.join(ROOT, "smallvcm_amd", "host", "vcm_render")
 # (scene, algorithm name, oracle algorithm id, resolution, iterations)
 CONFIGS = [(1, "vcm", 4, 256, 2), (3, "bpm", 2, 192, 2)]
 SWITCHES = [
-    "SMALLVCM_AMD_MERGE_DEAL=slab",            # k_merge_walk: one slab of the sorted queries per XCD, with stealing
-    "SMALLVCM_AMD_MERGE_DEAL=slab SMALLVCM_AMD_MERGE_SLAB_BLOCKS=64",
     "SMALLVCM_AMD_MERGE=walk",                 # k_merge_walk (the default is k_merge_pairs)
-    "SMALLVCM_AMD_MERGE_CHUNK=3",
-    "SMALLVCM_AMD_MERGE_BLOCKS=64",
     "SMALLVCM_AMD_NO_RECTS=1",                 # the Pluecker filter (SceneQuads kernels) instead of the rectangles
     "SMALLVCM_AMD_NO_RECTS=1 SMALLVCM_AMD_NO_ONEPLANE=1",   # ... and the general list (SceneList kernels)
     "SMALLVCM_AMD_FORCE_BVH=1",                # the boxes through the BVH kernels
     "SMALLVCM_AMD_GENERAL_POW=1",              # the kernels that keep the general powf (non-integer Phong exponents)
     "SMALLVCM_AMD_GENERAL_POW=1 SMALLVCM_AMD_FORCE_BVH=1",   # SceneBvhG
-    "SMALLVCM_AMD_NO_SIDE=1",                  # grid build in line
-    "SMALLVCM_AMD_STREAM_PRIO=1",
-    "SMALLVCM_AMD_SPLAT_STREAM=0",             # light splats in line
-    "SMALLVCM_AMD_VC_STREAM=1",
-    "SMALLVCM_AMD_VC_STREAM=0",
-    "SMALLVCM_AMD_NO_K1_BBOX=1",               # k_bbox instead of the box K1 keeps
-    "SMALLVCM_AMD_TRACE_WAVES=512 SMALLVCM_AMD_TRACE_CHUNK=64",
-    "SMALLVCM_AMD_LIGHT_WAVES=1024",
-    "SMALLVCM_AMD_TASK_BLOCKS=96",
     "SMALLVCM_AMD_SPLAT_LONG=8",
-    "SMALLVCM_AMD_NO_STAMPS=1",
     "SMALLVCM_AMD_TIMING=events",
     "SMALLVCM_AMD_STRICT_ORDER=1 SMALLVCM_AMD_ARENAS=1",
-    # round 5
-    "SMALLVCM_AMD_SORT_INLINE=0",              # the query sort's scan + scatter on the side stream whatever the frame size
-    "SMALLVCM_AMD_SORT_INLINE=1",
-    "SMALLVCM_AMD_BUCKETS_PER_PATH=16",
-    "SMALLVCM_AMD_BUCKETS_PER_PATH=1",
-    "SMALLVCM_AMD_AUX_BLOCKS=64",
-    "SMALLVCM_AMD_MERGE_BLOCKS=16384 SMALLVCM_AMD_TASK_BLOCKS=3072 SMALLVCM_AMD_TRACE_WAVES=4096",   # the launch shapes of a 2048^2 frame
-    "SMALLVCM_AMD_MERGE_ASIDE=0",              # K4 on the main stream (rounds 1-4) instead of on the side stream beside the next K1
-    "SMALLVCM_AMD_MERGE_ASIDE=1",              # ... forced (the default decides by frame size and algorithm)
-    "SMALLVCM_AMD_RESOLVE_ASIDE=0",            # K5 in line on the main stream (rounds 1-4) instead of on the splat stream beside the next K1
-    "SMALLVCM_AMD_SPLATS_AFTER_K3=1",          # measurement: K1c / K1d start when K3 has ended
-    "SMALLVCM_AMD_HELPER_CUS=4",               # measurement: the helper streams on half of the CUs (hipExtStreamCreateWithCUMask)
     "SMALLVCM_AMD_GRID_SORT=count",            # HashGrid::Build as rounds 1-5 did it: a counter per cell, one atomic per vertex, a ranking pass
-    "SMALLVCM_AMD_GRID_SORT_BLOCKS=1",         # the radix sort with ONE workgroup: ~70 000 vertices = 35 tiles in a row
-    "SMALLVCM_AMD_GRID_SORT_BLOCKS=7",         # chunks that are not a multiple of the tile
-    "SMALLVCM_AMD_GRID_SORT_BLOCKS=4096",      # more workgroups than 256-vertex chunks: most of them have nothing to do
-    "SMALLVCM_AMD_GRID_SORT=count SMALLVCM_AMD_SORT_INLINE=0 SMALLVCM_AMD_RESOLVE_BLOCKS=2048",   # the launch plan of the round-4 build
-    "SMALLVCM_AMD_RESOLVE_BLOCKS=3",
+    # launch shapes, all through the ONE switch (round 6; rounds 2-5: ten variables)
+    "SMALLVCM_AMD_SHAPE=trace_waves=512,trace_chunk=64,light_waves=1024,task_blocks=96",
+    "SMALLVCM_AMD_SHAPE=merge_blocks=64,merge_chunk=3,aux_blocks=64,resolve_blocks=3,buckets_per_path=1",
+    "SMALLVCM_AMD_SHAPE=merge_blocks=16384,task_blocks=3072,trace_waves=4096,buckets_per_path=16",   # the launch shapes of a 2048^2 frame
+    "SMALLVCM_AMD_SHAPE=grid_sort_blocks=1",   # the radix sort with ONE workgroup: ~70 000 vertices = 35 tiles in a row
+    "SMALLVCM_AMD_SHAPE=grid_sort_blocks=7",   # chunks that are not a multiple of the tile
+    "SMALLVCM_AMD_SHAPE=grid_sort_blocks=4096",   # more workgroups than 256-vertex chunks: most of them have nothing to do
+    "SMALLVCM_AMD_GRID_SORT=count SMALLVCM_AMD_SHAPE=resolve_blocks=2048,merge_blocks=64",
+    "SMALLVCM_AMD_MERGE=walk SMALLVCM_AMD_SHAPE=merge_blocks=64,merge_chunk=3",
 ]
 
 _oracle_cache = {}
@@ -91,7 +69,7 @@ def test_switch_renders_the_default_frames(tmp_path, switch):
     strict = False
     if switch != "(default)":
         for kv in switch.split():
-            k, v = kv.split("=")
+            k, v = kv.split("=", 1)
             env[k] = v
             strict = strict or k == "SMALLVCM_AMD_STRICT_ORDER"
     for cfg in CONFIGS:
