@@ -193,6 +193,29 @@ def test_merge_kernels_equal_oracle(sid, algo, res, nit, mx, kind):
     r.close()
 
 
+def test_merge_kernels_agree_on_cells_with_more_than_65535_photons():
+    """k_merge_pairs keeps a lane's cell runs in LDS as {start, 16-bit length}; a run of 65535 or more saturates and the lane
+    re-reads the cell's end when it gets there (merge_pairs_run_end) -- caustics and point lights next to a wall make such cells.
+    A merge radius of 0.6 scene radii puts the whole Cornell box into a handful of cells: 310 000 light vertices, the
+    fullest cell far beyond 65535.  Both kernels, same bits, same counters (k_merge_walk keeps 32-bit ranges)."""
+    frames, stats, fullest = {}, {}, 0
+    for kind in ("walk", "pairs"):
+        r = VertexCM(cornell_scene(1, 384, 384), VertexCM.kBpm, 0.6, 0.75, 1234)
+        r.backend.set_merge_kernel(kind)
+        r.mMaxPathLength = 10
+        r.RunIteration(0)
+        frames[kind] = r.framebuffer_sum()
+        stats[kind] = r.stats()
+        cs, _, _ = r.backend.grid()
+        fullest = int(np.diff(cs.astype(np.int64)).max())
+        r.close()
+    assert fullest > 65535 * 1.5, fullest
+    for k in ("mergeQueries", "mergeCandidates", "mergeAccepted"):
+        assert stats["walk"][k] == stats["pairs"][k], (k, stats["walk"][k], stats["pairs"][k])
+    assert stats["pairs"]["mergeAccepted"] > 10_000_000
+    assert np.array_equal(frames["walk"].view(np.uint32), frames["pairs"].view(np.uint32))
+
+
 @pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not shipped")
 @pytest.mark.parametrize("sid,algo,res,nit", [(1, 4, 128, 2), (3, 4, 128, 1), (0, 2, 96, 1), (2, 1, 96, 2), (1, 3, 96, 1)])
 @pytest.mark.parametrize("strict", [False, True], ids=["wavefront", "strict"])
