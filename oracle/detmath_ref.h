@@ -19,7 +19,7 @@
  * the dynamic linker picks on this host: binary64 evaluation, every multiply-add fused, one rounding to binary32.
  * libm is a third-party dependency absent from /root/reference; the restatement is PINNED against the libm of this
  * image: oracle/libm_check.c, all 2^32 arguments of sinf / cosf / sincosf, 19 x 2^32 argument pairs of powf, no
- * difference (profiles/r06_libm_check.txt).  One deviation (dmr_powf): integer exponents 1..65536 are the correctly
+ * difference (profiles/archive/r06_libm_check.txt).  One deviation (dmr_powf): integer exponents 1..65536 are the correctly
  * rounded power (binary exponentiation in binary64), which glibc's powf misses by one ulp for 0.17 % of the arguments.
  */
 #ifndef ORACLE_DETMATH_REF_H

@@ -15,7 +15,7 @@ iteration (iteration 0, seed 1234, maxPathLength 10), same random numbers:
              round once" (liboracle_cr.so) against the checker (liboracle.so): paths whose random-float count differs,
              RMSE.
 
-    make -C oracle glibc && python oracle/libm_tolerance.py [--full]   -> profiles/r06_libm_tolerance.json
+    make -C oracle glibc && python oracle/libm_tolerance.py [--full]   -> profiles/archive/r06_libm_tolerance.json
 (--full adds the two 2048^2 configurations C3 and C4: the serial reference takes a few minutes for each.)
 Rounds 2-3 (binary32 polynomials, <= 1.9 ulp) measured RMSE 2.2e-4 at C1 and 7.9e-5 at C4 with this tool
 (profiles/archive/r05_libm_tolerance.json)."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The scene loader (plain C++: smallvcm_amd/csrc/scene_file.cpp + scene_cornell.cpp) under AddressSanitizer + UBSan against 6000
-# mangled files.  Round 4: no report (profiles/r06_loader_asan.txt).
+# mangled files.  Round 4: no report (profiles/archive/r06_loader_asan.txt).
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 mkdir -p /tmp/asan

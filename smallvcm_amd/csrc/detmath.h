@@ -23,7 +23,7 @@
 // PINNED against that libm itself: oracle/libm_check.c compares the restatement with the host's sinf, cosf, sincosf
 // over ALL 2^32 arguments and with powf over 19 x 2^32 argument pairs (every x for the exponents the path uses and a
 // dozen others, 2^32 random bit patterns, 2^32 pairs spanning overflow to underflow): no difference
-// (profiles/r06_libm_check.txt); tests/test_rng_detmath.py keeps a sampled version under test.
+// (profiles/archive/r06_libm_check.txt); tests/test_rng_detmath.py keeps a sampled version under test.
 //
 // ONE deliberate deviation, for the GPU's sake: a POSITIVE INTEGER exponent n <= 65536 (the Phong lobe: pow(x, 90),
 // bsdf.hxx:317, :445, utils.hxx:111 -- evaluated once per accepted photon of the merge, 2 x 10^8 times per iteration)

@@ -438,7 +438,7 @@ static int ensure_device(vcm_ctx *c)
         if (c->ownStream) HIPCHK(hipStreamCreate(&c->stream));
         for (int i = 0; i < EV_COUNT; i++) HIPCHK(hipEventCreate(&c->ev[i]));
         /* the helper streams: equal priorities (lowest priority for them bought 0.5-0.9 % at 2048^2 and cost 28 % at 512^2, a CU mask
-           for them cost 7-12 %: profiles/archive/r05k_prio.txt, r05r_configs.txt, profiles/r07l_ab_2048_vcm_s1.txt; both switches retired in round 6) */
+           for them cost 7-12 %: profiles/archive/r05k_prio.txt, r05r_configs.txt, profiles/archive/r07l_ab_2048_vcm_s1.txt; both switches retired in round 6) */
         HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&c->splat, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->evSortFork, hipEventDisableTiming));
@@ -671,7 +671,7 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPa
        3072 waves a third of the lanes take a second path: K3 0.41 -> 0.36 ms (profiles/archive/r05c_ab_summary.txt; at 1024^2
        4096 is best) */
     /* ... and so does 1024^2 (round 5): 3072 waves and chunks of 128 -- a third of the chunks dealt dynamically -- K3 0.83 -> 0.72 ms
-       on scene 3, 1.02 -> 0.82 on scene 1 (1068 -> 1116 and 808 -> 896 Mpaths/s, profiles/r07g_ab_1024_*.txt); no effect at 2048^2 */
+       on scene 3, 1.02 -> 0.82 on scene 1 (1068 -> 1116 and 808 -> 896 Mpaths/s, profiles/archive/r07g_ab_1024_*.txt); no effect at 2048^2 */
     if (!tw && nLocal <= (1 << 20)) maxWaves = 256 * 12;
     const int lw = shape_knob("light_waves");   /* K1 needs fewer registers than K3: 5 waves per SIMD fit */
     if (lightPass && lw) maxWaves = lw;
@@ -689,7 +689,7 @@ static void trace_launch_shape(int nLocal, int *blocks, int *chunk, bool lightPa
     const int ce = shape_knob("trace_chunk");
     if (ce) ch = ce;
     /* up to 1024^2 (round 5): chunks of 128.  At 1024^2 a third of the 8192 chunks is then dealt dynamically; at 512^2 it means
-       2048 waves with two paths per lane instead of 3072 with one and a third (584 -> 608 Mpaths/s, profiles/r07h_ab_512_vcm_s1.txt;
+       2048 waves with two paths per lane instead of 3072 with one and a third (584 -> 608 Mpaths/s, profiles/archive/r07h_ab_512_vcm_s1.txt;
        chunks of 64: 566) */
     if (!ce && !tw && nLocal <= (1 << 20)) {
         ch = 128;
@@ -1002,7 +1002,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
     {
         const int perPath = shape_knob("buckets_per_path");   /* buckets of the query sort per path */
         /* (round 5: 4 buckets per path up to 1024^2 -- the in-line scan of the table is on the critical path there: 1024^2 scene 3
-           1123 -> 1188 Mpaths/s, 512^2 588 -> 605, profiles/r07h_ab_*.txt; 16 from 2^21 paths, where it makes no difference) */
+           1123 -> 1188 Mpaths/s, 512^2 588 -> 605, profiles/archive/r07h_ab_*.txt; 16 from 2^21 paths, where it makes no difference) */
         const int per = perPath ? perPath : (c->nLocal > (1 << 20) ? 16 : 4);
         long long nb = (long long)per * c->nLocal;
         if (nb < (1 << 18)) nb = 1 << 18;
@@ -1036,7 +1036,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
 static int task_blocks(int nLocal)
 {
     const int n = shape_knob("task_blocks");
-    /* Small frames (round 5, profiles/r07c_ab_*.txt, r07d_ab_*.txt; 400-iteration runs): rounds 1-4 kept 2048 workgroups up to
+    /* Small frames (round 5, profiles/archive/r07c_ab_*.txt, r07d_ab_*.txt; 400-iteration runs): rounds 1-4 kept 2048 workgroups up to
        1024^2 -- 8192 waves where ~6144 are resident, for one or two tasks per thread, next to K3c / K4 which want wave slots at
        the same time.  512 workgroups at 512^2 (five tasks per thread; 256 / 384 / 512 / 768 / 1024 / 1536 / 2048: 531 / 534 /
        543 / 503 / 497 / 447 / 426 Mpaths/s) and 1024 at 1024^2 (512 / 768 / 1024 / 1536 / 2048 / 3072: 1013 / 1036 / 1070 / 1006 /
@@ -1056,7 +1056,7 @@ static int merge_blocks(int nLocal, int N)
     /* smaller frames have fewer batches than that.  2048 until round 4 (16384 at 1024^2: 0.40 -> 1.08 ms, r03m); round 5
        measured the small end: 512^2 with 512 / 768 / 1024 / 1536 / 2048 / 4096 workgroups: K4 0.18 / 0.19 / 0.21 / 0.24 / 0.27 /
        0.31 ms (571 / 559 / 543 / 529 / 497 / 475 Mpaths/s with 512 task workgroups); 1024^2 scene 3 with 1024 / 2048 / 4096 /
-       8192: K4 0.40 / 0.42 / 0.52 / 0.86 ms (profiles/r07d_ab_*.txt) */
+       8192: K4 0.40 / 0.42 / 0.52 / 0.86 ms (profiles/archive/r07d_ab_*.txt) */
     if (n) return n;
     if (nLocal >= (1 << 21)) return 16384;
     int b = (nLocal / 1024) & ~7;
@@ -1076,7 +1076,7 @@ static int aux_blocks(int nLocal)
 }
 /* K5; `heavy` = beside the next iteration's K1 with the addends of a VC algorithm to replay: with 2048
    workgroups its 8192 waves took the wave slots K1's persistent waves were about to claim.  At 2048^2 VCM (K5 replays 41 M addends, 2.3 GB) 2048 / 1024 / 768 / 512 / 256 workgroups:
-   1014 / 1035 / 1058 / 1062 / 1044 Mpaths/s (5 pairs of 40 iterations, profiles/r11l_ab_summary.txt); BPM at 2048^2, 1024^2 and
+   1014 / 1035 / 1058 / 1062 / 1044 Mpaths/s (5 pairs of 40 iterations, profiles/archive/r11l_ab_summary.txt); BPM at 2048^2, 1024^2 and
    512^2 do not care down to 512 and lose below (r11m). */
 static int resolve_blocks(int nLocal, bool heavy) { const int n = shape_knob("resolve_blocks"); return n ? n : ((heavy && nLocal >= (1 << 21)) ? 512 : aux_blocks(nLocal)); }
 /* K2's sort (vcm_kernels.h, "K2 as a radix sort"): SMALLVCM_AMD_GRID_SORT=count keeps the reference's counting sort with one
@@ -1091,7 +1091,7 @@ static int radix_sort_blocks(int nLocal)
 {
     const int forced = shape_knob("grid_sort_blocks");
     if (forced) return forced < VCM_RSORT_MAX_BLOCKS ? forced : VCM_RSORT_MAX_BLOCKS;
-    int v = nLocal / 2048;   /* ~2200 vertices per workgroup at the reference's path lengths (4096 / 2048 / 1024 / 512 workgroups at 2048^2: 1000-1009 / 1006-1016 / 1001-1022 / 1008-1019 Mpaths/s, profiles/r11h) */
+    int v = nLocal / 2048;   /* ~2200 vertices per workgroup at the reference's path lengths (4096 / 2048 / 1024 / 512 workgroups at 2048^2: 1000-1009 / 1006-1016 / 1001-1022 / 1008-1019 Mpaths/s, profiles/archive/r11h) */
     return v < 64 ? 64 : (v > VCM_RSORT_MAX_BLOCKS ? VCM_RSORT_MAX_BLOCKS : v);
 }
 /* the main stream continues only after the splat stream's K1c / K1d (before anything else touches the framebuffer) */
@@ -1167,7 +1167,7 @@ static int vcm_trace_light_impl(vcm_ctx *c)
         /* The tables the passes after K1 count into -- cells of the hash grid, pixels of the light splats, buckets of the
            query sort: 100 MB at 2048^2 -- are zeroed NOW, on the side stream next to K1 (VALU-bound, 0.9 ms).  Zeroed where
            they are used, the two memsets sat between K1 and K3 on the critical path and took 0.3 + 0.5 ms there, because
-           they shared the memory system with the light splats and the cell count (profiles/r06d_timeline2048.txt: K3
+           they shared the memory system with the light splats and the cell count (profiles/archive/r06d_timeline2048.txt: K3
            started 0.9 ms after K1 had ended).  The consumers wait for evZero on their own streams. */
         HIPCHK(hipEventRecord(c->evFork, c->stream));   /* behind the previous users of the arena */
         HIPCHK(hipStreamWaitEvent(c->side, c->evFork, 0));
@@ -1616,21 +1616,21 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             /* Small frames (round 5): K3b and K3c are grid-stride kernels whose workgroups hold every wave slot of the chip
                until they end, so a scan on another stream gets its workgroups only when K3b's are done and its second launch
                when K3c's are: at 512^2 the two launches took 101 + 169 us (12 us alone), K4 started 200 us after K3b had ended
-               and the main stream idled for 16 % of the iteration (profiles/r06t_timeline512.txt).  Up to 1024^2 the scan
+               and the main stream idled for 16 % of the iteration (profiles/archive/r06t_timeline512.txt).  Up to 1024^2 the scan
                therefore runs IN LINE between K3 and K3b (nothing else is resident at that moment: its 12-25 us are all it
                costs) and K3b scatters the sorted order as it goes.  At 2048^2 the in-line scan shared the memory system with the
                tail of the counting-sort grid build and took 0.9 ms (r06d); beside the radix-sort build it takes 0.1-0.2 ms and
                frees the side stream, whose scan + k_query_scatter (0.42 ms behind the build) were what K4 waited for: in line
-               there too, +1.7 % (profiles/r11l_ab_summary.txt); the side-stream form stays for large frames with the counting-sort build
+               there too, +1.7 % (profiles/archive/r11l_ab_summary.txt); the side-stream form stays for large frames with the counting-sort build
                (SMALLVCM_AMD_GRID_SORT=count). */
             const bool inlineSort = c->scatteredInDI && (c->nLocal <= (1 << 20) || grid_sort_is_radix(c));
             if (c->countedInCamera && c->world == 1 && !inlineSort) {
                 /* The scan of the bucket table (16.8 M entries at 2048^2) and the scatter of the sorted order run on the SIDE
                    stream, behind the grid build and next to K3b: in line, between K3 and K3b, the scan took 0.9 ms -- 70 us
                    alone, but it shared the memory system with the tail of the grid build and the light splats while the VALU
-                   idled (profiles/r06d_timeline2048.txt).  K4 waits for evSorted.  (Not a stream of its own: HIP maps the
+                   idled (profiles/archive/r06d_timeline2048.txt).  K4 waits for evSorted.  (Not a stream of its own: HIP maps the
                    streams of a process onto four hardware queues, a fifth stream shared the splat stream's and its work
-                   queued behind K3c -- at 512^2 the main stream then idled 0.3 of 1.33 ms, profiles/r06r_timeline512.txt.) */
+                   queued behind K3c -- at 512^2 the main stream then idled 0.3 of 1.33 ms, profiles/archive/r06r_timeline512.txt.) */
                 HIPCHK(hipEventRecord(c->evSortFork, c->stream));   /* behind K3 */
                 HIPCHK(hipStreamWaitEvent(c->side, c->evSortFork, 0));
                 const StampArgs none = { { NULL, NULL, NULL, NULL } };
@@ -1645,7 +1645,7 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
             {
                 /* behind K3 -- and behind the in-line scan of the bucket table: launched at the same moment as K3c, the scan's
                    8192 workgroups shared the chip with K3c's resident ones and took 93 + 127 us instead of ~25 at 1024^2, on the
-                   critical path (profiles/r07f_timeline1024.txt) */
+                   critical path (profiles/archive/r07f_timeline1024.txt) */
                 HIPCHK(hipEventRecord(c->evSplatFork, c->stream));
                 HIPCHK(hipStreamWaitEvent(c->splat, c->evSplatFork, 0));
                 LAUNCH_SC(c, k_connect_vc, dim3(task_blocks(c->nLocal)), dim3(VCM_TASK_BLOCK), 0, c->splat, c->dScene, c->P, c->vs,
@@ -1710,8 +1710,8 @@ static int vcm_merge_impl(vcm_ctx *c)
                header (vcm_trace_light); the next grid build and table zeroing queue behind it on the side stream, which they have
                to.  K5 follows K4 through an event (it runs on the splat stream, see below).  Same conditions as for K5.  (A stream of
                its own was the first attempt: HIP gave it the splat stream's hardware queue and K4 waited for K3c,
-               profiles/r09b_timeline2048.txt.) */
-            /* Measured (profiles/r09c_ab_*.txt, pairs of 40-400 iteration runs, bit-exact): 1024^2 scene 3 1206 -> 1344 Mpaths/s
+               profiles/archive/r09b_timeline2048.txt.) */
+            /* Measured (profiles/archive/r09c_ab_*.txt, pairs of 40-400 iteration runs, bit-exact): 1024^2 scene 3 1206 -> 1344 Mpaths/s
                (+11 %), 1024^2 scene 1 962 -> 1049 (+9 %), 2048^2 BPM 1240 -> 1264 (+2 %), 512^2 equal -- and 2048^2 VCM 1012 -> 989
                (-2 %): there K4 already shares the chip with K3c, and K1 beside both costs more than it hides.  So: by default up to
                1024^2, and at any size for the algorithms without vertex connection (re-measured with k_merge_pairs in round 6: forced at

@@ -93,7 +93,7 @@ struct GridStore {
     const F4 *g2;           /* throughput.xyz | dVCM */
     const F2 *g3;           /* dVM | pathLength bits */
     /* (the three as ONE array of 48-byte records -- one or two cache lines per accepted photon instead of three -- was
-       measured in round 4: K4 itself 3.0 -> 2.7 ms, the grid build's strided writes slower by as much: profiles/r06i_ab.txt) */
+       measured in round 4: K4 itself 3.0 -> 2.7 ms, the grid build's strided writes slower by as much: profiles/archive/r06i_ab.txt) */
     const GridHeader *hdr;
 };
 
@@ -130,11 +130,11 @@ struct VertexStore {
        of the longer path lengths are sparse, and a 16-byte entry read there is a 64-byte fetch from each array); three
        other layouts were measured in round 4 and none kept:  indexed by queue position (dense arrays + a 4-byte
        slot -> vertex plane) k_resolve fetched 20 % MORE -- a wave of K3 appends the vertices of 64 paths at different
-       depths, neighbouring paths' vertices of one length are not neighbours in the queue (profiles/r06v_fetch.txt);
+       depths, neighbouring paths' vertices of one length are not neighbours in the queue (profiles/archive/r06v_fetch.txt);
        one 32-byte record per slot {di.xyz, mg.xyz, first VC task, count} -35 % fetch and k_resolve 413 -> 320 us, one
        48-byte record {meta, di, mg} -23 % and 353 us -- but K3b's and K4's stores, 16 bytes next to their neighbours' in
        an array of their own, become strided partial lines: K3b 420 -> 525 / 574 us, the iteration 1.5 % / 3 % SLOWER
-       (profiles/r06w_ab_slot32.txt, r06x_ab_slot48.txt); {meta, di} as one 32-byte record that K3b writes whole, so that K3 has
+       (profiles/archive/r06w_ab_slot32.txt, r06x_ab_slot48.txt); {meta, di} as one 32-byte record that K3b writes whole, so that K3 has
        no slot store of its own: K3 -0.23 GB written, k_resolve -39 us, K3b +52 us, the iteration equal (r06y_ab_metadi.txt). */
     F4 *diOut;       /* per path slot: throughput * DirectIllumination()  (:491)   */
     F4 *vcOut;       /* per VC task:   throughput * lvThroughput * ConnectVertices() (:523) */
@@ -2396,7 +2396,7 @@ VCM_HD void merge_drain(const IterParams &P, const GridStore &g, const MergeEval
 {
     /* software-pipelined: the loads of entry k+1 are in flight while entry k is evaluated.  Unrolled by two with the two
        register sets taking turns (round 4): as a rotating pair the compiler copied the eleven registers of `nxt` into `cur`
-       every step, 10 of the step's ~150 instructions (profiles/r06n_ab.txt) */
+       every step, 10 of the step's ~150 instructions (profiles/archive/r06n_ab.txt) */
     if (!wave_any(0 < qn)) return;
     MergePhoton pa, pb;
     merge_photon_load(g, ms, 0, qn, pa);
@@ -2531,7 +2531,7 @@ VCM_HD V3 merge_query(const DScene &sc, const IterParams &P, const GridStore &g,
  * before anything is coarsened: 257 x 251 x 257 still fits 2^24.) */
 /* (Keyed by the lattice CORNER nearest to the query instead -- floor(cellPt + 0.5): the 2x2x2 block HashGrid::Process probes,
  * hashgrid.hxx:124-141, so equal keys walk the same eight buckets -- K4 was no faster and the iteration 1.5 % slower,
- * three runs of 40 iterations each way: profiles/r06k_ab.txt.  With ~2 queries per cell there is little to share.) */
+ * three runs of 40 iterations each way: profiles/archive/r06k_ab.txt.  With ~2 queries per cell there is little to share.) */
 struct QueryBuckets { uint32_t nx, ny; int sx, sy, sz; };
 VCM_HD QueryBuckets query_buckets(const IterParams &P, const GridHeader *hdr)
 {   /* wave-uniform */
@@ -2873,7 +2873,7 @@ VCM_HD bool camera_path_step(const SC &sc, const IterParams &P, CameraPath &cp, 
 #else
                 /* the place the atomic hands back goes to memory at the lane's NEXT append (or when the kernel ends): a whole bounce
                    later, so no wave waits for the round trip (stored at the end of the same step -- rounds 3-4 -- the wait was
-                   still visible at the end of the step: +0.6 %, four pairs of 40 iterations, profiles/r06zd_defer_ab.txt) */
+                   still visible at the end of the step: +0.6 %, four pairs of 40 iterations, profiles/archive/r06zd_defer_ab.txt) */
                 if (wqs.pendingVertex >= 0) vs.sortArrival[wqs.pendingVertex] = wqs.pendingArrival;
                 wqs.pendingVertex = -1;
                 if (k >= 0) { wqs.pendingVertex = vi; wqs.pendingArrival = atomicAdd(&vs.bucketCount[k], 1); }

@@ -318,9 +318,9 @@ k_eye_light(const DScene *__restrict__ scp, IterParams P, F4 *camOut, unsigned c
 #define VCM_TASK_BLOCK 256
 /* (Round 4 dealt the tasks of K3b / K3c out by (cell of the ray's origin, cell of its end point) for scenes behind a BVH --
  * a counting sort with chunk histograms in LDS.  The host replay had promised half the wave-instructions per ray
- * (profiles/r06m1_bvh_sim.txt) and the kernels delivered: K3b 850 -> 360 us, K3c 1040 -> 700 us on the mesh scene.  The two
+ * (profiles/archive/r06m1_bvh_sim.txt) and the kernels delivered: K3b 850 -> 360 us, K3c 1040 -> 700 us on the mesh scene.  The two
  * sorts cost what they saved -- 452 against 455 Mpaths/s, the same on meshes of 80 000 and 320 000 triangles -- because
- * everything behind K3 is throughput-bound there and K4 is the longest of it: profiles/r06ts_tasksort_m1.txt.  Commit ce1ce6b
+ * everything behind K3 is throughput-bound there and K4 is the longest of it: profiles/archive/r06ts_tasksort_m1.txt.  Commit ce1ce6b
  * has the code.) */
 #if defined(VCM_TASK_WAVES)   /* experiment: cap the registers of K3b / K3c for more waves per SIMD */
 #define VCM_TASK_ATTR __attribute__((amdgpu_waves_per_eu(VCM_TASK_WAVES, VCM_TASK_WAVES)))

@@ -143,7 +143,7 @@ def test_deterministic_libm_against_the_hosts_libm():
     rounded power), so the bound is asserted directly, at BASELINE's 512^2 (C1) and on the three other scenes:
       (1) the UNMODIFIED reference, its own libm (oracle/_ref/libsmallvcm_ref_tape_libm.so: nothing interposed), replays
           the oracle's tape: no desynchronisation -- every path draws the same number of random floats -- and one
-          iteration's framebuffer within RMSE 1e-6 (measured: 1e-10 .. 2e-9, profiles/r06_libm_tolerance.json);
+          iteration's framebuffer within RMSE 1e-6 (measured: 1e-10 .. 2e-9, profiles/archive/r06_libm_tolerance.json);
       (2) the oracle built over the host's libm calls (liboracle_glibc.so) against the checker: the same bound, no path
           with a different float count."""
     import os

@@ -87,7 +87,7 @@ def _same(a, b):
 def test_detmath_is_the_hosts_libm_and_product_equals_oracle():
     """detmath (round 4) RESTATES the libm of the reference's image: glibc 2.35's sinf / cosf / powf, FMA variants
     (smallvcm_amd/csrc/detmath.h, oracle/detmath_ref.h).  oracle/libm_check.c compares them over all 2^32 arguments
-    (profiles/r06_libm_check.txt: no difference); this is the sampled version that stays under test -- oracle == the host's
+    (profiles/archive/r06_libm_check.txt: no difference); this is the sampled version that stays under test -- oracle == the host's
     libm bit for bit, and product (host build of detmath.h) == oracle bit for bit.  The one deviation: integer exponents
     1..65536 are the correctly rounded power."""
     if not host_libm_is_the_restated_one():
