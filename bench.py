@@ -613,15 +613,29 @@ def cpu_port(scene, algo, res, iteration, budget_rows=8):
 
 
 def host_memory_GB():
-    """(total, available) of the host in GB, from /proc/meminfo; (None, None) if unreadable"""
+    """(total, available) in GB as THIS PROCESS may use it: /proc/meminfo capped by the container's cgroup limit (a pod on a 3 TB
+    host may own a fraction of it -- round 6 lost a box to an all-cores leg that trusted /proc/meminfo alone); (None, None) if unreadable"""
     try:
         kv = {}
         for ln in open("/proc/meminfo"):
             k, _, v = ln.partition(":")
             kv[k.strip()] = float(v.split()[0]) / 1048576.0
-        return round(kv["MemTotal"], 1), round(kv.get("MemAvailable", kv["MemFree"]), 1)
+        total, avail = kv["MemTotal"], kv.get("MemAvailable", kv["MemFree"])
     except Exception:
         return None, None
+    for lim, use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            t = open(lim).read().strip()
+            if t and t != "max":
+                cap = float(t) / 2 ** 30
+                used = float(open(use).read().strip()) / 2 ** 30
+                if cap < total:
+                    total, avail = cap, min(avail, max(cap - used, 0.0))
+            break
+        except Exception:
+            continue
+    return round(total, 1), round(avail, 1)
 
 
 REF_GB_PER_RENDERER_2048 = 1.3   # one VertexCM of the reference at 2048^2: mLightVertices 8.9 M x 120 B + the hash grid + the framebuffer
@@ -1080,7 +1094,7 @@ def main():
                 need = round(REF_GB_PER_RENDERER_2048 * cores * (res / 2048.0) ** 2, 1)
                 base["host_ram_GB"] = ram_total
                 base["all_cores_at_this_res"] = {"needed_GB": need, "present_GB": ram_total, "available_GB": ram_avail,
-                                                 "fits": bool(ram_avail is not None and need < 0.8 * ram_avail)}
+                                                 "fits": bool(ram_avail is not None and need < 0.5 * ram_avail)}   # (half: the reference's allocations peak above their steady state)
                 if threads < cores and args.cpu_all_cores_2048:
                     if base["all_cores_at_this_res"]["fits"]:
                         try:
