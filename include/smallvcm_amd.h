@@ -223,6 +223,35 @@ int vcm_set_strict_order(vcm_ctx *ctx, int on);
  * host asks this to know whether vcm_trace_camera may run before vcm_build_grid. */
 int vcm_is_wavefront(vcm_ctx *ctx, unsigned maxPathLength);
 
+/* The merge sharded by SPACE (round 6 prototype).  With the calls above every rank merges ITS pixels' camera
+ * vertices against ALL ranks' light vertices (vertexcm.hxx:532-533): the grid and the merge do not shrink with the shard.  Here rank s
+ * owns a SLAB of un-hashed grid cells along one axis -- cells [X[s], X[s+1]) -- and one cell of halo: it receives the light vertices of
+ * cells [X[s] - 1, X[s+1]] only, builds HashGrid::Build's grid over those (vcm_import_light_records + vcm_build_grid: records arrive grouped by
+ * source rank = in global index order, so the in-cell order is the reference's), receives the camera vertices whose base cell lies in its slab
+ * from every rank, evaluates RangeQuery::Process for them and sends the 16-byte terms back to the pixels' owner.  A query's accepted photons
+ * all lie in its own 2 x 2 x 2 block of cells (hashgrid.hxx:124-155), so its accepted sequence -- and the frame -- are the unsharded
+ * renderer's; the candidate COUNT is not (a hash bucket no longer holds the far-away cells that collide into it).
+ *   vcm_space_histogram          after vcm_trace_light: 256 bins of the local light vertices' coordinate along `axis` over the scene's
+ *                                bounding sphere ([*lo, *lo + 256 * *binWidth)); the ranks sum them and pick S - 1 split coordinates
+ *   vcm_space_set_slabs          after vcm_set_grid_bbox: splits[1 .. S-1] = the world coordinates where slab s begins (every rank
+ *                                passes the same values)
+ *   vcm_space_partition_light    the local light records (13 floats each) grouped by destination slab, index order inside a destination,
+ *                                halo vertices once per destination: destination d at dstDev + d * strideRecords records; counts[d] to
+ *                                the host (one stream synchronisation).  The host exchanges the groups all-to-all and hands what it received
+ *                                to vcm_import_light_records (segment s = what rank s sent), then vcm_build_grid
+ *   vcm_space_partition_queries  after vcm_trace_camera: the camera vertices (64-byte records) grouped by the slab of their base cell
+ *   vcm_space_merge              after vcm_build_grid: queriesDev = nSeg segments (rank order) of counts[s] queries at a stride of
+ *                                `stride` queries; sorts and merges them against this rank's grid; resultsDev gets the terms (16 bytes
+ *                                each) in the same layout
+ *   vcm_space_import_results     resultsDev = for every destination d the terms of the queries this rank sent to d (the layout
+ *                                vcm_space_partition_queries wrote); vcm_merge then skips its own merge and resolves */
+int vcm_space_histogram(vcm_ctx *ctx, int axis, float *lo, float *binWidth, int *hist256);
+int vcm_space_set_slabs(vcm_ctx *ctx, int axis, const float *splits, int nSlabs);
+int vcm_space_partition_light(vcm_ctx *ctx, void *dstDev, long long strideRecords, long long *counts);
+int vcm_space_partition_queries(vcm_ctx *ctx, void *dstDev, long long strideQueries, long long *counts);
+int vcm_space_merge(vcm_ctx *ctx, const void *queriesDev, const long long *counts, int nSeg, long long stride, void *resultsDev);
+int vcm_space_import_results(vcm_ctx *ctx, const void *resultsDev, long long stride);
+
 /* Which kernel evaluates the range merges (HashGrid::Process, hashgrid.hxx:110-169) in wavefront mode: both produce the
  * same bits, they differ in who evaluates an accepted photon (vcm_kernels.h; measured in DESIGN.md 5).
  * The environment variable SMALLVCM_AMD_MERGE=walk|pairs sets the default (pairs). */

@@ -175,6 +175,12 @@ struct vcm_ctx : Scratch {
     bool importedSorted;              /* vcm_import_sorted_light_records: the grid build merges the ranks' cell-sorted slabs */
     bool sortedExchange;              /* sharded context that expects the sorted exchange: K1b does not materialise the records */
     SortedSlabs sortedIn;
+    /* the merge sharded by space (round 6 prototype, include/smallvcm_amd.h "merge sharded by SPACE") */
+    SpaceSlabs space; bool spaceSet, mergeImported;
+    float presetMin[3];               /* host copy of the box vcm_set_grid_bbox installed */
+    int *dSpaceMatrix, *dSpaceScanned, *dSpaceTotals, *dSpaceHist;
+    int *dWhereDest, *dWherePos; size_t whereCap;
+    F4 *fQ, *fRes; int *fKey, *fArrival, *fSorted, *fCount; size_t fCap;   /* the queries other ranks sent, their sort, their terms */
     bool gridBuilt, cameraTraced, merged, splatsPending, recordsValid, countedInCamera, scatteredInDI, bboxPreset;
     bool bboxFromLight;               /* K1 of this iteration accumulated the vertices' box into dHdr (single rank) */
     bool bboxFinal;                   /* ... and k_compact_records has turned it into floats already */
@@ -882,6 +888,8 @@ void vcm_destroy(vcm_ctx *c)
     delete c->scene;
     c->scene = NULL;
     if (c->deviceReady) {
+        DFREE(c->dSpaceMatrix); DFREE(c->dSpaceScanned); DFREE(c->dSpaceTotals); DFREE(c->dSpaceHist); DFREE(c->dWhereDest); DFREE(c->dWherePos);
+        DFREE(c->fQ); DFREE(c->fRes); DFREE(c->fKey); DFREE(c->fArrival); DFREE(c->fSorted); DFREE(c->fCount);
         c->dScene = NULL; DFREE(c->dSceneBlob); DFREE(c->dFb); DFREE(c->dRngLight); DFREE(c->dRngCam); DFREE(c->dHdr); DFREE(c->dStatsRing); DFREE(c->dStamps);
         for (int i = 0; i < EV_COUNT; i++) (void)hipEventDestroy(c->ev[i]);
         (void)hipStreamSynchronize(c->side);
@@ -1008,6 +1016,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
         if (nb < (1 << 18)) nb = 1 << 18;
         P.nBuckets = nb < VCM_QSORT_BUCKETS ? (int)nb : VCM_QSORT_BUCKETS;
     }
+    P.foreignOut = 0;
 
     c->nPend[0] = c->nPend[1] = 0;
     if (mark(c, EV_START)) return -1;
@@ -1018,7 +1027,7 @@ static int vcm_begin_iteration_impl(vcm_ctx *c, int iteration, unsigned minLen, 
                     c->dHdr, 6 * sizeof(uint32_t) /* bboxMinU / bboxMaxU: K1 accumulates into them with atomicMax */)) return -1;
     c->importedRecords = false;
     c->importedSorted = false;
-    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->splatInFlight = c->bboxPreset = c->bboxFromLight = c->bboxFinal = c->prezeroed = c->sortInFlight = false;
+    c->gridBuilt = c->cameraTraced = c->merged = c->splatsPending = c->recordsValid = c->countedInCamera = c->scatteredInDI = c->gridInFlight = c->splatInFlight = c->bboxPreset = c->bboxFromLight = c->bboxFinal = c->prezeroed = c->sortInFlight = c->spaceSet = c->mergeImported = false;
     c->splatInFlight = c->resolveInFlight;   /* whoever reads the framebuffer still has the last iteration's K5 to wait for */
     c->inIteration = true;
     c->evValid = false;
@@ -1288,6 +1297,7 @@ static int vcm_set_grid_bbox_impl(vcm_ctx *c, const float *min3, const float *ma
     if (use_device(c)) return -1;
     hipLaunchKernelGGL(k_set_bbox, dim3(1), dim3(1), 0, c->stream, c->dHdr, min3[0], min3[1], min3[2], max3[0], max3[1], max3[2]);
     HIPCHK(hipGetLastError());
+    for (int k = 0; k < 3; k++) c->presetMin[k] = min3[k];
     c->bboxPreset = true;
     return 0;
 }
@@ -1670,6 +1680,180 @@ static int vcm_trace_camera_impl(vcm_ctx *c)
     return 0;
 }
 
+/* ---- the merge sharded by SPACE (round 6 prototype; include/smallvcm_amd.h, kernels: vcm_kernels.h) ---- */
+#define VCM_SPACE_BLOCKS 512
+static int space_scratch(vcm_ctx *c)
+{
+    if (c->dSpaceMatrix) return 0;
+    HIPCHK(hipMalloc((void **)&c->dSpaceMatrix, sizeof(int) * VCM_SPACE_MAX_SLABS * VCM_SPACE_BLOCKS));
+    HIPCHK(hipMalloc((void **)&c->dSpaceScanned, sizeof(int) * (VCM_SPACE_MAX_SLABS * VCM_SPACE_BLOCKS + 1)));
+    HIPCHK(hipMalloc((void **)&c->dSpaceTotals, sizeof(int) * VCM_SPACE_MAX_SLABS));
+    HIPCHK(hipMalloc((void **)&c->dSpaceHist, sizeof(int) * 256));
+    return 0;
+}
+static int space_ready(vcm_ctx *c, const char *who)
+{
+    if (!c || !c->inIteration) return fail(who, "no iteration in progress");
+    if (c->world <= 1) return fail(who, "the context is not sharded");
+    if (!c->useVM || !c->P.wavefront) return fail(who, "needs a merging algorithm in wavefront mode");
+    if (use_device(c)) return -1;
+    return space_scratch(c);
+}
+static int vcm_space_histogram_impl(vcm_ctx *c, int axis, float *lo, float *binWidth, int *hist256)
+{
+    if (space_ready(c, "vcm_space_histogram")) return -1;
+    if (axis < 0 || axis > 2 || !lo || !binWidth || !hist256) return fail("vcm_space_histogram", "bad argument");
+    if (ensure_records(c)) return -1;
+    const float R = c->scene->sceneRadius, L = c->scene->sceneCenter[axis] - R, w = 2.f * R / 256.f;
+    HIPCHK(hipMemsetAsync(c->dSpaceHist, 0, sizeof(int) * 256, c->stream));
+    hipLaunchKernelGGL(k_space_hist, dim3(VCM_SPACE_BLOCKS), dim3(256), 0, c->stream, (const float *)c->dRecordsLocal, (const int *)c->dLocalTotal, axis, L, 1.f / w, c->dSpaceHist);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hist256, c->dSpaceHist, sizeof(int) * 256, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *lo = L; *binWidth = w;
+    return 0;
+}
+static int vcm_space_set_slabs_impl(vcm_ctx *c, int axis, const float *splits, int nSlabs)
+{
+    if (space_ready(c, "vcm_space_set_slabs")) return -1;
+    if (!c->bboxPreset) return fail("vcm_space_set_slabs", "call vcm_set_grid_bbox first: slabs are ranges of cells");
+    if (axis < 0 || axis > 2 || !splits || nSlabs != c->world || nSlabs > VCM_SPACE_MAX_SLABS) return fail("vcm_space_set_slabs", "one slab per shard, at most 64");
+    SpaceSlabs &sl = c->space;
+    sl.S = nSlabs; sl.axis = axis;
+    sl.X[0] = -(1 << 30); sl.X[nSlabs] = 1 << 30;
+    for (int s2 = 1; s2 < nSlabs; s2++) {
+        const float f = floorf(c->P.invCellSize * (splits[s2] - c->presetMin[axis]));
+        int x = f < -1e9f ? -(1 << 30) : (f > 1e9f ? (1 << 30) : (int)f);
+        if (x < sl.X[s2 - 1]) x = sl.X[s2 - 1];
+        sl.X[s2] = x;
+    }
+    c->spaceSet = true;
+    return 0;
+}
+/* the stable partition of `n` elements (device count) by destination slab; the counts per destination come back to the host */
+static int space_partition(vcm_ctx *c, int kind, const char *who, const float *src, const int *nPtr, void *dstDev, long long stride, long long *counts,
+                           int *whereDest, int *wherePos)
+{
+    if (!c->spaceSet) return fail(who, "call vcm_space_set_slabs first");
+    if (!dstDev || !counts || stride < 1) return fail(who, "bad argument");
+    const int S = c->space.S, V = VCM_SPACE_BLOCKS;
+    HIPCHK(hipMemsetAsync(c->dSpaceTotals, 0, sizeof(int) * VCM_SPACE_MAX_SLABS, c->stream));
+    if (kind == 0) hipLaunchKernelGGL(k_space_count<0>, dim3(V), dim3(256), 0, c->stream, c->P, (const GridHeader *)c->dHdr, c->space, src, nPtr, c->dSpaceMatrix, c->dSpaceTotals);
+    else hipLaunchKernelGGL(k_space_count<1>, dim3(V), dim3(256), 0, c->stream, c->P, (const GridHeader *)c->dHdr, c->space, src, nPtr, c->dSpaceMatrix, c->dSpaceTotals);
+    HIPCHK(hipGetLastError());
+    if (launch_scan<int>(c, c->dSpaceMatrix, S * V, c->dSpaceScanned, NULL, 0)) return -1;
+    if (kind == 0) hipLaunchKernelGGL(k_space_scatter<0>, dim3(V), dim3(256), 0, c->stream, c->P, (const GridHeader *)c->dHdr, c->space, src, nPtr, (const int *)c->dSpaceScanned,
+                                      (float *)dstDev, stride, whereDest, wherePos);
+    else hipLaunchKernelGGL(k_space_scatter<1>, dim3(V), dim3(256), 0, c->stream, c->P, (const GridHeader *)c->dHdr, c->space, src, nPtr, (const int *)c->dSpaceScanned,
+                            (float *)dstDev, stride, whereDest, wherePos);
+    HIPCHK(hipGetLastError());
+    int h[VCM_SPACE_MAX_SLABS];
+    HIPCHK(hipMemcpyAsync(h, c->dSpaceTotals, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < S; d++) {
+        counts[d] = h[d];
+        if (h[d] > stride) return fail(who, "a destination's share exceeds the stride of the buffer");
+    }
+    return 0;
+}
+static int vcm_space_partition_light_impl(vcm_ctx *c, void *dstDev, long long strideRecords, long long *counts)
+{
+    if (space_ready(c, "vcm_space_partition_light")) return -1;
+    if (ensure_records(c)) return -1;
+    return space_partition(c, 0, "vcm_space_partition_light", (const float *)c->dRecordsLocal, (const int *)c->dLocalTotal, dstDev, strideRecords, counts, NULL, NULL);
+}
+static int vcm_space_partition_queries_impl(vcm_ctx *c, void *dstDev, long long strideQueries, long long *counts)
+{
+    if (space_ready(c, "vcm_space_partition_queries")) return -1;
+    if (!c->cameraTraced) return fail("vcm_space_partition_queries", "call vcm_trace_camera first");
+    if (c->whereCap < c->vs.qcap) {
+        if (c->dWhereDest) { (void)hipFree(c->dWhereDest); (void)hipFree(c->dWherePos); c->dWhereDest = c->dWherePos = NULL; }
+        HIPCHK(hipMalloc((void **)&c->dWhereDest, sizeof(int) * c->vs.qcap));
+        HIPCHK(hipMalloc((void **)&c->dWherePos, sizeof(int) * c->vs.qcap));
+        c->whereCap = c->vs.qcap;
+    }
+    return space_partition(c, 1, "vcm_space_partition_queries", (const float *)c->vs.q, (const int *)c->vs.count, dstDev, strideQueries, counts, c->dWhereDest, c->dWherePos);
+}
+/* K4a + K4 over the queries the other ranks sent, against this rank's grid; their terms in the queries' order */
+static int vcm_space_merge_impl(vcm_ctx *c, const void *queriesDev, const long long *counts, int nSeg, long long stride, void *resultsDev)
+{
+    if (space_ready(c, "vcm_space_merge")) return -1;
+    if (!c->gridBuilt) return fail("vcm_space_merge", "call vcm_build_grid first");
+    if (!queriesDev || !counts || !resultsDev || nSeg != c->world || stride < 1) return fail("vcm_space_merge", "bad argument");
+    long long M = 0;
+    for (int s2 = 0; s2 < nSeg; s2++) { if (counts[s2] < 0 || counts[s2] > stride) return fail("vcm_space_merge", "a count exceeds the stride"); M += counts[s2]; }
+    const size_t need = (size_t)(M > 0 ? M : 1);
+    if (c->fCap < need) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->fQ) { (void)hipFree(c->fQ); (void)hipFree(c->fRes); (void)hipFree(c->fKey); (void)hipFree(c->fArrival); (void)hipFree(c->fSorted); }
+        c->fCap = need + need / 8 + 1024;
+        HIPCHK(hipMalloc((void **)&c->fQ, sizeof(F4) * 4 * c->fCap));
+        HIPCHK(hipMalloc((void **)&c->fRes, sizeof(F4) * c->fCap));
+        HIPCHK(hipMalloc((void **)&c->fKey, sizeof(int) * c->fCap));
+        HIPCHK(hipMalloc((void **)&c->fArrival, sizeof(int) * c->fCap));
+        HIPCHK(hipMalloc((void **)&c->fSorted, sizeof(int) * c->fCap));
+    }
+    if (!c->fCount) { HIPCHK(hipMalloc((void **)&c->fCount, sizeof(int) * 32)); HIPCHK(hipMemsetAsync(c->fCount, 0, sizeof(int) * 32, c->stream)); }
+    long long at = 0;
+    for (int s2 = 0; s2 < nSeg; s2++) {   /* the segments back to back: positions = the order the terms go back in */
+        if (counts[s2] > 0)
+            HIPCHK(hipMemcpyAsync((char *)c->fQ + (size_t)at * 64, (const char *)queriesDev + (size_t)s2 * (size_t)stride * 64, (size_t)counts[s2] * 64, hipMemcpyDeviceToDevice, c->stream));
+        at += counts[s2];
+    }
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->fCount, (int)M);
+    if (join_grid(c)) return -1;
+    if (M > 0) {
+        IterParams P2 = c->P;
+        P2.foreignOut = 1;
+        VertexStore fvs = c->vs;
+        fvs.q = c->fQ; fvs.q4 = NULL; fvs.qcap = c->fCap; fvs.count = c->fCount; fvs.mergeOut = c->fRes;
+        fvs.sortHdr = NULL; fvs.sortKey = NULL; fvs.sortArrival = NULL; fvs.bucketCount = NULL;
+        const int nb = c->P.nBuckets;
+        if (c->prezeroed) HIPCHK(hipStreamWaitEvent(c->stream, c->evZero, 0));
+        if (zero_ranges(c->stream, c->dQueryCount, ((size_t)nb + 1) * sizeof(int))) return -1;
+        const StampArgs none = { { NULL, NULL, NULL, NULL } };
+        const int nLoc = (int)(M < (1ll << 30) ? M : (1ll << 30));
+        hipLaunchKernelGGL(k_query_count, dim3(aux_blocks(nLoc)), dim3(256), 0, c->stream, P2, fvs, (const GridHeader *)c->dHdr, c->fKey, c->fArrival, c->dQueryCount, none);
+        HIPCHK(hipGetLastError());
+        if (launch_scan<int>(c, c->dQueryCount, nb, c->dQueryStart, NULL, 1)) return -1;
+        hipLaunchKernelGGL(k_query_scatter, dim3(aux_blocks(nLoc)), dim3(256), 0, c->stream, fvs, (const int *)c->fKey, (const int *)c->fArrival, (const int *)c->dQueryStart, c->fSorted);
+        const int blocks = merge_blocks(nLoc, c->N);
+        int kind = c->mergeKind;
+        if (kind == VCM_MERGE_PAIRS && (int)c->scene->materials.size() > VCM_PAIR_MATERIALS) kind = VCM_MERGE_WALK;
+        const int chunk = shape_knob("merge_chunk") ? shape_knob("merge_chunk") : 16;
+        if (kind == VCM_MERGE_PAIRS) {
+            if (c->intPhong) hipLaunchKernelGGL(k_merge_pairs<true>, dim3(blocks), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, P2, grid_of(c), fvs, (const int *)c->fSorted, (const int *)(c->dQueryStart + nb), c->dStats, chunk, none);
+            else hipLaunchKernelGGL(k_merge_pairs<false>, dim3(blocks), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, P2, grid_of(c), fvs, (const int *)c->fSorted, (const int *)(c->dQueryStart + nb), c->dStats, chunk, none);
+        } else {
+            if (c->intPhong) hipLaunchKernelGGL(k_merge_walk<true>, dim3(blocks), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, P2, grid_of(c), fvs, (const int *)c->fSorted, (const int *)(c->dQueryStart + nb), c->dStats, chunk, none);
+            else hipLaunchKernelGGL(k_merge_walk<false>, dim3(blocks), dim3(VCM_MERGE_BLOCK), 0, c->stream, c->dScene, P2, grid_of(c), fvs, (const int *)c->fSorted, (const int *)(c->dQueryStart + nb), c->dStats, chunk, none);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    at = 0;
+    for (int s2 = 0; s2 < nSeg; s2++) {
+        if (counts[s2] > 0)
+            HIPCHK(hipMemcpyAsync((char *)resultsDev + (size_t)s2 * (size_t)stride * 16, (const char *)c->fRes + (size_t)at * 16, (size_t)counts[s2] * 16, hipMemcpyDeviceToDevice, c->stream));
+        at += counts[s2];
+    }
+    return 0;
+}
+static int vcm_space_import_results_impl(vcm_ctx *c, const void *resultsDev, long long stride)
+{
+    if (space_ready(c, "vcm_space_import_results")) return -1;
+    if (!c->dWhereDest || !resultsDev) return fail("vcm_space_import_results", "call vcm_space_partition_queries first");
+    hipLaunchKernelGGL(k_space_results, dim3(aux_blocks(c->nLocal)), dim3(256), 0, c->stream, c->P, c->vs, (const int *)c->dWhereDest, (const int *)c->dWherePos, (const F4 *)resultsDev, stride);
+    HIPCHK(hipGetLastError());
+    c->mergeImported = true;
+    return 0;
+}
+extern "C" int vcm_space_histogram(vcm_ctx *c, int axis, float *lo, float *binWidth, int *hist256) { g_hipFailed = false; return abort_iteration(c, vcm_space_histogram_impl(c, axis, lo, binWidth, hist256)); }
+extern "C" int vcm_space_set_slabs(vcm_ctx *c, int axis, const float *splits, int nSlabs) { g_hipFailed = false; return abort_iteration(c, vcm_space_set_slabs_impl(c, axis, splits, nSlabs)); }
+extern "C" int vcm_space_partition_light(vcm_ctx *c, void *dstDev, long long strideRecords, long long *counts) { g_hipFailed = false; return abort_iteration(c, vcm_space_partition_light_impl(c, dstDev, strideRecords, counts)); }
+extern "C" int vcm_space_partition_queries(vcm_ctx *c, void *dstDev, long long strideQueries, long long *counts) { g_hipFailed = false; return abort_iteration(c, vcm_space_partition_queries_impl(c, dstDev, strideQueries, counts)); }
+extern "C" int vcm_space_merge(vcm_ctx *c, const void *queriesDev, const long long *counts, int nSeg, long long stride, void *resultsDev) { g_hipFailed = false; return abort_iteration(c, vcm_space_merge_impl(c, queriesDev, counts, nSeg, stride, resultsDev)); }
+extern "C" int vcm_space_import_results(vcm_ctx *c, const void *resultsDev, long long stride) { g_hipFailed = false; return abort_iteration(c, vcm_space_import_results_impl(c, resultsDev, stride)); }
+
 static int vcm_merge_impl(vcm_ctx *c)
 {   /* vertexcm.hxx:530-538 for all camera vertices, then :544 */
     if (!c || !c->inIteration) return fail("vcm_merge", "no iteration in progress");
@@ -1678,7 +1862,10 @@ static int vcm_merge_impl(vcm_ctx *c)
     if (!c->lightTraceOnly) {
         bool mergeAside = false;
         if (mark(c, EV_MERGE_K0)) return -1;
-        if (c->P.wavefront && c->useVM) {
+        if (c->P.wavefront && c->useVM && c->mergeImported) {
+            /* merge sharded by space: the slabs' owners evaluated this rank's queries, vcm_space_import_results wrote their terms */
+            if (mark(c, EV_SORT_K1)) return -1;
+        } else if (c->P.wavefront && c->useVM) {
             if (!c->gridBuilt) return fail("vcm_merge", "call vcm_build_grid first");
             /* K4a: counting sort of the camera vertices by the Morton code of their base cell */
             const int nb = c->P.nBuckets;

@@ -39,6 +39,8 @@ struct IterParams {
     int   iteration;               /* aIteration as passed to RunIteration (EyeLight reads it, eyelight.hxx:61) */
     int   qblockVertex, qblockDI, qblockVC;   /* slots a wave of K3 reserves per atomic (wave_queue_alloc) */
     int   nBuckets;                /* entries of the query-sort bucket table in use (<= VCM_QSORT_BUCKETS) */
+    int   foreignOut;              /* 1: the merge kernels evaluate queries another rank sent (merge sharded by space): a query's term goes to
+                                      mergeOut[its position in the query array], not to its path slot */
 };
 
 /* device-resident hash-grid header: bbox is reduced on the device */
@@ -149,6 +151,11 @@ VCM_HD F4 &vq(const VertexStore &vs, int k, size_t i) { return k < 4 ? vs.q[i * 
 VCM_HD size_t path_slot(const IterParams &P, uint32_t pathLength, uint32_t lp)
 {
     return (size_t)(pathLength - 1u) * (size_t)P.nLocal + (size_t)lp;
+}
+/* where the merge term of camera vertex `vi` goes */
+VCM_HD size_t merge_out_slot(const IterParams &P, uint32_t pathLength, uint32_t lp, int vi)
+{
+    return P.foreignOut ? (size_t)vi : path_slot(P, pathLength, lp);
 }
 
 struct LaneStats {

@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256) k_query_count(IterParams P, VertexStore v
         if (f2u(r0.w) != 0xffffffffu) {
             k = query_sort_key(P, hdr, mk3(r0.x, r0.y, r0.z));
             if (k < 0)   /* empty query: contrib = 0 */
-                vs.mergeOut[path_slot(P, f2u(vq(vs, 1, q).w) & 0xffu, f2u(r0.w))] = mk4(0.f, 0.f, 0.f, 0.f);
+                vs.mergeOut[merge_out_slot(P, f2u(vq(vs, 1, q).w) & 0xffu, f2u(r0.w), q)] = mk4(0.f, 0.f, 0.f, 0.f);
         }
         key[q] = k;
         /* the value the atomic returns is the vertex's place in its bucket: the scatter needs no second atomic */
@@ -421,7 +421,9 @@ __global__ void __launch_bounds__(256) k_query_scatter(VertexStore vs, const int
  * order (:157-168).
  * (A wave-per-query mapping was measured too: 17 ms vs 6 ms for this one at
  * 2048^2 -- one query per wave exposes its 4 dependent memory round trips.) */
+#ifndef VCM_MERGE_BLOCK
 #define VCM_MERGE_BLOCK 256
+#endif
 /* (k_merge_lane, the lockstep kernel of round 1 -- merge_query of vcm_core.h as a task kernel, 3.93 ms at 2048^2 -- was retired in
    round 6; merge_query itself stays: the fused in-path variant k_camera_trace<0> and the host emulation run it) */
 
@@ -580,7 +582,7 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
         if (q < nQ) {   /* the runs of a lane are private to it: no barrier */
             const int vi = sortedVertex[q];
             const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
-            const size_t ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
+            const size_t ps = merge_out_slot(P, f2u(bq.w) & 0xffu, f2u(a.w), vi);
             Bsdf bsdf;
             bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
             SubPathState sps;
@@ -872,7 +874,7 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
         if (q < nQ) {
             const int vi = sortedVertex[q];
             const F4 a = vq(vs, 0, vi), bq = vq(vs, 1, vi), c = vq(vs, 2, vi), d = vq(vs, 3, vi);
-            ps = path_slot(P, f2u(bq.w) & 0xffu, f2u(a.w));
+            ps = merge_out_slot(P, f2u(bq.w) & 0xffu, f2u(a.w), vi);
             Bsdf bsdf;
             bsdf_restore(bsdf, mk3(bq.x, bq.y, bq.z), mk3(c.x, c.y, c.z), f2u(bq.w) >> 8, sc, false);
             vcm_f4 r;
@@ -953,6 +955,135 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
 /* (k_merge_staged -- a workgroup of 512 staging the cell lists of its queries through LDS behind an open-addressed table, 27 % less
    HBM traffic than the lockstep kernel and slower than it: 4.2 ms, barriers and a lockstep scan -- was retired in round 6 with the
    kernel it was measured against; the record is HISTORY.md and profiles/archive/r02c_ab_summary.txt.) */
+
+/* ---------------- the merge sharded by SPACE (round 6 prototype) ---------------- */
+/* Ranks own slabs of UN-hashed cell coordinates along one axis: slab s = cells [X[s], X[s+1]) (X[0] = -inf, X[S] = +inf).  A query in slab
+ * s probes its base cell and one neighbour per axis (hashgrid.hxx:124-155), so the slab's owner needs the photons of cells
+ * [X[s] - 1, X[s+1]]: a light vertex goes to every slab whose range, widened by one cell on both sides, holds its cell -- one, two,
+ * rarely three owners.  Both partitions below are STABLE (element order inside a destination = index order): the receiver's grid build
+ * then reproduces HashGrid::Build's in-cell order (hashgrid.hxx:83-88) on the photons it was given. */
+#define VCM_SPACE_MAX_SLABS 64
+struct SpaceSlabs { int S, axis; int X[VCM_SPACE_MAX_SLABS + 1]; };
+__device__ __forceinline__ int space_cell(const IterParams &P, const GridHeader *hdr, int axis, float coord)
+{   /* HashGrid::GetCellIndex's floor (:189-193) for one axis */
+    return int(floorf(P.invCellSize * (coord - hdr->bboxMin[axis])));
+}
+/* histogram of the local light vertices' coordinate along `axis` in 256 bins over [lo, lo + 256 / invBin) (the split points of the slabs
+   come out of the sum over the ranks) */
+__global__ void __launch_bounds__(256) k_space_hist(const float *__restrict__ records, const int *__restrict__ nPtr, int axis, float lo, float invBin, int *hist)
+{
+    __shared__ int sH[256];
+    sH[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = *nPtr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int b = int((records[(size_t)i * VCM_MERGE_RECORD_FLOATS + axis] - lo) * invBin);
+        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        atomicAdd(&sH[b], 1);
+    }
+    __syncthreads();
+    if (sH[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sH[threadIdx.x]);
+}
+/* KIND 0: light records (13 floats; halo: up to three destinations).  KIND 1: camera vertices = queries (the 4 x 16-byte record of
+   VertexStore::q; ONE destination, the slab of the base cell; holes and vertices outside the photon box have none: their merge term is 0
+   and K3 has written it). */
+template <int KIND>
+__device__ __forceinline__ void space_dest_range(const IterParams &P, const GridHeader *hdr, const SpaceSlabs &sl, const float *rec, int &d0, int &d1)
+{
+    d0 = 0; d1 = -1;
+    if (KIND == 1) {
+        const uint32_t tag = f2u(rec[3]);
+        if (tag == 0xffffffffu) return;   /* hole */
+        const V3 p = mk3(rec[0], rec[1], rec[2]);
+        const V3 dmin = p - ld3(hdr->bboxMin), dmax = ld3(hdr->bboxMax) - p;   /* hashgrid.hxx:116-122 */
+        if (dmin.x < 0.f || dmax.x < 0.f || dmin.y < 0.f || dmax.y < 0.f || dmin.z < 0.f || dmax.z < 0.f) return;
+    }
+    const int c = space_cell(P, hdr, sl.axis, rec[sl.axis]);
+    const int lo = KIND == 0 ? c - 1 : c, hi = KIND == 0 ? c + 1 : c;   /* slab s takes cells [X[s] - 1, X[s+1]] of photons, [X[s], X[s+1]) of queries */
+    int a = 0;
+    while (a + 1 < sl.S && sl.X[a + 1] <= lo) a++;   /* first slab whose end is beyond lo */
+    int b = a;
+    while (b + 1 < sl.S && sl.X[b + 1] <= hi) b++;
+    d0 = a; d1 = b;
+}
+__device__ __forceinline__ int space_chunk(int n, int V) { return (((n + V - 1) / V) + 255) & ~255; }
+template <int KIND>
+__global__ void __launch_bounds__(256) k_space_count(IterParams P, const GridHeader *__restrict__ hdr, SpaceSlabs sl, const float *__restrict__ recs,
+                                                     const int *__restrict__ nPtr, int *matrix /* [dest * V + workgroup] */, int *totals /* [dest] */)
+{
+    __shared__ int sC[VCM_SPACE_MAX_SLABS];
+    const int tid = (int)threadIdx.x, V = (int)gridDim.x, n = *nPtr;
+    const int W = KIND == 0 ? VCM_MERGE_RECORD_FLOATS : 16;
+    if (tid < VCM_SPACE_MAX_SLABS) sC[tid] = 0;
+    __syncthreads();
+    const int chunk = space_chunk(n, V);
+    const long long lo64 = (long long)blockIdx.x * chunk;
+    const int lo = lo64 < n ? (int)lo64 : n, hi = (n - lo < chunk) ? n : lo + chunk;
+    for (int i = lo + tid; i < hi; i += 256) {
+        int d0, d1;
+        space_dest_range<KIND>(P, hdr, sl, recs + (size_t)i * W, d0, d1);
+        for (int d = d0; d <= d1; d++) atomicAdd(&sC[d], 1);
+    }
+    __syncthreads();
+    if (tid < sl.S) { matrix[tid * V + (int)blockIdx.x] = sC[tid]; if (sC[tid]) atomicAdd(&totals[tid], sC[tid]); }
+}
+/* scattered[dest * V + workgroup] = the exclusive scan of `matrix` taken as ONE array (dest-major): where this workgroup's first element
+   of `dest` goes = that value - the scan's value at [dest * V] (the start of the destination's row) */
+template <int KIND>
+__global__ void __launch_bounds__(256) k_space_scatter(IterParams P, const GridHeader *__restrict__ hdr, SpaceSlabs sl, const float *__restrict__ recs,
+                                                       const int *__restrict__ nPtr, const int *__restrict__ scanned, float *out, long long strideElems,
+                                                       int *whereDest /* KIND 1: per source element its destination (-1: none) */, int *wherePos)
+{
+    __shared__ int sBase[VCM_SPACE_MAX_SLABS];   /* next position of this workgroup in every destination */
+    __shared__ int sWave[4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, V = (int)gridDim.x, n = *nPtr;
+    const int W = KIND == 0 ? VCM_MERGE_RECORD_FLOATS : 16;
+    if (tid < sl.S) sBase[tid] = scanned[tid * V + (int)blockIdx.x] - scanned[tid * V];
+    __syncthreads();
+    const int chunk = space_chunk(n, V);
+    const long long lo64 = (long long)blockIdx.x * chunk;
+    const int lo = lo64 < n ? (int)lo64 : n, hi = (n - lo < chunk) ? n : lo + chunk;
+    for (int t0 = lo; t0 < hi; t0 += 256) {   /* tiles in index order, waves in index order inside a tile: stable */
+        const int i = t0 + tid;
+        int d0 = 0, d1 = -1;
+        if (i < hi) space_dest_range<KIND>(P, hdr, sl, recs + (size_t)i * W, d0, d1);
+        if (KIND == 1 && i < hi) { whereDest[i] = d1 >= d0 ? d0 : -1; }
+        for (int d = 0; d < sl.S; d++) {   /* wave-uniform loop; most destinations take nothing from a tile */
+            const bool mine = d >= d0 && d <= d1;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            if (lane == 0) sWave[w] = (int)__popcll(m);
+            __syncthreads();
+            const int tileTotal = sWave[0] + sWave[1] + sWave[2] + sWave[3];
+            if (tileTotal) {   /* workgroup-uniform */
+                int before = 0;
+                for (int x = 0; x < w; x++) before += sWave[x];
+                if (mine) {
+                    const int pos = sBase[d] + before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    float *o = out + ((size_t)d * (size_t)strideElems + (size_t)pos) * W;
+                    const float *r = recs + (size_t)i * W;
+                    if (KIND == 1) { const F4 *r4 = (const F4 *)r; F4 *o4 = (F4 *)o; o4[0] = r4[0]; o4[1] = r4[1]; o4[2] = r4[2]; o4[3] = r4[3]; wherePos[i] = pos; }
+                    else { for (int k = 0; k < VCM_MERGE_RECORD_FLOATS; k++) o[k] = r[k]; }
+                }
+            }
+            __syncthreads();
+            if (tid == 0 && tileTotal) sBase[d] += tileTotal;
+            __syncthreads();
+        }
+    }
+}
+__global__ void k_set_int(int *p, int v) { p[0] = v; }
+/* the merge terms of this rank's queries, evaluated by the slabs' owners, back into mergeOut (what K4 would have written) */
+__global__ void __launch_bounds__(256) k_space_results(IterParams P, VertexStore vs, const int *__restrict__ whereDest, const int *__restrict__ wherePos,
+                                                       const F4 *__restrict__ results, long long strideElems)
+{
+    const int n = vs.count[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int d = whereDest[i];
+        if (d < 0) continue;
+        const F4 a = vq(vs, 0, i), b = vq(vs, 1, i);
+        vs.mergeOut[path_slot(P, f2u(b.w) & 0xffu, f2u(a.w))] = results[(size_t)d * (size_t)strideElems + (size_t)wherePos[i]];
+    }
+}
 
 /* ---------------- K5: Framebuffer::AddColor of camera colours ----------- */
 /* vertexcm.hxx:544 adds colour p to the pixel of its jittered sample, in path

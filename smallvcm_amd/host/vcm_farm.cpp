@@ -80,7 +80,20 @@ static bool exchange_is_direct()
 }
 
 // what the ranks of a group tell each other before the vertices travel: 7 numbers (hashgrid.hxx:47-61)
-struct Xchg { long long n; float mn[3], mx[3]; };
+struct Xchg { long long n; float mn[3], mx[3]; int hist[256]; };   // hist: the second exchange of the space-sharded merge (else unused)
+#define XCHG_WORDS (8 + 256)
+
+// How a sharded renderer MERGES.  SMALLVCM_AMD_FARM_MERGE =
+//   index  (default) north_star's decomposition: every rank merges its pixels' camera vertices against ALL ranks' light vertices
+//   space  round 6 prototype: ranks own slabs of grid cells; light vertices go to the owners of their cell (+ one cell of
+//          halo), camera vertices to the owner of their base cell, the 16-byte merge terms back to the pixels' owner -- the grid build and
+//          the merge shrink with the shard, three all-to-alls replace the all-gather.  Wavefront mode, merging algorithms, one renderer in
+//          flight per group.
+static bool merge_by_space()
+{
+    static const bool on = [] { const char *e = getenv("SMALLVCM_AMD_FARM_MERGE"); return e && !strcmp(e, "space"); }();
+    return on;
+}
 
 // ---- collectives of one communicator (the ranks of a group, or all ranks); `rank` = rank INSIDE the communicator ----
 class Collectives {
@@ -89,6 +102,10 @@ public:
     // every rank: `send` (floatsPerRank floats, device) -> slot `rank` of everybody's `recv` (size ranks * floatsPerRank)
     virtual bool allGather(Shared &sh, int rank, const float *send, float *recv, size_t floatsPerRank, hipStream_t s) = 0;
     virtual bool allReduceSum(Shared &sh, int rank, float *buf, size_t n, hipStream_t s) = 0;
+    // every rank: sendCounts[d] elements of `elemFloats` floats for rank d at send + d * strideElems * elemFloats -> what rank r sent to
+    // `rank` lands at recv + r * strideElems * elemFloats, recvCounts[r] = its number of elements (host values, known when the call returns)
+    virtual bool allToAllV(Shared &sh, int rank, const float *send, const long long *sendCounts, long long strideElems, int elemFloats,
+                           float *recv, long long *recvCounts, hipStream_t s) = 0;
     // before `rank` overwrites a buffer it has handed to allGather as `send`: wait (on s) until nobody reads it any more
     virtual bool sendBufferFree(Shared &sh, int rank, hipStream_t s) = 0;
     // all[r] = what rank r passed as `mine`; returns when every rank's numbers are known to the caller (host side)
@@ -200,6 +217,36 @@ public:
         NCCLOK(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, mComms[(size_t)(rank - mFirst)], s));
         return true;
     }
+    bool allToAllV(Shared &sh, int rank, const float *send, const long long *sendCounts, long long strideElems, int elemFloats,
+                   float *recv, long long *recvCounts, hipStream_t s) override
+    {
+        if (mComms.empty() || !scratch(sh, rank) || mRanks > 128) return false;
+        const size_t i = (size_t)(rank - mFirst);
+        // the counts first: every rank's row of the matrix (2 words per entry) through the small communicator, host-synchronous
+        uint32_t *host = mPinned[i], *dev = mScratch[i];
+        if (2 * mRanks > XCHG_WORDS) { sh.fail("allToAllV: more ranks than the count exchange holds"); return false; }
+        for (int d = 0; d < mRanks; d++) { host[2 * d] = (uint32_t)((unsigned long long)sendCounts[d] & 0xffffffffu); host[2 * d + 1] = (uint32_t)((unsigned long long)sendCounts[d] >> 32); }
+        ncclComm_t small = mComms[i]; hipStream_t ss = s;
+        if (!mSmallComms.empty()) { small = mSmallComms[i]; ss = mSmallStreams[i]; HIPOK(hipStreamSynchronize(s)); }
+        HIPOK(hipMemcpyAsync(dev, host, 8 * (size_t)mRanks, hipMemcpyHostToDevice, ss));
+        NCCLOK(ncclAllGather(dev, dev + XCHG_WORDS, 2 * (size_t)mRanks, ncclUint32, small, ss));
+        HIPOK(hipMemcpyAsync(host + XCHG_WORDS, dev + XCHG_WORDS, 8 * (size_t)mRanks * (size_t)mRanks, hipMemcpyDeviceToHost, ss));
+        HIPOK(hipStreamSynchronize(ss));
+        for (int r = 0; r < mRanks; r++) {
+            const uint32_t *w = host + XCHG_WORDS + 2 * ((size_t)r * (size_t)mRanks + (size_t)rank);
+            recvCounts[r] = (long long)((unsigned long long)w[0] | ((unsigned long long)w[1] << 32));
+        }
+        const size_t ef = (size_t)elemFloats, st = (size_t)strideElems * ef;
+        if (recvCounts[rank] > 0) HIPOK(hipMemcpyAsync(recv + (size_t)rank * st, send + (size_t)rank * st, (size_t)recvCounts[rank] * ef * sizeof(float), hipMemcpyDeviceToDevice, s));
+        NCCLOK(ncclGroupStart());
+        for (int d = 1; d < mRanks; d++) {
+            const int to = (rank + d) % mRanks, from = (rank - d + mRanks) % mRanks;
+            if (sendCounts[to] > 0) NCCLOK(ncclSend(send + (size_t)to * st, (size_t)sendCounts[to] * ef, ncclFloat, to, mComms[i], s));
+            if (recvCounts[from] > 0) NCCLOK(ncclRecv(recv + (size_t)from * st, (size_t)recvCounts[from] * ef, ncclFloat, from, mComms[i], s));
+        }
+        NCCLOK(ncclGroupEnd());
+        return true;
+    }
     bool sendBufferFree(Shared &, int, hipStream_t) override { return true; }   // RCCL reads `send` in stream order
     bool exchange(Shared &sh, int rank, const Xchg &mine, Xchg *all, hipStream_t s) override
     {
@@ -209,17 +256,17 @@ public:
         const size_t i = (size_t)(rank - mFirst);
         uint32_t *host = mPinned[i], *dev = mScratch[i];
         host[0] = (uint32_t)((unsigned long long)mine.n & 0xffffffffu); host[7] = (uint32_t)((unsigned long long)mine.n >> 32);
-        memcpy(host + 1, mine.mn, 12); memcpy(host + 4, mine.mx, 12);
+        memcpy(host + 1, mine.mn, 12); memcpy(host + 4, mine.mx, 12); memcpy(host + 8, mine.hist, 1024);
         ncclComm_t comm = mComms[i];
         if (!mSmallComms.empty()) { comm = mSmallComms[i]; s = mSmallStreams[i]; }   // never behind an all-gather of records
-        HIPOK(hipMemcpyAsync(dev, host, 32, hipMemcpyHostToDevice, s));
-        NCCLOK(ncclAllGather(dev, dev + 8, 8, ncclUint32, comm, s));
-        HIPOK(hipMemcpyAsync(host + 8, dev + 8, 32 * (size_t)mRanks, hipMemcpyDeviceToHost, s));
+        HIPOK(hipMemcpyAsync(dev, host, 4 * XCHG_WORDS, hipMemcpyHostToDevice, s));
+        NCCLOK(ncclAllGather(dev, dev + XCHG_WORDS, XCHG_WORDS, ncclUint32, comm, s));
+        HIPOK(hipMemcpyAsync(host + XCHG_WORDS, dev + XCHG_WORDS, 4 * XCHG_WORDS * (size_t)mRanks, hipMemcpyDeviceToHost, s));
         HIPOK(hipStreamSynchronize(s));
         for (int r = 0; r < mRanks; r++) {
-            const uint32_t *w = host + 8 + 8 * (size_t)r;
+            const uint32_t *w = host + XCHG_WORDS + XCHG_WORDS * (size_t)r;
             all[r].n = (long long)((unsigned long long)w[0] | ((unsigned long long)w[7] << 32));
-            memcpy(all[r].mn, w + 1, 12); memcpy(all[r].mx, w + 4, 12);
+            memcpy(all[r].mn, w + 1, 12); memcpy(all[r].mx, w + 4, 12); memcpy(all[r].hist, w + 8, 1024);
         }
         return true;
     }
@@ -241,9 +288,9 @@ private:
     {
         const size_t i = (size_t)(rank - mFirst);
         if (!mScratch[i]) {   // the calling rank thread has its device current
-            HIPOK(hipMalloc((void **)&mScratch[i], 32 * (size_t)(mRanks + 1)));
-            HIPOK(hipMemset(mScratch[i], 0, 32 * (size_t)(mRanks + 1)));
-            HIPOK(hipHostMalloc((void **)&mPinned[i], 32 * (size_t)(mRanks + 1), hipHostMallocDefault));
+            HIPOK(hipMalloc((void **)&mScratch[i], 4 * XCHG_WORDS * (size_t)(mRanks + 1)));
+            HIPOK(hipMemset(mScratch[i], 0, 4 * XCHG_WORDS * (size_t)(mRanks + 1)));
+            HIPOK(hipHostMalloc((void **)&mPinned[i], 4 * XCHG_WORDS * (size_t)(mRanks + 1), hipHostMallocDefault));
         }
         return true;
     }
@@ -260,7 +307,7 @@ private:
 // moves with device-to-device copies ordered by events.  Same interface, same call pattern as the RCCL class.
 class ThreadCollectives : public Collectives {
 public:
-    ThreadCollectives(Shared &sh, int ranks) : Collectives(sh, ranks, ranks), mSend((size_t)ranks, NULL), mRecv((size_t)ranks, NULL), mFree((size_t)ranks, (hipEvent_t)NULL), mReady((size_t)ranks),
+    ThreadCollectives(Shared &sh, int ranks) : Collectives(sh, ranks, ranks), mSend((size_t)ranks, NULL), mRecv((size_t)ranks, NULL), mCounts((size_t)ranks), mFree((size_t)ranks, (hipEvent_t)NULL), mReady((size_t)ranks),
                                                mDone((size_t)ranks), mHave((size_t)ranks, 0), mHost((size_t)ranks)
     {
         for (int r = 0; r < ranks; r++) { mReady[(size_t)r] = NULL; mDone[(size_t)r] = NULL; }
@@ -303,6 +350,25 @@ public:
         mHave[(size_t)rank] = 1;
         return mBar.wait();
     }
+    bool allToAllV(Shared &sh, int rank, const float *send, const long long *sendCounts, long long strideElems, int elemFloats,
+                   float *recv, long long *recvCounts, hipStream_t s) override
+    {
+        if (!events(sh, rank)) return false;
+        mSend[(size_t)rank] = send;
+        mCounts[(size_t)rank].assign(sendCounts, sendCounts + mRanks);
+        HIPOK(hipEventRecord(mReady[(size_t)rank], s));
+        if (!mBar.wait()) return false;
+        const size_t ef = (size_t)elemFloats, st = (size_t)strideElems * ef;
+        for (int r = 0; r < mRanks; r++) {   // pull what everybody has for me
+            recvCounts[r] = mCounts[(size_t)r][(size_t)rank];
+            HIPOK(hipStreamWaitEvent(s, mReady[(size_t)r], 0));
+            if (recvCounts[r] > 0)
+                HIPOK(hipMemcpyAsync(recv + (size_t)r * st, mSend[(size_t)r] + (size_t)rank * st, (size_t)recvCounts[r] * ef * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        HIPOK(hipEventRecord(mDone[(size_t)rank], s));
+        mHave[(size_t)rank] = 1;
+        return mBar.wait();
+    }
     bool sendBufferFree(Shared &sh, int rank, hipStream_t s) override
     {
         (void)rank;
@@ -335,6 +401,7 @@ private:
     }
     std::vector<const float *> mSend;
     std::vector<float *> mRecv;
+    std::vector<std::vector<long long>> mCounts;
     std::vector<hipEvent_t> mFree;
     std::vector<hipEvent_t> mReady, mDone;
     std::vector<char> mHave;   // one byte per rank: the rank threads write their own element concurrently
@@ -368,11 +435,17 @@ struct Slot {
     bool sorted;                 // this iteration uses the sorted exchange (every rank decides the same: same counts, same context shape)
     int first, count;            // iterations of this renderer
     std::vector<long long> counts;
-    long long stride, nLocal;
+    long long stride, nLocal, nLocalPaths;
     bool exchanging, live;
     Xchg mine;
+    // the merge sharded by space: send / receive buffers of the three all-to-alls (light records; queries; merge terms), S segments each
+    bool space;
+    float *spLight, *spLightIn, *spQ, *spQIn, *spRes, *spResIn;
+    long long spLightStride, spQStride;          // elements per segment the buffers hold
+    std::vector<long long> spCounts, spCountsIn, spQCounts, spQCountsIn, spResCountsIn;
     Slot() : ctx(NULL), group(NULL), stream(NULL), commStream(NULL), evRecords(NULL), evGathered(NULL), local(NULL), gathered(NULL),
-             capWords(0), slabWords(0), sorted(false), first(0), count(0), stride(0), nLocal(0), exchanging(false), live(false) {}
+             capWords(0), slabWords(0), sorted(false), first(0), count(0), stride(0), nLocal(0), exchanging(false), live(false), space(false),
+             spLight(NULL), spLightIn(NULL), spQ(NULL), spQIn(NULL), spRes(NULL), spResIn(NULL), spLightStride(0), spQStride(0) {}
 };
 
 struct RankArgs {
@@ -418,6 +491,30 @@ bool step_counts(Shared &sh, Slot &sl, int shard)
             for (int k = 0; k < 3; k++) { gmn[k] = std::min(gmn[k], all[r].mn[k]); gmx[k] = std::max(gmx[k], all[r].mx[k]); }
     }
     { GpuTurn turn(sl.stream, NULL); VCMOK(vcm_set_grid_bbox(sl.ctx, gmn, gmx)); }
+    sl.space = merge_by_space() && vcm_is_wavefront(sl.ctx, 0) && vcm_sorted_slab_words(sl.ctx, sl.stride) > 0;   // (a merging algorithm, <= 64 shards)
+    if (sl.space) {
+        // slabs of cells along the box's longest axis, split where the SUM of the ranks' histograms reaches s / S of the photons
+        int axis = 0;
+        for (int k = 1; k < 3; k++) if (gmx[k] - gmn[k] > gmx[axis] - gmn[axis]) axis = k;
+        float lo = 0.f, bw = 1.f;
+        Xchg h = sl.mine;
+        { GpuTurn turn(sl.stream, NULL); VCMOK(vcm_space_histogram(sl.ctx, axis, &lo, &bw, h.hist)); }
+        if (!sl.group->exchange(sh, shard, h, all, sl.commStream)) return false;
+        // equal photon COUNTS per slab.  (Weighing a bin by photons^1.5 .. ^3 -- the merge costs ~ photons x queries of a region -- was
+        // measured and is worse: a wall perpendicular to the axis puts a fifth of all photons into ONE cell layer, several split points
+        // fall onto that layer and slabs come out empty; profiles/r18_space_k4_shards.txt.)
+        double sum[256], total = 0;
+        for (int b = 0; b < 256; b++) { double n = 0; for (int r = 0; r < S; r++) n += all[r].hist[b]; sum[b] = n; total += n; }
+        float splits[VCM_FARM_MAX_RANKS + 1];
+        double cum = 0; int b = 0;
+        splits[0] = lo;
+        for (int s2 = 1; s2 < S; s2++) {
+            const double want = total * s2 / S;
+            while (b < 256 && cum + sum[b] <= want) { cum += sum[b]; b++; }
+            splits[s2] = lo + bw * (float)b;
+        }
+        { GpuTurn turn(sl.stream, NULL); VCMOK(vcm_space_set_slabs(sl.ctx, axis, splits, S)); }
+    }
     return true;
 }
 bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard)
@@ -430,6 +527,29 @@ bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard
     // for shapes the sorted slabs do not cover (vcm_sorted_slab_words says so; every rank of the group gets the same answer).
     GpuTurn *turn = new GpuTurn(sl.stream, NULL);
     struct Release { GpuTurn *&t; ~Release() { delete t; t = NULL; } } release = { turn };
+    if (sl.space) {
+        // light records grouped by the slab that owns their cell (+ halo), all-to-all on the communication stream beside the camera pass
+        if (sl.spLightStride < sl.stride) {
+            HIPOK(hipStreamSynchronize(sl.stream)); HIPOK(hipStreamSynchronize(sl.commStream));
+            if (sl.spLight) { (void)hipFree(sl.spLight); (void)hipFree(sl.spLightIn); }
+            sl.spLightStride = sl.stride + sl.stride / 16 + 1024;
+            const size_t bytes = (size_t)S * (size_t)sl.spLightStride * VCM_MERGE_RECORD_FLOATS * sizeof(float);
+            HIPOK(hipMalloc((void **)&sl.spLight, bytes));
+            HIPOK(hipMalloc((void **)&sl.spLightIn, bytes));
+        }
+        sl.spCounts.assign((size_t)S, 0); sl.spCountsIn.assign((size_t)S, 0);
+        if (!sl.group->sendBufferFree(sh, shard, sl.stream)) return false;
+        VCMOK(vcm_space_partition_light(sl.ctx, sl.spLight, sl.spLightStride, sl.spCounts.data()));
+        HIPOK(hipEventRecord(sl.evRecords, sl.stream));
+        HIPOK(hipStreamWaitEvent(sl.commStream, sl.evRecords, 0));
+        delete turn; turn = NULL;
+        if (!sl.group->allToAllV(sh, shard, sl.spLight, sl.spCounts.data(), sl.spLightStride, VCM_MERGE_RECORD_FLOATS, sl.spLightIn, sl.spCountsIn.data(), sl.commStream)) return false;
+        HIPOK(hipEventRecord(sl.evGathered, sl.commStream));
+        sl.exchanging = true;
+        turn = new GpuTurn(sl.stream, sl.commStream);
+        VCMOK(vcm_trace_camera(sl.ctx));
+        return true;
+    }
     static const bool allowSorted = [] { const char *e = getenv("SMALLVCM_AMD_SORTED_EXCHANGE"); return !(e && e[0] == '0'); }();
     const long long sortedWords = allowSorted ? vcm_sorted_slab_words(sl.ctx, sl.stride) : -1;
     sl.sorted = sortedWords > 0;
@@ -457,8 +577,47 @@ bool step_exchange_camera(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard
     if (vcm_is_wavefront(sl.ctx, cfg.maxLen)) VCMOK(vcm_trace_camera(sl.ctx));   // needs only the local light vertices
     return true;
 }
-bool step_finish(Shared &sh, const FarmConfig &cfg, Slot &sl)
+bool step_finish_space(Shared &sh, Slot &sl, int shard)
+{   // the merge sharded by space: own photons' grid, queries to their owners, terms back, resolve
+    const int S = sl.group->size();
+    {
+        GpuTurn turn(sl.stream, sl.commStream);
+        HIPOK(hipStreamWaitEvent(sl.stream, sl.evGathered, 0));
+        VCMOK(vcm_import_light_records(sl.ctx, sl.spLightIn, sl.spCountsIn.data(), S, sl.spLightStride));
+        VCMOK(vcm_build_grid(sl.ctx));
+        const long long want = 4 * std::max<long long>(sl.nLocalPaths, 1);
+        if (sl.spQStride < want) {
+            HIPOK(hipStreamSynchronize(sl.stream)); HIPOK(hipStreamSynchronize(sl.commStream));
+            if (sl.spQ) { (void)hipFree(sl.spQ); (void)hipFree(sl.spQIn); (void)hipFree(sl.spRes); (void)hipFree(sl.spResIn); }
+            sl.spQStride = want;
+            const size_t q = (size_t)S * (size_t)sl.spQStride;
+            HIPOK(hipMalloc((void **)&sl.spQ, q * 64)); HIPOK(hipMalloc((void **)&sl.spQIn, q * 64));
+            HIPOK(hipMalloc((void **)&sl.spRes, q * 16)); HIPOK(hipMalloc((void **)&sl.spResIn, q * 16));
+        }
+        sl.spQCounts.assign((size_t)S, 0); sl.spQCountsIn.assign((size_t)S, 0); sl.spResCountsIn.assign((size_t)S, 0);
+        if (!sl.group->sendBufferFree(sh, shard, sl.stream)) return false;
+        VCMOK(vcm_space_partition_queries(sl.ctx, sl.spQ, sl.spQStride, sl.spQCounts.data()));
+    }
+    if (!sl.group->allToAllV(sh, shard, sl.spQ, sl.spQCounts.data(), sl.spQStride, 16, sl.spQIn, sl.spQCountsIn.data(), sl.stream)) return false;
+    {
+        GpuTurn turn(sl.stream, sl.commStream);
+        if (!sl.group->sendBufferFree(sh, shard, sl.stream)) return false;
+        VCMOK(vcm_space_merge(sl.ctx, sl.spQIn, sl.spQCountsIn.data(), S, sl.spQStride, sl.spRes));
+    }
+    // the terms travel the other way: what I evaluated for rank r goes to r; what comes back from d are the terms of the queries I sent to d
+    if (!sl.group->allToAllV(sh, shard, sl.spRes, sl.spQCountsIn.data(), sl.spQStride, 4, sl.spResIn, sl.spResCountsIn.data(), sl.stream)) return false;
+    {
+        GpuTurn turn(sl.stream, sl.commStream);
+        for (int d = 0; d < S; d++) if (sl.spResCountsIn[(size_t)d] != sl.spQCounts[(size_t)d]) { sh.fail("space merge: a rank returned another number of terms than it was sent queries"); return false; }
+        VCMOK(vcm_space_import_results(sl.ctx, sl.spResIn, sl.spQStride));
+        VCMOK(vcm_merge(sl.ctx));
+        VCMOK(vcm_end_iteration(sl.ctx));
+    }
+    return true;
+}
+bool step_finish(Shared &sh, const FarmConfig &cfg, Slot &sl, int shard)
 {   // wait for the exchange, grid build, (camera pass,) merge, resolve
+    if (sl.space && sl.exchanging) return step_finish_space(sh, sl, shard);
     GpuTurn turn(sl.stream, sl.commStream);
     if (sl.exchanging) {
         HIPOK(hipStreamWaitEvent(sl.stream, sl.evGathered, 0));
@@ -479,7 +638,7 @@ bool run_steps(Shared &sh, const FarmConfig &cfg, std::vector<Slot> &slots, int 
         for (Slot &sl : slots) if (sl.live && !step_light(sh, cfg, sl, warm ? t : sl.first + t)) return false;
         for (Slot &sl : slots) if (sl.live && !step_counts(sh, sl, shard)) return false;
         for (Slot &sl : slots) if (sl.live && !step_exchange_camera(sh, cfg, sl, shard)) return false;
-        for (Slot &sl : slots) if (sl.live && !step_finish(sh, cfg, sl)) return false;
+        for (Slot &sl : slots) if (sl.live && !step_finish(sh, cfg, sl, shard)) return false;
     }
     return true;
 }
@@ -526,6 +685,10 @@ bool rank_main(RankArgs &a)
         VCMOK(vcm_set_stream(sl.ctx, sl.stream));
         VCMOK(vcm_reserve(sl.ctx, cfg.maxLen));
         sl.group = cfg.shards > 1 ? a.groupComm : NULL;
+        {   // paths of this shard (the library's own split: contiguous index blocks)
+            const long long N = (long long)cfg.scene.camera.resolution[0] * (long long)cfg.scene.camera.resolution[1];
+            sl.nLocalPaths = (N + cfg.shards - 1) / cfg.shards;
+        }
         renderer_schedule(cfg, R, rid, &sl.first, &sl.count);
         maxCount = std::max(maxCount, sl.count);
     }
@@ -633,6 +796,8 @@ bool rank_main(RankArgs &a)
         vcm_destroy(sl.ctx);
         if (sl.local) (void)hipFree(sl.local);
         if (sl.gathered) (void)hipFree(sl.gathered);
+        if (sl.spLight) { (void)hipFree(sl.spLight); (void)hipFree(sl.spLightIn); }
+        if (sl.spQ) { (void)hipFree(sl.spQ); (void)hipFree(sl.spQIn); (void)hipFree(sl.spRes); (void)hipFree(sl.spResIn); }
         (void)hipEventDestroy(sl.evRecords); (void)hipEventDestroy(sl.evGathered);
         (void)hipStreamDestroy(sl.stream);
     }

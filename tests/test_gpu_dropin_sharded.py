@@ -588,6 +588,40 @@ def test_eight_shards_at_full_size_equal_one_renderer(tmp_path):
     assert float(np.sqrt(np.mean(d * d))) < 1e-7 * float(one.mean())
 
 
+@pytest.mark.skipif(not os.path.exists(HOST), reason="vcm_render not built")
+@pytest.mark.parametrize("ranks,algo,scene,res", [(2, "vcm", 1, (96, 80)), (4, "vcm", 1, (96, 80)), (8, "vcm", 1, (64, 48)), (5, "bpm", 3, (50, 50)),
+                                                  (3, "ppm", 0, (40, 56)), (4, "bpm", 2, (72, 72))])
+def test_merge_sharded_by_space_renders_the_same_bits(tmp_path, ranks, algo, scene, res):
+    """SMALLVCM_AMD_FARM_MERGE=space (round 6 prototype): the ranks own slabs of grid cells; light vertices travel to the owners
+    of their cell (+ one cell of halo), camera vertices to the owner of their base cell, the merge terms back -- instead of every rank
+    merging against ALL light vertices (vertexcm.hxx:532-533).  A query's accepted photons all lie in its own 2 x 2 x 2 block of cells
+    (hashgrid.hxx:124-155), each rank's grid keeps HashGrid::Build's in-cell order on the photons it holds, so the frame is the index-sharded
+    renderer's bit for bit and every work counter but the candidate count is equal (a hash bucket no longer holds the far-away cells that
+    collide into it: fewer distance tests, the same acceptances)."""
+    args = ("--gpus", str(ranks), "--shards", str(ranks), "--inflight", "1", "--collectives", "threads")
+    a, ia = _farm(tmp_path, "index", *args, iters=1, res=res, algo=algo, scene=scene)
+    b, ib = _farm(tmp_path, "space", *args, iters=1, res=res, algo=algo, scene=scene, env={"SMALLVCM_AMD_FARM_MERGE": "space"})
+    c, _ = _farm(tmp_path, "turns", *args, iters=3, res=res, algo=algo, scene=scene, env={"SMALLVCM_AMD_FARM_MERGE": "space", "SMALLVCM_AMD_FARM_SERIALIZE": "1"})
+    d, _ = _farm(tmp_path, "index3", *args, iters=3, res=res, algo=algo, scene=scene)
+    assert a.max() > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(c.view(np.uint32), d.view(np.uint32))
+    for k, v in ia["last_iteration_counters"].items():
+        if k == "mergeCandidates":
+            assert 0 < ib["last_iteration_counters"][k] <= v
+        else:
+            assert ib["last_iteration_counters"][k] == v, (k, v, ib["last_iteration_counters"][k])
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="vcm_render not built")
+def test_merge_sharded_by_space_at_full_size(tmp_path):
+    """... and at BASELINE's fifth configuration: scene 1 VCM 2048 x 2048 on 8 shards, one iteration, ranks taking turns."""
+    args = ("--gpus", "8", "--shards", "8", "--inflight", "1", "--collectives", "threads")
+    a, ia = _farm(tmp_path, "index", *args, iters=1, res=(2048, 2048), env={"SMALLVCM_AMD_FARM_SERIALIZE": "1"})
+    b, ib = _farm(tmp_path, "space", *args, iters=1, res=(2048, 2048), env={"SMALLVCM_AMD_FARM_SERIALIZE": "1", "SMALLVCM_AMD_FARM_MERGE": "space"})
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert ia["last_iteration_counters"]["mergeAccepted"] == ib["last_iteration_counters"]["mergeAccepted"] > 100_000_000
+    assert ib["last_iteration_counters"]["mergeCandidates"] < ia["last_iteration_counters"]["mergeCandidates"]
+
+
 def test_sorted_exchange_and_pinning_entry_points_say_what_they_refuse():
     """vcm_sorted_slab_words / vcm_sort_light_records / vcm_import_sorted_light_records (include/smallvcm_amd.h): the slab size
     is records x 13 words + one block-start word per block of cells (+ padding to 16 bytes); contexts that cannot use the

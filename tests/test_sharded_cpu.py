@@ -89,3 +89,21 @@ def test_static_schedule_is_openmp_static():
     assert [list(static_schedule(10, 4, t)) for t in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
     assert [len(static_schedule(2, 4, t)) for t in range(4)] == [1, 1, 0, 0]
     assert sorted(i for t in range(7) for i in static_schedule(23, 7, t)) == list(range(23))
+
+
+@pytest.mark.parametrize("world,nP,nQ", [(2, 3000, 600), (8, 4000, 800), (3, 2500, 500)])
+def test_space_sharded_merge_protocol(tmp_path, world, nP, nQ):
+    """The merge sharded by SPACE (round 6 prototype: include/smallvcm_amd.h, vcm_farm.cpp step_finish_space) restated in numpy over gloo:
+    slabs of cells from the summed histogram, light vertices to the owners of their cell + one cell of halo, queries to the owner of
+    their base cell, HashGrid::Process against the owner's vertices only -- every query's ACCEPTED SEQUENCE (order included: it is the
+    order of the sum, vertexcm.hxx:168) equals the walk over all vertices, at 2, 3 and 8 ranks; fewer than 2 x the vertices travel."""
+    import json
+    port = _free_port()
+    out = str(tmp_path / "space.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "space_worker.py"), str(r), str(world), str(port), "77", str(nP), str(nQ), out])
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    d = json.load(open(out))
+    assert d["mismatches"] == 0 and d["accepted"] > nQ, d
+    assert nP <= d["sent_photons"] < 2 * nP, d   # the halo: some vertices go to two owners, none to all
