@@ -2363,6 +2363,12 @@ unsigned vcm_sizeof_stats(void) { return (unsigned)sizeof(vcm_stats); }
 
 } // extern "C"
 
+#if defined(VCM_K4_TIMES)   /* measurement variant only: profiles/tools/k4_tail.py */
+extern "C" int k4_times_read(unsigned long long *out /* 2 x 32768 */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vcm::g_k4Times), sizeof(unsigned long long) * 2 * 32768) == hipSuccess ? 0 : -1;
+}
+#endif
 #if defined(VCM_REGION_CLOCK)   /* measurement variant only: profiles/tools/region_clock.py */
 extern "C" int region_clock_read(unsigned long long *out, int reset)   /* out: 3 x VCM_RC_IDS words */
 {

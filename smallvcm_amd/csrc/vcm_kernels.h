@@ -599,6 +599,9 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #endif
 }
 
+#if defined(VCM_K4_TIMES)
+__device__ unsigned long long g_k4Times[2 * 32768];
+#endif
 /* ---------------- K4 (pairs): the scan per lane, RangeQuery::Process per PAIR ---------------- */
 /* Round 6 (profiles/r13a_pmc_mem.json): k_merge_walk is bound by the texture path -- TD busy 97 % of the kernel's cycles, TA
  * 83 %, 46 % of the cycles moving data at the full 64 bytes per clock, the rest stalled behind L1 misses -- and that path is
@@ -843,6 +846,9 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
 {
     stamp_entry(st);
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(VCM_K4_TIMES)   /* measurement variant: when every workgroup of the launch started and ended (profiles/tools/k4_tail.py) */
+    if (threadIdx.x == 0 && blockIdx.x < 32768) g_k4Times[2 * blockIdx.x] = wall_clock64();
+#endif
     const DScene &sc = *scp;
     const int nQ = *nSorted;
     __shared__ __attribute__((aligned(16))) PairLds L;
@@ -949,6 +955,10 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
     }
     if (lane == 0) ls.mergeAccepted = waveAccepted;
     flush_stats(ls, gstats);
+#if defined(VCM_K4_TIMES)
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 32768) g_k4Times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 #endif
 }
 
