@@ -2369,6 +2369,12 @@ extern "C" int k4_times_read(unsigned long long *out /* 2 x 32768 */)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(vcm::g_k4Times), sizeof(unsigned long long) * 2 * 32768) == hipSuccess ? 0 : -1;
 }
 #endif
+#if defined(VCM_K4_STEPS)   /* measurement variant only: profiles/tools/k4_lanes.py */
+extern "C" int k4_steps_read(unsigned short *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vcm::g_k4Steps), sizeof(unsigned short) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 #if defined(VCM_REGION_CLOCK)   /* measurement variant only: profiles/tools/region_clock.py */
 extern "C" int region_clock_read(unsigned long long *out, int reset)   /* out: 3 x VCM_RC_IDS words */
 {

@@ -602,6 +602,9 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #if defined(VCM_K4_TIMES)
 __device__ unsigned long long g_k4Times[2 * 32768];
 #endif
+#if defined(VCM_K4_STEPS)   /* measurement variant: the scan steps every query needs, in the order K4 takes them (profiles/tools/k4_lanes.py) */
+__device__ unsigned short g_k4Steps[1 << 24];
+#endif
 /* ---------------- K4 (pairs): the scan per lane, RangeQuery::Process per PAIR ---------------- */
 /* Round 6 (profiles/r13a_pmc_mem.json): k_merge_walk is bound by the texture path -- TD busy 97 % of the kernel's cycles, TA
  * 83 %, 46 % of the cycles moving data at the full 64 bytes per clock, the rest stalled behind L1 misses -- and that path is
@@ -615,8 +618,9 @@ __device__ unsigned long long g_k4Times[2 * 32768];
  * only a Phong lobe reads behind them); the material constants come from a table staged at kernel start.
  * ORDER, and why the sum is still the reference's (vertexcm.hxx:168): a query's pairs enter the ring in the order its lane
  * walks its candidates (cells in the reference's order, hashgrid.hxx:142-155, vertices in index order) and leave it first
- * in, first out.  Every entry carries how many pairs of ITS query precede it in its batch of 64 (`occ`, counted by the
- * query's lane as it pushes); the terms are added to the queries' accumulators in rounds -- round r: the lanes whose entry
+ * in, first out.  Every entry carries how many pairs ITS query had pushed before it (`seq`, counted by the query's lane); in a batch
+ * of 64 the pairs of a query have consecutive counts, so `occ` = seq - the smallest of them = how many pairs of its query precede the
+ * entry in its batch; the terms are added to the queries' accumulators in rounds -- round r: the lanes whose entry
  * has occ = r, which are pairs of DIFFERENT queries, each a plain read-add-write on its query's three words.  (ds_add_f32
  * would do the same in one instruction -- the LDS serialises it by lane -- at 195 cycles per wave-instruction against 4-5 for
  * a read or a write: profiles/r13d_lds_bench.txt; the first version of this kernel spent its time there.)
@@ -627,11 +631,12 @@ __device__ unsigned long long g_k4Times[2 * 32768];
 #define VCM_PAIR_ROW 5             /* 16-byte words of a query's row */
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float vcm_f4 __attribute__((ext_vector_type(4)));
-struct alignas(8) PairEntry { uint32_t idx, meta; };   /* photon | query lane (bits 0-5), occ (bits 8-14) */
+struct alignas(8) PairEntry { uint32_t idx, meta; };   /* photon | query lane (bits 0-5), seq (bits 6-31): how many pairs its query had before it */
+typedef uint32_t __attribute__((may_alias)) vcm_u32_alias;
 struct PairLds {
     int runLo[8 * VCM_MERGE_BLOCK];
     unsigned short runLen[8 * VCM_MERGE_BLOCK];   /* saturates at 65535: the lane then re-reads the cell's end (merge_pairs_run_end) */
-    vcm_f4 row[VCM_MERGE_BLOCK * VCM_PAIR_ROW];   /* {mZ | ldf.z}, {diffProb, phongProb, contProb, code}, {camTerm, camdVM, revPdfDiffuse, -}; Phong only: {mX | ldf.x}, {mY | ldf.y} */
+    vcm_f4 row[VCM_MERGE_BLOCK * VCM_PAIR_ROW];   /* {mZ | ldf.z}, {diffProb, phongProb, contProb, code}, {camTerm, camdVM, revPdfDiffuse, seqMin}; Phong only: {mX | ldf.x}, {mY | ldf.y} */
     float acc[3 * VCM_MERGE_BLOCK];
     PairEntry ring[(VCM_MERGE_BLOCK / 64) * VCM_PAIR_RING];
     vcm_f4 mat[VCM_PAIR_MATERIALS * 2];           /* {diffuse / pi, phongExp}, {rho, -} */
@@ -747,7 +752,16 @@ __device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L
 {
     V3 term = sp3(0.f);
     const int ql = waveBase + (int)(b.meta & 63u);
-    const uint32_t occ = b.valid ? ((b.meta >> 8) & 127u) : 0u;
+    /* how many pairs of ITS query precede the entry in this batch: a query's pairs in a batch have consecutive `seq` (they enter the
+       ring in its lane's order and a batch is a contiguous piece of the ring), so seq minus the smallest of them -- one ds_min_u32
+       per batch on the free word of the query's row (15 cycles per wave-instruction against ds_add_f32's 195: r13d_lds_bench.txt) */
+    const uint32_t seq = b.meta >> 6;
+    vcm_u32_alias *seqMin = (vcm_u32_alias *)(L.row + ql * VCM_PAIR_ROW + 2) + 3;
+    if (b.valid) __hip_atomic_fetch_min(seqMin, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t occ = b.valid ? seq - *seqMin : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (b.valid) *seqMin = 0xffffffffu;   /* (in order behind the reads: LDS operations of a wave complete in order) */
     if (b.valid) {
         const vcm_f4 *row = L.row + ql * VCM_PAIR_ROW;
         const vcm_f4 h0 = row[0], h1 = row[1], h2 = row[2];
@@ -800,43 +814,59 @@ __device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L
         if (!wave_any(live && occ > r)) break;
     }
 }
-/* the four candidates of a step: the accepted ones to the ring, one candidate column at a time as a REAL loop (the drain
-   exists once per call site; unrolled, four copies of it cost a register shuffle of the batch in flight at every step) */
+/* the four candidates of a step: the accepted ones to the ring.  Four ballots and their counts first; if the ring takes all of
+   them -- 63 pending + 64 is the most it holds; the usual step accepts ~30 -- the four candidate COLUMNS (candidate u of all 64
+   lanes) go in one after the other without a test in between: a lane's place = the entries before its column + the accepting
+   lanes below it.  Then the batches that are full leave.  Nothing in the push depends on where a batch ends (the entries carry a
+   running count per query, merge_pairs_eval makes it relative): round 6's first version kept a per-batch count, tested for a full
+   batch after every column in a real loop and patched the entries behind the cut -- 36 instructions per column against 15.
+   A step that accepts more than the ring has room for (a caustic) goes column by column. */
+#define VCM_PAIR_COLUMN(u, mu, au, before)                                                                              \
+    {                                                                                                                   \
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((mu) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mu), (uint32_t)(before))); \
+        if (au) { PairEntry e; e.idx = (uint32_t)(blk + (u)); e.meta = metaCur; ring[pos & (VCM_PAIR_RING - 1)] = e; metaCur += 64u; } \
+    }
 template <bool IP>
 __device__ __forceinline__ void merge_pairs_push(const IterParams &P, const GridStore &g, PairLds &L, PairEntry *ring, int lane, int waveBase,
                                                  int lo, int hi, float d0, float d1, float d2, float d3,
-                                                 int &head, int &cnt, uint32_t &occ, bool &inflight, PairBatch &pb, uint32_t &waveAccepted)
+                                                 int &head, int &cnt, uint32_t &metaCur, bool &inflight, PairBatch &pb, uint32_t &waveAccepted)
 {
-    int idx = lo & ~3;   /* the step's block of four; its candidates are those of [lo, hi) */
-    const uint32_t len = (uint32_t)(hi - lo);
-#pragma unroll 1
-    for (int u = 0; u < VCM_MERGE_UNROLL; u++) {
-        const bool acc = ((uint32_t)(idx - lo) < len) & (d0 <= P.radiusSqr);   /* :165 */
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(acc);
-        if (m) {   /* scalar branch */
-            const int rel = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (acc) {
-                PairEntry e; e.idx = (uint32_t)idx; e.meta = (uint32_t)lane | (occ << 8);
-                ring[(head + rel) & (VCM_PAIR_RING - 1)] = e;
-                occ++;
-            }
-            const int add = __popcll(m);
-            cnt += add;
-            waveAccepted += (uint32_t)add;
-            if (cnt >= 64) {
-                if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
-                const int headWas = head;
-                merge_pairs_issue(g, ring, lane, head, cnt, pb);
-                inflight = true;
-                /* the entries of this column that did not fit open the next batch */
-                const bool left = acc && rel >= 64;
-                if (left) ring[(headWas + rel) & (VCM_PAIR_RING - 1)].meta = (uint32_t)lane;
-                occ = left ? 1u : 0u;
-            }
+    const int blk = lo & ~3;   /* the step's block of four; its candidates are those of [lo, hi) */
+    const uint32_t first = (uint32_t)(lo & 3), len = (uint32_t)(hi - lo);
+    const bool v0 = (0u - first) < len, v1 = (1u - first) < len, v2 = (2u - first) < len, v3 = (3u - first) < len;
+    const bool c0 = d0 <= P.radiusSqr, c1 = d1 <= P.radiusSqr, c2 = d2 <= P.radiusSqr, c3 = d3 <= P.radiusSqr;   /* :165 */
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(v0) & __builtin_amdgcn_ballot_w64(c0),
+                             m1 = __builtin_amdgcn_ballot_w64(v1) & __builtin_amdgcn_ballot_w64(c1),
+                             m2 = __builtin_amdgcn_ballot_w64(v2) & __builtin_amdgcn_ballot_w64(c2),
+                             m3 = __builtin_amdgcn_ballot_w64(v3) & __builtin_amdgcn_ballot_w64(c3);
+    const int t0 = __popcll(m0), t1 = __popcll(m1), t2 = __popcll(m2), t3 = __popcll(m3);
+    const int T = t0 + t1 + t2 + t3;
+    waveAccepted += (uint32_t)T;
+    int u = 0;
+    do {
+        if (u == 0 && cnt + T <= VCM_PAIR_RING) {
+            const int at = head + cnt;
+            VCM_PAIR_COLUMN(0, m0, v0 & c0, at)
+            VCM_PAIR_COLUMN(1, m1, v1 & c1, at + t0)
+            VCM_PAIR_COLUMN(2, m2, v2 & c2, at + t0 + t1)
+            VCM_PAIR_COLUMN(3, m3, v3 & c3, at + t0 + t1 + t2)
+            cnt += T;
+            u = 4;
+        } else {   /* cold */
+            const unsigned long long m = u == 0 ? m0 : u == 1 ? m1 : u == 2 ? m2 : m3;
+            const bool a = ((m >> lane) & 1ull) != 0ull;
+            VCM_PAIR_COLUMN(u, m, a, head + cnt)
+            cnt += __popcll(m);
+            u++;
         }
-        d0 = d1; d1 = d2; d2 = d3; idx++;
-    }
+        while (cnt >= 64) {   /* a batch is full: it leaves, the one in flight is evaluated */
+            if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
+            merge_pairs_issue(g, ring, lane, head, cnt, pb);
+            inflight = true;
+        }
+    } while (u < 4);
 }
+#undef VCM_PAIR_COLUMN
 #endif
 
 template <bool IP>
@@ -890,7 +920,7 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
             r.x = c.w * P.misVcWeightFactor;                                              /* vertexcm.hxx:160 */
             r.y = d.w;
             r.z = bsdf.diffProb * smax(0.f, bsdf.localDirFix.z * VCM_INV_PI_F);           /* bsdf.hxx:408 */
-            r.w = 0.f; row[2] = r;
+            r.w = u2f(0xffffffffu); row[2] = r;   /* seqMin (merge_pairs_eval) */
             if (bsdf.phongProb != 0.f) {
                 r.x = bsdf.frame.mX.x; r.y = bsdf.frame.mX.y; r.z = bsdf.frame.mX.z; r.w = bsdf.localDirFix.x; row[3] = r;
                 r.x = bsdf.frame.mY.x; r.y = bsdf.frame.mY.y; r.z = bsdf.frame.mY.z; r.w = bsdf.localDirFix.y; row[4] = r;
@@ -899,6 +929,13 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
             int total;
             n = merge_pairs_runs(P, g, qp, L, tid, total, probes);
             ls.mergeCandidates += (uint32_t)total;
+#if defined(VCM_K4_STEPS)
+            if (q < (1 << 24)) {
+                int steps = 0;
+                for (int k = 0; k < n; k++) steps += ((L.runLo[k * VCM_MERGE_BLOCK + tid] & 3) + (int)L.runLen[k * VCM_MERGE_BLOCK + tid] + 3) >> 2;
+                g_k4Steps[q] = (unsigned short)(steps < 65535 ? steps : 65535);
+            }
+#endif
         }
         L.acc[tid] = 0.f; L.acc[VCM_MERGE_BLOCK + tid] = 0.f; L.acc[2 * VCM_MERGE_BLOCK + tid] = 0.f;
         /* ---- scan (merge_query_walk's) with the accepted pairs to the wave's ring.  The candidates of a step are loaded TWO
@@ -907,7 +944,7 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
            free the moment its distances are formed, and takes the candidates of the step after next. */
         const f2 qx = f2_sp(qp.x), qy = f2_sp(qp.y), qz = f2_sp(qp.z);
         int head = 0, cnt = 0;
-        uint32_t occ = 0u;   /* this lane's pairs in the batch that is filling */
+        uint32_t metaCur = (uint32_t)lane;   /* the next entry's meta: lane | the pairs this lane has pushed << 6 */
         bool inflight = false;
         PairBatch pb;
         pb.valid = false; pb.meta = 0u;
@@ -929,7 +966,7 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
                 d0 = da.x; d1 = da.y; d2 = db.x; d3 = db.y;                                                                    \
             }                                                                                                                  \
             VCM_PAIR_LOAD(SX, SY, SZ, VCM_PAIR_AHEAD.lo)                                                                       \
-            merge_pairs_push<IP>(P, g, L, ring, lane, waveBase, it0.lo, it0.hi, d0, d1, d2, d3, head, cnt, occ, inflight, pb, waveAccepted); \
+            merge_pairs_push<IP>(P, g, L, ring, lane, waveBase, it0.lo, it0.hi, d0, d1, d2, d3, head, cnt, metaCur, inflight, pb, waveAccepted); \
             VCM_PAIR_SHIFT                                                                                                     \
         }
         for (;;) {
