@@ -2369,6 +2369,15 @@ extern "C" int k4_times_read(unsigned long long *out /* 2 x 32768 */)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(vcm::g_k4Times), sizeof(unsigned long long) * 2 * 32768) == hipSuccess ? 0 : -1;
 }
 #endif
+#if defined(VCM_K4_REGIONS)   /* measurement variant only: profiles/tools/k4_regions.py */
+extern "C" int k4_regions_read(unsigned long long *out /* 16 */, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vcm::g_k4Regions), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vcm::g_k4Regions), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #if defined(VCM_K4_STEPS)   /* measurement variant only: profiles/tools/k4_lanes.py */
 extern "C" int k4_steps_read(unsigned short *out, int n)
 {

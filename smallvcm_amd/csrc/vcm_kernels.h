@@ -602,6 +602,19 @@ k_merge_walk(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexSt
 #if defined(VCM_K4_TIMES)
 __device__ unsigned long long g_k4Times[2 * 32768];
 #endif
+#if defined(VCM_K4_REGIONS)   /* measurement variant: where the residence time of k_merge_pairs' waves goes (profiles/tools/k4_regions.py).
+   The clock is the wave's, kept in registers (the kernel's LDS is spent); a mark charges the cycles since the previous one to its region and
+   leaves its own cost out; s_memtime also waits for the wave's outstanding LDS operations, which the region before the mark is charged. */
+__device__ unsigned long long g_k4Regions[16];
+struct K4Regions { unsigned long long t, c[8]; };
+#define K4R_PARAM , K4Regions &k4r
+#define K4R_ARG , k4r
+#define K4R(id) { const unsigned long long n_ = clock64(); k4r.c[id] += n_ - k4r.t; k4r.t = clock64(); }
+#else
+#define K4R_PARAM
+#define K4R_ARG
+#define K4R(id)
+#endif
 #if defined(VCM_K4_STEPS)   /* measurement variant: the scan steps every query needs, in the order K4 takes them (profiles/tools/k4_lanes.py) */
 __device__ unsigned short g_k4Steps[1 << 24];
 #endif
@@ -728,7 +741,7 @@ __device__ __forceinline__ PairPos merge_pairs_next(const IterParams &P, const G
 }
 
 /* a batch leaves the ring: its (at most 64) entries, the gathers of their photons */
-__device__ __forceinline__ void merge_pairs_issue(const GridStore &g, const PairEntry *ring, int lane, int &head, int &cnt, PairBatch &b)
+__device__ __forceinline__ void merge_pairs_issue(const GridStore &g, const PairEntry *ring, int lane, int &head, int &cnt, PairBatch &b K4R_PARAM)
 {
     const int n = cnt < 64 ? cnt : 64;
     b.valid = lane < n;
@@ -744,11 +757,12 @@ __device__ __forceinline__ void merge_pairs_issue(const GridStore &g, const Pair
     b.ph.dVM = t.x;
     head = (head + n) & (VCM_PAIR_RING - 1);
     cnt -= n;
+    K4R(3)
 }
 /* RangeQuery::Process (vertexcm.hxx:130-169) for the pair of every lane: merge_eval_setup + merge_eval_photon (vcm_core.h)
    statement by statement, the query's side out of its LDS row; then the terms to the accumulators, round by round */
 template <bool IP>
-__device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L, int waveBase, const PairBatch &b)
+__device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L, int waveBase, const PairBatch &b K4R_PARAM)
 {
     V3 term = sp3(0.f);
     const int ql = waveBase + (int)(b.meta & 63u);
@@ -803,6 +817,7 @@ __device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L
             term = term + misWeight * result * mk3(b.ph.c.x, b.ph.c.y, b.ph.c.z);           /* :168: 0 + x is x */
         }
     }
+    K4R(4)
     /* contrib += term, a query's terms in the order of its pairs: round r = the entries with r pairs of their query before them */
     const bool live = b.valid && (term.x != 0.f || term.y != 0.f || term.z != 0.f);
     for (uint32_t r = 0;; r++) {
@@ -813,6 +828,7 @@ __device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L
         __builtin_amdgcn_wave_barrier();
         if (!wave_any(live && occ > r)) break;
     }
+    K4R(5)
 }
 /* the four candidates of a step: the accepted ones to the ring.  Four ballots and their counts first; if the ring takes all of
    them -- 63 pending + 64 is the most it holds; the usual step accepts ~30 -- the four candidate COLUMNS (candidate u of all 64
@@ -829,7 +845,7 @@ __device__ __forceinline__ void merge_pairs_eval(const IterParams &P, PairLds &L
 template <bool IP>
 __device__ __forceinline__ void merge_pairs_push(const IterParams &P, const GridStore &g, PairLds &L, PairEntry *ring, int lane, int waveBase,
                                                  int lo, int hi, float d0, float d1, float d2, float d3,
-                                                 int &head, int &cnt, uint32_t &metaCur, bool &inflight, PairBatch &pb, uint32_t &waveAccepted)
+                                                 int &head, int &cnt, uint32_t &metaCur, bool &inflight, PairBatch &pb, uint32_t &waveAccepted K4R_PARAM)
 {
     const int blk = lo & ~3;   /* the step's block of four; its candidates are those of [lo, hi) */
     const uint32_t first = (uint32_t)(lo & 3), len = (uint32_t)(hi - lo);
@@ -859,9 +875,10 @@ __device__ __forceinline__ void merge_pairs_push(const IterParams &P, const Grid
             cnt += __popcll(m);
             u++;
         }
+        K4R(2)
         while (cnt >= 64) {   /* a batch is full: it leaves, the one in flight is evaluated */
-            if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
-            merge_pairs_issue(g, ring, lane, head, cnt, pb);
+            if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb K4R_ARG);
+            merge_pairs_issue(g, ring, lane, head, cnt, pb K4R_ARG);
             inflight = true;
         }
     } while (u < 4);
@@ -896,6 +913,11 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
     __syncthreads();   /* the only barrier: from here on a wave touches its own quarter of the LDS */
     LaneStats ls; lane_stats_zero(ls);
     uint32_t waveAccepted = 0;   /* wave-uniform */
+#if defined(VCM_K4_REGIONS)
+    K4Regions k4r;
+    for (int i = 0; i < 8; i++) k4r.c[i] = 0ull;
+    k4r.t = clock64();
+#endif
     const int nBatches = (nQ + VCM_MERGE_BLOCK - 1) / VCM_MERGE_BLOCK;
     const int xcd = blockIdx.x & 7, wgOfXcd = blockIdx.x >> 3, wgPerXcd = gridDim.x >> 3;
     for (int t = wgOfXcd;; t += wgPerXcd) {   /* k_merge_walk's static dealing: chunks of batches round-robin over the XCDs */
@@ -953,8 +975,14 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
         vcm_f4 AX, AY, AZ, BX, BY, BZ;
         VCM_PAIR_LOAD(AX, AY, AZ, it0.lo)
         VCM_PAIR_LOAD(BX, BY, BZ, it1.lo)
+        K4R(0)
 #define VCM_PAIR_AHEAD it2
 #define VCM_PAIR_SHIFT it0 = it1; it1 = it2; it2 = merge_pairs_next(P, g, L, tid, n, qp, probes, it2);
+#if defined(VCM_K4_REGIONS)   /* (the distances must exist before the mark: they wait for the step's loads) */
+#define K4R_DIST(a, b, c, d) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d)); K4R(1) }
+#else
+#define K4R_DIST(a, b, c, d)
+#endif
 #define VCM_PAIR_STEP(SX, SY, SZ)                                                                                              \
         {                                                                                                                      \
             float d0, d1, d2, d3;                                                                                              \
@@ -966,8 +994,10 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
                 d0 = da.x; d1 = da.y; d2 = db.x; d3 = db.y;                                                                    \
             }                                                                                                                  \
             VCM_PAIR_LOAD(SX, SY, SZ, VCM_PAIR_AHEAD.lo)                                                                       \
-            merge_pairs_push<IP>(P, g, L, ring, lane, waveBase, it0.lo, it0.hi, d0, d1, d2, d3, head, cnt, metaCur, inflight, pb, waveAccepted); \
+            K4R_DIST(d0, d1, d2, d3)                                                                                           \
+            merge_pairs_push<IP>(P, g, L, ring, lane, waveBase, it0.lo, it0.hi, d0, d1, d2, d3, head, cnt, metaCur, inflight, pb, waveAccepted K4R_ARG); \
             VCM_PAIR_SHIFT                                                                                                     \
+            K4R(6)                                                                                                             \
         }
         for (;;) {
             if (!wave_any(it0.lo < it0.hi)) break;
@@ -979,17 +1009,21 @@ k_merge_pairs(const DScene *__restrict__ scp, IterParams P, GridStore g, VertexS
 #undef VCM_PAIR_LOAD
 #undef VCM_PAIR_AHEAD
 #undef VCM_PAIR_SHIFT
-        if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb);
+        if (inflight) merge_pairs_eval<IP>(P, L, waveBase, pb K4R_ARG);
         while (cnt > 0) {
-            merge_pairs_issue(g, ring, lane, head, cnt, pb);
-            merge_pairs_eval<IP>(P, L, waveBase, pb);
+            merge_pairs_issue(g, ring, lane, head, cnt, pb K4R_ARG);
+            merge_pairs_eval<IP>(P, L, waveBase, pb K4R_ARG);
         }
         if (q < nQ) {
             const V3 contrib = mk3(L.acc[tid], L.acc[VCM_MERGE_BLOCK + tid], L.acc[2 * VCM_MERGE_BLOCK + tid]);
             const V3 v = thr * P.vmNormalization * contrib;
             vs.mergeOut[ps] = mk4(v.x, v.y, v.z, 0.f);
         }
+        K4R(7)
     }
+#if defined(VCM_K4_REGIONS)
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_k4Regions[i], k4r.c[i]);
+#endif
     if (lane == 0) ls.mergeAccepted = waveAccepted;
     flush_stats(ls, gstats);
 #if defined(VCM_K4_TIMES)
