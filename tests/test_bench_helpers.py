@@ -222,7 +222,7 @@ def test_a_kernel_launched_three_times_per_iteration_counts_three_times():
     assert bench._sum_over(c, ["vcm::k_resolve"], "FETCH_SIZE") == 10.0
     assert bench._sum_over(c, ["vcm::k_absent"], "FETCH_SIZE") is None
     # the recorded set of the final sources: K2 = keys + 3 scatter passes + 2 histograms + starts + gather
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r25_counters_C4.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r30_counters_C4.json")
     if os.path.exists(path):
         k = json.load(open(path))["kernels"]
         grid = ["vcm::k_cell_", "vcm::k_radix_", "vcm::k_grid_", "vcm::k_bbox"]
